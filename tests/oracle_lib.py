@@ -1,0 +1,131 @@
+"""ctypes binding for the CPU oracle (oracle/_build/liboracle.so).
+
+Test infrastructure: only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+leg import this module.  The product package (vpin_amd/) never does.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+LIB_PATH = os.path.join(ORACLE_DIR, "_build", "liboracle.so")
+
+_u64p = C.POINTER(C.c_uint64)
+_u8p = C.POINTER(C.c_uint8)
+
+
+class Fq(C.Structure):
+    _fields_ = [("l", C.c_uint64 * 4)]
+
+    def limbs(self):
+        return [int(x) for x in self.l]
+
+
+def build(force=False):
+    srcs = [os.path.join(ORACLE_DIR, f) for f in os.listdir(ORACLE_DIR) if f.endswith((".c", ".h"))]
+    if (not force and os.path.exists(LIB_PATH)
+            and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in srcs)):
+        return LIB_PATH
+    subprocess.check_call(["make", "-s", "-C", ORACLE_DIR])
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(LIB_PATH)
+        _declare(_lib)
+    return _lib
+
+
+def _declare(L):
+    P = C.POINTER(Fq)
+    for name in ("fq_add", "fq_sub", "fq_mul"):
+        getattr(L, name).restype = Fq
+        getattr(L, name).argtypes = [P, P]
+    for name in ("fq_neg", "fq_square", "fq_invert"):
+        getattr(L, name).restype = Fq
+        getattr(L, name).argtypes = [P]
+    L.fq_from_u64.restype = Fq
+    L.fq_from_u64.argtypes = [C.c_uint64]
+    L.fq_from_raw.restype = Fq
+    L.fq_from_raw.argtypes = [_u64p]
+    L.fq_from_bytes.restype = C.c_int
+    L.fq_from_bytes.argtypes = [P, _u8p]
+    L.fq_to_bytes.restype = None
+    L.fq_to_bytes.argtypes = [_u8p, P]
+    L.fq_from_bytes_wide.restype = Fq
+    L.fq_from_bytes_wide.argtypes = [_u8p]
+    L.fq_from_bytes_mod_order.restype = Fq
+    L.fq_from_bytes_mod_order.argtypes = [_u8p]
+    L.fq_pow_vartime.restype = Fq
+    L.fq_pow_vartime.argtypes = [P, _u64p]
+    L.fq_batch_invert.restype = Fq
+    L.fq_batch_invert.argtypes = [C.c_void_p, C.c_size_t]
+    L.oracle_eq_evals.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    L.oracle_bound_poly_var_top.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
+    L.oracle_sc_cubic_round.argtypes = [C.c_void_p] * 4 + [C.c_size_t, C.c_void_p]
+    L.oracle_sc_quad_round.argtypes = [C.c_void_p] * 2 + [C.c_size_t, C.c_void_p]
+    L.oracle_poly_bound.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p]
+    L.oracle_dotproduct.restype = Fq
+    L.oracle_dotproduct.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    L.oracle_poly_evaluate.restype = Fq
+    L.oracle_poly_evaluate.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    L.oracle_unipoly_from_evals.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    L.oracle_unipoly_evaluate.restype = Fq
+    L.oracle_unipoly_evaluate.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    for fn in ("oracle_eq_evals", "oracle_bound_poly_var_top", "oracle_sc_cubic_round",
+               "oracle_sc_quad_round", "oracle_poly_bound", "oracle_unipoly_from_evals"):
+        getattr(L, fn).restype = None
+
+
+# ---- numpy helpers: a table is an (n,4) uint64 C-contiguous array (Montgomery limbs) ----
+
+def ptr(a):
+    assert a.dtype == np.uint64 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def fq_from_limbs(limbs):
+    f = Fq()
+    for i in range(4):
+        f.l[i] = int(limbs[i])
+    return f
+
+
+def fq_arr(f):
+    return np.array(f.limbs(), dtype=np.uint64)
+
+
+def eq_evals(r):
+    r = np.ascontiguousarray(r, dtype=np.uint64).reshape(-1, 4)
+    out = np.zeros((1 << r.shape[0], 4), dtype=np.uint64)
+    lib().oracle_eq_evals(ptr(r), r.shape[0], ptr(out))
+    return out
+
+
+def bound_top(Z, r):
+    """returns the folded copy (length n/2)."""
+    Z = np.array(Z, dtype=np.uint64).reshape(-1, 4).copy()
+    r = np.ascontiguousarray(r, dtype=np.uint64).reshape(4)
+    lib().oracle_bound_poly_var_top(ptr(Z), Z.shape[0], ptr(r))
+    return Z[: Z.shape[0] // 2].copy()
+
+
+def sc_cubic_round(A, B, Cc, D):
+    out = np.zeros((3, 4), dtype=np.uint64)
+    lib().oracle_sc_cubic_round(ptr(A), ptr(B), ptr(Cc), ptr(D), A.shape[0], ptr(out))
+    return out
+
+
+def sc_quad_round(A, B):
+    out = np.zeros((2, 4), dtype=np.uint64)
+    lib().oracle_sc_quad_round(ptr(A), ptr(B), A.shape[0], ptr(out))
+    return out

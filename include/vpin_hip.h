@@ -1,0 +1,118 @@
+/*
+ * vpin_hip.h -- C ABI of the MI355X (gfx950) Spartan sat-proof hot path.
+ *
+ * This is the drop-in boundary for vt-asaplab/vPIN's prover.  The reference has no
+ * FFI seam of its own; the seam is the set of plain Rust functions that
+ * vPIN_proof_generation/src/commit_test.rs calls into libspartan (SURVEY.md 8(b),
+ * rows B1-B5).  Each entry point below names the reference function it replaces
+ * (paths relative to src/proof_generation/).  INTEGRATION.md shows the Rust `extern "C"`
+ * block a vPIN maintainer would add.
+ *
+ * Conventions
+ *  - A scalar is 32 bytes: the reference's in-memory `Scalar([u64;4])`, little-endian
+ *    limbs, Montgomery form with R = 2^256 (Spartan/src/scalar/ristretto255.rs:199-200).
+ *    A table is a flat array of scalars == the memory image of a Vec<Scalar>.
+ *  - A group element crosses as 128 bytes of extended twisted-Edwards coordinates
+ *    (X,Y,Z,T; each 32-byte canonical little-endian mod 2^255-19) or as a 32-byte
+ *    compressed ristretto255 encoding (curve25519-dalek CompressedRistretto).
+ *  - Every call returns 0 on success or a negative VPIN_E* code; nothing aborts across
+ *    the boundary.  The caller owns host buffers; the library owns device memory behind
+ *    opaque handles.  One host thread drives one ctx (the reference's protocol loop is
+ *    single-threaded); calls are synchronous from the caller's point of view.
+ *  - There is NO CPU fallback: every entry point fails with VPIN_ENODEV when no gfx950
+ *    device is usable.
+ */
+#ifndef VPIN_HIP_H
+#define VPIN_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VPIN_OK 0
+#define VPIN_EINVAL (-1)  /* bad argument (null handle, length not a power of two, ...) */
+#define VPIN_ENODEV (-2)  /* no usable HIP device */
+#define VPIN_ENOMEM (-3)  /* device or host allocation failed */
+#define VPIN_EHIP (-4)    /* a HIP runtime call failed; see vpin_last_error() */
+#define VPIN_ESHAPE (-5)  /* operand shapes do not match (the reference would assert) */
+
+typedef struct vpin_ctx vpin_ctx;
+typedef struct vpin_table vpin_table;
+
+const char* vpin_strerror(int code);
+/* text of the last HIP failure seen by this thread ("" if none) */
+const char* vpin_last_error(void);
+/* ABI version of this library (bumped on any signature change) */
+int vpin_abi_version(void);
+
+/* ---- context ------------------------------------------------------------------- */
+int vpin_ctx_create(int device, vpin_ctx** out);
+void vpin_ctx_destroy(vpin_ctx* ctx);
+/* hipStream_t the ctx launches on (as void*), for callers that time with HIP events */
+void* vpin_ctx_stream(vpin_ctx* ctx);
+int vpin_ctx_sync(vpin_ctx* ctx);
+
+/* ---- tables: device-resident Vec<Scalar> ---------------------------------------- */
+/* DensePolynomial::new (Spartan/src/dense_mlpoly.rs:132-138): len must be a power of 2 */
+int vpin_table_upload(vpin_ctx* ctx, const uint8_t* mont32, size_t len, vpin_table** out);
+int vpin_table_alloc(vpin_ctx* ctx, size_t len, vpin_table** out); /* zero-filled */
+/* adopt caller-owned device memory (e.g. a framework tensor) without copying */
+int vpin_table_wrap(vpin_ctx* ctx, void* device_ptr, size_t len, vpin_table** out);
+int vpin_table_clone(vpin_ctx* ctx, const vpin_table* src, vpin_table** out);
+void vpin_table_free(vpin_ctx* ctx, vpin_table* t);
+size_t vpin_table_len(const vpin_table* t); /* DensePolynomial::len(), halves on every bind */
+void* vpin_table_device_ptr(const vpin_table* t);
+/* Index<usize> for DensePolynomial (dense_mlpoly.rs:295-302): read n scalars from off */
+int vpin_table_read(vpin_ctx* ctx, const vpin_table* t, size_t off, size_t n, uint8_t* out);
+
+/* ---- sum-check round reductions -------------------------------------------------- */
+/* Round evaluation loop of ZKSumcheckInstanceProof::prove_cubic_with_additive_term
+ * (Spartan/src/sumcheck.rs:624-652) with R1CSProof::prove_phase_one's combiner
+ * A*(B*C-D) (Spartan/src/r1csproof.rs:104-108).  out = e0|e2|e3, 3 x 32 B Montgomery. */
+int vpin_sc_cubic_round(vpin_ctx* ctx, const vpin_table* tau, const vpin_table* Az,
+                        const vpin_table* Bz, const vpin_table* Cz, uint8_t out_e0_e2_e3[96]);
+/* Round evaluation loop of ZKSumcheckInstanceProof::prove_quad (sumcheck.rs:460-469)
+ * with prove_phase_two's combiner A*B (r1csproof.rs:139-140).  out = e0|e2. */
+int vpin_sc_quad_round(vpin_ctx* ctx, const vpin_table* A, const vpin_table* B,
+                       uint8_t out_e0_e2[64]);
+/* DensePolynomial::bound_poly_var_top (dense_mlpoly.rs:229-236) on k tables at once
+ * (sumcheck.rs:673-676 / :485-486): Z[i] += r*(Z[i+n]-Z[i]); len /= 2. In place. */
+int vpin_sc_bind(vpin_ctx* ctx, vpin_table* const* tables, int k, const uint8_t r[32]);
+/* Fused single pass: bind the four (two) tables with r, then evaluate the NEXT round on
+ * the folded tables -- one read of every live element and one write of every folded
+ * element per round (SURVEY.md 8(d) "algorithmic bytes").  Same results as
+ * vpin_sc_bind followed by vpin_sc_*_round.  Requires len >= 4. */
+int vpin_sc_cubic_bind_round(vpin_ctx* ctx, vpin_table* tau, vpin_table* Az, vpin_table* Bz,
+                             vpin_table* Cz, const uint8_t r[32], uint8_t out_e0_e2_e3[96]);
+int vpin_sc_quad_bind_round(vpin_ctx* ctx, vpin_table* A, vpin_table* B, const uint8_t r[32],
+                            uint8_t out_e0_e2[64]);
+
+/* EqPolynomial::evals (dense_mlpoly.rs:78-94): r = ell x 32 B, result has 2^ell entries */
+int vpin_eq_table(vpin_ctx* ctx, const uint8_t* r, int ell, vpin_table** out);
+
+/* ---- built-in kernel timing (HIP events on the ctx stream) ------------------------ */
+/* kernel classes */
+#define VPIN_K_SC_CUBIC 0
+#define VPIN_K_SC_QUAD 1
+#define VPIN_K_SC_BIND 2
+#define VPIN_K_SC_CUBIC_FUSED 3
+#define VPIN_K_SC_QUAD_FUSED 4
+#define VPIN_K_EQ 5
+#define VPIN_K_MSM 6
+#define VPIN_K_COUNT 16
+typedef struct {
+  uint64_t launches;
+  double ms;         /* sum of event-measured durations */
+  double alg_bytes;  /* sum of algorithmic bytes moved by those launches */
+} vpin_kstat;
+int vpin_prof_enable(vpin_ctx* ctx, int on);
+int vpin_prof_reset(vpin_ctx* ctx);
+/* resolves outstanding events; stats must have VPIN_K_COUNT entries */
+int vpin_prof_read(vpin_ctx* ctx, vpin_kstat* stats);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,184 @@
+"""GPU parity: HIP sum-check round reductions / folds / eq tables, called through the C ABI,
+against the CPU oracle on identical seeded inputs (bit-exact: integer work)."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import pymodel as M
+
+pytestmark = pytest.mark.gpu
+
+Q = M.Q
+
+
+def rand_table(rng, n, zero_frac=0.0):
+    """n random field elements in Montgomery form, as (n,4) uint64."""
+    raw = rng.integers(0, 2**64, size=(n, 8), dtype=np.uint64)
+    out = np.zeros((n, 4), dtype=np.uint64)
+    L = O.lib()
+    import ctypes as C
+    for i in range(n):
+        f = L.fq_from_bytes_wide(raw[i].ctypes.data_as(C.POINTER(C.c_uint8)))
+        out[i] = f.limbs()
+    if zero_frac:
+        out[rng.random(n) < zero_frac] = 0
+    return out
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import vpin_amd
+    c = vpin_amd.Context(0)
+    yield c
+    c.close()
+
+
+def test_micro_kat_on_gpu(ctx):
+    T = lambda xs: M.ints_to_table(xs)
+    tabs = [T([1, 2, 3, 4]), T([5, 6, 7, 8]), T([9, 10, 11, 12]), T([13, 14, 15, 16])]
+    d = [ctx.upload(t) for t in tabs]
+    assert M.table_to_ints(ctx.sc_cubic_round(*d)) == [124, 1232, 2398]
+    ctx.sc_bind(d, T([5])[0])
+    assert [M.table_to_ints(t.read()) for t in d] == [[11, 12], [15, 16], [19, 20], [23, 24]]
+
+
+@pytest.mark.parametrize("ell", [1, 2, 3, 6, 10, 13])
+def test_cubic_rounds_unfused_vs_oracle(ctx, ell):
+    rng = np.random.default_rng(1000 + ell)
+    n = 1 << ell
+    host = [rand_table(rng, n, zero_frac=0.2 if k else 0.0) for k in range(4)]
+    dev = [ctx.upload(t) for t in host]
+    while n >= 2:
+        got = ctx.sc_cubic_round(*dev)
+        exp = O.sc_cubic_round(*[np.ascontiguousarray(t[:n]) for t in host])
+        assert np.array_equal(got, exp), f"round at len {n}"
+        r = rand_table(rng, 1)[0]
+        ctx.sc_bind(dev, r)
+        host = [O.bound_top(t[:n], r) for t in host]
+        n //= 2
+        for t, h in zip(dev, host):
+            assert len(t) == n
+            assert np.array_equal(t.read(), h)
+
+
+@pytest.mark.parametrize("ell", [2, 3, 7, 12, 15])
+def test_cubic_rounds_fused_vs_oracle(ctx, ell):
+    rng = np.random.default_rng(2000 + ell)
+    n = 1 << ell
+    host = [rand_table(rng, n, zero_frac=0.3 if k else 0.0) for k in range(4)]
+    dev = [ctx.upload(t) for t in host]
+    got = ctx.sc_cubic_round(*dev)
+    assert np.array_equal(got, O.sc_cubic_round(*host))
+    while n >= 4:
+        r = rand_table(rng, 1)[0]
+        got = ctx.sc_cubic_bind_round(*dev, r)
+        host = [O.bound_top(t[:n], r) for t in host]
+        n //= 2
+        assert np.array_equal(got, O.sc_cubic_round(*host)), f"fused round -> len {n}"
+        for t, h in zip(dev, host):
+            assert len(t) == n and np.array_equal(t.read(), h)
+    r = rand_table(rng, 1)[0]
+    ctx.sc_bind(dev, r)
+    host = [O.bound_top(t[:n], r) for t in host]
+    for t, h in zip(dev, host):
+        assert len(t) == 1 and np.array_equal(t.read(), h)
+
+
+@pytest.mark.parametrize("ell", [1, 2, 5, 11, 14])
+def test_quad_rounds_vs_oracle(ctx, ell):
+    rng = np.random.default_rng(3000 + ell)
+    n = 1 << ell
+    host = [rand_table(rng, n, zero_frac=0.4 * k) for k in range(2)]
+    dev = [ctx.upload(t) for t in host]
+    dev2 = [t.clone() for t in dev]
+    host2 = [h.copy() for h in host]
+    # unfused
+    m = n
+    while m >= 2:
+        assert np.array_equal(ctx.sc_quad_round(*dev), O.sc_quad_round(*[np.ascontiguousarray(t[:m]) for t in host]))
+        r = rand_table(rng, 1)[0]
+        ctx.sc_bind(dev, r)
+        host = [O.bound_top(t[:m], r) for t in host]
+        m //= 2
+        for t, h in zip(dev, host):
+            assert np.array_equal(t.read(), h)
+    # fused
+    m = n
+    while m >= 4:
+        r = rand_table(rng, 1)[0]
+        got = ctx.sc_quad_bind_round(*dev2, r)
+        host2 = [O.bound_top(t[:m], r) for t in host2]
+        m //= 2
+        assert np.array_equal(got, O.sc_quad_round(*host2))
+        for t, h in zip(dev2, host2):
+            assert np.array_equal(t.read(), h)
+
+
+@pytest.mark.parametrize("ell", [0, 1, 2, 5, 9, 16])
+def test_eq_table_vs_oracle(ctx, ell):
+    rng = np.random.default_rng(4000 + ell)
+    r = rand_table(rng, max(ell, 1))[:ell]
+    t = ctx.eq_table(r)
+    assert len(t) == 1 << ell
+    exp = O.eq_evals(r) if ell else np.array([M.to_mont_limbs(1)], dtype=np.uint64)
+    assert np.array_equal(t.read(), exp)
+
+
+def test_edge_values(ctx):
+    """all-zero tables, q-1 everywhere, and mixed: exercises the conditional-subtract paths."""
+    n = 64
+    zero = np.zeros((n, 4), dtype=np.uint64)
+    m1 = M.ints_to_table([Q - 1] * n)
+    one = M.ints_to_table([1] * n)
+    for combo in ([zero] * 4, [m1] * 4, [m1, one, m1, zero], [one, m1, m1, m1]):
+        dev = [ctx.upload(t) for t in combo]
+        assert np.array_equal(ctx.sc_cubic_round(*dev), O.sc_cubic_round(*combo))
+        r = M.ints_to_table([Q - 1])[0]
+        got = ctx.sc_cubic_bind_round(*dev, r)
+        host = [O.bound_top(t, r) for t in combo]
+        assert np.array_equal(got, O.sc_cubic_round(*host))
+
+
+def test_shape_errors(ctx):
+    import vpin_amd
+    a = ctx.upload(np.zeros((8, 4), dtype=np.uint64))
+    b = ctx.upload(np.zeros((4, 4), dtype=np.uint64))
+    with pytest.raises(vpin_amd.VpinError) as ei:
+        ctx.sc_quad_round(a, b)
+    assert ei.value.code == -5
+    with pytest.raises(vpin_amd.VpinError):
+        ctx.upload(np.zeros((3, 4), dtype=np.uint64))  # not a power of two
+
+
+def test_round_trip_property_large(ctx):
+    """Size-independent property at a BASELINE-scale table (2^20): the sum-check identity
+    e0 + e1 == claim carried across rounds, with e1 recovered from the folded tables:
+    after binding with r, the next round's e0' + e1' must equal poly(r) interpolated from
+    (e0, claim-e0, e2, e3)."""
+    rng = np.random.default_rng(77)
+    n = 1 << 20
+    # cheap wide random elements: random 252-bit values are already canonical Montgomery images
+    def fast_rand(n):
+        a = rng.integers(0, 2**64, size=(n, 4), dtype=np.uint64)
+        a[:, 3] &= np.uint64(0x0FFFFFFFFFFFFFFF)
+        return a
+    host = [fast_rand(n) for _ in range(4)]
+    dev = [ctx.upload(t) for t in host]
+    e = M.table_to_ints(ctx.sc_cubic_round(*dev))
+    # e1 = sum over the high half = eval of the same combiner on the "hi" elements
+    hi = [ctx.upload(np.ascontiguousarray(np.concatenate([t[n // 2:], t[n // 2:]]))) for t in host]
+    e1 = M.table_to_ints(ctx.sc_cubic_round(*hi))[0]
+    claim = (e[0] + e1) % Q
+    for _ in range(6):
+        coeffs = M.unipoly_from_evals([e[0], (claim - e[0]) % Q, e[1], e[2]])
+        r_int = int(rng.integers(1, 2**62))
+        r = M.ints_to_table([r_int])[0]
+        e = M.table_to_ints(ctx.sc_cubic_bind_round(*dev, r))
+        claim = M.unipoly_eval(coeffs, r_int)
+        # next round: e0' + e1' == claim; recover e1' from the cubic through (e0', e2', e3') needs
+        # claim itself, so check with an explicit evaluation of the high half instead
+        m = len(dev[0])
+        his = [t.read(m // 2, m // 2) for t in dev]
+        hi = [ctx.upload(np.ascontiguousarray(np.concatenate([h, h]))) for h in his]
+        e1 = M.table_to_ints(ctx.sc_cubic_round(*hi))[0]
+        assert (e[0] + e1) % Q == claim

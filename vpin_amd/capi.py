@@ -1,0 +1,233 @@
+"""ctypes binding of include/vpin_hip.h (the C ABI of libvpin_hip.so)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+HEADER = os.path.join(ROOT, "include", "vpin_hip.h")
+
+KERNEL_CLASSES = {
+    0: "sc_cubic", 1: "sc_quad", 2: "sc_bind", 3: "sc_cubic_fused", 4: "sc_quad_fused", 5: "eq", 6: "msm",
+}
+K_COUNT = 16
+
+
+class VpinError(RuntimeError):
+    def __init__(self, code, where):
+        self.code = code
+        L = lib()
+        msg = L.vpin_strerror(code).decode()
+        last = L.vpin_last_error().decode()
+        super().__init__(f"{where}: {msg} ({code})" + (f" [{last}]" if last else ""))
+
+
+class KStat(C.Structure):
+    _fields_ = [("launches", C.c_uint64), ("ms", C.c_double), ("alg_bytes", C.c_double)]
+
+
+def lib_path():
+    return os.path.join(HERE, "lib", "libvpin_hip.so")
+
+
+_lib = None
+
+
+def lib():
+    """Load libvpin_hip.so.  Raises (never falls back) when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    p = lib_path()
+    if not os.path.exists(p):
+        raise ImportError(
+            f"{p} is missing: build it with `python vpin_amd/build.py` (hipcc, gfx950). "
+            "vpin_amd has no CPU fallback.")
+    L = C.CDLL(p)
+    vp = C.c_void_p
+    L.vpin_strerror.restype = C.c_char_p
+    L.vpin_strerror.argtypes = [C.c_int]
+    L.vpin_last_error.restype = C.c_char_p
+    L.vpin_abi_version.restype = C.c_int
+    L.vpin_ctx_create.argtypes = [C.c_int, C.POINTER(vp)]
+    L.vpin_ctx_destroy.argtypes = [vp]
+    L.vpin_ctx_destroy.restype = None
+    L.vpin_ctx_stream.argtypes = [vp]
+    L.vpin_ctx_stream.restype = vp
+    L.vpin_ctx_sync.argtypes = [vp]
+    L.vpin_table_upload.argtypes = [vp, vp, C.c_size_t, C.POINTER(vp)]
+    L.vpin_table_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
+    L.vpin_table_wrap.argtypes = [vp, vp, C.c_size_t, C.POINTER(vp)]
+    L.vpin_table_clone.argtypes = [vp, vp, C.POINTER(vp)]
+    L.vpin_table_free.argtypes = [vp, vp]
+    L.vpin_table_free.restype = None
+    L.vpin_table_len.argtypes = [vp]
+    L.vpin_table_len.restype = C.c_size_t
+    L.vpin_table_device_ptr.argtypes = [vp]
+    L.vpin_table_device_ptr.restype = vp
+    L.vpin_table_read.argtypes = [vp, vp, C.c_size_t, C.c_size_t, vp]
+    L.vpin_sc_cubic_round.argtypes = [vp, vp, vp, vp, vp, vp]
+    L.vpin_sc_quad_round.argtypes = [vp, vp, vp, vp]
+    L.vpin_sc_bind.argtypes = [vp, C.POINTER(vp), C.c_int, vp]
+    L.vpin_sc_cubic_bind_round.argtypes = [vp, vp, vp, vp, vp, vp, vp]
+    L.vpin_sc_quad_bind_round.argtypes = [vp, vp, vp, vp, vp]
+    L.vpin_eq_table.argtypes = [vp, vp, C.c_int, C.POINTER(vp)]
+    L.vpin_prof_enable.argtypes = [vp, C.c_int]
+    L.vpin_prof_reset.argtypes = [vp]
+    L.vpin_prof_read.argtypes = [vp, C.POINTER(KStat)]
+    _lib = L
+    return L
+
+
+def declared_symbols():
+    """Every function name declared in include/vpin_hip.h."""
+    with open(HEADER) as f:
+        text = re.sub(r"/\*.*?\*/", "", f.read(), flags=re.S)
+    return sorted(set(re.findall(r"\b(vpin_[a-z0-9_]+)\s*\(", text)))
+
+
+def exported_symbols():
+    L = lib()
+    return [s for s in declared_symbols() if hasattr(L, s)]
+
+
+def _chk(code, where):
+    if code != 0:
+        raise VpinError(code, where)
+
+
+def _u8(a):
+    a = np.ascontiguousarray(a)
+    return a, a.ctypes.data_as(C.c_void_p)
+
+
+class Table:
+    """Device-resident Vec<Scalar> (DensePolynomial.Z of the reference)."""
+
+    def __init__(self, ctx, handle):
+        self.ctx = ctx
+        self.h = handle
+
+    def __len__(self):
+        return int(lib().vpin_table_len(self.h))
+
+    @property
+    def device_ptr(self):
+        return lib().vpin_table_device_ptr(self.h)
+
+    def read(self, off=0, n=None):
+        """-> (n,4) uint64 Montgomery limbs"""
+        if n is None:
+            n = len(self) - off
+        out = np.zeros((n, 4), dtype=np.uint64)
+        _chk(lib().vpin_table_read(self.ctx.h, self.h, off, n, out.ctypes.data_as(C.c_void_p)), "vpin_table_read")
+        return out
+
+    def clone(self):
+        h = C.c_void_p()
+        _chk(lib().vpin_table_clone(self.ctx.h, self.h, C.byref(h)), "vpin_table_clone")
+        return Table(self.ctx, h)
+
+    def free(self):
+        if self.h:
+            lib().vpin_table_free(self.ctx.h, self.h)
+            self.h = None
+
+
+class Context:
+    def __init__(self, device=0):
+        self.h = C.c_void_p()
+        _chk(lib().vpin_ctx_create(device, C.byref(self.h)), "vpin_ctx_create")
+
+    def close(self):
+        if self.h:
+            lib().vpin_ctx_destroy(self.h)
+            self.h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    @property
+    def stream(self):
+        return lib().vpin_ctx_stream(self.h)
+
+    def sync(self):
+        _chk(lib().vpin_ctx_sync(self.h), "vpin_ctx_sync")
+
+    # ---- tables ----
+    def upload(self, arr):
+        """arr: (n,4) uint64 Montgomery limbs (or n*32 bytes)."""
+        a = np.ascontiguousarray(arr)
+        n = a.nbytes // 32
+        h = C.c_void_p()
+        _chk(lib().vpin_table_upload(self.h, a.ctypes.data_as(C.c_void_p), n, C.byref(h)), "vpin_table_upload")
+        return Table(self, h)
+
+    def alloc(self, n):
+        h = C.c_void_p()
+        _chk(lib().vpin_table_alloc(self.h, n, C.byref(h)), "vpin_table_alloc")
+        return Table(self, h)
+
+    def wrap(self, device_ptr, n):
+        h = C.c_void_p()
+        _chk(lib().vpin_table_wrap(self.h, C.c_void_p(device_ptr), n, C.byref(h)), "vpin_table_wrap")
+        return Table(self, h)
+
+    def eq_table(self, r):
+        r = np.ascontiguousarray(r, dtype=np.uint64).reshape(-1, 4)
+        h = C.c_void_p()
+        _chk(lib().vpin_eq_table(self.h, r.ctypes.data_as(C.c_void_p), r.shape[0], C.byref(h)), "vpin_eq_table")
+        return Table(self, h)
+
+    # ---- sum-check ----
+    def sc_cubic_round(self, tau, A, B, Cc):
+        out = np.zeros((3, 4), dtype=np.uint64)
+        _chk(lib().vpin_sc_cubic_round(self.h, tau.h, A.h, B.h, Cc.h, out.ctypes.data_as(C.c_void_p)),
+             "vpin_sc_cubic_round")
+        return out
+
+    def sc_quad_round(self, A, B):
+        out = np.zeros((2, 4), dtype=np.uint64)
+        _chk(lib().vpin_sc_quad_round(self.h, A.h, B.h, out.ctypes.data_as(C.c_void_p)), "vpin_sc_quad_round")
+        return out
+
+    def sc_bind(self, tables, r):
+        r = np.ascontiguousarray(r, dtype=np.uint64).reshape(4)
+        arr = (C.c_void_p * len(tables))(*[t.h for t in tables])
+        _chk(lib().vpin_sc_bind(self.h, arr, len(tables), r.ctypes.data_as(C.c_void_p)), "vpin_sc_bind")
+
+    def sc_cubic_bind_round(self, tau, A, B, Cc, r):
+        r = np.ascontiguousarray(r, dtype=np.uint64).reshape(4)
+        out = np.zeros((3, 4), dtype=np.uint64)
+        _chk(lib().vpin_sc_cubic_bind_round(self.h, tau.h, A.h, B.h, Cc.h, r.ctypes.data_as(C.c_void_p),
+                                            out.ctypes.data_as(C.c_void_p)), "vpin_sc_cubic_bind_round")
+        return out
+
+    def sc_quad_bind_round(self, A, B, r):
+        r = np.ascontiguousarray(r, dtype=np.uint64).reshape(4)
+        out = np.zeros((2, 4), dtype=np.uint64)
+        _chk(lib().vpin_sc_quad_bind_round(self.h, A.h, B.h, r.ctypes.data_as(C.c_void_p),
+                                           out.ctypes.data_as(C.c_void_p)), "vpin_sc_quad_bind_round")
+        return out
+
+    # ---- profiling ----
+    def prof_enable(self, on=True):
+        _chk(lib().vpin_prof_enable(self.h, 1 if on else 0), "vpin_prof_enable")
+
+    def prof_reset(self):
+        _chk(lib().vpin_prof_reset(self.h), "vpin_prof_reset")
+
+    def prof_read(self):
+        arr = (KStat * K_COUNT)()
+        _chk(lib().vpin_prof_read(self.h, arr), "vpin_prof_read")
+        out = {}
+        for k, name in KERNEL_CLASSES.items():
+            if arr[k].launches:
+                out[name] = {"launches": int(arr[k].launches), "ms": float(arr[k].ms),
+                             "alg_bytes": float(arr[k].alg_bytes)}
+        return out

@@ -1,0 +1,218 @@
+// capi.hip -- context, table management and profiling behind include/vpin_hip.h
+#include <cstdio>
+#include <cstring>
+
+#include "ctx.h"
+
+namespace vpin {
+
+static thread_local std::string g_last_error;
+
+void set_last_error(const char* what, hipError_t e) {
+  g_last_error = std::string(what) + ": " + hipGetErrorString(e);
+}
+
+static hipEvent_t get_event(vpin_ctx* c) {
+  if (!c->free_events.empty()) {
+    hipEvent_t e = c->free_events.back();
+    c->free_events.pop_back();
+    return e;
+  }
+  hipEvent_t e = nullptr;
+  (void)hipEventCreate(&e);
+  return e;
+}
+
+ProfScope::ProfScope(vpin_ctx* c, int kclass, double bytes) : ctx(c) {
+  if (!c->prof) return;
+  ProfRec r;
+  r.kclass = kclass;
+  r.bytes = bytes;
+  r.start = get_event(c);
+  r.stop = get_event(c);
+  (void)hipEventRecord(r.start, c->stream);
+  c->recs.push_back(r);
+  rec = (int)c->recs.size() - 1;
+}
+
+ProfScope::~ProfScope() {
+  if (rec >= 0) (void)hipEventRecord(ctx->recs[rec].stop, ctx->stream);
+}
+
+}  // namespace vpin
+
+using namespace vpin;
+
+extern "C" {
+
+const char* vpin_strerror(int code) {
+  switch (code) {
+    case VPIN_OK: return "ok";
+    case VPIN_EINVAL: return "invalid argument";
+    case VPIN_ENODEV: return "no usable HIP device (this library has no CPU fallback)";
+    case VPIN_ENOMEM: return "out of memory";
+    case VPIN_EHIP: return "HIP runtime error";
+    case VPIN_ESHAPE: return "operand shapes do not match";
+    default: return "unknown error";
+  }
+}
+
+const char* vpin_last_error(void) { return g_last_error.c_str(); }
+
+int vpin_abi_version(void) { return 1; }
+
+int vpin_ctx_create(int device, vpin_ctx** out) {
+  if (!out) return VPIN_EINVAL;
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return VPIN_ENODEV;
+  if (device < 0 || device >= n) return VPIN_EINVAL;
+  VPIN_HIP_TRY(hipSetDevice(device));
+  vpin_ctx* c = new (std::nothrow) vpin_ctx();
+  if (!c) return VPIN_ENOMEM;
+  c->device = device;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->num_cus = prop.multiProcessorCount;
+  hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+  if (e != hipSuccess) { set_last_error("hipStreamCreate", e); delete c; return VPIN_EHIP; }
+  c->partials_cap = 8192 * 4;
+  if (hipMalloc(&c->d_partials, c->partials_cap * sizeof(fq)) != hipSuccess ||
+      hipMalloc(&c->d_out, 8 * sizeof(fq)) != hipSuccess ||
+      hipHostMalloc(&c->h_out, 8 * sizeof(fq), hipHostMallocDefault) != hipSuccess) {
+    vpin_ctx_destroy(c);
+    return VPIN_ENOMEM;
+  }
+  *out = c;
+  return VPIN_OK;
+}
+
+void vpin_ctx_destroy(vpin_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  for (auto& r : c->recs) { (void)hipEventDestroy(r.start); (void)hipEventDestroy(r.stop); }
+  for (auto e : c->free_events) (void)hipEventDestroy(e);
+  if (c->d_partials) (void)hipFree(c->d_partials);
+  if (c->d_out) (void)hipFree(c->d_out);
+  if (c->h_out) (void)hipHostFree(c->h_out);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+void* vpin_ctx_stream(vpin_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
+int vpin_ctx_sync(vpin_ctx* c) {
+  if (!c) return VPIN_EINVAL;
+  VPIN_HIP_TRY(hipStreamSynchronize(c->stream));
+  return VPIN_OK;
+}
+
+int vpin_table_alloc(vpin_ctx* c, size_t len, vpin_table** out) {
+  if (!c || !out || !is_pow2(len)) return VPIN_EINVAL;
+  (void)hipSetDevice(c->device);
+  vpin_table* t = new (std::nothrow) vpin_table();
+  if (!t) return VPIN_ENOMEM;
+  if (hipMalloc(&t->d, len * sizeof(fq)) != hipSuccess) { delete t; return VPIN_ENOMEM; }
+  t->len = t->cap = len;
+  hipError_t e = hipMemsetAsync(t->d, 0, len * sizeof(fq), c->stream);
+  if (e != hipSuccess) { set_last_error("hipMemsetAsync", e); (void)hipFree(t->d); delete t; return VPIN_EHIP; }
+  *out = t;
+  return VPIN_OK;
+}
+
+int vpin_table_upload(vpin_ctx* c, const uint8_t* mont32, size_t len, vpin_table** out) {
+  if (!c || !out || !mont32 || !is_pow2(len)) return VPIN_EINVAL;
+  (void)hipSetDevice(c->device);
+  vpin_table* t = new (std::nothrow) vpin_table();
+  if (!t) return VPIN_ENOMEM;
+  if (hipMalloc(&t->d, len * sizeof(fq)) != hipSuccess) { delete t; return VPIN_ENOMEM; }
+  t->len = t->cap = len;
+  hipError_t e = hipMemcpyAsync(t->d, mont32, len * sizeof(fq), hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  if (e != hipSuccess) { set_last_error("hipMemcpy H2D", e); (void)hipFree(t->d); delete t; return VPIN_EHIP; }
+  *out = t;
+  return VPIN_OK;
+}
+
+int vpin_table_wrap(vpin_ctx* c, void* device_ptr, size_t len, vpin_table** out) {
+  if (!c || !out || !device_ptr || !is_pow2(len) || ((uintptr_t)device_ptr & 15)) return VPIN_EINVAL;
+  vpin_table* t = new (std::nothrow) vpin_table();
+  if (!t) return VPIN_ENOMEM;
+  t->d = (fq*)device_ptr;
+  t->len = t->cap = len;
+  t->owned = false;
+  *out = t;
+  return VPIN_OK;
+}
+
+int vpin_table_clone(vpin_ctx* c, const vpin_table* src, vpin_table** out) {
+  if (!c || !src || !out) return VPIN_EINVAL;
+  (void)hipSetDevice(c->device);
+  vpin_table* t = new (std::nothrow) vpin_table();
+  if (!t) return VPIN_ENOMEM;
+  if (hipMalloc(&t->d, src->len * sizeof(fq)) != hipSuccess) { delete t; return VPIN_ENOMEM; }
+  t->len = t->cap = src->len;
+  hipError_t e = hipMemcpyAsync(t->d, src->d, src->len * sizeof(fq), hipMemcpyDeviceToDevice, c->stream);
+  if (e != hipSuccess) { set_last_error("hipMemcpy D2D", e); (void)hipFree(t->d); delete t; return VPIN_EHIP; }
+  *out = t;
+  return VPIN_OK;
+}
+
+void vpin_table_free(vpin_ctx* c, vpin_table* t) {
+  if (!t) return;
+  if (c) { (void)hipSetDevice(c->device); (void)hipStreamSynchronize(c->stream); }
+  if (t->owned && t->d) (void)hipFree(t->d);
+  delete t;
+}
+
+size_t vpin_table_len(const vpin_table* t) { return t ? t->len : 0; }
+void* vpin_table_device_ptr(const vpin_table* t) { return t ? (void*)t->d : nullptr; }
+
+int vpin_table_read(vpin_ctx* c, const vpin_table* t, size_t off, size_t n, uint8_t* out) {
+  if (!c || !t || !out) return VPIN_EINVAL;
+  if (off + n > t->len) return VPIN_ESHAPE;
+  if (n == 0) return VPIN_OK;
+  (void)hipSetDevice(c->device);
+  VPIN_HIP_TRY(hipMemcpyAsync(out, t->d + off, n * sizeof(fq), hipMemcpyDeviceToHost, c->stream));
+  VPIN_HIP_TRY(hipStreamSynchronize(c->stream));
+  return VPIN_OK;
+}
+
+int vpin_prof_enable(vpin_ctx* c, int on) {
+  if (!c) return VPIN_EINVAL;
+  c->prof = on != 0;
+  return VPIN_OK;
+}
+
+static int prof_drain(vpin_ctx* c) {
+  if (c->recs.empty()) return VPIN_OK;
+  VPIN_HIP_TRY(hipStreamSynchronize(c->stream));
+  for (auto& r : c->recs) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, r.start, r.stop) == hipSuccess) {
+      c->stats[r.kclass].launches += 1;
+      c->stats[r.kclass].ms += ms;
+      c->stats[r.kclass].alg_bytes += r.bytes;
+    }
+    c->free_events.push_back(r.start);
+    c->free_events.push_back(r.stop);
+  }
+  c->recs.clear();
+  return VPIN_OK;
+}
+
+int vpin_prof_reset(vpin_ctx* c) {
+  if (!c) return VPIN_EINVAL;
+  int rc = prof_drain(c);
+  memset(c->stats, 0, sizeof(c->stats));
+  return rc;
+}
+
+int vpin_prof_read(vpin_ctx* c, vpin_kstat* stats) {
+  if (!c || !stats) return VPIN_EINVAL;
+  int rc = prof_drain(c);
+  memcpy(stats, c->stats, sizeof(c->stats));
+  return rc;
+}
+
+}  // extern "C"

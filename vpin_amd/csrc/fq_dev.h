@@ -1,0 +1,194 @@
+// fq_dev.h -- device-side F_q arithmetic for gfx950 (CDNA4).
+//
+// q = 2^252 + 27742317777372353535851937790883648493 (ristretto255 scalar field).
+// Elements are kept in Montgomery form with R = 2^256, eight 32-bit little-endian
+// limbs: byte-for-byte the reference's in-memory `Scalar([u64;4])`
+// (Spartan/src/scalar/ristretto255.rs:199-200), so tables cross the C ABI by memcpy.
+//
+// 255-bit modular integer work: no MFMA.  The multiplier is v_mad_u64_u32
+// (32x32+64 -> 64); the Montgomery reduction exploits q's shape: limbs 4..6 of q are
+// zero and limb 7 is 2^28, so a reduction step costs 4 multiplies and one shift.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#ifndef VPIN_MUL_INLINE
+#define VPIN_MUL_INLINE __forceinline__
+#endif
+
+namespace vpin {
+
+struct alignas(16) fq {
+  uint32_t v[8];
+};
+
+// q, little-endian 32-bit limbs
+#define VPIN_Q0 0x5cf5d3edu
+#define VPIN_Q1 0x5812631au
+#define VPIN_Q2 0xa2f79cd6u
+#define VPIN_Q3 0x14def9deu
+#define VPIN_Q7 0x10000000u
+// -q^{-1} mod 2^32 (low word of the reference's INV, ristretto255.rs:298)
+#define VPIN_QINV32 0x12547e1bu
+
+__host__ __device__ __forceinline__ constexpr uint32_t fq_modulus_limb(int i) {
+  return i == 0 ? VPIN_Q0 : i == 1 ? VPIN_Q1 : i == 2 ? VPIN_Q2 : i == 3 ? VPIN_Q3 : i == 7 ? VPIN_Q7 : 0u;
+}
+
+__device__ __forceinline__ fq fq_zero() {
+  fq r;
+#pragma unroll
+  for (int i = 0; i < 8; i++) r.v[i] = 0;
+  return r;
+}
+
+// R mod q = Montgomery one (ristretto255.rs:301-306)
+__device__ __forceinline__ fq fq_one() {
+  fq r;
+  r.v[0] = 0x8d98951du; r.v[1] = 0xd6ec3174u; r.v[2] = 0x737dcf70u; r.v[3] = 0xc6ef5bf4u;
+  r.v[4] = 0xfffffffeu; r.v[5] = 0xffffffffu; r.v[6] = 0xffffffffu; r.v[7] = 0x0fffffffu;
+  return r;
+}
+
+__device__ __forceinline__ fq fq_load(const fq* __restrict__ p) {
+  const uint4* q = reinterpret_cast<const uint4*>(p);
+  uint4 lo = q[0], hi = q[1];
+  fq r;
+  r.v[0] = lo.x; r.v[1] = lo.y; r.v[2] = lo.z; r.v[3] = lo.w;
+  r.v[4] = hi.x; r.v[5] = hi.y; r.v[6] = hi.z; r.v[7] = hi.w;
+  return r;
+}
+
+__device__ __forceinline__ void fq_store(fq* __restrict__ p, const fq& a) {
+  uint4* q = reinterpret_cast<uint4*>(p);
+  q[0] = make_uint4(a.v[0], a.v[1], a.v[2], a.v[3]);
+  q[1] = make_uint4(a.v[4], a.v[5], a.v[6], a.v[7]);
+}
+
+__device__ __forceinline__ bool fq_is_zero(const fq& a) {
+  uint32_t o = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) o |= a.v[i];
+  return o == 0;
+}
+
+// r = (t >= q) ? t - q : t      (t < 2q)
+__device__ __forceinline__ fq fq_cond_sub_q(const fq& t) {
+  fq d;
+  int64_t c = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    c += (int64_t)t.v[i] - (int64_t)fq_modulus_limb(i);
+    d.v[i] = (uint32_t)c;
+    c >>= 32;  // arithmetic shift: borrow propagates as -1
+  }
+  bool ge = (c == 0);
+  fq r;
+#pragma unroll
+  for (int i = 0; i < 8; i++) r.v[i] = ge ? d.v[i] : t.v[i];
+  return r;
+}
+
+// ristretto255.rs:746-757
+__device__ __forceinline__ fq fq_add(const fq& a, const fq& b) {
+  fq t;
+  uint64_t c = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    c += (uint64_t)a.v[i] + b.v[i];
+    t.v[i] = (uint32_t)c;
+    c >>= 32;
+  }
+  return fq_cond_sub_q(t);  // a+b < 2q < 2^254: no carry out of limb 7
+}
+
+// ristretto255.rs:729-743
+__device__ __forceinline__ fq fq_sub(const fq& a, const fq& b) {
+  fq d;
+  int64_t c = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    c += (int64_t)a.v[i] - (int64_t)b.v[i];
+    d.v[i] = (uint32_t)c;
+    c >>= 32;
+  }
+  uint32_t mask = (uint32_t)c;  // 0xffffffff on underflow
+  uint64_t k = 0;
+  fq r;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    k += (uint64_t)d.v[i] + (fq_modulus_limb(i) & mask);
+    r.v[i] = (uint32_t)k;
+    k >>= 32;
+  }
+  return r;
+}
+
+__device__ __forceinline__ fq fq_neg(const fq& a) { return fq_sub(fq_zero(), a); }
+
+__device__ __forceinline__ fq fq_dbl(const fq& a) { return fq_add(a, a); }
+
+// One Montgomery reduction step on a 9-word window t[0..8] (+ overflow t9):
+// adds m*q with m = t0 * (-q^{-1}) so the low word cancels, then shifts down 32 bits.
+// q's limbs 4..6 are zero and limb 7 is 2^28, so only 4 multiplies are needed.
+#define VPIN_MONT_STEP(t, t9)                                              \
+  {                                                                        \
+    uint32_t m_ = (t)[0] * VPIN_QINV32;                                    \
+    uint64_t c_ = (uint64_t)m_ * VPIN_Q0 + (t)[0];                         \
+    c_ >>= 32;                                                             \
+    c_ += (uint64_t)m_ * VPIN_Q1 + (t)[1]; (t)[0] = (uint32_t)c_; c_ >>= 32; \
+    c_ += (uint64_t)m_ * VPIN_Q2 + (t)[2]; (t)[1] = (uint32_t)c_; c_ >>= 32; \
+    c_ += (uint64_t)m_ * VPIN_Q3 + (t)[3]; (t)[2] = (uint32_t)c_; c_ >>= 32; \
+    c_ += (t)[4]; (t)[3] = (uint32_t)c_; c_ >>= 32;                         \
+    c_ += (t)[5]; (t)[4] = (uint32_t)c_; c_ >>= 32;                         \
+    c_ += (t)[6]; (t)[5] = (uint32_t)c_; c_ >>= 32;                         \
+    c_ += ((uint64_t)m_ << 28) + (t)[7]; (t)[6] = (uint32_t)c_; c_ >>= 32;  \
+    c_ += (t)[8]; (t)[7] = (uint32_t)c_; c_ >>= 32;                         \
+    (t)[8] = (t9) + (uint32_t)c_;                                          \
+  }
+
+// Montgomery product a*b*R^{-1} mod q (ristretto255.rs:701-726 + :653-698), CIOS form.
+__device__ VPIN_MUL_INLINE fq fq_mul(fq a, fq b) {
+  uint32_t t[9];
+#pragma unroll
+  for (int i = 0; i < 9; i++) t[i] = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    uint64_t c = 0;
+    uint32_t bi = b.v[i];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      c += (uint64_t)a.v[j] * bi + t[j];
+      t[j] = (uint32_t)c;
+      c >>= 32;
+    }
+    c += t[8];
+    t[8] = (uint32_t)c;
+    uint32_t t9 = (uint32_t)(c >> 32);
+    VPIN_MONT_STEP(t, t9);
+  }
+  fq r;
+#pragma unroll
+  for (int i = 0; i < 8; i++) r.v[i] = t[i];
+  return fq_cond_sub_q(r);  // t < 2q, t[8] == 0
+}
+
+__device__ __forceinline__ fq fq_sqr(const fq& a) { return fq_mul(a, a); }
+
+// ---- wave / block reductions (64-wide wavefront) ----------------------------------
+
+__device__ __forceinline__ fq fq_shfl_xor(const fq& a, int mask) {
+  fq r;
+#pragma unroll
+  for (int i = 0; i < 8; i++) r.v[i] = __shfl_xor(a.v[i], mask, 64);
+  return r;
+}
+
+// sum over the 64 lanes of a wavefront; every lane gets the total
+__device__ __forceinline__ fq fq_wave_sum(fq a) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) a = fq_add(a, fq_shfl_xor(a, off));
+  return a;
+}
+
+}  // namespace vpin

@@ -1,0 +1,373 @@
+// sumcheck.hip -- multilinear sum-check round reductions and table folds for gfx950.
+//
+// Replaces the two hot loops of the reference's ZK sum-checks
+//   Spartan/src/sumcheck.rs:624-652  (cubic, 4 tables, comb A*(B*C-D))
+//   Spartan/src/sumcheck.rs:460-469  (quadratic, 2 tables, comb A*B)
+// and DensePolynomial::bound_poly_var_top (Spartan/src/dense_mlpoly.rs:229-236).
+//
+// Data layout: a table is a flat array of 32-byte Montgomery elements in HBM; element i
+// of the low half pairs with element i+len/2 (the TOP variable is bound first), so both
+// streams are unit-stride and every lane issues 2 x global_load_dwordx4 per element.
+// The fused kernel reads each live element once and writes each folded element once per
+// round: 32*(len + len/2) bytes per table -- the algorithmic minimum of SURVEY.md 8(d).
+// HBM-streaming integer work: no LDS tiling is useful (no reuse), no MFMA (255-bit
+// modular arithmetic).  Per-thread partial sums are reduced with wavefront shuffles
+// (64 lanes), then across the 4 waves of a block through LDS, then by a 1-block finisher.
+#include <cstring>
+
+#include "ctx.h"
+
+namespace vpin {
+
+constexpr int kBlock = 256;
+constexpr int kMinWaves = 2;      // waves per SIMD asked of the register allocator (<=256 VGPRs)
+constexpr int kMaxBlocks = 2048;  // 256 CUs x 8 blocks/CU, grid-stride beyond that
+
+// ---- per-pair evaluation -------------------------------------------------------------
+
+// phase-1 combiner (r1csproof.rs:104-108): A * (B*C - D)
+__device__ __forceinline__ fq comb_cubic(const fq& a, const fq& b, const fq& c, const fq& d) {
+  return fq_mul(a, fq_sub(fq_mul(b, c), d));
+}
+
+template <int K>
+struct Acc;
+
+template <>
+struct Acc<4> {
+  static constexpr int NE = 3;
+  fq e[3];
+  __device__ __forceinline__ void init() { e[0] = e[1] = e[2] = fq_zero(); }
+  // p = low element, d = high - low of each of the 4 tables (sumcheck.rs:631-650).
+  // The evaluation points are low (x=0), 2*high-low = low+2d (x=2), low+3d (x=3); p walks
+  // along the line so only p[4], d[4] stay live.
+  __device__ __forceinline__ void add_pair(fq* p, const fq* d) {
+    e[0] = fq_add(e[0], comb_cubic(p[0], p[1], p[2], p[3]));
+#pragma unroll
+    for (int k = 0; k < 4; k++) p[k] = fq_add(fq_add(p[k], d[k]), d[k]);
+    e[1] = fq_add(e[1], comb_cubic(p[0], p[1], p[2], p[3]));
+#pragma unroll
+    for (int k = 0; k < 4; k++) p[k] = fq_add(p[k], d[k]);
+    e[2] = fq_add(e[2], comb_cubic(p[0], p[1], p[2], p[3]));
+  }
+};
+
+template <>
+struct Acc<2> {
+  static constexpr int NE = 2;
+  fq e[2];
+  __device__ __forceinline__ void init() { e[0] = e[1] = fq_zero(); }
+  // sumcheck.rs:460-469, comb A*B (r1csproof.rs:139-140)
+  __device__ __forceinline__ void add_pair(fq* p, const fq* d) {
+    e[0] = fq_add(e[0], fq_mul(p[0], p[1]));
+#pragma unroll
+    for (int k = 0; k < 2; k++) p[k] = fq_add(fq_add(p[k], d[k]), d[k]);
+    e[1] = fq_add(e[1], fq_mul(p[0], p[1]));
+  }
+};
+
+template <int K>
+struct Tabs {
+  fq* t[K];
+};
+
+// block-level reduction of NE accumulators; thread e < NE of the block writes partial e
+template <int NE>
+__device__ __forceinline__ void block_reduce_store(fq* e, fq* __restrict__ partials) {
+  __shared__ fq sh[kBlock / 64][NE];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < NE; k++) {
+    fq s = fq_wave_sum(e[k]);
+    if (lane == 0) sh[wave][k] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < NE) {
+    fq s = sh[0][threadIdx.x];
+#pragma unroll
+    for (int w = 1; w < kBlock / 64; w++) s = fq_add(s, sh[w][threadIdx.x]);
+    fq_store(&partials[(size_t)blockIdx.x * NE + threadIdx.x], s);
+  }
+}
+
+// Round evaluation on tables of live length 2*half: pairs (i, i+half).
+template <int K>
+__global__ __launch_bounds__(kBlock, kMinWaves) void sc_eval_kernel(Tabs<K> tabs, size_t half,
+                                                         fq* __restrict__ partials) {
+  Acc<K> acc;
+  acc.init();
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < half; i += (size_t)gridDim.x * kBlock) {
+    fq p[K], d[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+      p[k] = fq_load(tabs.t[k] + i);
+      d[k] = fq_sub(fq_load(tabs.t[k] + half + i), p[k]);
+    }
+    acc.add_pair(p, d);
+  }
+  block_reduce_store<Acc<K>::NE>(acc.e, partials);
+}
+
+// Fused: fold the tables (live length 4*quarter) with r, store the folded halves, and
+// evaluate the next round on the folded pair (i, i+quarter).
+template <int K>
+__global__ __launch_bounds__(kBlock, kMinWaves) void sc_bind_eval_kernel(Tabs<K> tabs, size_t quarter, fq r,
+                                                              fq* __restrict__ partials) {
+  Acc<K> acc;
+  acc.init();
+  const size_t half = 2 * quarter;
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < quarter; i += (size_t)gridDim.x * kBlock) {
+    fq p[K], d[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+      fq a0 = fq_load(tabs.t[k] + i);
+      fq a1 = fq_load(tabs.t[k] + half + i);
+      fq b0 = fq_load(tabs.t[k] + quarter + i);
+      fq b1 = fq_load(tabs.t[k] + half + quarter + i);
+      // dense_mlpoly.rs:232: Z[i] = Z[i] + r * (Z[i+n] - Z[i])
+      p[k] = fq_add(a0, fq_mul(r, fq_sub(a1, a0)));
+      fq hi = fq_add(b0, fq_mul(r, fq_sub(b1, b0)));
+      fq_store(tabs.t[k] + i, p[k]);
+      fq_store(tabs.t[k] + quarter + i, hi);
+      d[k] = fq_sub(hi, p[k]);
+    }
+    acc.add_pair(p, d);
+  }
+  block_reduce_store<Acc<K>::NE>(acc.e, partials);
+}
+
+// Plain fold of K tables (live length 2*half).
+template <int K>
+__global__ __launch_bounds__(kBlock) void sc_bind_kernel(Tabs<K> tabs, size_t half, fq r) {
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < half; i += (size_t)gridDim.x * kBlock) {
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+      fq a0 = fq_load(tabs.t[k] + i);
+      fq a1 = fq_load(tabs.t[k] + half + i);
+      fq_store(tabs.t[k] + i, fq_add(a0, fq_mul(r, fq_sub(a1, a0))));
+    }
+  }
+}
+
+// Sum nblocks x NE block partials into out[NE].
+template <int NE>
+__global__ __launch_bounds__(kBlock) void sc_finish_kernel(const fq* __restrict__ partials, int nblocks,
+                                                           fq* __restrict__ out) {
+  fq e[NE];
+#pragma unroll
+  for (int k = 0; k < NE; k++) e[k] = fq_zero();
+  for (int b = threadIdx.x; b < nblocks; b += kBlock)
+#pragma unroll
+    for (int k = 0; k < NE; k++) e[k] = fq_add(e[k], fq_load(&partials[(size_t)b * NE + k]));
+  __shared__ fq sh[kBlock / 64][NE];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < NE; k++) {
+    fq s = fq_wave_sum(e[k]);
+    if (lane == 0) sh[wave][k] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < NE) {
+    fq s = sh[0][threadIdx.x];
+#pragma unroll
+    for (int w = 1; w < kBlock / 64; w++) s = fq_add(s, sh[w][threadIdx.x]);
+    fq_store(&out[threadIdx.x], s);
+  }
+}
+
+// EqPolynomial::evals (dense_mlpoly.rs:78-94), one doubling step j: for the current size
+// `size` (already doubled), evals[i] = evals[i/2]*r_j (i odd), evals[i-1] = evals[i/2]-evals[i].
+// Out-of-place ping-pong so every thread reads src[i] and writes dst[2i], dst[2i+1].
+__global__ __launch_bounds__(kBlock) void eq_step_kernel(const fq* __restrict__ src, fq* __restrict__ dst,
+                                                         size_t prev, fq rj) {
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < prev; i += (size_t)gridDim.x * kBlock) {
+    fq s = fq_load(src + i);
+    fq hi = fq_mul(s, rj);
+    fq_store(dst + 2 * i + 1, hi);
+    fq_store(dst + 2 * i, fq_sub(s, hi));
+  }
+}
+
+static inline int grid_for(size_t work) {
+  size_t b = (work + kBlock - 1) / kBlock;
+  if (b < 1) b = 1;
+  if (b > (size_t)kMaxBlocks) b = kMaxBlocks;
+  return (int)b;
+}
+
+static inline fq load_host_fq(const uint8_t* p) {
+  fq r;
+  memcpy(r.v, p, 32);
+  return r;
+}
+
+template <int K>
+static int check_tabs(vpin_ctx* c, const vpin_table* const* t, size_t min_len) {
+  if (!c) return VPIN_EINVAL;
+  for (int k = 0; k < K; k++)
+    if (!t[k] || !t[k]->d) return VPIN_EINVAL;
+  for (int k = 1; k < K; k++)
+    if (t[k]->len != t[0]->len) return VPIN_ESHAPE;
+  if (!is_pow2(t[0]->len) || t[0]->len < min_len) return VPIN_ESHAPE;
+  return VPIN_OK;
+}
+
+template <int NE>
+static int finish_and_fetch(vpin_ctx* c, int nblocks, uint8_t* out) {
+  hipLaunchKernelGGL((sc_finish_kernel<NE>), dim3(1), dim3(kBlock), 0, c->stream, c->d_partials, nblocks, c->d_out);
+  VPIN_HIP_TRY(hipGetLastError());
+  VPIN_HIP_TRY(hipMemcpyAsync(c->h_out, c->d_out, NE * sizeof(fq), hipMemcpyDeviceToHost, c->stream));
+  VPIN_HIP_TRY(hipStreamSynchronize(c->stream));
+  memcpy(out, c->h_out, NE * sizeof(fq));
+  return VPIN_OK;
+}
+
+template <int K>
+static int run_eval(vpin_ctx* c, const vpin_table* const* t, uint8_t* out, int kclass) {
+  int rc = check_tabs<K>(c, t, 2);
+  if (rc) return rc;
+  (void)hipSetDevice(c->device);
+  Tabs<K> tabs;
+  for (int k = 0; k < K; k++) tabs.t[k] = t[k]->d;
+  size_t half = t[0]->len / 2;
+  int grid = grid_for(half);
+  {
+    ProfScope ps(c, kclass, (double)K * 32.0 * (double)t[0]->len);
+    hipLaunchKernelGGL((sc_eval_kernel<K>), dim3(grid), dim3(kBlock), 0, c->stream, tabs, half, c->d_partials);
+  }
+  VPIN_HIP_TRY(hipGetLastError());
+  return finish_and_fetch<Acc<K>::NE>(c, grid, out);
+}
+
+template <int K>
+static int run_bind_eval(vpin_ctx* c, vpin_table* const* t, const uint8_t* r, uint8_t* out, int kclass) {
+  int rc = check_tabs<K>(c, t, 4);
+  if (rc) return rc;
+  if (!r || !out) return VPIN_EINVAL;
+  (void)hipSetDevice(c->device);
+  Tabs<K> tabs;
+  for (int k = 0; k < K; k++) tabs.t[k] = t[k]->d;
+  size_t len = t[0]->len, quarter = len / 4;
+  int grid = grid_for(quarter);
+  {
+    // one read of every live element + one write of every folded element
+    ProfScope ps(c, kclass, (double)K * 32.0 * ((double)len + (double)len / 2));
+    hipLaunchKernelGGL((sc_bind_eval_kernel<K>), dim3(grid), dim3(kBlock), 0, c->stream, tabs, quarter,
+                       load_host_fq(r), c->d_partials);
+  }
+  VPIN_HIP_TRY(hipGetLastError());
+  for (int k = 0; k < K; k++) t[k]->len = len / 2;
+  return finish_and_fetch<Acc<K>::NE>(c, grid, out);
+}
+
+}  // namespace vpin
+
+using namespace vpin;
+
+extern "C" {
+
+int vpin_sc_cubic_round(vpin_ctx* c, const vpin_table* tau, const vpin_table* Az, const vpin_table* Bz,
+                        const vpin_table* Cz, uint8_t out[96]) {
+  if (!out) return VPIN_EINVAL;
+  const vpin_table* t[4] = {tau, Az, Bz, Cz};
+  return run_eval<4>(c, t, out, VPIN_K_SC_CUBIC);
+}
+
+int vpin_sc_quad_round(vpin_ctx* c, const vpin_table* A, const vpin_table* B, uint8_t out[64]) {
+  if (!out) return VPIN_EINVAL;
+  const vpin_table* t[2] = {A, B};
+  return run_eval<2>(c, t, out, VPIN_K_SC_QUAD);
+}
+
+int vpin_sc_bind(vpin_ctx* c, vpin_table* const* tables, int k, const uint8_t r[32]) {
+  if (!c || !tables || !r || k < 1 || k > 4) return VPIN_EINVAL;
+  for (int i = 0; i < k; i++)
+    if (!tables[i] || !tables[i]->d) return VPIN_EINVAL;
+  for (int i = 1; i < k; i++)
+    if (tables[i]->len != tables[0]->len) return VPIN_ESHAPE;
+  size_t len = tables[0]->len;
+  if (!is_pow2(len) || len < 2) return VPIN_ESHAPE;
+  (void)hipSetDevice(c->device);
+  size_t half = len / 2;
+  int grid = grid_for(half);
+  fq rr = load_host_fq(r);
+  {
+    ProfScope ps(c, VPIN_K_SC_BIND, (double)k * 32.0 * ((double)len + (double)half));
+    // fold in groups so one launch covers up to 4 tables
+    Tabs<4> t4;
+    Tabs<2> t2;
+    Tabs<1> t1;
+    switch (k) {
+      case 4:
+        for (int i = 0; i < 4; i++) t4.t[i] = tables[i]->d;
+        hipLaunchKernelGGL((sc_bind_kernel<4>), dim3(grid), dim3(kBlock), 0, c->stream, t4, half, rr);
+        break;
+      case 3:
+        for (int i = 0; i < 2; i++) t2.t[i] = tables[i]->d;
+        hipLaunchKernelGGL((sc_bind_kernel<2>), dim3(grid), dim3(kBlock), 0, c->stream, t2, half, rr);
+        t1.t[0] = tables[2]->d;
+        hipLaunchKernelGGL((sc_bind_kernel<1>), dim3(grid), dim3(kBlock), 0, c->stream, t1, half, rr);
+        break;
+      case 2:
+        for (int i = 0; i < 2; i++) t2.t[i] = tables[i]->d;
+        hipLaunchKernelGGL((sc_bind_kernel<2>), dim3(grid), dim3(kBlock), 0, c->stream, t2, half, rr);
+        break;
+      default:
+        t1.t[0] = tables[0]->d;
+        hipLaunchKernelGGL((sc_bind_kernel<1>), dim3(grid), dim3(kBlock), 0, c->stream, t1, half, rr);
+    }
+  }
+  VPIN_HIP_TRY(hipGetLastError());
+  for (int i = 0; i < k; i++) tables[i]->len = half;
+  VPIN_HIP_TRY(hipStreamSynchronize(c->stream));
+  return VPIN_OK;
+}
+
+int vpin_sc_cubic_bind_round(vpin_ctx* c, vpin_table* tau, vpin_table* Az, vpin_table* Bz, vpin_table* Cz,
+                             const uint8_t r[32], uint8_t out[96]) {
+  vpin_table* t[4] = {tau, Az, Bz, Cz};
+  return run_bind_eval<4>(c, t, r, out, VPIN_K_SC_CUBIC_FUSED);
+}
+
+int vpin_sc_quad_bind_round(vpin_ctx* c, vpin_table* A, vpin_table* B, const uint8_t r[32], uint8_t out[64]) {
+  vpin_table* t[2] = {A, B};
+  return run_bind_eval<2>(c, t, r, out, VPIN_K_SC_QUAD_FUSED);
+}
+
+int vpin_eq_table(vpin_ctx* c, const uint8_t* r, int ell, vpin_table** out) {
+  if (!c || !out || ell < 0 || ell > 40 || (ell > 0 && !r)) return VPIN_EINVAL;
+  (void)hipSetDevice(c->device);
+  size_t n = (size_t)1 << ell;
+  vpin_table *a = nullptr, *b = nullptr;
+  int rc = vpin_table_alloc(c, n, &a);
+  if (rc) return rc;
+  if (ell > 0) {
+    rc = vpin_table_alloc(c, n, &b);
+    if (rc) { vpin_table_free(c, a); return rc; }
+  }
+  // evals[0] = 1 (Montgomery R), then ell doubling steps, ping-ponging a <-> b
+  static const uint32_t kOne[8] = {0x8d98951du, 0xd6ec3174u, 0x737dcf70u, 0xc6ef5bf4u,
+                                   0xfffffffeu, 0xffffffffu, 0xffffffffu, 0x0fffffffu};
+  vpin_table* src = (ell % 2 == 0) ? a : b;  // so that the final result lands in `a`
+  hipError_t e = hipMemcpyAsync(src->d, kOne, 32, hipMemcpyHostToDevice, c->stream);
+  if (e != hipSuccess) { set_last_error("eq init", e); vpin_table_free(c, a); vpin_table_free(c, b); return VPIN_EHIP; }
+  vpin_table* dst = (src == a) ? b : a;
+  {
+    ProfScope ps(c, VPIN_K_EQ, 32.0 * 3.0 * (double)(n - 1));
+    size_t prev = 1;
+    for (int j = 0; j < ell; j++) {
+      hipLaunchKernelGGL(eq_step_kernel, dim3(grid_for(prev)), dim3(kBlock), 0, c->stream, src->d, dst->d, prev,
+                         load_host_fq(r + 32 * (size_t)j));
+      prev *= 2;
+      vpin_table* tmp = src; src = dst; dst = tmp;
+    }
+  }
+  e = hipGetLastError();
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  if (b) vpin_table_free(c, b);
+  if (e != hipSuccess) { set_last_error("eq_table", e); vpin_table_free(c, a); return VPIN_EHIP; }
+  *out = a;  // src == a after an even number of swaps from the chosen start
+  return VPIN_OK;
+}
+
+}  // extern "C"

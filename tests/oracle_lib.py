@@ -24,6 +24,22 @@ class Fq(C.Structure):
         return [int(x) for x in self.l]
 
 
+class Fe(C.Structure):
+    _fields_ = [("l", C.c_uint64 * 5)]
+
+
+class Ge(C.Structure):
+    _fields_ = [("X", Fe), ("Y", Fe), ("Z", Fe), ("T", Fe)]
+
+
+class Shake(C.Structure):
+    _fields_ = [("st", C.c_uint64 * 25), ("pos", C.c_size_t), ("squeezing", C.c_int)]
+
+
+class Merlin(C.Structure):
+    _fields_ = [("st", C.c_uint8 * 200), ("pos", C.c_uint8), ("pos_begin", C.c_uint8), ("cur_flags", C.c_uint8)]
+
+
 def build(force=False):
     srcs = [os.path.join(ORACLE_DIR, f) for f in os.listdir(ORACLE_DIR) if f.endswith((".c", ".h"))]
     if (not force and os.path.exists(LIB_PATH)
@@ -81,6 +97,19 @@ def _declare(L):
     L.oracle_unipoly_from_evals.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
     L.oracle_unipoly_evaluate.restype = Fq
     L.oracle_unipoly_evaluate.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    L.tr_challenge_scalar.restype = Fq
+    L.ge_eq.restype = C.c_int
+    L.ge_decompress.restype = C.c_int
+    L.ge_msm.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+    L.oracle_gens_new.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+    L.oracle_commit.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.oracle_hyrax_commit.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p,
+                                      C.c_void_p, C.c_int]
+    L.merlin_init.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    L.merlin_append_message.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t]
+    L.merlin_challenge_bytes.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t]
+    L.shake256_absorb.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    L.shake256_squeeze.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
     for fn in ("oracle_eq_evals", "oracle_bound_poly_var_top", "oracle_sc_cubic_round",
                "oracle_sc_quad_round", "oracle_poly_bound", "oracle_unipoly_from_evals"):
         getattr(L, fn).restype = None

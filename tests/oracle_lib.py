@@ -158,3 +158,88 @@ def sc_quad_round(A, B):
     out = np.zeros((2, 4), dtype=np.uint64)
     lib().oracle_sc_quad_round(ptr(A), ptr(B), A.shape[0], ptr(out))
     return out
+
+
+# ---- R1CS / sat proof -------------------------------------------------------------------------
+
+class R1CS(C.Structure):
+    _fields_ = [("num_cons", C.c_size_t), ("num_vars", C.c_size_t), ("num_inputs", C.c_size_t),
+                ("nnz", C.c_size_t * 3), ("row", C.c_void_p * 3), ("col", C.c_void_p * 3), ("val", C.c_void_p * 3)]
+
+
+def make_r1cs(inst):
+    """inst: dict from gadgets_model.instance_new. Keeps references alive on the struct."""
+    r = R1CS()
+    r.num_cons, r.num_vars, r.num_inputs = inst["num_cons"], inst["num_vars"], inst["num_inputs"]
+    keep = []
+    for m, name in enumerate("ABC"):
+        rows, cols, vals = (np.ascontiguousarray(x) for x in inst[name])
+        keep += [rows, cols, vals]
+        r.nnz[m] = len(rows)
+        r.row[m] = rows.ctypes.data
+        r.col[m] = cols.ctypes.data
+        r.val[m] = vals.ctypes.data
+    r._keep = keep
+    return r
+
+
+def log2(n):
+    return int(n).bit_length() - 1
+
+
+def sat_prove(inst, seed_commit, seed_proof, threads=8):
+    L = lib()
+    L.oracle_sat_proof_max_bytes.restype = C.c_size_t
+    L.oracle_sat_proof_max_bytes.argtypes = [C.c_size_t, C.c_size_t]
+    L.oracle_vpin_sat_prove.restype = C.c_size_t
+    L.oracle_vpin_sat_prove.argtypes = [C.c_void_p] * 7 + [C.c_int, C.c_void_p, C.c_size_t] + [C.c_void_p] * 5
+    r = make_r1cs(inst)
+    nv, nc = inst["num_vars"], inst["num_cons"]
+    ell = log2(nv)
+    Lsz = 1 << (ell // 2)
+    cap = L.oracle_sat_proof_max_bytes(nc, nv)
+    proof = np.zeros(cap, dtype=np.uint8)
+    comm_para = np.zeros((Lsz, 32), dtype=np.uint8)
+    comm_input = np.zeros((Lsz, 32), dtype=np.uint8)
+    evals = np.zeros((3, 4), dtype=np.uint64)
+    rx = np.zeros((log2(nc), 4), dtype=np.uint64)
+    ry = np.zeros((log2(nv) + 1, 4), dtype=np.uint64)
+    sc = np.frombuffer(bytes(seed_commit), dtype=np.uint8).copy()
+    sp = np.frombuffer(bytes(seed_proof), dtype=np.uint8).copy()
+    inputs = np.ascontiguousarray(inst["inputs"])
+    n = L.oracle_vpin_sat_prove(C.byref(r), ptr(inst["vars_para"]), ptr(inst["vars_input"]), ptr(inst["vars"]),
+                                inputs.ctypes.data_as(C.c_void_p), sc.ctypes.data_as(C.c_void_p),
+                                sp.ctypes.data_as(C.c_void_p), threads, proof.ctypes.data_as(C.c_void_p), cap,
+                                comm_para.ctypes.data_as(C.c_void_p), comm_input.ctypes.data_as(C.c_void_p),
+                                ptr(evals), ptr(rx), ptr(ry))
+    return dict(proof=bytes(proof[:n]), comm_para=comm_para, comm_input=comm_input, inst_evals=evals, rx=rx, ry=ry)
+
+
+def sat_verify(inst, res, proof=None):
+    L = lib()
+    L.oracle_vpin_sat_verify.restype = C.c_int
+    L.oracle_vpin_sat_verify.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t,
+                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    pb = np.frombuffer(proof if proof is not None else res["proof"], dtype=np.uint8).copy()
+    rx = np.zeros((64, 4), dtype=np.uint64)
+    ry = np.zeros((64, 4), dtype=np.uint64)
+    inputs = np.ascontiguousarray(inst["inputs"])
+    return L.oracle_vpin_sat_verify(pb.ctypes.data_as(C.c_void_p), len(pb), inst["num_cons"], inst["num_vars"],
+                                    inputs.ctypes.data_as(C.c_void_p), inst["num_inputs"],
+                                    ptr(np.ascontiguousarray(res["inst_evals"])),
+                                    res["comm_para"].ctypes.data_as(C.c_void_p),
+                                    res["comm_input"].ctypes.data_as(C.c_void_p), ptr(rx), ptr(ry))
+
+
+def is_sat(inst):
+    L = lib()
+    L.oracle_r1cs_is_sat.restype = C.c_int
+    r = make_r1cs(inst)
+    inputs = np.ascontiguousarray(inst["inputs"])
+    return L.oracle_r1cs_is_sat(C.byref(r), ptr(inst["vars"]), inputs.ctypes.data_as(C.c_void_p))
+
+
+def sat_timings():
+    out = (C.c_double * 5)()
+    lib().oracle_sat_last_timings(out)
+    return dict(zip(("polycommit", "sc_phase_one", "sc_phase_two", "polyeval", "total"), out))

@@ -92,6 +92,32 @@ int vpin_sc_quad_bind_round(vpin_ctx* ctx, vpin_table* A, vpin_table* B, const u
 /* EqPolynomial::evals (dense_mlpoly.rs:78-94): r = ell x 32 B, result has 2^ell entries */
 int vpin_eq_table(vpin_ctx* ctx, const uint8_t* r, int ell, vpin_table** out);
 
+/* ---- Pedersen generators and fixed-base MSM ----------------------------------------- */
+/* The generator stream of MultiCommitGens::new (Spartan/src/commitments.rs:20-38):
+ * nb points g[0..nb) as 128-byte X|Y|Z|T each.  Builds the device window table
+ * T[w][j][k] = (k+1) * 2^(8w) * g_j once; every MSM below is a gather-and-add over it.
+ * For R1CSGens (Spartan/src/r1csproof.rs:84-89) the stream is g[0..R+2): G = g[0..R),
+ * gens_1.G[0] = g[R], h = g[R+1]; gens_3 / gens_4 are prefixes with h = g[3] / g[4]. */
+typedef struct vpin_gens vpin_gens;
+int vpin_gens_create(vpin_ctx* ctx, const uint8_t* gens_xyzt, size_t nb, vpin_gens** out);
+void vpin_gens_free(vpin_ctx* ctx, vpin_gens* g);
+size_t vpin_gens_count(const vpin_gens* g);
+/* DensePolynomial::commit_inner (Spartan/src/dense_mlpoly.rs:160-175): Z viewed as L rows
+ * of R = len/L scalars; out[i] = compress( sum_j Z[iR+j]*g[j] + blinds[i]*g[blind_base] ).
+ * blinds = L x 32 B Montgomery scalars on the host. */
+int vpin_hyrax_commit(vpin_ctx* ctx, const vpin_gens* g, const vpin_table* Z, const uint8_t* blinds,
+                      size_t L, size_t blind_base, uint8_t* out_compressed /* L*32 */);
+/* The two commitments of proof_point_{add,mult}.rs:44-52 plus their row-wise sum
+ * (:75-80) in one call: out_sum[i] = compress(decompress(a[i]) + decompress(b[i])). */
+int vpin_hyrax_commit_pair(vpin_ctx* ctx, const vpin_gens* g, const vpin_table* Za, const vpin_table* Zb,
+                           const uint8_t* blinds_a, const uint8_t* blinds_b, size_t L, size_t blind_base,
+                           uint8_t* out_a, uint8_t* out_b, uint8_t* out_sum);
+/* GroupElement::vartime_multiscalar_mul (Spartan/src/group.rs:103-122) over a prefix of the
+ * generator stream: out[r] = sum_{j<ncols} s[r][j] * g[j] for `rows` independent rows of
+ * host scalars (Montgomery).  Either output may be NULL. */
+int vpin_gens_msm(vpin_ctx* ctx, const vpin_gens* g, const uint8_t* scalars_mont, size_t rows, size_t ncols,
+                  uint8_t* out_compressed /* rows*32 */, uint8_t* out_xyzt /* rows*128 */);
+
 /* ---- built-in kernel timing (HIP events on the ctx stream) ------------------------ */
 /* kernel classes */
 #define VPIN_K_SC_CUBIC 0

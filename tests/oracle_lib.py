@@ -243,3 +243,26 @@ def sat_timings():
     out = (C.c_double * 5)()
     lib().oracle_sat_last_timings(out)
     return dict(zip(("polycommit", "sc_phase_one", "sc_phase_two", "polyeval", "total"), out))
+
+
+def gens_stream_xyzt(nb, label=b"gens_r1cs_sat"):
+    """First nb points of MultiCommitGens::new's stream under `label`, as (nb,128) uint8 X|Y|Z|T,
+    plus the oracle's own ge_t array (for oracle-side commits)."""
+    L = lib()
+    gens = (Ge * nb)()
+    lab = (C.c_uint8 * len(label))(*label)
+    L.oracle_gens_new(gens, nb - 1, lab, len(label))
+    out = np.zeros((nb, 128), dtype=np.uint8)
+    for i in range(nb):
+        L.ge_to_xyzt(out[i].ctypes.data_as(C.c_void_p), C.byref(gens[i]))
+    return out, gens
+
+
+def hyrax_commit(Z, Ls, blinds, gens, blind_index, threads=8):
+    Z = np.ascontiguousarray(Z, dtype=np.uint64).reshape(-1, 4)
+    Rs = Z.shape[0] // Ls
+    out = np.zeros((Ls, 32), dtype=np.uint8)
+    lib().oracle_hyrax_commit(out.ctypes.data_as(C.c_void_p), ptr(Z), Ls, Rs,
+                              ptr(np.ascontiguousarray(blinds, dtype=np.uint64)), gens, C.byref(gens[blind_index]),
+                              threads)
+    return out

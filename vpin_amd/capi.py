@@ -74,6 +74,14 @@ def lib():
     L.vpin_sc_cubic_bind_round.argtypes = [vp, vp, vp, vp, vp, vp, vp]
     L.vpin_sc_quad_bind_round.argtypes = [vp, vp, vp, vp, vp]
     L.vpin_eq_table.argtypes = [vp, vp, C.c_int, C.POINTER(vp)]
+    L.vpin_gens_create.argtypes = [vp, vp, C.c_size_t, C.POINTER(vp)]
+    L.vpin_gens_free.argtypes = [vp, vp]
+    L.vpin_gens_free.restype = None
+    L.vpin_gens_count.argtypes = [vp]
+    L.vpin_gens_count.restype = C.c_size_t
+    L.vpin_hyrax_commit.argtypes = [vp, vp, vp, vp, C.c_size_t, C.c_size_t, vp]
+    L.vpin_hyrax_commit_pair.argtypes = [vp, vp, vp, vp, vp, vp, C.c_size_t, C.c_size_t, vp, vp, vp]
+    L.vpin_gens_msm.argtypes = [vp, vp, vp, C.c_size_t, C.c_size_t, vp, vp]
     L.vpin_prof_enable.argtypes = [vp, C.c_int]
     L.vpin_prof_reset.argtypes = [vp]
     L.vpin_prof_read.argtypes = [vp, C.POINTER(KStat)]
@@ -133,6 +141,22 @@ class Table:
     def free(self):
         if self.h:
             lib().vpin_table_free(self.ctx.h, self.h)
+            self.h = None
+
+
+class Gens:
+    """Device window table over a Pedersen generator stream (MultiCommitGens)."""
+
+    def __init__(self, ctx, handle):
+        self.ctx = ctx
+        self.h = handle
+
+    def __len__(self):
+        return int(lib().vpin_gens_count(self.h))
+
+    def free(self):
+        if self.h:
+            lib().vpin_gens_free(self.ctx.h, self.h)
             self.h = None
 
 
@@ -214,6 +238,41 @@ class Context:
         _chk(lib().vpin_sc_quad_bind_round(self.h, A.h, B.h, r.ctypes.data_as(C.c_void_p),
                                            out.ctypes.data_as(C.c_void_p)), "vpin_sc_quad_bind_round")
         return out
+
+    # ---- generators / MSM ----
+    def gens_create(self, xyzt):
+        """xyzt: (nb,128) uint8 generator stream (X|Y|Z|T canonical LE)."""
+        a = np.ascontiguousarray(xyzt, dtype=np.uint8).reshape(-1, 128)
+        h = C.c_void_p()
+        _chk(lib().vpin_gens_create(self.h, a.ctypes.data_as(C.c_void_p), a.shape[0], C.byref(h)), "vpin_gens_create")
+        return Gens(self, h)
+
+    def hyrax_commit(self, gens, Z, blinds, blind_base):
+        b = np.ascontiguousarray(blinds, dtype=np.uint64).reshape(-1, 4)
+        Ls = b.shape[0]
+        out = np.zeros((Ls, 32), dtype=np.uint8)
+        _chk(lib().vpin_hyrax_commit(self.h, gens.h, Z.h, b.ctypes.data_as(C.c_void_p), Ls, blind_base,
+                                     out.ctypes.data_as(C.c_void_p)), "vpin_hyrax_commit")
+        return out
+
+    def hyrax_commit_pair(self, gens, Za, Zb, blinds_a, blinds_b, blind_base):
+        ba = np.ascontiguousarray(blinds_a, dtype=np.uint64).reshape(-1, 4)
+        bb = np.ascontiguousarray(blinds_b, dtype=np.uint64).reshape(-1, 4)
+        Ls = ba.shape[0]
+        outs = [np.zeros((Ls, 32), dtype=np.uint8) for _ in range(3)]
+        _chk(lib().vpin_hyrax_commit_pair(self.h, gens.h, Za.h, Zb.h, ba.ctypes.data_as(C.c_void_p),
+                                          bb.ctypes.data_as(C.c_void_p), Ls, blind_base,
+                                          *[o.ctypes.data_as(C.c_void_p) for o in outs]), "vpin_hyrax_commit_pair")
+        return outs
+
+    def gens_msm(self, gens, scalars, rows, ncols, want_xyzt=False):
+        s = np.ascontiguousarray(scalars, dtype=np.uint64).reshape(rows * ncols, 4)
+        out = np.zeros((rows, 32), dtype=np.uint8)
+        ox = np.zeros((rows, 128), dtype=np.uint8) if want_xyzt else None
+        _chk(lib().vpin_gens_msm(self.h, gens.h, s.ctypes.data_as(C.c_void_p), rows, ncols,
+                                 out.ctypes.data_as(C.c_void_p),
+                                 ox.ctypes.data_as(C.c_void_p) if want_xyzt else None), "vpin_gens_msm")
+        return (out, ox) if want_xyzt else out
 
     # ---- profiling ----
     def prof_enable(self, on=True):

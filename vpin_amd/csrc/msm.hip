@@ -1,0 +1,311 @@
+// msm.hip -- fixed-base multi-scalar multiplication over the Pedersen generators, gfx950.
+//
+// Replaces the reference's polynomial-commitment MSMs:
+//   DensePolynomial::commit_inner   Spartan/src/dense_mlpoly.rs:160-175  (L row commitments)
+//   Commitments for [Scalar]        Spartan/src/commitments.rs:93-98     (MSM + blind*h)
+//   vartime_multiscalar_mul         Spartan/src/group.rs:103-122         (dalek Straus/Pippenger)
+//
+// MI355X-first design: every MSM of the sat proof is over the SAME generator stream
+// g[0..R+2) (MultiCommitGens::new, commitments.rs:20-38), so instead of per-row Pippenger
+// buckets we spend HBM (288 GB) on a window table  T[w][j][k] = (k+1) * 2^(8w) * g_j
+// (32 windows x 128 signed-digit multiples x 128 B "cached" points = 512 KiB per base) and
+// turn each row commitment into a pure gather-and-add: a non-zero scalar costs at most 32
+// table additions, no doublings, no bucket reduction, no atomics.  Zero scalars and zero
+// digits are skipped (the witness is ~40% zero padding and full of 0/1 bits), like dalek's
+// vartime MSM.  One 256-thread workgroup per row; per-thread partial sums are combined by
+// an LDS tree.  Integer-ALU bound (~8 field multiplies per table add); no MFMA.
+#include <cstring>
+
+#include "ctx.h"
+#include "fp_dev.h"
+
+struct vpin_gens {
+  vpin::ge_cached* table = nullptr;  // [32][nb][128]
+  vpin::ge_ext* shifts = nullptr;    // scratch [nb][32]: 2^(8w) * g_j
+  size_t nb = 0;                     // number of bases in the stream
+};
+
+namespace vpin {
+
+constexpr int kWin = 32;      // 8-bit windows
+constexpr int kEntries = 128; // multiples 1..128 per window (signed digits)
+
+// ---- table construction ---------------------------------------------------------------
+
+// one thread per base: shifts[j][w] = 2^(8w) * g_j
+__global__ __launch_bounds__(64) void gens_shift_kernel(const fp* __restrict__ xyzt, size_t nb, ge_ext* __restrict__ shifts) {
+  size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= nb) return;
+  ge_ext p;
+  p.X = fp_load(xyzt + 4 * j); p.Y = fp_load(xyzt + 4 * j + 1); p.Z = fp_load(xyzt + 4 * j + 2); p.T = fp_load(xyzt + 4 * j + 3);
+  for (int w = 0; w < kWin; w++) {
+    ge_ext* o = shifts + j * kWin + w;
+    fp_store(&o->X, p.X); fp_store(&o->Y, p.Y); fp_store(&o->Z, p.Z); fp_store(&o->T, p.T);
+    for (int k = 0; k < 8; k++) p = ge_double(p);
+  }
+}
+
+__device__ __forceinline__ void cached_store(ge_cached* o, const ge_cached& c) {
+  fp_store(&o->YpX, c.YpX); fp_store(&o->YmX, c.YmX); fp_store(&o->Z, c.Z); fp_store(&o->T2d, c.T2d);
+}
+__device__ __forceinline__ ge_cached cached_load(const ge_cached* o) {
+  ge_cached c;
+  c.YpX = fp_load(&o->YpX); c.YmX = fp_load(&o->YmX); c.Z = fp_load(&o->Z); c.T2d = fp_load(&o->T2d);
+  return c;
+}
+
+// one thread per (base, window): the 128 multiples of the shifted base
+__global__ __launch_bounds__(64) void gens_table_kernel(const ge_ext* __restrict__ shifts, size_t nb, ge_cached* __restrict__ table) {
+  size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= nb * kWin) return;
+  size_t j = idx / kWin;
+  int w = (int)(idx % kWin);
+  const ge_ext* s = shifts + j * kWin + w;
+  ge_ext p;
+  p.X = fp_load(&s->X); p.Y = fp_load(&s->Y); p.Z = fp_load(&s->Z); p.T = fp_load(&s->T);
+  ge_cached pc = ge_to_cached(p);
+  ge_cached* out = table + ((size_t)w * nb + j) * kEntries;
+  ge_ext q = p;
+  cached_store(out, pc);
+  for (int k = 1; k < kEntries; k++) {
+    q = ge_add_cached(q, pc);
+    cached_store(out + k, ge_to_cached(q));
+  }
+}
+
+// ---- scalar handling --------------------------------------------------------------------
+
+// Montgomery form -> canonical integer (Scalar::to_bytes, ristretto255.rs:426-438):
+// montgomery_reduce(a, 0) = a * R^-1 mod q
+__device__ __forceinline__ fq fq_from_mont(const fq& a) {
+  uint32_t t[9];
+#pragma unroll
+  for (int i = 0; i < 8; i++) t[i] = a.v[i];
+  t[8] = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    VPIN_MONT_STEP(t, 0u);
+  }
+  fq r;
+#pragma unroll
+  for (int i = 0; i < 8; i++) r.v[i] = t[i];
+  return fq_cond_sub_q(r);
+}
+
+// accumulate s * g_j into acc through the window table; s canonical, non-zero
+__device__ __forceinline__ void table_mul_acc(ge_ext& acc, fq s, const ge_cached* __restrict__ table, size_t nb, size_t j) {
+  uint32_t carry = 0;
+#pragma unroll 1
+  for (int w = 0; w < kWin; w++) {
+    uint32_t v = (s.v[0] & 0xffu) + carry;
+    // shift the 256-bit scalar right by one byte (static register indices only)
+#pragma unroll
+    for (int i = 0; i < 7; i++) s.v[i] = __builtin_amdgcn_alignbyte(s.v[i + 1], s.v[i], 1);
+    s.v[7] >>= 8;
+    bool neg = v > 128u;
+    uint32_t mag = neg ? 256u - v : v;
+    carry = neg ? 1u : 0u;
+    if (mag != 0) {
+      ge_cached e = cached_load(table + ((size_t)w * nb + j) * kEntries + (mag - 1));
+      acc = ge_add_cached(acc, e, neg);
+    }
+  }
+}
+
+// ---- row-batched commitment -------------------------------------------------------------
+
+constexpr int kMsmBlock = 256;
+
+// rows x (ncols scalars from Z with row stride `stride`) + optional extra scalars on bases
+// [extra_base0, extra_base0 + n_extra).  out[row] = sum_j s[row][j] * g_j  (extended coords)
+__global__ __launch_bounds__(kMsmBlock) void msm_rows_kernel(const fq* __restrict__ Z, size_t stride, size_t ncols,
+                                                             const fq* __restrict__ extra, int n_extra, size_t extra_base0,
+                                                             const ge_cached* __restrict__ table, size_t nb,
+                                                             ge_ext* __restrict__ out) {
+  const size_t row = blockIdx.x;
+  ge_ext acc = ge_identity();
+  const size_t total = ncols + (size_t)n_extra;
+  for (size_t j = threadIdx.x; j < total; j += kMsmBlock) {
+    fq s;
+    size_t base;
+    if (j < ncols) { s = fq_load(Z + row * stride + j); base = j; }
+    else { s = fq_load(extra + row * (size_t)n_extra + (j - ncols)); base = extra_base0 + (j - ncols); }
+    if (fq_is_zero(s)) continue;  // vartime: skip zero scalars (padding, unset variables)
+    table_mul_acc(acc, fq_from_mont(s), table, nb, base);
+  }
+  __shared__ ge_ext sh[kMsmBlock];
+  sh[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = kMsmBlock / 2; s >= 1; s >>= 1) {
+    if ((int)threadIdx.x < s) {
+      acc = ge_add(acc, sh[threadIdx.x + s]);
+      sh[threadIdx.x] = acc;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    ge_ext* o = out + row;
+    fp_store(&o->X, acc.X); fp_store(&o->Y, acc.Y); fp_store(&o->Z, acc.Z); fp_store(&o->T, acc.T);
+  }
+}
+
+// out[i] = a[i] + b[i]  (row-wise commitment combination, proof_point_mult.rs:75-80)
+__global__ __launch_bounds__(64) void ge_add_rows_kernel(const ge_ext* __restrict__ a, const ge_ext* __restrict__ b, size_t n,
+                                                         ge_ext* __restrict__ out) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  ge_ext p, q;
+  p.X = fp_load(&a[i].X); p.Y = fp_load(&a[i].Y); p.Z = fp_load(&a[i].Z); p.T = fp_load(&a[i].T);
+  q.X = fp_load(&b[i].X); q.Y = fp_load(&b[i].Y); q.Z = fp_load(&b[i].Z); q.T = fp_load(&b[i].T);
+  ge_ext r = ge_add(p, q);
+  fp_store(&out[i].X, r.X); fp_store(&out[i].Y, r.Y); fp_store(&out[i].Z, r.Z); fp_store(&out[i].T, r.T);
+}
+
+// RistrettoPoint::compress for n points, one thread each; also emits canonical X|Y|Z|T
+__global__ __launch_bounds__(64) void ge_compress_kernel(const ge_ext* __restrict__ pts, size_t n, fp* __restrict__ out32,
+                                                         fp* __restrict__ out_xyzt) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  ge_ext p;
+  p.X = fp_load(&pts[i].X); p.Y = fp_load(&pts[i].Y); p.Z = fp_load(&pts[i].Z); p.T = fp_load(&pts[i].T);
+  if (out32) fp_store(out32 + i, ge_compress(p));
+  if (out_xyzt) {
+    fp_store(out_xyzt + 4 * i, fp_freeze(p.X)); fp_store(out_xyzt + 4 * i + 1, fp_freeze(p.Y));
+    fp_store(out_xyzt + 4 * i + 2, fp_freeze(p.Z)); fp_store(out_xyzt + 4 * i + 3, fp_freeze(p.T));
+  }
+}
+
+struct DevBuf {
+  void* p = nullptr;
+  ~DevBuf() { if (p) (void)hipFree(p); }
+  int alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16) == hipSuccess ? VPIN_OK : VPIN_ENOMEM; }
+};
+
+}  // namespace vpin
+
+using namespace vpin;
+
+extern "C" {
+
+int vpin_gens_create(vpin_ctx* c, const uint8_t* gens_xyzt, size_t nb, vpin_gens** out) {
+  if (!c || !gens_xyzt || !out || nb == 0) return VPIN_EINVAL;
+  (void)hipSetDevice(c->device);
+  vpin_gens* g = new (std::nothrow) vpin_gens();
+  if (!g) return VPIN_ENOMEM;
+  g->nb = nb;
+  DevBuf raw;
+  if (raw.alloc(nb * 128) != VPIN_OK || hipMalloc(&g->shifts, nb * kWin * sizeof(ge_ext)) != hipSuccess ||
+      hipMalloc(&g->table, nb * (size_t)kWin * kEntries * sizeof(ge_cached)) != hipSuccess) {
+    if (g->shifts) (void)hipFree(g->shifts);
+    if (g->table) (void)hipFree(g->table);
+    delete g;
+    return VPIN_ENOMEM;
+  }
+  hipError_t e = hipMemcpyAsync(raw.p, gens_xyzt, nb * 128, hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(gens_shift_kernel, dim3((unsigned)((nb + 63) / 64)), dim3(64), 0, c->stream, (const fp*)raw.p, nb, g->shifts);
+    hipLaunchKernelGGL(gens_table_kernel, dim3((unsigned)((nb * kWin + 63) / 64)), dim3(64), 0, c->stream, g->shifts, nb, g->table);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  (void)hipFree(g->shifts);
+  g->shifts = nullptr;
+  if (e != hipSuccess) {
+    set_last_error("vpin_gens_create", e);
+    (void)hipFree(g->table);
+    delete g;
+    return VPIN_EHIP;
+  }
+  *out = g;
+  return VPIN_OK;
+}
+
+void vpin_gens_free(vpin_ctx* c, vpin_gens* g) {
+  if (!g) return;
+  if (c) { (void)hipSetDevice(c->device); (void)hipStreamSynchronize(c->stream); }
+  if (g->table) (void)hipFree(g->table);
+  delete g;
+}
+
+size_t vpin_gens_count(const vpin_gens* g) { return g ? g->nb : 0; }
+
+// shared implementation: rows of scalars -> points (kept on device), then optional outputs
+static int msm_rows(vpin_ctx* c, const vpin_gens* g, const fq* dZ, size_t rows, size_t stride, size_t ncols,
+                    const fq* d_extra, int n_extra, size_t extra_base0, ge_ext* d_points) {
+  double nz_est = (double)rows * ((double)ncols + n_extra);
+  ProfScope ps(c, VPIN_K_MSM, 32.0 * nz_est);
+  hipLaunchKernelGGL(msm_rows_kernel, dim3((unsigned)rows), dim3(kMsmBlock), 0, c->stream, dZ, stride, ncols, d_extra,
+                     n_extra, extra_base0, g->table, g->nb, d_points);
+  VPIN_HIP_TRY(hipGetLastError());
+  return VPIN_OK;
+}
+
+int vpin_hyrax_commit(vpin_ctx* c, const vpin_gens* g, const vpin_table* Z, const uint8_t* blinds, size_t L,
+                      size_t blind_base, uint8_t* out_compressed) {
+  if (!c || !g || !Z || !Z->d || !blinds || !out_compressed || L == 0) return VPIN_EINVAL;
+  if (Z->len % L != 0) return VPIN_ESHAPE;  // assert_eq!(L_size * R_size, self.Z.len())
+  size_t R = Z->len / L;
+  if (R > g->nb || blind_base >= g->nb) return VPIN_ESHAPE;  // assert_eq!(gens_n.n, self.len())
+  (void)hipSetDevice(c->device);
+  DevBuf dbl, dpts, dout;
+  if (dbl.alloc(L * 32) || dpts.alloc(L * sizeof(ge_ext)) || dout.alloc(L * 32)) return VPIN_ENOMEM;
+  VPIN_HIP_TRY(hipMemcpyAsync(dbl.p, blinds, L * 32, hipMemcpyHostToDevice, c->stream));
+  int rc = msm_rows(c, g, Z->d, L, R, R, (const fq*)dbl.p, 1, blind_base, (ge_ext*)dpts.p);
+  if (rc) return rc;
+  hipLaunchKernelGGL(ge_compress_kernel, dim3((unsigned)((L + 63) / 64)), dim3(64), 0, c->stream, (const ge_ext*)dpts.p, L,
+                     (fp*)dout.p, (fp*)nullptr);
+  VPIN_HIP_TRY(hipGetLastError());
+  VPIN_HIP_TRY(hipMemcpyAsync(out_compressed, dout.p, L * 32, hipMemcpyDeviceToHost, c->stream));
+  VPIN_HIP_TRY(hipStreamSynchronize(c->stream));
+  return VPIN_OK;
+}
+
+int vpin_hyrax_commit_pair(vpin_ctx* c, const vpin_gens* g, const vpin_table* Za, const vpin_table* Zb,
+                           const uint8_t* blinds_a, const uint8_t* blinds_b, size_t L, size_t blind_base,
+                           uint8_t* out_a, uint8_t* out_b, uint8_t* out_sum) {
+  if (!c || !g || !Za || !Zb || !blinds_a || !blinds_b || !out_a || !out_b || !out_sum || L == 0) return VPIN_EINVAL;
+  if (Za->len != Zb->len || Za->len % L != 0) return VPIN_ESHAPE;
+  size_t R = Za->len / L;
+  if (R > g->nb || blind_base >= g->nb) return VPIN_ESHAPE;
+  (void)hipSetDevice(c->device);
+  DevBuf dbl, dpts, dout;
+  if (dbl.alloc(2 * L * 32) || dpts.alloc(3 * L * sizeof(ge_ext)) || dout.alloc(3 * L * 32)) return VPIN_ENOMEM;
+  VPIN_HIP_TRY(hipMemcpyAsync(dbl.p, blinds_a, L * 32, hipMemcpyHostToDevice, c->stream));
+  VPIN_HIP_TRY(hipMemcpyAsync((uint8_t*)dbl.p + L * 32, blinds_b, L * 32, hipMemcpyHostToDevice, c->stream));
+  ge_ext* pts = (ge_ext*)dpts.p;
+  int rc = msm_rows(c, g, Za->d, L, R, R, (const fq*)dbl.p, 1, blind_base, pts);
+  if (rc) return rc;
+  rc = msm_rows(c, g, Zb->d, L, R, R, (const fq*)dbl.p + L, 1, blind_base, pts + L);
+  if (rc) return rc;
+  hipLaunchKernelGGL(ge_add_rows_kernel, dim3((unsigned)((L + 63) / 64)), dim3(64), 0, c->stream, pts, pts + L, L, pts + 2 * L);
+  hipLaunchKernelGGL(ge_compress_kernel, dim3((unsigned)((3 * L + 63) / 64)), dim3(64), 0, c->stream, (const ge_ext*)pts, 3 * L,
+                     (fp*)dout.p, (fp*)nullptr);
+  VPIN_HIP_TRY(hipGetLastError());
+  VPIN_HIP_TRY(hipMemcpyAsync(out_a, dout.p, L * 32, hipMemcpyDeviceToHost, c->stream));
+  VPIN_HIP_TRY(hipMemcpyAsync(out_b, (uint8_t*)dout.p + L * 32, L * 32, hipMemcpyDeviceToHost, c->stream));
+  VPIN_HIP_TRY(hipMemcpyAsync(out_sum, (uint8_t*)dout.p + 2 * L * 32, L * 32, hipMemcpyDeviceToHost, c->stream));
+  VPIN_HIP_TRY(hipStreamSynchronize(c->stream));
+  return VPIN_OK;
+}
+
+int vpin_gens_msm(vpin_ctx* c, const vpin_gens* g, const uint8_t* scalars_mont, size_t rows, size_t ncols,
+                  uint8_t* out_compressed, uint8_t* out_xyzt) {
+  if (!c || !g || !scalars_mont || rows == 0 || ncols == 0 || (!out_compressed && !out_xyzt)) return VPIN_EINVAL;
+  if (ncols > g->nb) return VPIN_ESHAPE;  // dalek asserts equal lengths (group.rs:105)
+  (void)hipSetDevice(c->device);
+  DevBuf ds, dpts, dout, dx;
+  if (ds.alloc(rows * ncols * 32) || dpts.alloc(rows * sizeof(ge_ext)) || dout.alloc(rows * 32) || dx.alloc(rows * 128))
+    return VPIN_ENOMEM;
+  VPIN_HIP_TRY(hipMemcpyAsync(ds.p, scalars_mont, rows * ncols * 32, hipMemcpyHostToDevice, c->stream));
+  int rc = msm_rows(c, g, (const fq*)ds.p, rows, ncols, ncols, nullptr, 0, 0, (ge_ext*)dpts.p);
+  if (rc) return rc;
+  hipLaunchKernelGGL(ge_compress_kernel, dim3((unsigned)((rows + 63) / 64)), dim3(64), 0, c->stream, (const ge_ext*)dpts.p,
+                     rows, out_compressed ? (fp*)dout.p : (fp*)nullptr, out_xyzt ? (fp*)dx.p : (fp*)nullptr);
+  VPIN_HIP_TRY(hipGetLastError());
+  if (out_compressed) VPIN_HIP_TRY(hipMemcpyAsync(out_compressed, dout.p, rows * 32, hipMemcpyDeviceToHost, c->stream));
+  if (out_xyzt) VPIN_HIP_TRY(hipMemcpyAsync(out_xyzt, dx.p, rows * 128, hipMemcpyDeviceToHost, c->stream));
+  VPIN_HIP_TRY(hipStreamSynchronize(c->stream));
+  return VPIN_OK;
+}
+
+}  // extern "C"

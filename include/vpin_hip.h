@@ -118,6 +118,50 @@ int vpin_hyrax_commit_pair(vpin_ctx* ctx, const vpin_gens* g, const vpin_table* 
 int vpin_gens_msm(vpin_ctx* ctx, const vpin_gens* g, const uint8_t* scalars_mont, size_t rows, size_t ncols,
                   uint8_t* out_compressed /* rows*32 */, uint8_t* out_xyzt /* rows*128 */);
 
+/* DensePolynomial::bound (Spartan/src/dense_mlpoly.rs:220-227): LZ[i] = sum_j L[j]*Z[j*R+i],
+ * Lvec = L_size host scalars, out = R = len/L_size host scalars. */
+int vpin_poly_bound(vpin_ctx* ctx, const vpin_table* Z, const uint8_t* Lvec, size_t L_size, uint8_t* out_LZ);
+
+/* ---- the sat proof (host orchestration over the kernels above) ------------------------ */
+/* R1CSInstance after Instance::new's padding and column remap (Spartan/src/lib.rs:138-244):
+ * num_cons / num_vars are powers of two; col indexes z = [vars | 1 | inputs | 0...] of length
+ * 2*num_vars; val = 32-byte Montgomery scalars. */
+typedef struct {
+  size_t num_cons, num_vars, num_inputs;
+  size_t nnz[3];          /* A, B, C */
+  const uint32_t* row[3];
+  const uint32_t* col[3];
+  const uint8_t* val[3];
+} vpin_r1cs;
+/* One gadget instance's satisfiability proof exactly as vPIN drives it:
+ * proof_point_{add,mult}.rs:38-94 (commit para / input under RandomTape::new(&[2]), combine)
+ * + commit_test.rs:59-109 my_lib_prove up to the Ar/Br/Cr claims (= my_R1CSProof_prove,
+ * commit_test.rs:136-334, + inst.evaluate).  The reference seeds its two RandomTapes from
+ * OsRng (Spartan/src/random.rs:14-22); the two 64-byte draws are explicit inputs here, which
+ * is what makes proofs reproducible.  Outputs: bincode bytes of R1CSProof, the two L x 32 B
+ * commitments the verifier needs, inst_evals = Ar|Br|Cr, rx (log2 num_cons scalars),
+ * ry (log2 num_vars + 1 scalars).  rx_out / ry_out may be NULL. */
+int vpin_sat_prove(vpin_ctx* ctx, const vpin_r1cs* inst, const uint8_t* vars_para, const uint8_t* vars_input,
+                   const uint8_t* vars, const uint8_t* inputs, const uint8_t seed_commit64[64],
+                   const uint8_t seed_proof64[64], uint8_t* proof_out, size_t proof_cap, size_t* proof_len,
+                   uint8_t* comm_para_out, uint8_t* comm_input_out, uint8_t inst_evals_out[96],
+                   uint8_t* rx_out, uint8_t* ry_out);
+size_t vpin_sat_proof_max_bytes(size_t num_cons, size_t num_vars);
+/* wall-clock spans of the last vpin_sat_prove call on this thread's process, seconds:
+ * [0] polycommit (uploads + 2 commits + combine)  [1] prove_sc_phase_one (eq table, SpMV, 4 uploads, rounds)
+ * [2] prove_sc_phase_two  [3] polyeval  [4] total  [5] generators (0 when cached)
+ * [6] host SpMV share of [1]+[2]  [7] inst.evaluate */
+void vpin_sat_last_timings(double out[8]);
+
+/* ---- host-only entry points (no GPU needed) -------------------------------------------- */
+/* MultiCommitGens::new (Spartan/src/commitments.rs:20-38): first nb points of the stream */
+int vpin_host_gens_derive(const char* label, size_t nb, uint8_t* out_xyzt /* nb*128 */);
+/* Merlin: Transcript::new(proto); append_message(label,msg); challenge_bytes(clabel,out) */
+int vpin_host_merlin_kat(const char* proto, const char* label, const uint8_t* msg, size_t n, const char* clabel,
+                         uint8_t* out, size_t out_n);
+/* Commitments::commit (commitments.rs:85-98) under MultiCommitGens::new(n,label), n <= 4 */
+int vpin_host_commit(const char* label, const uint8_t* v_mont, size_t n, const uint8_t* blind_mont, uint8_t out[32]);
+
 /* ---- built-in kernel timing (HIP events on the ctx stream) ------------------------ */
 /* kernel classes */
 #define VPIN_K_SC_CUBIC 0

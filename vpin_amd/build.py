@@ -53,7 +53,7 @@ def build(force=False, verbose=False):
         newest_dep = max(os.path.getmtime(d) for d in deps() if not d.endswith((".hip", ".cpp")) or d == src)
         if not force and os.path.exists(obj) and os.path.getmtime(obj) >= newest_dep:
             continue
-        cmd = [hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-c", src, "-o", obj,
+        cmd = [hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-fopenmp", "-c", src, "-o", obj,
                "-I", os.path.join(os.path.dirname(HERE), "include")]
         if verbose:
             print(" ".join(cmd))
@@ -61,7 +61,7 @@ def build(force=False, verbose=False):
     for src, p in procs:
         if p.wait() != 0:
             raise RuntimeError(f"hipcc failed on {src}")
-    cmd = [hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB_PATH] + objs
+    cmd = [hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-fopenmp", "-o", LIB_PATH] + objs
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

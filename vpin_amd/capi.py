@@ -24,6 +24,27 @@ class VpinError(RuntimeError):
         super().__init__(f"{where}: {msg} ({code})" + (f" [{last}]" if last else ""))
 
 
+class R1CS(C.Structure):
+    _fields_ = [("num_cons", C.c_size_t), ("num_vars", C.c_size_t), ("num_inputs", C.c_size_t),
+                ("nnz", C.c_size_t * 3), ("row", C.c_void_p * 3), ("col", C.c_void_p * 3), ("val", C.c_void_p * 3)]
+
+
+def make_r1cs(inst):
+    """inst: dict with num_cons/num_vars/num_inputs and A/B/C = (rows u32, cols u32, vals (n,4) u64)."""
+    r = R1CS()
+    r.num_cons, r.num_vars, r.num_inputs = inst["num_cons"], inst["num_vars"], inst["num_inputs"]
+    keep = []
+    for m, name in enumerate("ABC"):
+        rows, cols, vals = (np.ascontiguousarray(x) for x in inst[name])
+        keep += [rows, cols, vals]
+        r.nnz[m] = len(rows)
+        r.row[m] = rows.ctypes.data
+        r.col[m] = cols.ctypes.data
+        r.val[m] = vals.ctypes.data
+    r._keep = keep
+    return r
+
+
 class KStat(C.Structure):
     _fields_ = [("launches", C.c_uint64), ("ms", C.c_double), ("alg_bytes", C.c_double)]
 
@@ -82,6 +103,15 @@ def lib():
     L.vpin_hyrax_commit.argtypes = [vp, vp, vp, vp, C.c_size_t, C.c_size_t, vp]
     L.vpin_hyrax_commit_pair.argtypes = [vp, vp, vp, vp, vp, vp, C.c_size_t, C.c_size_t, vp, vp, vp]
     L.vpin_gens_msm.argtypes = [vp, vp, vp, C.c_size_t, C.c_size_t, vp, vp]
+    L.vpin_poly_bound.argtypes = [vp, vp, vp, C.c_size_t, vp]
+    L.vpin_sat_prove.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_size_t, C.POINTER(C.c_size_t), vp, vp, vp, vp, vp]
+    L.vpin_sat_proof_max_bytes.argtypes = [C.c_size_t, C.c_size_t]
+    L.vpin_sat_proof_max_bytes.restype = C.c_size_t
+    L.vpin_sat_last_timings.argtypes = [C.POINTER(C.c_double)]
+    L.vpin_sat_last_timings.restype = None
+    L.vpin_host_gens_derive.argtypes = [C.c_char_p, C.c_size_t, vp]
+    L.vpin_host_merlin_kat.argtypes = [C.c_char_p, C.c_char_p, vp, C.c_size_t, C.c_char_p, vp, C.c_size_t]
+    L.vpin_host_commit.argtypes = [C.c_char_p, vp, C.c_size_t, vp, vp]
     L.vpin_prof_enable.argtypes = [vp, C.c_int]
     L.vpin_prof_reset.argtypes = [vp]
     L.vpin_prof_read.argtypes = [vp, C.POINTER(KStat)]
@@ -273,6 +303,44 @@ class Context:
                                  out.ctypes.data_as(C.c_void_p),
                                  ox.ctypes.data_as(C.c_void_p) if want_xyzt else None), "vpin_gens_msm")
         return (out, ox) if want_xyzt else out
+
+    def poly_bound(self, Z, Lvec):
+        lv = np.ascontiguousarray(Lvec, dtype=np.uint64).reshape(-1, 4)
+        out = np.zeros((len(Z) // lv.shape[0], 4), dtype=np.uint64)
+        _chk(lib().vpin_poly_bound(self.h, Z.h, lv.ctypes.data_as(C.c_void_p), lv.shape[0],
+                                   out.ctypes.data_as(C.c_void_p)), "vpin_poly_bound")
+        return out
+
+    # ---- sat proof ----
+    def sat_prove(self, inst, seed_commit, seed_proof):
+        """inst: dict as produced by the gadget builders (padded instance + three assignments)."""
+        r = make_r1cs(inst)
+        nv, nc = inst["num_vars"], inst["num_cons"]
+        ell = nv.bit_length() - 1
+        Ls = 1 << (ell // 2)
+        cap = lib().vpin_sat_proof_max_bytes(nc, nv)
+        proof = np.zeros(cap, dtype=np.uint8)
+        n = C.c_size_t(0)
+        cp = np.zeros((Ls, 32), dtype=np.uint8)
+        ci = np.zeros((Ls, 32), dtype=np.uint8)
+        ev = np.zeros((3, 4), dtype=np.uint64)
+        rx = np.zeros((nc.bit_length() - 1, 4), dtype=np.uint64)
+        ry = np.zeros((ell + 1, 4), dtype=np.uint64)
+        sc = np.frombuffer(bytes(seed_commit), dtype=np.uint8).copy()
+        sp = np.frombuffer(bytes(seed_proof), dtype=np.uint8).copy()
+        p = lambda a: np.ascontiguousarray(a).ctypes.data_as(C.c_void_p)
+        keep = [np.ascontiguousarray(inst[k]) for k in ("vars_para", "vars_input", "vars", "inputs")]
+        _chk(lib().vpin_sat_prove(self.h, C.byref(r), p(keep[0]), p(keep[1]), p(keep[2]),
+                                  p(keep[3]) if keep[3].size else None, p(sc), p(sp), p(proof), cap, C.byref(n),
+                                  p(cp), p(ci), p(ev), p(rx), p(ry)), "vpin_sat_prove")
+        return dict(proof=bytes(proof[:n.value]), comm_para=cp, comm_input=ci, inst_evals=ev, rx=rx, ry=ry)
+
+    @staticmethod
+    def sat_timings():
+        out = (C.c_double * 8)()
+        lib().vpin_sat_last_timings(out)
+        names = ("polycommit", "sc_phase_one", "sc_phase_two", "polyeval", "total", "gens", "host_spmv", "inst_evaluate")
+        return dict(zip(names, out))
 
     # ---- profiling ----
     def prof_enable(self, on=True):

@@ -90,6 +90,7 @@ void vpin_ctx_destroy(vpin_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
+  if (c->prover_cache_free) c->prover_cache_free(c);
   for (auto& r : c->recs) { (void)hipEventDestroy(r.start); (void)hipEventDestroy(r.stop); }
   for (auto e : c->free_events) (void)hipEventDestroy(e);
   if (c->d_partials) (void)hipFree(c->d_partials);

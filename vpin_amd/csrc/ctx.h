@@ -50,6 +50,9 @@ struct vpin_ctx {
   std::vector<vpin::ProfRec> recs;
   std::vector<hipEvent_t> free_events;
   vpin_kstat stats[VPIN_K_COUNT] = {};
+  // host-side prover state (generator sets per polynomial size), owned by prover.cpp
+  void* prover_cache = nullptr;
+  void (*prover_cache_free)(vpin_ctx*) = nullptr;
 };
 
 namespace vpin {

@@ -125,7 +125,10 @@ __global__ __launch_bounds__(kMsmBlock) void msm_rows_kernel(const fq* __restric
   const size_t row = blockIdx.x;
   ge_ext acc = ge_identity();
   const size_t total = ncols + (size_t)n_extra;
-  for (size_t j = threadIdx.x; j < total; j += kMsmBlock) {
+  // gridDim.y column chunks per row (few-row MSMs need more than `rows` workgroups)
+  const size_t per = (total + gridDim.y - 1) / gridDim.y;
+  const size_t j0 = (size_t)blockIdx.y * per, j1 = (j0 + per < total) ? j0 + per : total;
+  for (size_t j = j0 + threadIdx.x; j < j1; j += kMsmBlock) {
     fq s;
     size_t base;
     if (j < ncols) { s = fq_load(Z + row * stride + j); base = j; }
@@ -144,9 +147,25 @@ __global__ __launch_bounds__(kMsmBlock) void msm_rows_kernel(const fq* __restric
     __syncthreads();
   }
   if (threadIdx.x == 0) {
-    ge_ext* o = out + row;
+    ge_ext* o = out + row * gridDim.y + blockIdx.y;
     fp_store(&o->X, acc.X); fp_store(&o->Y, acc.Y); fp_store(&o->Z, acc.Z); fp_store(&o->T, acc.T);
   }
+}
+
+// out[row] = sum of the `chunks` partial points of that row
+__global__ __launch_bounds__(64) void ge_sum_chunks_kernel(const ge_ext* __restrict__ parts, size_t rows, int chunks,
+                                                           ge_ext* __restrict__ out) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows) return;
+  ge_ext acc;
+  const ge_ext* p = parts + i * chunks;
+  acc.X = fp_load(&p->X); acc.Y = fp_load(&p->Y); acc.Z = fp_load(&p->Z); acc.T = fp_load(&p->T);
+  for (int k = 1; k < chunks; k++) {
+    ge_ext q;
+    q.X = fp_load(&p[k].X); q.Y = fp_load(&p[k].Y); q.Z = fp_load(&p[k].Z); q.T = fp_load(&p[k].T);
+    acc = ge_add(acc, q);
+  }
+  fp_store(&out[i].X, acc.X); fp_store(&out[i].Y, acc.Y); fp_store(&out[i].Z, acc.Z); fp_store(&out[i].T, acc.T);
 }
 
 // out[i] = a[i] + b[i]  (row-wise commitment combination, proof_point_mult.rs:75-80)
@@ -233,10 +252,28 @@ size_t vpin_gens_count(const vpin_gens* g) { return g ? g->nb : 0; }
 static int msm_rows(vpin_ctx* c, const vpin_gens* g, const fq* dZ, size_t rows, size_t stride, size_t ncols,
                     const fq* d_extra, int n_extra, size_t extra_base0, ge_ext* d_points) {
   double nz_est = (double)rows * ((double)ncols + n_extra);
-  ProfScope ps(c, VPIN_K_MSM, 32.0 * nz_est);
-  hipLaunchKernelGGL(msm_rows_kernel, dim3((unsigned)rows), dim3(kMsmBlock), 0, c->stream, dZ, stride, ncols, d_extra,
-                     n_extra, extra_base0, g->table, g->nb, d_points);
+  size_t total = ncols + (size_t)n_extra;
+  int chunks = 1;
+  if (rows < 128) {  // spread a few rows over the chip: ~one scalar per thread, <= 64 chunks per row
+    size_t want = (total + kMsmBlock - 1) / kMsmBlock * 4;
+    chunks = (int)(want < 1 ? 1 : want > 64 ? 64 : want);
+  }
+  DevBuf parts;
+  ge_ext* dst = d_points;
+  if (chunks > 1) {
+    if (parts.alloc(rows * (size_t)chunks * sizeof(ge_ext))) return VPIN_ENOMEM;
+    dst = (ge_ext*)parts.p;
+  }
+  {
+    ProfScope ps(c, VPIN_K_MSM, 32.0 * nz_est);
+    hipLaunchKernelGGL(msm_rows_kernel, dim3((unsigned)rows, (unsigned)chunks), dim3(kMsmBlock), 0, c->stream, dZ, stride,
+                       ncols, d_extra, n_extra, extra_base0, g->table, g->nb, dst);
+  }
+  if (chunks > 1)
+    hipLaunchKernelGGL(ge_sum_chunks_kernel, dim3((unsigned)((rows + 63) / 64)), dim3(64), 0, c->stream, (const ge_ext*)dst,
+                       rows, chunks, d_points);
   VPIN_HIP_TRY(hipGetLastError());
+  if (chunks > 1) VPIN_HIP_TRY(hipStreamSynchronize(c->stream));  // parts is freed on return
   return VPIN_OK;
 }
 

@@ -153,6 +153,32 @@ size_t vpin_sat_proof_max_bytes(size_t num_cons, size_t num_vars);
  * [6] host SpMV share of [1]+[2]  [7] inst.evaluate */
 void vpin_sat_last_timings(double out[8]);
 
+/* ---- gadgets: the R1CS instances vPIN proves (host, no GPU needed) ----------------------- */
+/* Owns the (A,B,C) triplets after Instance::new padding (Spartan/src/lib.rs:138-244) and the
+ * three padded assignments vPIN commits to (para / input / all). */
+typedef struct vpin_instance vpin_instance;
+/* vPIN_proof_generation/src/point_addition.rs:67-327.  px,py,rx,ry: N x 32 LE bytes as in
+ * rust_files/<label>/pointAdd/point_add_{px,py,rx,ry}_byte.json; rz: N bytes 0/1 (load_data_add.rs) */
+int vpin_gadget_point_add(const uint8_t* px, const uint8_t* py, const uint8_t* rx, const uint8_t* ry,
+                          const uint8_t* rz, size_t N, vpin_instance** out);
+/* vPIN_proof_generation/src/point_mult.rs:61-704 (n = 128 bits, load_data.rs:62).
+ * weights: N x 16 bytes (u128 little-endian, weight.json parsed as u128); px,py: N x 32 LE bytes */
+int vpin_gadget_point_mult(const uint8_t* weights_le16, const uint8_t* px, const uint8_t* py, size_t N,
+                           vpin_instance** out);
+void vpin_instance_free(vpin_instance* g);
+const vpin_r1cs* vpin_instance_r1cs(const vpin_instance* g);
+size_t vpin_instance_num_cons_unpadded(const vpin_instance* g);
+size_t vpin_instance_num_vars_unpadded(const vpin_instance* g);
+const uint8_t* vpin_instance_vars_para(const vpin_instance* g);  /* num_vars (padded) x 32 B */
+const uint8_t* vpin_instance_vars_input(const vpin_instance* g);
+const uint8_t* vpin_instance_vars(const vpin_instance* g);
+const uint8_t* vpin_instance_inputs(const vpin_instance* g);     /* num_inputs x 32 B or NULL */
+/* Instance::is_sat (lib.rs:246-275): 1 satisfied, 0 not */
+int vpin_instance_is_sat(const vpin_instance* g);
+/* synthetic stand-in for the Python inference service's witness dump: count points k*G on the
+ * curve E2 (src/convolution/Client.py:134-143), k from SplitMix64(seed); 32-byte LE x and y */
+int vpin_synthetic_points(uint64_t seed, size_t count, uint8_t* out_x, uint8_t* out_y);
+
 /* ---- host-only entry points (no GPU needed) -------------------------------------------- */
 /* MultiCommitGens::new (Spartan/src/commitments.rs:20-38): first nb points of the stream */
 int vpin_host_gens_derive(const char* label, size_t nb, uint8_t* out_xyzt /* nb*128 */);

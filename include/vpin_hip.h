@@ -133,6 +133,26 @@ typedef struct {
   const uint32_t* col[3];
   const uint8_t* val[3];
 } vpin_r1cs;
+/* Device-resident instance: CSR + CSC copies of (A,B,C) in HBM (the reference's
+ * SparseMatPolynomial, Spartan/src/sparse_mlpoly.rs:330-380), built once per instance. */
+typedef struct vpin_r1cs_dev vpin_r1cs_dev;
+int vpin_r1cs_upload(vpin_ctx* ctx, const vpin_r1cs* inst, vpin_r1cs_dev** out);
+void vpin_r1cs_free(vpin_ctx* ctx, vpin_r1cs_dev* d);
+void vpin_r1cs_dims(const vpin_r1cs_dev* d, size_t* num_cons, size_t* num_vars, size_t* num_inputs);
+/* z = [vars | 1 | inputs | 0...] (vPIN_proof_generation/src/commit_test.rs:162-170); inputs on the host */
+int vpin_r1cs_build_z(vpin_ctx* ctx, const vpin_r1cs_dev* d, const vpin_table* vars, const uint8_t* inputs,
+                      vpin_table** out_z);
+/* R1CSInstance::multiply_vec (Spartan/src/r1csinstance.rs:272-285 -> sparse_mlpoly.rs:467-481) */
+int vpin_r1cs_multiply_vec(vpin_ctx* ctx, const vpin_r1cs_dev* d, const vpin_table* z, vpin_table** Az,
+                           vpin_table** Bz, vpin_table** Cz);
+/* R1CSInstance::compute_eval_table_sparse (r1csinstance.rs:287-295 -> sparse_mlpoly.rs:483-498) folded with
+ * the three challenges r_A|r_B|r_C as at commit_test.rs:257-268: out[i] = r_A*A(rx,i)+r_B*B(rx,i)+r_C*C(rx,i) */
+int vpin_r1cs_eval_table(vpin_ctx* ctx, const vpin_r1cs_dev* d, const vpin_table* evals_rx, const uint8_t r_abc[96],
+                         vpin_table** out);
+/* R1CSInstance::evaluate (r1csinstance.rs:297-302) from the two eq tables; out = Ar|Br|Cr */
+int vpin_r1cs_evaluate(vpin_ctx* ctx, const vpin_r1cs_dev* d, const vpin_table* evals_rx, const vpin_table* evals_ry,
+                       uint8_t out[96]);
+
 /* One gadget instance's satisfiability proof exactly as vPIN drives it:
  * proof_point_{add,mult}.rs:38-94 (commit para / input under RandomTape::new(&[2]), combine)
  * + commit_test.rs:59-109 my_lib_prove up to the Ar/Br/Cr claims (= my_R1CSProof_prove,
@@ -146,6 +166,12 @@ int vpin_sat_prove(vpin_ctx* ctx, const vpin_r1cs* inst, const uint8_t* vars_par
                    const uint8_t seed_proof64[64], uint8_t* proof_out, size_t proof_cap, size_t* proof_len,
                    uint8_t* comm_para_out, uint8_t* comm_input_out, uint8_t inst_evals_out[96],
                    uint8_t* rx_out, uint8_t* ry_out);
+/* Same proof with the instance and the three assignments already resident in HBM (what bench.py times). */
+int vpin_sat_prove_resident(vpin_ctx* ctx, const vpin_r1cs_dev* inst, const vpin_table* vars_para,
+                            const vpin_table* vars_input, const vpin_table* vars, const uint8_t* inputs,
+                            const uint8_t seed_commit64[64], const uint8_t seed_proof64[64], uint8_t* proof_out,
+                            size_t proof_cap, size_t* proof_len, uint8_t* comm_para_out, uint8_t* comm_input_out,
+                            uint8_t inst_evals_out[96], uint8_t* rx_out, uint8_t* ry_out);
 size_t vpin_sat_proof_max_bytes(size_t num_cons, size_t num_vars);
 /* wall-clock spans of the last vpin_sat_prove call on this thread's process, seconds:
  * [0] polycommit (uploads + 2 commits + combine)  [1] prove_sc_phase_one (eq table, SpMV, 4 uploads, rounds)

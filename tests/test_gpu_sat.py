@@ -60,3 +60,52 @@ def test_point_mult_small_weights(ctx):
     """conv-style weights {0,1,2}: exercises the infinity / all-zero-bit paths of the gadget"""
     inst = GM.instance_new(GM.build_point_mult(GM.synthetic_mult_ops(0x5650494E + 3, 3, weights=[0, 1, 2])))
     check(ctx, inst)
+
+
+def test_r1cs_kernels_vs_oracle(ctx):
+    """device SpMV / sparse eval table / matrix evaluation against the oracle's host loops"""
+    import ctypes as C
+    import pymodel as M
+    inst = GM.instance_new(GM.build_point_mult(GM.synthetic_mult_ops(31, 2)))
+    L = O.lib()
+    r = O.make_r1cs(inst)
+    nv, nc = inst["num_vars"], inst["num_cons"]
+    di = ctx.r1cs_upload(inst)
+    tv = ctx.upload(inst["vars"])
+    z = ctx.r1cs_build_z(di, tv, inst["inputs"])
+    zh = z.read()
+    assert np.array_equal(zh[:nv], inst["vars"]) and M.table_to_ints(zh[nv:nv + 3]) == [1, GM.E2_A, 0]
+    Az, Bz, Cz = ctx.r1cs_multiply_vec(di, z)
+    exp = [np.zeros((nc, 4), dtype=np.uint64) for _ in range(3)]
+    L.oracle_r1cs_multiply_vec(C.byref(r), O.ptr(zh), *[O.ptr(e) for e in exp])
+    for got, e in zip((Az, Bz, Cz), exp):
+        assert np.array_equal(got.read(), e)
+    rng = np.random.default_rng(1)
+    rx = M.ints_to_table([int(rng.integers(1, 2**62)) ** 4 % M.Q for _ in range(O.log2(nc))])
+    ry = M.ints_to_table([int(rng.integers(1, 2**62)) ** 4 % M.Q for _ in range(O.log2(nv) + 1)])
+    rabc = M.ints_to_table([int(rng.integers(1, 2**62)) ** 4 % M.Q for _ in range(3)])
+    erx, ery = ctx.eq_table(rx), ctx.eq_table(ry)
+    tabs = [np.zeros((2 * nv, 4), dtype=np.uint64) for _ in range(3)]
+    erx_h = erx.read()
+    L.oracle_r1cs_eval_table_sparse(C.byref(r), O.ptr(erx_h), *[O.ptr(t) for t in tabs])
+    ints = [M.table_to_ints(t) for t in tabs]
+    ra, rb, rc = M.table_to_ints(rabc)
+    comb = M.ints_to_table([(ra * a + rb * b + rc * c) % M.Q for a, b, c in zip(*ints)])
+    assert np.array_equal(ctx.r1cs_eval_table(di, erx, rabc).read(), comb)
+    ev = np.zeros((3, 4), dtype=np.uint64)
+    L.oracle_r1cs_evaluate(C.byref(r), O.ptr(rx), O.ptr(ry), O.ptr(ev))
+    assert np.array_equal(ctx.r1cs_evaluate(di, erx, ery), ev)
+    di.free()
+
+
+def test_resident_path_same_proof(ctx):
+    inst = GM.instance_new(GM.build_point_add(GM.synthetic_add_ops(9, 5, rz_one_every=2)))
+    di = ctx.r1cs_upload(inst)
+    tabs = [ctx.upload(inst[k]) for k in ("vars_para", "vars_input", "vars")]
+    a = ctx.sat_prove_resident(di, *tabs, inst["inputs"], SEED_C, SEED_P)
+    b = ctx.sat_prove(inst, SEED_C, SEED_P)
+    assert a["proof"] == b["proof"] and O.sat_verify(inst, a) == 1
+    # the assignments must be untouched by the proof (they are inputs, not scratch)
+    for t, k in zip(tabs, ("vars_para", "vars_input", "vars")):
+        assert np.array_equal(t.read(), inst[k])
+    di.free()

@@ -105,6 +105,16 @@ def lib():
     L.vpin_gens_msm.argtypes = [vp, vp, vp, C.c_size_t, C.c_size_t, vp, vp]
     L.vpin_poly_bound.argtypes = [vp, vp, vp, C.c_size_t, vp]
     L.vpin_sat_prove.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_size_t, C.POINTER(C.c_size_t), vp, vp, vp, vp, vp]
+    L.vpin_sat_prove_resident.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_size_t, C.POINTER(C.c_size_t), vp, vp, vp, vp, vp]
+    L.vpin_r1cs_upload.argtypes = [vp, vp, C.POINTER(vp)]
+    L.vpin_r1cs_free.argtypes = [vp, vp]
+    L.vpin_r1cs_free.restype = None
+    L.vpin_r1cs_dims.argtypes = [vp, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+    L.vpin_r1cs_dims.restype = None
+    L.vpin_r1cs_build_z.argtypes = [vp, vp, vp, vp, C.POINTER(vp)]
+    L.vpin_r1cs_multiply_vec.argtypes = [vp, vp, vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
+    L.vpin_r1cs_eval_table.argtypes = [vp, vp, vp, vp, C.POINTER(vp)]
+    L.vpin_r1cs_evaluate.argtypes = [vp, vp, vp, vp, vp]
     L.vpin_sat_proof_max_bytes.argtypes = [C.c_size_t, C.c_size_t]
     L.vpin_sat_proof_max_bytes.restype = C.c_size_t
     L.vpin_sat_last_timings.argtypes = [C.POINTER(C.c_double)]
@@ -171,6 +181,19 @@ class Table:
     def free(self):
         if self.h:
             lib().vpin_table_free(self.ctx.h, self.h)
+            self.h = None
+
+
+class R1csDev:
+    """Device-resident (A,B,C): CSR + CSC copies in HBM."""
+
+    def __init__(self, ctx, handle, num_cons, num_vars, num_inputs):
+        self.ctx, self.h = ctx, handle
+        self.num_cons, self.num_vars, self.num_inputs = num_cons, num_vars, num_inputs
+
+    def free(self):
+        if self.h:
+            lib().vpin_r1cs_free(self.ctx.h, self.h)
             self.h = None
 
 
@@ -333,6 +356,58 @@ class Context:
         _chk(lib().vpin_sat_prove(self.h, C.byref(r), p(keep[0]), p(keep[1]), p(keep[2]),
                                   p(keep[3]) if keep[3].size else None, p(sc), p(sp), p(proof), cap, C.byref(n),
                                   p(cp), p(ci), p(ev), p(rx), p(ry)), "vpin_sat_prove")
+        return dict(proof=bytes(proof[:n.value]), comm_para=cp, comm_input=ci, inst_evals=ev, rx=rx, ry=ry)
+
+    def r1cs_upload(self, inst):
+        r = make_r1cs(inst)
+        h = C.c_void_p()
+        _chk(lib().vpin_r1cs_upload(self.h, C.byref(r), C.byref(h)), "vpin_r1cs_upload")
+        return R1csDev(self, h, inst["num_cons"], inst["num_vars"], inst["num_inputs"])
+
+    def r1cs_build_z(self, dinst, vars_t, inputs):
+        inp = np.ascontiguousarray(inputs, dtype=np.uint64)
+        h = C.c_void_p()
+        _chk(lib().vpin_r1cs_build_z(self.h, dinst.h, vars_t.h, inp.ctypes.data_as(C.c_void_p) if inp.size else None,
+                                     C.byref(h)), "vpin_r1cs_build_z")
+        return Table(self, h)
+
+    def r1cs_multiply_vec(self, dinst, z):
+        hs = [C.c_void_p() for _ in range(3)]
+        _chk(lib().vpin_r1cs_multiply_vec(self.h, dinst.h, z.h, *[C.byref(h) for h in hs]), "vpin_r1cs_multiply_vec")
+        return [Table(self, h) for h in hs]
+
+    def r1cs_eval_table(self, dinst, evals_rx, r_abc):
+        r = np.ascontiguousarray(r_abc, dtype=np.uint64).reshape(3, 4)
+        h = C.c_void_p()
+        _chk(lib().vpin_r1cs_eval_table(self.h, dinst.h, evals_rx.h, r.ctypes.data_as(C.c_void_p), C.byref(h)),
+             "vpin_r1cs_eval_table")
+        return Table(self, h)
+
+    def r1cs_evaluate(self, dinst, evals_rx, evals_ry):
+        out = np.zeros((3, 4), dtype=np.uint64)
+        _chk(lib().vpin_r1cs_evaluate(self.h, dinst.h, evals_rx.h, evals_ry.h, out.ctypes.data_as(C.c_void_p)),
+             "vpin_r1cs_evaluate")
+        return out
+
+    def sat_prove_resident(self, dinst, t_para, t_input, t_vars, inputs, seed_commit, seed_proof):
+        nv, nc = dinst.num_vars, dinst.num_cons
+        ell = nv.bit_length() - 1
+        Ls = 1 << (ell // 2)
+        cap = lib().vpin_sat_proof_max_bytes(nc, nv)
+        proof = np.zeros(cap, dtype=np.uint8)
+        n = C.c_size_t(0)
+        cp = np.zeros((Ls, 32), dtype=np.uint8)
+        ci = np.zeros((Ls, 32), dtype=np.uint8)
+        ev = np.zeros((3, 4), dtype=np.uint64)
+        rx = np.zeros((nc.bit_length() - 1, 4), dtype=np.uint64)
+        ry = np.zeros((ell + 1, 4), dtype=np.uint64)
+        sc = np.frombuffer(bytes(seed_commit), dtype=np.uint8).copy()
+        sp = np.frombuffer(bytes(seed_proof), dtype=np.uint8).copy()
+        inp = np.ascontiguousarray(inputs, dtype=np.uint64)
+        p = lambda a: a.ctypes.data_as(C.c_void_p)
+        _chk(lib().vpin_sat_prove_resident(self.h, dinst.h, t_para.h, t_input.h, t_vars.h, p(inp) if inp.size else None,
+                                           p(sc), p(sp), p(proof), cap, C.byref(n), p(cp), p(ci), p(ev), p(rx), p(ry)),
+             "vpin_sat_prove_resident")
         return dict(proof=bytes(proof[:n.value]), comm_para=cp, comm_input=ci, inst_evals=ev, rx=rx, ry=ry)
 
     @staticmethod

@@ -23,7 +23,10 @@
 #include "host/curve.h"
 #include "host/transcript.h"
 
-extern "C" int vpin_poly_bound(vpin_ctx* c, const vpin_table* Z, const uint8_t* Lvec, size_t L_size, uint8_t* out_LZ);
+extern "C" {
+int vpin_poly_bound(vpin_ctx* c, const vpin_table* Z, const uint8_t* Lvec, size_t L_size, uint8_t* out_LZ);
+void vpin_r1cs_dims(const vpin_r1cs_dev* d, size_t* num_cons, size_t* num_vars, size_t* num_inputs);
+}
 
 namespace {
 
@@ -320,7 +323,7 @@ static int zk_sumcheck(vpin_ctx* c, int K, vpin_table** tabs, const Fq& claim, c
 
 // ---- R1CS helpers (host, O(nnz)) -------------------------------------------------------------
 
-static inline void acc_mul(Fq& dst, const Fq& val, const Fq& x, const Fq& one, const Fq& m1) {
+[[maybe_unused]] static inline void acc_mul(Fq& dst, const Fq& val, const Fq& x, const Fq& one, const Fq& m1) {
   if (x.is_zero()) return;
   if (val == one) dst = dst + x;
   else if (val == m1) dst = dst - x;
@@ -382,18 +385,13 @@ size_t vpin_sat_proof_max_bytes(size_t num_cons, size_t num_vars) {
   return 8 + 32 * L + (lx + ly) * 400 + 2048 + 64 * lgR;
 }
 
-int vpin_sat_prove(vpin_ctx* c, const vpin_r1cs* inst, const uint8_t* vars_para, const uint8_t* vars_input,
-                   const uint8_t* vars, const uint8_t* inputs, const uint8_t seed_commit64[64],
-                   const uint8_t seed_proof64[64], uint8_t* proof_out, size_t proof_cap, size_t* proof_len,
-                   uint8_t* comm_para_out, uint8_t* comm_input_out, uint8_t inst_evals_out[96], uint8_t* rx_out,
-                   uint8_t* ry_out) {
-  if (!c || !inst || !vars_para || !vars_input || !vars || !seed_commit64 || !seed_proof64 || !proof_out || !proof_len ||
-      !comm_para_out || !comm_input_out || !inst_evals_out)
-    return VPIN_EINVAL;
-  const size_t nv = inst->num_vars, ncons = inst->num_cons, ni = inst->num_inputs;
-  if (!vpin::is_pow2(nv) || !vpin::is_pow2(ncons) || ni >= nv || (ni && !inputs)) return VPIN_ESHAPE;
-  for (int m = 0; m < 3; m++)
-    if (inst->nnz[m] && (!inst->row[m] || !inst->col[m] || !inst->val[m])) return VPIN_EINVAL;
+}  // extern "C"
+
+static int sat_prove_core(vpin_ctx* c, const vpin_r1cs_dev* dinst, size_t nv, size_t ncons, size_t ni,
+                          const vpin_table* d_para, const vpin_table* d_input, const vpin_table* d_vars, const uint8_t* inputs,
+                          const uint8_t seed_commit64[64], const uint8_t seed_proof64[64], uint8_t* proof_out, size_t proof_cap,
+                          size_t* proof_len, uint8_t* comm_para_out, uint8_t* comm_input_out, uint8_t inst_evals_out[96],
+                          uint8_t* rx_out, uint8_t* ry_out) {
   auto t_begin = Clock::now();
   memset(g_timings, 0, sizeof g_timings);
   (void)hipSetDevice(c->device);
@@ -404,8 +402,6 @@ int vpin_sat_prove(vpin_ctx* c, const vpin_r1cs* inst, const uint8_t* vars_para,
   if (rc) return rc;
   g_timings[5] = secs(t0, Clock::now());
   const size_t L = sg->L, R = sg->R;
-  const Fq* V = reinterpret_cast<const Fq*>(vars);
-  const Fq* IN = reinterpret_cast<const Fq*>(inputs);
   TableGuard tg(c);
 
   // ---- polycommit: proof_point_mult.rs:44-80 ----
@@ -416,13 +412,6 @@ int vpin_sat_prove(vpin_ctx* c, const vpin_r1cs* inst, const uint8_t* vars_para,
   std::vector<Fq> blind_input = tape1.challenge_vector("poly_blinds", L);
   std::vector<Fq> blind_vars(L);
   for (size_t i = 0; i < L; i++) blind_vars[i] = blind_para[i] + blind_input[i];  // commit_test.rs:42-54
-  vpin_table *d_para = nullptr, *d_input = nullptr, *d_vars = nullptr;
-  if ((rc = vpin_table_upload(c, vars_para, nv, &d_para))) return rc;
-  tg.add(d_para);
-  if ((rc = vpin_table_upload(c, vars_input, nv, &d_input))) return rc;
-  tg.add(d_input);
-  if ((rc = vpin_table_upload(c, vars, nv, &d_vars))) return rc;
-  tg.add(d_vars);
   std::vector<CG> comm_vars(L);
   rc = vpin_hyrax_commit_pair(c, sg->dev, d_para, d_input, B(blind_para.data()), B(blind_input.data()), L, R + 1,
                               comm_para_out, comm_input_out, comm_vars[0].b);
@@ -441,30 +430,20 @@ int vpin_sat_prove(vpin_ctx* c, const vpin_r1cs* inst, const uint8_t* vars_para,
   // ---- phase 1 ----
   t0 = Clock::now();
   const size_t zl = 2 * nv;
-  std::vector<Fq> z(zl, Fq::zero());
-  memcpy(z.data(), V, nv * 32);
-  z[nv] = Fq::one();
-  for (size_t i = 0; i < ni; i++) z[nv + 1 + i] = IN[i];
+  vpin_table* d_z = nullptr;
+  if ((rc = vpin_r1cs_build_z(c, dinst, d_vars, inputs, &d_z))) return rc;
+  tg.add(d_z);
   const int nrx = (int)log2z(ncons), nry = (int)log2z(zl);
   std::vector<Fq> tau = tr.challenge_vector("challenge_tau", nrx);
   vpin_table* d_tau = nullptr;
   if ((rc = vpin_eq_table(c, B(tau.data()), nrx, &d_tau))) return rc;
   tg.add(d_tau);
-  const Fq one = Fq::one(), m1 = one.neg();
-  std::vector<Fq> ABCz(3 * ncons, Fq::zero());
+  const Fq one = Fq::one();
+  vpin_table* d_abc[3] = {nullptr, nullptr, nullptr};
   auto t_spmv = Clock::now();
-#pragma omp parallel for schedule(static) num_threads(3)
-  for (int m = 0; m < 3; m++) {  // SparseMatPolynomial::multiply_vec (sparse_mlpoly.rs:467-481)
-    Fq* out = ABCz.data() + (size_t)m * ncons;
-    const Fq* val = reinterpret_cast<const Fq*>(inst->val[m]);
-    for (size_t k = 0; k < inst->nnz[m]; k++) acc_mul(out[inst->row[m][k]], val[k], z[inst->col[m][k]], one, m1);
-  }
+  if ((rc = vpin_r1cs_multiply_vec(c, dinst, d_z, &d_abc[0], &d_abc[1], &d_abc[2]))) return rc;
+  for (int m = 0; m < 3; m++) tg.add(d_abc[m]);
   g_timings[6] += secs(t_spmv, Clock::now());
-  vpin_table* d_abc[3];
-  for (int m = 0; m < 3; m++) {
-    if ((rc = vpin_table_upload(c, B(ABCz.data() + (size_t)m * ncons), ncons, &d_abc[m]))) return rc;
-    tg.add(d_abc[m]);
-  }
   ZkSc sc1, sc2;
   std::vector<Fq> rx, ry;
   Fq claims1[4], blind_post1;
@@ -497,40 +476,17 @@ int vpin_sat_prove(vpin_ctx* c, const vpin_r1cs* inst, const uint8_t* vars_para,
      r_C = tr.challenge_scalar("challenege_Cz");
   Fq claim2 = r_A * Az_claim + r_B * Bz_claim + r_C * Cz_claim;
   Fq blind_claim2 = r_A * Az_blind + r_B * Bz_blind + r_C * Cz_blind;
-  std::vector<Fq> evals_rx(ncons);
-  {
-    vpin_table* d_eq = nullptr;
-    if ((rc = vpin_eq_table(c, B(rx.data()), nrx, &d_eq))) return rc;
-    tg.add(d_eq);
-    if ((rc = vpin_table_read(c, d_eq, 0, ncons, B(evals_rx.data())))) return rc;
-  }
-  // r_A*A(rx,.) + r_B*B(rx,.) + r_C*C(rx,.): compute_eval_table_sparse (sparse_mlpoly.rs:483-498)
-  // folded with the three challenges as the entries are visited (commit_test.rs:257-268)
-  std::vector<Fq> eABC(zl, Fq::zero());
+  vpin_table *d_eq_rx = nullptr, *d_eabc = nullptr;
+  if ((rc = vpin_eq_table(c, B(rx.data()), nrx, &d_eq_rx))) return rc;
+  tg.add(d_eq_rx);
   t_spmv = Clock::now();
   {
-    std::vector<Fq> part(3 * zl, Fq::zero());
-    const Fq rr[3] = {r_A, r_B, r_C};
-#pragma omp parallel for schedule(static) num_threads(3)
-    for (int m = 0; m < 3; m++) {
-      Fq* out = part.data() + (size_t)m * zl;
-      const Fq* val = reinterpret_cast<const Fq*>(inst->val[m]);
-      for (size_t k = 0; k < inst->nnz[m]; k++) acc_mul(out[inst->col[m][k]], val[k], evals_rx[inst->row[m][k]], one, m1);
-    }
-#pragma omp parallel for schedule(static)
-    for (long i = 0; i < (long)zl; i++) {
-      Fq s = Fq::zero();
-      for (int m = 0; m < 3; m++)
-        if (!part[(size_t)m * zl + i].is_zero()) s = s + rr[m] * part[(size_t)m * zl + i];
-      eABC[i] = s;
-    }
+    // r_A*A(rx,.) + r_B*B(rx,.) + r_C*C(rx,.) (compute_eval_table_sparse x3, commit_test.rs:257-268)
+    Fq rabc[3] = {r_A, r_B, r_C};
+    if ((rc = vpin_r1cs_eval_table(c, dinst, d_eq_rx, B(rabc), &d_eabc))) return rc;
+    tg.add(d_eabc);
   }
   g_timings[6] += secs(t_spmv, Clock::now());
-  vpin_table *d_z = nullptr, *d_eabc = nullptr;
-  if ((rc = vpin_table_upload(c, B(z.data()), zl, &d_z))) return rc;
-  tg.add(d_z);
-  if ((rc = vpin_table_upload(c, B(eABC.data()), zl, &d_eabc))) return rc;
-  tg.add(d_eabc);
   Fq claims2[2], blind_post2;
   vpin_table* tabs2[2] = {d_z, d_eabc};
   rc = zk_sumcheck(c, 2, tabs2, claim2, blind_claim2, nry, sg->gens_1, sg->gens_3, tr, tape, sc2, ry, claims2, blind_post2);
@@ -658,21 +614,10 @@ int vpin_sat_prove(vpin_ctx* c, const vpin_r1cs* inst, const uint8_t* vars_para,
   t0 = Clock::now();
   Fq ie[3];
   {
-    std::vector<Fq> evals_ry(zl);
-    vpin_table* d_eq = nullptr;
-    if ((rc = vpin_eq_table(c, B(ry.data()), nry, &d_eq))) return rc;
-    tg.add(d_eq);
-    if ((rc = vpin_table_read(c, d_eq, 0, zl, B(evals_ry.data())))) return rc;
-#pragma omp parallel for schedule(static) num_threads(3)
-    for (int m = 0; m < 3; m++) {  // evaluate_with_tables (sparse_mlpoly.rs:440-452)
-      const Fq* val = reinterpret_cast<const Fq*>(inst->val[m]);
-      Fq acc = Fq::zero();
-      for (size_t k = 0; k < inst->nnz[m]; k++) {
-        Fq t = evals_rx[inst->row[m][k]] * evals_ry[inst->col[m][k]];
-        acc_mul(acc, val[k], t, one, m1);
-      }
-      ie[m] = acc;
-    }
+    vpin_table* d_eq_ry = nullptr;
+    if ((rc = vpin_eq_table(c, B(ry.data()), nry, &d_eq_ry))) return rc;
+    tg.add(d_eq_ry);
+    if ((rc = vpin_r1cs_evaluate(c, dinst, d_eq_rx, d_eq_ry, B(ie)))) return rc;
   }
   tr.append_scalar("Ar_claim", ie[0]);
   tr.append_scalar("Br_claim", ie[1]);
@@ -703,6 +648,48 @@ int vpin_sat_prove(vpin_ctx* c, const vpin_r1cs* inst, const uint8_t* vars_para,
   if (ry_out) memcpy(ry_out, ry.data(), ry.size() * 32);
   g_timings[4] = secs(t_begin, Clock::now());
   return VPIN_OK;
+}
+
+extern "C" {
+
+int vpin_sat_prove_resident(vpin_ctx* c, const vpin_r1cs_dev* dinst, const vpin_table* vars_para, const vpin_table* vars_input,
+                            const vpin_table* vars, const uint8_t* inputs, const uint8_t seed_commit64[64],
+                            const uint8_t seed_proof64[64], uint8_t* proof_out, size_t proof_cap, size_t* proof_len,
+                            uint8_t* comm_para_out, uint8_t* comm_input_out, uint8_t inst_evals_out[96], uint8_t* rx_out,
+                            uint8_t* ry_out) {
+  if (!c || !dinst || !vars_para || !vars_input || !vars || !seed_commit64 || !seed_proof64 || !proof_out || !proof_len ||
+      !comm_para_out || !comm_input_out || !inst_evals_out)
+    return VPIN_EINVAL;
+  size_t nv, ncons, ni;
+  vpin_r1cs_dims(dinst, &ncons, &nv, &ni);
+  if (vars_para->len != nv || vars_input->len != nv || vars->len != nv || (ni && !inputs)) return VPIN_ESHAPE;
+  return sat_prove_core(c, dinst, nv, ncons, ni, vars_para, vars_input, vars, inputs, seed_commit64, seed_proof64, proof_out,
+                        proof_cap, proof_len, comm_para_out, comm_input_out, inst_evals_out, rx_out, ry_out);
+}
+
+int vpin_sat_prove(vpin_ctx* c, const vpin_r1cs* inst, const uint8_t* vars_para, const uint8_t* vars_input,
+                   const uint8_t* vars, const uint8_t* inputs, const uint8_t seed_commit64[64],
+                   const uint8_t seed_proof64[64], uint8_t* proof_out, size_t proof_cap, size_t* proof_len,
+                   uint8_t* comm_para_out, uint8_t* comm_input_out, uint8_t inst_evals_out[96], uint8_t* rx_out,
+                   uint8_t* ry_out) {
+  if (!c || !inst || !vars_para || !vars_input || !vars) return VPIN_EINVAL;
+  const size_t nv = inst->num_vars;
+  if (!vpin::is_pow2(nv) || !vpin::is_pow2(inst->num_cons) || inst->num_inputs >= nv) return VPIN_ESHAPE;
+  vpin_r1cs_dev* dinst = nullptr;
+  int rc = vpin_r1cs_upload(c, inst, &dinst);
+  if (rc) return rc;
+  TableGuard tg(c);
+  vpin_table *d_para = nullptr, *d_input = nullptr, *d_vars = nullptr;
+  rc = vpin_table_upload(c, vars_para, nv, &d_para);
+  if (!rc) { tg.add(d_para); rc = vpin_table_upload(c, vars_input, nv, &d_input); }
+  if (!rc) { tg.add(d_input); rc = vpin_table_upload(c, vars, nv, &d_vars); }
+  if (!rc) {
+    tg.add(d_vars);
+    rc = vpin_sat_prove_resident(c, dinst, d_para, d_input, d_vars, inputs, seed_commit64, seed_proof64, proof_out, proof_cap,
+                                 proof_len, comm_para_out, comm_input_out, inst_evals_out, rx_out, ry_out);
+  }
+  vpin_r1cs_free(c, dinst);
+  return rc;
 }
 
 }  // extern "C"

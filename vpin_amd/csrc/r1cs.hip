@@ -1,0 +1,332 @@
+// r1cs.hip -- the sparse R1CS matrices (A,B,C) on the device, gfx950.
+//
+// Replaces the three O(nnz) host loops that sit between the kernels of the sat proof:
+//   SparseMatPolynomial::multiply_vec              Spartan/src/sparse_mlpoly.rs:467-481   (Az,Bz,Cz)
+//   SparseMatPolynomial::compute_eval_table_sparse Spartan/src/sparse_mlpoly.rs:483-498   (A(rx,.),...)
+//   SparseMatPolynomial::evaluate_with_tables      Spartan/src/sparse_mlpoly.rs:440-452   (A(rx,ry),...)
+// The reference scatters (`Mz[row] += val*z[col]`); 32-byte field elements have no atomics, so
+// the instance is kept twice in HBM -- row-sorted (CSR) for the SpMV, column-sorted (CSC) for
+// the eval table -- and every output element is produced by exactly one thread (short
+// rows/columns) or one workgroup (the few very long columns: the constant-1 column is touched
+// by every gadget copy).  Results are field sums, so any order gives the same bits.
+#include <algorithm>
+#include <cstring>
+#include <vector>
+
+#include "ctx.h"
+
+struct vpin_r1cs_dev {
+  size_t num_cons = 0, num_vars = 0, num_inputs = 0;
+  size_t nnz[3] = {0, 0, 0};
+  // CSR: rowptr[num_cons+1], col, val ; CSC: colptr[2*num_vars+1], row, val (val permuted)
+  uint32_t *rowptr[3] = {}, *csr_col[3] = {};
+  vpin::fq* csr_val[3] = {};
+  uint32_t *colptr[3] = {}, *csc_row[3] = {};
+  vpin::fq* csc_val[3] = {};
+  // long columns (> kLongCol entries), handled by one workgroup each
+  uint32_t* long_cols[3] = {};
+  size_t n_long[3] = {0, 0, 0};
+};
+
+namespace vpin {
+
+constexpr int kRB = 256;
+constexpr uint32_t kLongCol = 256;
+
+__device__ __forceinline__ fq mul_special(const fq& val, const fq& x) {
+  return fq_mul(val, x);
+}
+
+// out[row] = sum_k val[k] * z[col[k]]  over the row's CSR segment, for the 3 matrices
+__global__ __launch_bounds__(kRB) void spmv_kernel(const uint32_t* __restrict__ rowptr, const uint32_t* __restrict__ col,
+                                                   const fq* __restrict__ val, const fq* __restrict__ z, size_t nrows,
+                                                   fq* __restrict__ out) {
+  size_t r = (size_t)blockIdx.x * kRB + threadIdx.x;
+  if (r >= nrows) return;
+  uint32_t k0 = rowptr[r], k1 = rowptr[r + 1];
+  fq acc = fq_zero();
+  for (uint32_t k = k0; k < k1; k++) {
+    fq x = fq_load(z + col[k]);
+    if (fq_is_zero(x)) continue;
+    acc = fq_add(acc, fq_mul(fq_load(val + k), x));
+  }
+  fq_store(out + r, acc);
+}
+
+// partial eval table of one matrix scaled by its challenge: out[c] (+)= rc * sum_k val[k]*rx[row[k]]
+// accumulate != 0 adds onto the existing out[c] (used to fold A, B, C into one table)
+__global__ __launch_bounds__(kRB) void eval_table_kernel(const uint32_t* __restrict__ colptr, const uint32_t* __restrict__ row,
+                                                         const fq* __restrict__ val, const fq* __restrict__ rx, size_t ncols,
+                                                         fq rc, int accumulate, fq* __restrict__ out) {
+  size_t c = (size_t)blockIdx.x * kRB + threadIdx.x;
+  if (c >= ncols) return;
+  uint32_t k0 = colptr[c], k1 = colptr[c + 1];
+  if (k1 - k0 > kLongCol) return;  // long columns: eval_table_long_kernel
+  fq acc = fq_zero();
+  for (uint32_t k = k0; k < k1; k++) acc = fq_add(acc, fq_mul(fq_load(val + k), fq_load(rx + row[k])));
+  if (k1 > k0) acc = fq_mul(acc, rc);
+  if (accumulate) acc = fq_add(acc, fq_load(out + c));
+  fq_store(out + c, acc);
+}
+
+__global__ __launch_bounds__(kRB) void eval_table_long_kernel(const uint32_t* __restrict__ long_cols,
+                                                              const uint32_t* __restrict__ colptr, const uint32_t* __restrict__ row,
+                                                              const fq* __restrict__ val, const fq* __restrict__ rx, fq rc,
+                                                              int accumulate, fq* __restrict__ out) {
+  uint32_t c = long_cols[blockIdx.x];
+  uint32_t k0 = colptr[c], k1 = colptr[c + 1];
+  fq acc = fq_zero();
+  for (uint32_t k = k0 + threadIdx.x; k < k1; k += kRB) acc = fq_add(acc, fq_mul(fq_load(val + k), fq_load(rx + row[k])));
+  __shared__ fq sh[kRB / 64];
+  fq s = fq_wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    fq t = sh[0];
+    for (int w = 1; w < kRB / 64; w++) t = fq_add(t, sh[w]);
+    t = fq_mul(t, rc);
+    if (accumulate) t = fq_add(t, fq_load(out + c));
+    fq_store(out + c, t);
+  }
+}
+
+// partials[block] = sum_k rx[row[k]] * ry[col[k]] * val[k]   (CSR order: row index recovered by search)
+__global__ __launch_bounds__(kRB) void evaluate_kernel(const uint32_t* __restrict__ colptr, const uint32_t* __restrict__ row,
+                                                       const fq* __restrict__ val, const fq* __restrict__ rx,
+                                                       const fq* __restrict__ ry, size_t ncols, fq* __restrict__ partials) {
+  // one thread per column of the CSC form: sum_k val*rx[row] then * ry[col]
+  fq acc = fq_zero();
+  for (size_t c = (size_t)blockIdx.x * kRB + threadIdx.x; c < ncols; c += (size_t)gridDim.x * kRB) {
+    uint32_t k0 = colptr[c], k1 = colptr[c + 1];
+    if (k1 == k0 || k1 - k0 > kLongCol) continue;
+    fq s = fq_zero();
+    for (uint32_t k = k0; k < k1; k++) s = fq_add(s, fq_mul(fq_load(val + k), fq_load(rx + row[k])));
+    acc = fq_add(acc, fq_mul(s, fq_load(ry + c)));
+  }
+  __shared__ fq sh[kRB / 64];
+  fq s = fq_wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    fq t = sh[0];
+    for (int w = 1; w < kRB / 64; w++) t = fq_add(t, sh[w]);
+    fq_store(partials + blockIdx.x, t);
+  }
+}
+
+__global__ __launch_bounds__(kRB) void evaluate_long_kernel(const uint32_t* __restrict__ long_cols, const uint32_t* __restrict__ colptr,
+                                                            const uint32_t* __restrict__ row, const fq* __restrict__ val,
+                                                            const fq* __restrict__ rx, const fq* __restrict__ ry,
+                                                            fq* __restrict__ partials) {
+  uint32_t c = long_cols[blockIdx.x];
+  uint32_t k0 = colptr[c], k1 = colptr[c + 1];
+  fq acc = fq_zero();
+  for (uint32_t k = k0 + threadIdx.x; k < k1; k += kRB) acc = fq_add(acc, fq_mul(fq_load(val + k), fq_load(rx + row[k])));
+  __shared__ fq sh[kRB / 64];
+  fq s = fq_wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    fq t = sh[0];
+    for (int w = 1; w < kRB / 64; w++) t = fq_add(t, sh[w]);
+    fq_store(partials + blockIdx.x, fq_mul(t, fq_load(ry + c)));
+  }
+}
+
+__global__ __launch_bounds__(kRB) void sum_partials_kernel(const fq* __restrict__ partials, int n, fq* __restrict__ out) {
+  fq acc = fq_zero();
+  for (int i = threadIdx.x; i < n; i += kRB) acc = fq_add(acc, fq_load(partials + i));
+  __shared__ fq sh[kRB / 64];
+  fq s = fq_wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    fq t = sh[0];
+    for (int w = 1; w < kRB / 64; w++) t = fq_add(t, sh[w]);
+    fq_store(out, t);
+  }
+}
+
+// z = [vars | 1 | inputs | 0...] (commit_test.rs:162-170): fill the upper half
+__global__ __launch_bounds__(kRB) void build_z_hi_kernel(fq* __restrict__ z, size_t nv, const fq* __restrict__ inputs, size_t ni) {
+  size_t i = (size_t)blockIdx.x * kRB + threadIdx.x;
+  if (i >= nv) return;
+  fq v = fq_zero();
+  if (i == 0) v = fq_one();
+  else if (i <= ni) v = fq_load(inputs + (i - 1));
+  fq_store(z + nv + i, v);
+}
+
+template <typename T>
+static int up(vpin_ctx* c, T** dst, const T* src, size_t n) {
+  if (hipMalloc((void**)dst, (n ? n : 1) * sizeof(T)) != hipSuccess) return VPIN_ENOMEM;
+  if (n) VPIN_HIP_TRY(hipMemcpyAsync(*dst, src, n * sizeof(T), hipMemcpyHostToDevice, c->stream));
+  return VPIN_OK;
+}
+
+}  // namespace vpin
+
+using namespace vpin;
+
+extern "C" {
+
+void vpin_r1cs_dims(const vpin_r1cs_dev* d, size_t* num_cons, size_t* num_vars, size_t* num_inputs) {
+  if (num_cons) *num_cons = d ? d->num_cons : 0;
+  if (num_vars) *num_vars = d ? d->num_vars : 0;
+  if (num_inputs) *num_inputs = d ? d->num_inputs : 0;
+}
+
+void vpin_r1cs_free(vpin_ctx* c, vpin_r1cs_dev* d) {
+  if (!d) return;
+  if (c) { (void)hipSetDevice(c->device); (void)hipStreamSynchronize(c->stream); }
+  for (int m = 0; m < 3; m++) {
+    void* ps[] = {d->rowptr[m], d->csr_col[m], d->csr_val[m], d->colptr[m], d->csc_row[m], d->csc_val[m], d->long_cols[m]};
+    for (void* p : ps)
+      if (p) (void)hipFree(p);
+  }
+  delete d;
+}
+
+int vpin_r1cs_upload(vpin_ctx* c, const vpin_r1cs* inst, vpin_r1cs_dev** out) {
+  if (!c || !inst || !out) return VPIN_EINVAL;
+  if (!is_pow2(inst->num_cons) || !is_pow2(inst->num_vars) || inst->num_inputs >= inst->num_vars) return VPIN_ESHAPE;
+  (void)hipSetDevice(c->device);
+  vpin_r1cs_dev* d = new (std::nothrow) vpin_r1cs_dev();
+  if (!d) return VPIN_ENOMEM;
+  d->num_cons = inst->num_cons; d->num_vars = inst->num_vars; d->num_inputs = inst->num_inputs;
+  const size_t nrows = inst->num_cons, ncols = 2 * inst->num_vars;
+  int rc = VPIN_OK;
+  for (int m = 0; m < 3 && rc == VPIN_OK; m++) {
+    const size_t nnz = inst->nnz[m];
+    d->nnz[m] = nnz;
+    const uint32_t *row = inst->row[m], *col = inst->col[m];
+    const fq* val = reinterpret_cast<const fq*>(inst->val[m]);
+    for (size_t k = 0; k < nnz; k++)
+      if (row[k] >= nrows || col[k] >= ncols) { rc = VPIN_ESHAPE; break; }  // lib.rs:171-178 InvalidIndex
+    if (rc) break;
+    // counting sorts (stable): CSR by row, CSC by column
+    std::vector<uint32_t> rowptr(nrows + 1, 0), colptr(ncols + 1, 0);
+    for (size_t k = 0; k < nnz; k++) { rowptr[row[k] + 1]++; colptr[col[k] + 1]++; }
+    for (size_t i = 0; i < nrows; i++) rowptr[i + 1] += rowptr[i];
+    for (size_t i = 0; i < ncols; i++) colptr[i + 1] += colptr[i];
+    std::vector<uint32_t> ccol(nnz), crow(nnz), pos_r(rowptr.begin(), rowptr.end() - 1), pos_c(colptr.begin(), colptr.end() - 1);
+    std::vector<fq> rval(nnz), cval(nnz);
+    for (size_t k = 0; k < nnz; k++) {
+      uint32_t pr = pos_r[row[k]]++, pcn = pos_c[col[k]]++;
+      ccol[pr] = col[k]; rval[pr] = val[k];
+      crow[pcn] = row[k]; cval[pcn] = val[k];
+    }
+    std::vector<uint32_t> longs;
+    for (size_t i = 0; i < ncols; i++)
+      if (colptr[i + 1] - colptr[i] > kLongCol) longs.push_back((uint32_t)i);
+    d->n_long[m] = longs.size();
+    if ((rc = up(c, &d->rowptr[m], rowptr.data(), nrows + 1)) || (rc = up(c, &d->csr_col[m], ccol.data(), nnz)) ||
+        (rc = up(c, &d->csr_val[m], rval.data(), nnz)) || (rc = up(c, &d->colptr[m], colptr.data(), ncols + 1)) ||
+        (rc = up(c, &d->csc_row[m], crow.data(), nnz)) || (rc = up(c, &d->csc_val[m], cval.data(), nnz)) ||
+        (rc = up(c, &d->long_cols[m], longs.data(), longs.size())))
+      break;
+    if (hipStreamSynchronize(c->stream) != hipSuccess) rc = VPIN_EHIP;  // host vectors die at scope end
+  }
+  if (rc) { vpin_r1cs_free(c, d); return rc; }
+  *out = d;
+  return VPIN_OK;
+}
+
+// z table from the assignment: z = [vars | 1 | inputs | 0..] (commit_test.rs:162-170)
+int vpin_r1cs_build_z(vpin_ctx* c, const vpin_r1cs_dev* d, const vpin_table* vars, const uint8_t* inputs, vpin_table** out_z) {
+  if (!c || !d || !vars || !out_z || (d->num_inputs && !inputs)) return VPIN_EINVAL;
+  if (vars->len != d->num_vars) return VPIN_ESHAPE;
+  (void)hipSetDevice(c->device);
+  vpin_table* z = nullptr;
+  int rc = vpin_table_alloc(c, 2 * d->num_vars, &z);
+  if (rc) return rc;
+  fq* d_in = nullptr;
+  if (d->num_inputs) {
+    if (hipMalloc((void**)&d_in, d->num_inputs * 32) != hipSuccess) { vpin_table_free(c, z); return VPIN_ENOMEM; }
+    (void)hipMemcpyAsync(d_in, inputs, d->num_inputs * 32, hipMemcpyHostToDevice, c->stream);
+  }
+  (void)hipMemcpyAsync(z->d, vars->d, d->num_vars * 32, hipMemcpyDeviceToDevice, c->stream);
+  hipLaunchKernelGGL(build_z_hi_kernel, dim3((unsigned)((d->num_vars + kRB - 1) / kRB)), dim3(kRB), 0, c->stream, z->d,
+                     d->num_vars, d_in, d->num_inputs);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  if (d_in) (void)hipFree(d_in);
+  if (e != hipSuccess) { set_last_error("vpin_r1cs_build_z", e); vpin_table_free(c, z); return VPIN_EHIP; }
+  *out_z = z;
+  return VPIN_OK;
+}
+
+// R1CSInstance::multiply_vec (r1csinstance.rs:272-285): three fresh tables of num_cons entries
+int vpin_r1cs_multiply_vec(vpin_ctx* c, const vpin_r1cs_dev* d, const vpin_table* z, vpin_table** Az, vpin_table** Bz,
+                           vpin_table** Cz) {
+  if (!c || !d || !z || !Az || !Bz || !Cz) return VPIN_EINVAL;
+  if (z->len != 2 * d->num_vars) return VPIN_ESHAPE;  // assert_eq!(z.len(), num_cols)
+  (void)hipSetDevice(c->device);
+  vpin_table* t[3] = {nullptr, nullptr, nullptr};
+  for (int m = 0; m < 3; m++) {
+    int rc = vpin_table_alloc(c, d->num_cons, &t[m]);
+    if (rc) { for (int k = 0; k < m; k++) vpin_table_free(c, t[k]); return rc; }
+    hipLaunchKernelGGL(spmv_kernel, dim3((unsigned)((d->num_cons + kRB - 1) / kRB)), dim3(kRB), 0, c->stream, d->rowptr[m],
+                       d->csr_col[m], d->csr_val[m], z->d, d->num_cons, t[m]->d);
+  }
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { set_last_error("spmv", e); for (auto* p : t) vpin_table_free(c, p); return VPIN_EHIP; }
+  *Az = t[0]; *Bz = t[1]; *Cz = t[2];
+  return VPIN_OK;
+}
+
+// r_A*A(rx,.) + r_B*B(rx,.) + r_C*C(rx,.) over all 2*num_vars columns
+// (compute_eval_table_sparse x3 + the combination at commit_test.rs:257-268)
+int vpin_r1cs_eval_table(vpin_ctx* c, const vpin_r1cs_dev* d, const vpin_table* evals_rx, const uint8_t r_abc[96],
+                         vpin_table** out) {
+  if (!c || !d || !evals_rx || !r_abc || !out) return VPIN_EINVAL;
+  if (evals_rx->len != d->num_cons) return VPIN_ESHAPE;  // assert_eq!(rx.len(), num_rows)
+  (void)hipSetDevice(c->device);
+  const size_t ncols = 2 * d->num_vars;
+  vpin_table* t = nullptr;
+  int rc = vpin_table_alloc(c, ncols, &t);
+  if (rc) return rc;
+  for (int m = 0; m < 3; m++) {
+    fq rc_m;
+    memcpy(rc_m.v, r_abc + 32 * m, 32);
+    hipLaunchKernelGGL(eval_table_kernel, dim3((unsigned)((ncols + kRB - 1) / kRB)), dim3(kRB), 0, c->stream, d->colptr[m],
+                       d->csc_row[m], d->csc_val[m], evals_rx->d, ncols, rc_m, 1, t->d);
+    if (d->n_long[m])
+      hipLaunchKernelGGL(eval_table_long_kernel, dim3((unsigned)d->n_long[m]), dim3(kRB), 0, c->stream, d->long_cols[m],
+                         d->colptr[m], d->csc_row[m], d->csc_val[m], evals_rx->d, rc_m, 1, t->d);
+  }
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { set_last_error("eval_table", e); vpin_table_free(c, t); return VPIN_EHIP; }
+  *out = t;
+  return VPIN_OK;
+}
+
+// R1CSInstance::evaluate (r1csinstance.rs:297-302) given the two eq tables: out = Ar|Br|Cr
+int vpin_r1cs_evaluate(vpin_ctx* c, const vpin_r1cs_dev* d, const vpin_table* evals_rx, const vpin_table* evals_ry,
+                       uint8_t out[96]) {
+  if (!c || !d || !evals_rx || !evals_ry || !out) return VPIN_EINVAL;
+  if (evals_rx->len != d->num_cons || evals_ry->len != 2 * d->num_vars) return VPIN_ESHAPE;
+  (void)hipSetDevice(c->device);
+  const size_t ncols = 2 * d->num_vars;
+  fq* d_out = nullptr;
+  if (hipMalloc((void**)&d_out, 96) != hipSuccess) return VPIN_ENOMEM;
+  int grid = (int)std::min<size_t>((ncols + kRB - 1) / kRB, 1024);
+  for (int m = 0; m < 3; m++) {
+    int nparts = grid + (int)d->n_long[m];
+    if ((size_t)nparts > c->partials_cap) { (void)hipFree(d_out); return VPIN_ESHAPE; }
+    hipLaunchKernelGGL(evaluate_kernel, dim3(grid), dim3(kRB), 0, c->stream, d->colptr[m], d->csc_row[m], d->csc_val[m],
+                       evals_rx->d, evals_ry->d, ncols, c->d_partials);
+    if (d->n_long[m])
+      hipLaunchKernelGGL(evaluate_long_kernel, dim3((unsigned)d->n_long[m]), dim3(kRB), 0, c->stream, d->long_cols[m],
+                         d->colptr[m], d->csc_row[m], d->csc_val[m], evals_rx->d, evals_ry->d, c->d_partials + grid);
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(kRB), 0, c->stream, c->d_partials, nparts, d_out + m);
+  }
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, 96, hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  (void)hipFree(d_out);
+  if (e != hipSuccess) { set_last_error("vpin_r1cs_evaluate", e); return VPIN_EHIP; }
+  return VPIN_OK;
+}
+
+}  // extern "C"

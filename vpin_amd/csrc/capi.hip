@@ -1,5 +1,6 @@
 // capi.hip -- context, table management and profiling behind include/vpin_hip.h
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "ctx.h"
@@ -21,6 +22,40 @@ static hipEvent_t get_event(vpin_ctx* c) {
   hipEvent_t e = nullptr;
   (void)hipEventCreate(&e);
   return e;
+}
+
+int dev_alloc(vpin_ctx* c, size_t bytes, void** out) {
+  size_t cls = 256;
+  while (cls < bytes) cls <<= 1;
+  if (cls > (size_t)1 << 22) cls = (bytes + ((size_t)1 << 20) - 1) & ~(((size_t)1 << 20) - 1);  // MiB granularity above 4 MiB
+  auto it = c->pool_free_lists.find(cls);
+  if (it != c->pool_free_lists.end() && !it->second.empty()) {
+    *out = it->second.back();
+    it->second.pop_back();
+    return VPIN_OK;
+  }
+  void* p = nullptr;
+  if (hipMalloc(&p, cls) != hipSuccess) {
+    dev_pool_release(c);  // give cached blocks back and retry once
+    if (hipMalloc(&p, cls) != hipSuccess) return VPIN_ENOMEM;
+  }
+  c->pool_sizes[p] = cls;
+  *out = p;
+  return VPIN_OK;
+}
+
+void dev_free(vpin_ctx* c, void* p) {
+  if (!p) return;
+  auto it = c->pool_sizes.find(p);
+  if (it == c->pool_sizes.end()) { (void)hipFree(p); return; }
+  c->pool_free_lists[it->second].push_back(p);
+}
+
+void dev_pool_release(vpin_ctx* c) {
+  (void)hipStreamSynchronize(c->stream);
+  for (auto& kv : c->pool_free_lists)
+    for (void* p : kv.second) { c->pool_sizes.erase(p); (void)hipFree(p); }
+  c->pool_free_lists.clear();
 }
 
 ProfScope::ProfScope(vpin_ctx* c, int kclass, double bytes) : ctx(c) {
@@ -63,6 +98,9 @@ int vpin_abi_version(void) { return 1; }
 
 int vpin_ctx_create(int device, vpin_ctx** out) {
   if (!out) return VPIN_EINVAL;
+  // host OpenMP teams must wait passively (see prover.cpp host_threads); set before the runtime starts
+  setenv("KMP_BLOCKTIME", "0", 0);
+  setenv("OMP_WAIT_POLICY", "PASSIVE", 0);
   *out = nullptr;
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return VPIN_ENODEV;
@@ -91,6 +129,9 @@ void vpin_ctx_destroy(vpin_ctx* c) {
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->prover_cache_free) c->prover_cache_free(c);
+  dev_pool_release(c);
+  for (auto& kv : c->pool_sizes) (void)hipFree(kv.first);  // blocks still held by leaked handles
+  c->pool_sizes.clear();
   for (auto& r : c->recs) { (void)hipEventDestroy(r.start); (void)hipEventDestroy(r.stop); }
   for (auto e : c->free_events) (void)hipEventDestroy(e);
   if (c->d_partials) (void)hipFree(c->d_partials);
@@ -113,10 +154,10 @@ int vpin_table_alloc(vpin_ctx* c, size_t len, vpin_table** out) {
   (void)hipSetDevice(c->device);
   vpin_table* t = new (std::nothrow) vpin_table();
   if (!t) return VPIN_ENOMEM;
-  if (hipMalloc(&t->d, len * sizeof(fq)) != hipSuccess) { delete t; return VPIN_ENOMEM; }
+  if (dev_alloc(c, len * sizeof(fq), (void**)&t->d) != VPIN_OK) { delete t; return VPIN_ENOMEM; }
   t->len = t->cap = len;
   hipError_t e = hipMemsetAsync(t->d, 0, len * sizeof(fq), c->stream);
-  if (e != hipSuccess) { set_last_error("hipMemsetAsync", e); (void)hipFree(t->d); delete t; return VPIN_EHIP; }
+  if (e != hipSuccess) { set_last_error("hipMemsetAsync", e); dev_free(c, t->d); delete t; return VPIN_EHIP; }
   *out = t;
   return VPIN_OK;
 }
@@ -126,11 +167,11 @@ int vpin_table_upload(vpin_ctx* c, const uint8_t* mont32, size_t len, vpin_table
   (void)hipSetDevice(c->device);
   vpin_table* t = new (std::nothrow) vpin_table();
   if (!t) return VPIN_ENOMEM;
-  if (hipMalloc(&t->d, len * sizeof(fq)) != hipSuccess) { delete t; return VPIN_ENOMEM; }
+  if (dev_alloc(c, len * sizeof(fq), (void**)&t->d) != VPIN_OK) { delete t; return VPIN_ENOMEM; }
   t->len = t->cap = len;
   hipError_t e = hipMemcpyAsync(t->d, mont32, len * sizeof(fq), hipMemcpyHostToDevice, c->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-  if (e != hipSuccess) { set_last_error("hipMemcpy H2D", e); (void)hipFree(t->d); delete t; return VPIN_EHIP; }
+  if (e != hipSuccess) { set_last_error("hipMemcpy H2D", e); dev_free(c, t->d); delete t; return VPIN_EHIP; }
   *out = t;
   return VPIN_OK;
 }
@@ -151,18 +192,20 @@ int vpin_table_clone(vpin_ctx* c, const vpin_table* src, vpin_table** out) {
   (void)hipSetDevice(c->device);
   vpin_table* t = new (std::nothrow) vpin_table();
   if (!t) return VPIN_ENOMEM;
-  if (hipMalloc(&t->d, src->len * sizeof(fq)) != hipSuccess) { delete t; return VPIN_ENOMEM; }
+  if (dev_alloc(c, src->len * sizeof(fq), (void**)&t->d) != VPIN_OK) { delete t; return VPIN_ENOMEM; }
   t->len = t->cap = src->len;
   hipError_t e = hipMemcpyAsync(t->d, src->d, src->len * sizeof(fq), hipMemcpyDeviceToDevice, c->stream);
-  if (e != hipSuccess) { set_last_error("hipMemcpy D2D", e); (void)hipFree(t->d); delete t; return VPIN_EHIP; }
+  if (e != hipSuccess) { set_last_error("hipMemcpy D2D", e); dev_free(c, t->d); delete t; return VPIN_EHIP; }
   *out = t;
   return VPIN_OK;
 }
 
 void vpin_table_free(vpin_ctx* c, vpin_table* t) {
   if (!t) return;
-  if (c) { (void)hipSetDevice(c->device); (void)hipStreamSynchronize(c->stream); }
-  if (t->owned && t->d) (void)hipFree(t->d);
+  if (t->owned && t->d) {
+    if (c) dev_free(c, t->d);
+    else (void)hipFree(t->d);
+  }
   delete t;
 }
 

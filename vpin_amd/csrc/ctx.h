@@ -2,7 +2,9 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <map>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/vpin_hip.h"
@@ -50,6 +52,11 @@ struct vpin_ctx {
   std::vector<vpin::ProfRec> recs;
   std::vector<hipEvent_t> free_events;
   vpin_kstat stats[VPIN_K_COUNT] = {};
+  // device memory pool: freed blocks are kept by size class and reused (hipMalloc/hipFree cost
+  // hundreds of microseconds and hipFree synchronises the device; one proof makes ~100 of them).
+  // All work is issued on `stream`, so a recycled block is only touched by later-ordered work.
+  std::map<size_t, std::vector<void*>> pool_free_lists;
+  std::unordered_map<void*, size_t> pool_sizes;
   // host-side prover state (generator sets per polynomial size), owned by prover.cpp
   void* prover_cache = nullptr;
   void (*prover_cache_free)(vpin_ctx*) = nullptr;
@@ -64,6 +71,24 @@ struct ProfScope {
   ProfScope(vpin_ctx* c, int kclass, double bytes);
   ~ProfScope();
 };
+
+// pooled device allocation (see vpin_ctx::pool_free_lists)
+int dev_alloc(vpin_ctx* c, size_t bytes, void** out);
+void dev_free(vpin_ctx* c, void* p);
+void dev_pool_release(vpin_ctx* c);
+
+// scoped pooled buffer
+struct DevBuf {
+  vpin_ctx* c;
+  void* p = nullptr;
+  explicit DevBuf(vpin_ctx* ctx) : c(ctx) {}
+  ~DevBuf() { if (p) dev_free(c, p); }
+  int alloc(size_t bytes) { return dev_alloc(c, bytes, &p); }
+};
+
+// asynchronous round launch / collect (sumcheck.hip), for the host prover's overlap
+int sc_round_launch(vpin_ctx* c, int K, vpin_table* const* tabs, const uint8_t* r);
+int sc_round_wait(vpin_ctx* c, int K, uint8_t* out);
 
 inline bool is_pow2(size_t x) { return x && !(x & (x - 1)); }
 

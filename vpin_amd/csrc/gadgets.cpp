@@ -253,7 +253,7 @@ int vpin_gadget_point_mult(const uint8_t* weights_le16, const uint8_t* px_b, con
     for (size_t j = 0; j < N; j++) { inv_pa[j] = bx[j] - ax[j]; inv_pd[j] = two * ay[j]; }
     batch_invert(inv_pa);
     batch_invert(inv_pd);
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(8)
     for (long jj = 0; jj < (long)N; jj++) {
       const size_t j = (size_t)jj;
       Fq* vi = g->vars_input.data() + ov * j;
@@ -313,7 +313,7 @@ int vpin_synthetic_points(uint64_t seed, size_t count, uint8_t* out_x, uint8_t* 
   std::vector<uint64_t> ks(count);
   uint64_t st = seed;
   for (size_t i = 0; i < count; i++) { ks[i] = splitmix64(st); if (!ks[i]) ks[i] = 1; }
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(8)
   for (long ii = 0; ii < (long)count; ii++) {
     // Jacobian (X:Y:Z), x = X/Z^2, y = Y/Z^3
     Fq X = Fq::zero(), Y = one, Z = Fq::zero();

@@ -194,12 +194,6 @@ __global__ __launch_bounds__(64) void ge_compress_kernel(const ge_ext* __restric
   }
 }
 
-struct DevBuf {
-  void* p = nullptr;
-  ~DevBuf() { if (p) (void)hipFree(p); }
-  int alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16) == hipSuccess ? VPIN_OK : VPIN_ENOMEM; }
-};
-
 }  // namespace vpin
 
 using namespace vpin;
@@ -212,7 +206,7 @@ int vpin_gens_create(vpin_ctx* c, const uint8_t* gens_xyzt, size_t nb, vpin_gens
   vpin_gens* g = new (std::nothrow) vpin_gens();
   if (!g) return VPIN_ENOMEM;
   g->nb = nb;
-  DevBuf raw;
+  DevBuf raw(c);
   if (raw.alloc(nb * 128) != VPIN_OK || hipMalloc(&g->shifts, nb * kWin * sizeof(ge_ext)) != hipSuccess ||
       hipMalloc(&g->table, nb * (size_t)kWin * kEntries * sizeof(ge_cached)) != hipSuccess) {
     if (g->shifts) (void)hipFree(g->shifts);
@@ -258,7 +252,7 @@ static int msm_rows(vpin_ctx* c, const vpin_gens* g, const fq* dZ, size_t rows, 
     size_t want = (total + kMsmBlock - 1) / kMsmBlock * 4;
     chunks = (int)(want < 1 ? 1 : want > 64 ? 64 : want);
   }
-  DevBuf parts;
+  DevBuf parts(c);
   ge_ext* dst = d_points;
   if (chunks > 1) {
     if (parts.alloc(rows * (size_t)chunks * sizeof(ge_ext))) return VPIN_ENOMEM;
@@ -273,7 +267,6 @@ static int msm_rows(vpin_ctx* c, const vpin_gens* g, const fq* dZ, size_t rows, 
     hipLaunchKernelGGL(ge_sum_chunks_kernel, dim3((unsigned)((rows + 63) / 64)), dim3(64), 0, c->stream, (const ge_ext*)dst,
                        rows, chunks, d_points);
   VPIN_HIP_TRY(hipGetLastError());
-  if (chunks > 1) VPIN_HIP_TRY(hipStreamSynchronize(c->stream));  // parts is freed on return
   return VPIN_OK;
 }
 
@@ -284,7 +277,7 @@ int vpin_hyrax_commit(vpin_ctx* c, const vpin_gens* g, const vpin_table* Z, cons
   size_t R = Z->len / L;
   if (R > g->nb || blind_base >= g->nb) return VPIN_ESHAPE;  // assert_eq!(gens_n.n, self.len())
   (void)hipSetDevice(c->device);
-  DevBuf dbl, dpts, dout;
+  DevBuf dbl(c), dpts(c), dout(c);
   if (dbl.alloc(L * 32) || dpts.alloc(L * sizeof(ge_ext)) || dout.alloc(L * 32)) return VPIN_ENOMEM;
   VPIN_HIP_TRY(hipMemcpyAsync(dbl.p, blinds, L * 32, hipMemcpyHostToDevice, c->stream));
   int rc = msm_rows(c, g, Z->d, L, R, R, (const fq*)dbl.p, 1, blind_base, (ge_ext*)dpts.p);
@@ -305,7 +298,7 @@ int vpin_hyrax_commit_pair(vpin_ctx* c, const vpin_gens* g, const vpin_table* Za
   size_t R = Za->len / L;
   if (R > g->nb || blind_base >= g->nb) return VPIN_ESHAPE;
   (void)hipSetDevice(c->device);
-  DevBuf dbl, dpts, dout;
+  DevBuf dbl(c), dpts(c), dout(c);
   if (dbl.alloc(2 * L * 32) || dpts.alloc(3 * L * sizeof(ge_ext)) || dout.alloc(3 * L * 32)) return VPIN_ENOMEM;
   VPIN_HIP_TRY(hipMemcpyAsync(dbl.p, blinds_a, L * 32, hipMemcpyHostToDevice, c->stream));
   VPIN_HIP_TRY(hipMemcpyAsync((uint8_t*)dbl.p + L * 32, blinds_b, L * 32, hipMemcpyHostToDevice, c->stream));
@@ -330,7 +323,7 @@ int vpin_gens_msm(vpin_ctx* c, const vpin_gens* g, const uint8_t* scalars_mont, 
   if (!c || !g || !scalars_mont || rows == 0 || ncols == 0 || (!out_compressed && !out_xyzt)) return VPIN_EINVAL;
   if (ncols > g->nb) return VPIN_ESHAPE;  // dalek asserts equal lengths (group.rs:105)
   (void)hipSetDevice(c->device);
-  DevBuf ds, dpts, dout, dx;
+  DevBuf ds(c), dpts(c), dout(c), dx(c);
   if (ds.alloc(rows * ncols * 32) || dpts.alloc(rows * sizeof(ge_ext)) || dout.alloc(rows * 32) || dx.alloc(rows * 128))
     return VPIN_ENOMEM;
   VPIN_HIP_TRY(hipMemcpyAsync(ds.p, scalars_mont, rows * ncols * 32, hipMemcpyHostToDevice, c->stream));

@@ -45,12 +45,12 @@ extern "C" int vpin_poly_bound(vpin_ctx* c, const vpin_table* Z, const uint8_t* 
   (void)hipSetDevice(c->device);
   size_t rows_per_chunk = L_size / 64 ? L_size / 64 : 1;
   int chunks = (int)((L_size + rows_per_chunk - 1) / rows_per_chunk);
-  fq *dL = nullptr, *dpart = nullptr, *dout = nullptr;
+  DevBuf bL(c), bpart(c), bout(c);
   int rc = VPIN_OK;
-  if (hipMalloc(&dL, L_size * 32) != hipSuccess || hipMalloc(&dpart, (size_t)chunks * Rs * 32) != hipSuccess ||
-      hipMalloc(&dout, Rs * 32) != hipSuccess) {
+  if (bL.alloc(L_size * 32) || bpart.alloc((size_t)chunks * Rs * 32) || bout.alloc(Rs * 32)) {
     rc = VPIN_ENOMEM;
   } else {
+    fq *dL = (fq*)bL.p, *dpart = (fq*)bpart.p, *dout = (fq*)bout.p;
     hipError_t e = hipMemcpyAsync(dL, Lvec, L_size * 32, hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) {
       dim3 grid((unsigned)((Rs + kPB - 1) / kPB), (unsigned)chunks);
@@ -62,8 +62,5 @@ extern "C" int vpin_poly_bound(vpin_ctx* c, const vpin_table* Z, const uint8_t* 
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e != hipSuccess) { set_last_error("vpin_poly_bound", e); rc = VPIN_EHIP; }
   }
-  if (dL) (void)hipFree(dL);
-  if (dpart) (void)hipFree(dpart);
-  if (dout) (void)hipFree(dout);
   return rc;
 }

@@ -15,6 +15,7 @@
 #include <omp.h>
 
 #include <chrono>
+#include <cstdlib>
 #include <map>
 #include <memory>
 #include <vector>
@@ -33,6 +34,22 @@ namespace {
 using namespace vpin_host;
 using Clock = std::chrono::steady_clock;
 static double secs(Clock::time_point a, Clock::time_point b) { return std::chrono::duration<double>(b - a).count(); }
+
+// Host worker threads for the few batched host loops (generator derivation, per-round blind
+// commitments).  OpenMP workers that spin after a parallel region burn a container's CPU quota and
+// get the whole process throttled, so waiting is made passive and the team is kept small.
+static int host_threads() {
+  static int n = [] {
+    setenv("KMP_BLOCKTIME", "0", 0);
+    setenv("OMP_WAIT_POLICY", "PASSIVE", 0);
+    int hw = omp_get_num_procs();
+    const char* e = getenv("VPIN_HOST_THREADS");
+    int want = e ? atoi(e) : 8;
+    if (want < 1) want = 1;
+    return want < hw ? want : hw;
+  }();
+  return n;
+}
 
 static size_t log2z(size_t n) { size_t l = 0; while (((size_t)1 << l) < n) l++; return l; }
 static const uint8_t* B(const Fq* p) { return reinterpret_cast<const uint8_t*>(p); }
@@ -81,7 +98,7 @@ static void derive_gens(std::vector<Point>& g, size_t nb, const char* label) {
   std::vector<uint8_t> stream(64 * nb);
   sh.squeeze(stream.data(), stream.size());
   g.resize(nb);
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(host_threads())
   for (long i = 0; i < (long)nb; i++) g[i] = Point::from_uniform_bytes(stream.data() + 64 * i);
 }
 
@@ -98,7 +115,7 @@ static int get_gens(vpin_ctx* c, size_t num_vars, SatGens** out) {
   sg->R = (size_t)1 << (sg->ell - left);
   sg->nb = sg->R + 2 < 5 ? 5 : sg->R + 2;
   derive_gens(sg->g, sg->nb, "gens_r1cs_sat");
-#pragma omp parallel for schedule(dynamic, 1)
+#pragma omp parallel for schedule(dynamic, 1) num_threads(host_threads())
   for (int i = 0; i < 7; i++) {
     if (i < 5) sg->fb[i] = FixedBase(sg->g[i]);
     else if (i == 5) sg->fb_gR = FixedBase(sg->g[sg->R]);
@@ -141,7 +158,7 @@ struct DotProof { CG delta, beta; std::vector<Fq> z; Fq z_delta, z_beta; };
 
 // DotProductProof::prove (nizk/mod.rs:315-374).  Cx is known to the caller (it is the round's
 // comm_poly), so it is passed in instead of being recomputed.
-static void dotproduct_prove(DotProof& pf, const Mcg& g1, const Mcg& gn, Transcript& tr, Transcript& tape, const Fq* x,
+[[maybe_unused]] static void dotproduct_prove(DotProof& pf, const Mcg& g1, const Mcg& gn, Transcript& tr, Transcript& tape, const Fq* x,
                              const Fq& blind_x, const Fq* a, const Fq& y, const Fq& blind_y, int n, const CG& Cx) {
   tr.append_protocol_name("dot product proof");
   std::vector<Fq> d = tape.challenge_vector("d_vec", n);
@@ -259,37 +276,60 @@ static void write_zksc(Writer& w, const ZkSc& p) {
 // ZKSumcheckInstanceProof::prove_cubic_with_additive_term (K=4) / prove_quad (K=2)
 // (sumcheck.rs:428-776): the per-round evaluation loop and the table folds run on the GPU
 // (one fused kernel per round); everything between them is the reference's host sequence.
+// Two schedule changes that leave every transcript byte unchanged:
+//  * the RandomTape is a private transcript, so the per-round DotProductProof randomness
+//    (d_vec, r_delta, r_beta: nizk/mod.rs:333-335) is drawn up front in the reference's order and
+//    every commitment term that depends only on it (delta_j, blind*h parts) is computed for all
+//    rounds at once across the host cores;
+//  * round j+1's kernel is launched as soon as r_j is known and runs while the host finishes
+//    round j's dot-product proof.
 static int zk_sumcheck(vpin_ctx* c, int K, vpin_table** tabs, const Fq& claim, const Fq& blind_claim, int rounds,
                        const Mcg& g1, const Mcg& gn, Transcript& tr, Transcript& tape, ZkSc& pf, std::vector<Fq>& r_out,
                        Fq* final_claims, Fq& blind_last) {
   const int nc = (K == 4) ? 4 : 3;
   std::vector<Fq> blinds_poly = tape.challenge_vector("blinds_poly", rounds);
   std::vector<Fq> blinds_evals = tape.challenge_vector("blinds_evals", rounds);
+  struct RoundRand { Fq d[4], r_delta, r_beta; };
+  std::vector<RoundRand> rr(rounds);
+  for (int j = 0; j < rounds; j++) {
+    for (int i = 0; i < nc; i++) rr[j].d[i] = tape.challenge_scalar("d_vec");
+    rr[j].r_delta = tape.challenge_scalar("r_delta");
+    rr[j].r_beta = tape.challenge_scalar("r_beta");
+  }
+  std::vector<CG> delta(rounds);
+  std::vector<Point> P_bp(rounds), P_be(rounds), P_rb(rounds);
+#pragma omp parallel for schedule(dynamic, 1) num_threads(host_threads())
+  for (int j = 0; j < rounds; j++) {
+    delta[j] = compress(commit(rr[j].d, nc, rr[j].r_delta, gn));
+    P_bp[j] = gn.h->mul(blinds_poly[j]);
+    P_be[j] = g1.h->mul(blinds_evals[j]);
+    P_rb[j] = g1.h->mul(rr[j].r_beta);
+  }
   Fq claim_pr = claim;
   CG comm_claim = compress(commit1(claim_pr, blind_claim, g1));
   r_out.clear();
-  Fq r_prev = Fq::zero();
+  int rc = vpin::sc_round_launch(c, K, tabs, nullptr);
+  if (rc) return rc;
+  Fq r_j = Fq::zero();
   for (int j = 0; j < rounds; j++) {
     Fq e[3];
-    int rc;
-    if (j == 0) {
-      rc = (K == 4) ? vpin_sc_cubic_round(c, tabs[0], tabs[1], tabs[2], tabs[3], B(e))
-                    : vpin_sc_quad_round(c, tabs[0], tabs[1], B(e));
-    } else {
-      rc = (K == 4) ? vpin_sc_cubic_bind_round(c, tabs[0], tabs[1], tabs[2], tabs[3], B(&r_prev), B(e))
-                    : vpin_sc_quad_bind_round(c, tabs[0], tabs[1], B(&r_prev), B(e));
-    }
-    if (rc) return rc;
+    if ((rc = vpin::sc_round_wait(c, K, B(e)))) return rc;
     Fq evals[4], coeffs[4];
     evals[0] = e[0]; evals[1] = claim_pr - e[0]; evals[2] = e[1];
     if (K == 4) evals[3] = e[2];
     unipoly_from_evals(evals, nc, coeffs);
-    CG comm_poly = compress(commit(coeffs, nc, blinds_poly[j], gn));
+    Point cp = P_bp[j];
+    for (int i = 0; i < nc; i++) gn.G[i]->mul_acc(cp, coeffs[i]);
+    CG comm_poly = compress(cp);
     tr.append_point("comm_poly", comm_poly.b);
     pf.comm_polys.push_back(comm_poly);
-    Fq r_j = tr.challenge_scalar("challenge_nextround");
+    r_j = tr.challenge_scalar("challenge_nextround");
+    // fold with r_j and evaluate the next round while the host finishes this one
+    if (j + 1 < rounds && (rc = vpin::sc_round_launch(c, K, tabs, B(&r_j)))) return rc;
     Fq eval = unipoly_eval(coeffs, nc, r_j);
-    CG comm_eval = compress(commit1(eval, blinds_evals[j], g1));
+    Point ce = P_be[j];
+    g1.G[0]->mul_acc(ce, eval);
+    CG comm_eval = compress(ce);
     tr.append_point("comm_claim_per_round", comm_claim.b);
     tr.append_point("comm_eval", comm_eval.b);
     std::vector<Fq> w = tr.challenge_vector("combine_two_claims_to_one", 2);
@@ -302,16 +342,34 @@ static int zk_sumcheck(vpin_ctx* c, int K, vpin_table** tabs, const Fq& claim, c
       a[i] = w[0] * a_sc + w[1] * pw;
       pw = pw * r_j;
     }
+    // DotProductProof::prove (nizk/mod.rs:315-374); Cx is this round's comm_poly
     pf.proofs.emplace_back();
-    dotproduct_prove(pf.proofs.back(), g1, gn, tr, tape, coeffs, blinds_poly[j], a, target, blind, nc, comm_poly);
+    DotProof& dp = pf.proofs.back();
+    tr.append_protocol_name("dot product proof");
+    tr.append_point("Cx", comm_poly.b);
+    CG Cy = compress(commit1(target, blind, g1));
+    tr.append_point("Cy", Cy.b);
+    tr.append_scalars("a", a, nc);
+    dp.delta = delta[j];
+    tr.append_point("delta", dp.delta.b);
+    Fq ad = Fq::zero();
+    for (int i = 0; i < nc; i++) ad = ad + a[i] * rr[j].d[i];
+    Point pb = P_rb[j];
+    g1.G[0]->mul_acc(pb, ad);
+    dp.beta = compress(pb);
+    tr.append_point("beta", dp.beta.b);
+    Fq cc = tr.challenge_scalar("c");
+    dp.z.resize(nc);
+    for (int i = 0; i < nc; i++) dp.z[i] = cc * coeffs[i] + rr[j].d[i];
+    dp.z_delta = cc * blinds_poly[j] + rr[j].r_delta;
+    dp.z_beta = cc * blind + rr[j].r_beta;
     claim_pr = eval;
     comm_claim = comm_eval;
     r_out.push_back(r_j);
     pf.comm_evals.push_back(comm_eval);
-    r_prev = r_j;
   }
   // last fold (sumcheck.rs:673-676 of the final round), then the final claims P[0]
-  int rc = vpin_sc_bind(c, tabs, K, B(&r_prev));
+  rc = vpin_sc_bind(c, tabs, K, B(&r_j));
   if (rc) return rc;
   for (int k = 0; k < K; k++) {
     rc = vpin_table_read(c, tabs[k], 0, 1, B(&final_claims[k]));

@@ -240,17 +240,18 @@ int vpin_r1cs_build_z(vpin_ctx* c, const vpin_r1cs_dev* d, const vpin_table* var
   vpin_table* z = nullptr;
   int rc = vpin_table_alloc(c, 2 * d->num_vars, &z);
   if (rc) return rc;
+  DevBuf bin(c);
   fq* d_in = nullptr;
   if (d->num_inputs) {
-    if (hipMalloc((void**)&d_in, d->num_inputs * 32) != hipSuccess) { vpin_table_free(c, z); return VPIN_ENOMEM; }
+    if (bin.alloc(d->num_inputs * 32)) { vpin_table_free(c, z); return VPIN_ENOMEM; }
+    d_in = (fq*)bin.p;
     (void)hipMemcpyAsync(d_in, inputs, d->num_inputs * 32, hipMemcpyHostToDevice, c->stream);
   }
   (void)hipMemcpyAsync(z->d, vars->d, d->num_vars * 32, hipMemcpyDeviceToDevice, c->stream);
   hipLaunchKernelGGL(build_z_hi_kernel, dim3((unsigned)((d->num_vars + kRB - 1) / kRB)), dim3(kRB), 0, c->stream, z->d,
                      d->num_vars, d_in, d->num_inputs);
   hipError_t e = hipGetLastError();
-  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-  if (d_in) (void)hipFree(d_in);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);  // `inputs` is a caller buffer
   if (e != hipSuccess) { set_last_error("vpin_r1cs_build_z", e); vpin_table_free(c, z); return VPIN_EHIP; }
   *out_z = z;
   return VPIN_OK;
@@ -308,12 +309,13 @@ int vpin_r1cs_evaluate(vpin_ctx* c, const vpin_r1cs_dev* d, const vpin_table* ev
   if (evals_rx->len != d->num_cons || evals_ry->len != 2 * d->num_vars) return VPIN_ESHAPE;
   (void)hipSetDevice(c->device);
   const size_t ncols = 2 * d->num_vars;
-  fq* d_out = nullptr;
-  if (hipMalloc((void**)&d_out, 96) != hipSuccess) return VPIN_ENOMEM;
+  DevBuf bo(c);
+  if (bo.alloc(96)) return VPIN_ENOMEM;
+  fq* d_out = (fq*)bo.p;
   int grid = (int)std::min<size_t>((ncols + kRB - 1) / kRB, 1024);
   for (int m = 0; m < 3; m++) {
     int nparts = grid + (int)d->n_long[m];
-    if ((size_t)nparts > c->partials_cap) { (void)hipFree(d_out); return VPIN_ESHAPE; }
+    if ((size_t)nparts > c->partials_cap) return VPIN_ESHAPE;
     hipLaunchKernelGGL(evaluate_kernel, dim3(grid), dim3(kRB), 0, c->stream, d->colptr[m], d->csc_row[m], d->csc_val[m],
                        evals_rx->d, evals_ry->d, ncols, c->d_partials);
     if (d->n_long[m])
@@ -324,7 +326,6 @@ int vpin_r1cs_evaluate(vpin_ctx* c, const vpin_r1cs_dev* d, const vpin_table* ev
   hipError_t e = hipGetLastError();
   if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, 96, hipMemcpyDeviceToHost, c->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-  (void)hipFree(d_out);
   if (e != hipSuccess) { set_last_error("vpin_r1cs_evaluate", e); return VPIN_EHIP; }
   return VPIN_OK;
 }

@@ -213,17 +213,15 @@ static int check_tabs(vpin_ctx* c, const vpin_table* const* t, size_t min_len) {
 }
 
 template <int NE>
-static int finish_and_fetch(vpin_ctx* c, int nblocks, uint8_t* out) {
+static int finish_launch(vpin_ctx* c, int nblocks) {
   hipLaunchKernelGGL((sc_finish_kernel<NE>), dim3(1), dim3(kBlock), 0, c->stream, c->d_partials, nblocks, c->d_out);
   VPIN_HIP_TRY(hipGetLastError());
   VPIN_HIP_TRY(hipMemcpyAsync(c->h_out, c->d_out, NE * sizeof(fq), hipMemcpyDeviceToHost, c->stream));
-  VPIN_HIP_TRY(hipStreamSynchronize(c->stream));
-  memcpy(out, c->h_out, NE * sizeof(fq));
   return VPIN_OK;
 }
 
 template <int K>
-static int run_eval(vpin_ctx* c, const vpin_table* const* t, uint8_t* out, int kclass) {
+static int launch_eval(vpin_ctx* c, const vpin_table* const* t, int kclass) {
   int rc = check_tabs<K>(c, t, 2);
   if (rc) return rc;
   (void)hipSetDevice(c->device);
@@ -236,14 +234,14 @@ static int run_eval(vpin_ctx* c, const vpin_table* const* t, uint8_t* out, int k
     hipLaunchKernelGGL((sc_eval_kernel<K>), dim3(grid), dim3(kBlock), 0, c->stream, tabs, half, c->d_partials);
   }
   VPIN_HIP_TRY(hipGetLastError());
-  return finish_and_fetch<Acc<K>::NE>(c, grid, out);
+  return finish_launch<Acc<K>::NE>(c, grid);
 }
 
 template <int K>
-static int run_bind_eval(vpin_ctx* c, vpin_table* const* t, const uint8_t* r, uint8_t* out, int kclass) {
+static int launch_bind_eval(vpin_ctx* c, vpin_table* const* t, const uint8_t* r, int kclass) {
   int rc = check_tabs<K>(c, t, 4);
   if (rc) return rc;
-  if (!r || !out) return VPIN_EINVAL;
+  if (!r) return VPIN_EINVAL;
   (void)hipSetDevice(c->device);
   Tabs<K> tabs;
   for (int k = 0; k < K; k++) tabs.t[k] = t[k]->d;
@@ -257,8 +255,37 @@ static int run_bind_eval(vpin_ctx* c, vpin_table* const* t, const uint8_t* r, ui
   }
   VPIN_HIP_TRY(hipGetLastError());
   for (int k = 0; k < K; k++) t[k]->len = len / 2;
-  return finish_and_fetch<Acc<K>::NE>(c, grid, out);
+  return finish_launch<Acc<K>::NE>(c, grid);
 }
+
+static int fetch(vpin_ctx* c, int ne, uint8_t* out) {
+  VPIN_HIP_TRY(hipStreamSynchronize(c->stream));
+  memcpy(out, c->h_out, (size_t)ne * sizeof(fq));
+  return VPIN_OK;
+}
+
+template <int K>
+static int run_eval(vpin_ctx* c, const vpin_table* const* t, uint8_t* out, int kclass) {
+  int rc = launch_eval<K>(c, t, kclass);
+  return rc ? rc : fetch(c, Acc<K>::NE, out);
+}
+
+template <int K>
+static int run_bind_eval(vpin_ctx* c, vpin_table* const* t, const uint8_t* r, uint8_t* out, int kclass) {
+  if (!out) return VPIN_EINVAL;
+  int rc = launch_bind_eval<K>(c, t, r, kclass);
+  return rc ? rc : fetch(c, Acc<K>::NE, out);
+}
+
+// Asynchronous halves used by the host prover to overlap a round's kernel with the previous
+// round's transcript work: launch now, collect the 2-3 scalars later.  K = 4 (cubic) or 2 (quad);
+// r == nullptr evaluates the tables as they are, otherwise binds with r first (fused kernel).
+int sc_round_launch(vpin_ctx* c, int K, vpin_table* const* tabs, const uint8_t* r) {
+  if (K == 4) return r ? launch_bind_eval<4>(c, tabs, r, VPIN_K_SC_CUBIC_FUSED) : launch_eval<4>(c, tabs, VPIN_K_SC_CUBIC);
+  if (K == 2) return r ? launch_bind_eval<2>(c, tabs, r, VPIN_K_SC_QUAD_FUSED) : launch_eval<2>(c, tabs, VPIN_K_SC_QUAD);
+  return VPIN_EINVAL;
+}
+int sc_round_wait(vpin_ctx* c, int K, uint8_t* out) { return fetch(c, K == 4 ? 3 : 2, out); }
 
 }  // namespace vpin
 

@@ -118,6 +118,12 @@ int vpin_hyrax_commit_pair(vpin_ctx* ctx, const vpin_gens* g, const vpin_table* 
 int vpin_gens_msm(vpin_ctx* ctx, const vpin_gens* g, const uint8_t* scalars_mont, size_t rows, size_t ncols,
                   uint8_t* out_compressed /* rows*32 */, uint8_t* out_xyzt /* rows*128 */);
 
+/* Same MSM for the few-row, latency-bound case: returns the per-workgroup partial points
+ * (X|Y|Z|T, 128 B each, rows x vpin_gens_msm_parts_count(ncols)); the caller adds them. */
+size_t vpin_gens_msm_parts_count(size_t ncols);
+int vpin_gens_msm_parts(vpin_ctx* ctx, const vpin_gens* g, const uint8_t* scalars_mont, size_t rows, size_t ncols,
+                        uint8_t* parts_xyzt);
+
 /* DensePolynomial::bound (Spartan/src/dense_mlpoly.rs:220-227): LZ[i] = sum_j L[j]*Z[j*R+i],
  * Lvec = L_size host scalars, out = R = len/L_size host scalars. */
 int vpin_poly_bound(vpin_ctx* ctx, const vpin_table* Z, const uint8_t* Lvec, size_t L_size, uint8_t* out_LZ);
@@ -223,6 +229,7 @@ int vpin_host_commit(const char* label, const uint8_t* v_mont, size_t n, const u
 #define VPIN_K_SC_QUAD_FUSED 4
 #define VPIN_K_EQ 5
 #define VPIN_K_MSM 6
+#define VPIN_K_SC_TAIL 7 /* single-workgroup tail rounds (<= 512 pairs), latency bound */
 #define VPIN_K_COUNT 16
 typedef struct {
   uint64_t launches;

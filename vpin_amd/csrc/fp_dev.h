@@ -11,6 +11,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "fq_dev.h"  // acc96 / mac_column: the shared multiply-accumulate building block
+
 namespace vpin {
 
 struct alignas(16) fp {
@@ -102,23 +104,19 @@ __device__ __forceinline__ fp fp_neg(const fp& a) { return fp_sub(fp_zero(), a);
 #define VPIN_FPMUL_INLINE __forceinline__
 #endif
 
-// a*b mod p (weakly reduced): 8x8 schoolbook then fold the high half with 38
+// a*b mod p (weakly reduced): 8x8 product-scanning multiply on the asm MAC block (fq_dev.h),
+// then the high half folds in with 2^256 = 38 (mod p)
 __device__ VPIN_FPMUL_INLINE fp fp_mul(fp a, fp b) {
+  acc96 c{0, 0};
   uint32_t t[16];
-#pragma unroll
-  for (int i = 0; i < 16; i++) t[i] = 0;
-#pragma unroll
-  for (int i = 0; i < 8; i++) {
-    uint64_t c = 0;
-    uint32_t bi = b.v[i];
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-      c += (uint64_t)a.v[j] * bi + t[i + j];
-      t[i + j] = (uint32_t)c;
-      c >>= 32;
-    }
-    t[i + 8] = (uint32_t)c;
-  }
+#define VPIN_FP_COL(k)                                                            \
+  mac_column<k, (k > 7 ? k - 7 : 0), (k < 7 ? k : 7)>(c, a.v, b.v);                \
+  t[k] = (uint32_t)c.lo;                                                           \
+  acc_shift(c);
+  VPIN_FP_COL(0) VPIN_FP_COL(1) VPIN_FP_COL(2) VPIN_FP_COL(3) VPIN_FP_COL(4) VPIN_FP_COL(5) VPIN_FP_COL(6) VPIN_FP_COL(7)
+  VPIN_FP_COL(8) VPIN_FP_COL(9) VPIN_FP_COL(10) VPIN_FP_COL(11) VPIN_FP_COL(12) VPIN_FP_COL(13) VPIN_FP_COL(14)
+#undef VPIN_FP_COL
+  t[15] = (uint32_t)c.lo;
   fp r;
   uint64_t k = 0;
 #pragma unroll

@@ -147,30 +147,93 @@ __device__ __forceinline__ fq fq_dbl(const fq& a) { return fq_add(a, a); }
     (t)[8] = (t9) + (uint32_t)c_;                                          \
   }
 
-// Montgomery product a*b*R^{-1} mod q (ristretto255.rs:701-726 + :653-698), CIOS form.
+// ---- multiply-accumulate building block ------------------------------------------------------
+// A column accumulator is 96 bits: acc (64) + ovf (32).  One MAC is v_mad_u64_u32 (32x32+64,
+// carry-out to an SGPR pair) followed by v_addc_co_u32 folding that carry into ovf -- two
+// instructions per limb product, against ~6 for what hipcc derives from portable C (measured on
+// MI355X: profiles/r01_ubench_valu.txt).  MACs are issued in pairs (mad, mad, addc, addc) so the
+// VALU-writes-SGPR -> VALU-reads-SGPR wait state is filled with the second multiply instead of an
+// s_nop; each instruction is its own asm statement, so hipcc's hazard recognizer still sees every
+// operand and pads whatever this ordering leaves open.
+struct acc96 {
+  uint64_t lo;
+  uint32_t hi;
+};
+
+__device__ __forceinline__ void mac1(acc96& c, uint32_t a, uint32_t b) {
+  uint64_t cy;
+  asm("v_mad_u64_u32 %0, %1, %2, %3, %0" : "+v"(c.lo), "=s"(cy) : "v"(a), "v"(b));
+  asm("v_addc_co_u32 %0, vcc, %0, 0, %1" : "+v"(c.hi) : "s"(cy) : "vcc");
+}
+
+__device__ __forceinline__ void mac2(acc96& c, uint32_t a0, uint32_t b0, uint32_t a1, uint32_t b1) {
+  uint64_t cy0, cy1;
+  // volatile: keeps the (mad, mad, addc, addc) order, which is what fills the wait state
+  asm volatile("v_mad_u64_u32 %0, %1, %2, %3, %0" : "+v"(c.lo), "=s"(cy0) : "v"(a0), "v"(b0));
+  asm volatile("v_mad_u64_u32 %0, %1, %2, %3, %0" : "+v"(c.lo), "=s"(cy1) : "v"(a1), "v"(b1));
+  asm volatile("v_addc_co_u32 %0, vcc, %0, 0, %1" : "+v"(c.hi) : "s"(cy0) : "vcc");
+  asm volatile("v_addc_co_u32 %0, vcc, %0, 0, %1" : "+v"(c.hi) : "s"(cy1) : "vcc");
+}
+
+// c += x (64-bit) with carry into hi
+__device__ __forceinline__ void acc_add64(acc96& c, uint64_t x) {
+  uint64_t t = c.lo + x;
+  c.hi += (t < x) ? 1u : 0u;
+  c.lo = t;
+}
+
+// next column: drop the low 32 bits
+__device__ __forceinline__ void acc_shift(acc96& c) {
+  c.lo = (c.lo >> 32) | ((uint64_t)c.hi << 32);
+  c.hi = 0;
+}
+
+// sum_{i+j=k} a_i*b_j for the limb range [lo_i, hi_i], paired
+template <int K, int I0, int I1>
+__device__ __forceinline__ void mac_column(acc96& c, const uint32_t* a, const uint32_t* b) {
+  constexpr int n = I1 - I0 + 1;
+#pragma unroll
+  for (int t = 0; t + 1 < n; t += 2) mac2(c, a[I0 + t], b[K - I0 - t], a[I0 + t + 1], b[K - I0 - t - 1]);
+  if (n & 1) mac1(c, a[I1], b[K - I1]);
+}
+
+// Montgomery product a*b*R^{-1} mod q (ristretto255.rs:701-726 + :653-698), product-scanning
+// (FIPS) form: column k collects a_i*b_j (i+j=k) and m_i*q_j (i+j=k); q_4..q_6 = 0 and
+// q_7 = 2^28, so the reduction costs 4 multiplies and one shift-add per m_i.
 __device__ VPIN_MUL_INLINE fq fq_mul(fq a, fq b) {
-  uint32_t t[9];
-#pragma unroll
-  for (int i = 0; i < 9; i++) t[i] = 0;
-#pragma unroll
-  for (int i = 0; i < 8; i++) {
-    uint64_t c = 0;
-    uint32_t bi = b.v[i];
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-      c += (uint64_t)a.v[j] * bi + t[j];
-      t[j] = (uint32_t)c;
-      c >>= 32;
-    }
-    c += t[8];
-    t[8] = (uint32_t)c;
-    uint32_t t9 = (uint32_t)(c >> 32);
-    VPIN_MONT_STEP(t, t9);
-  }
+  acc96 c{0, 0};
+  uint32_t m[8];
   fq r;
-#pragma unroll
-  for (int i = 0; i < 8; i++) r.v[i] = t[i];
-  return fq_cond_sub_q(r);  // t < 2q, t[8] == 0
+  const uint32_t q0 = VPIN_Q0, q1 = VPIN_Q1, q2 = VPIN_Q2, q3 = VPIN_Q3;
+#define VPIN_M(i) m[(i) < 0 ? 0 : (i) > 7 ? 7 : (i)]
+  // columns 0..7: a*b terms, m_i*q_{k-i} for the earlier m's, then m_k cancels the low word
+#define VPIN_FQ_LOW_COL(k)                                                                  \
+  mac_column<k, 0, k>(c, a.v, b.v);                                                          \
+  if (k >= 2) mac2(c, VPIN_M(k - 1), q1, VPIN_M(k - 2), q2);                                  \
+  else if (k == 1) mac1(c, VPIN_M(0), q1);                                                   \
+  if (k >= 3) mac1(c, VPIN_M(k - 3), q3);                                                    \
+  if (k >= 7) acc_add64(c, (uint64_t)VPIN_M(k - 7) << 28);                                   \
+  m[k] = (uint32_t)c.lo * VPIN_QINV32;                                                       \
+  mac1(c, m[k], q0);                                                                         \
+  acc_shift(c);
+  VPIN_FQ_LOW_COL(0) VPIN_FQ_LOW_COL(1) VPIN_FQ_LOW_COL(2) VPIN_FQ_LOW_COL(3)
+  VPIN_FQ_LOW_COL(4) VPIN_FQ_LOW_COL(5) VPIN_FQ_LOW_COL(6) VPIN_FQ_LOW_COL(7)
+#undef VPIN_FQ_LOW_COL
+  // columns 8..14: remaining a*b terms and m_i*q_j with j = k-i in {1,2,3,7}, i <= 7
+#define VPIN_FQ_HIGH_COL(k)                                                                 \
+  mac_column<k, k - 7, 7>(c, a.v, b.v);                                                      \
+  if (k == 8) mac2(c, VPIN_M(7), q1, VPIN_M(6), q2);                                          \
+  if (k == 9) mac1(c, VPIN_M(7), q2);                                                        \
+  if (k <= 10) mac1(c, VPIN_M(k - 3), q3);                                                   \
+  acc_add64(c, (uint64_t)VPIN_M(k - 7) << 28);                                               \
+  r.v[k - 8] = (uint32_t)c.lo;                                                               \
+  acc_shift(c);
+  VPIN_FQ_HIGH_COL(8) VPIN_FQ_HIGH_COL(9) VPIN_FQ_HIGH_COL(10) VPIN_FQ_HIGH_COL(11)
+  VPIN_FQ_HIGH_COL(12) VPIN_FQ_HIGH_COL(13) VPIN_FQ_HIGH_COL(14)
+#undef VPIN_FQ_HIGH_COL
+#undef VPIN_M
+  r.v[7] = (uint32_t)c.lo;  // column 15: only the carry
+  return fq_cond_sub_q(r);  // result < 2q
 }
 
 __device__ __forceinline__ fq fq_sqr(const fq& a) { return fq_mul(a, a); }

@@ -152,6 +152,59 @@ __global__ __launch_bounds__(kMsmBlock) void msm_rows_kernel(const fq* __restric
   }
 }
 
+// Few-row MSMs (the evaluation proof's bullet rounds: 1-2 rows of R+2 scalars) are latency bound,
+// so the 32 windows of a scalar are spread over 8 threads (4 table adds each) and a 256-thread
+// workgroup covers 32 scalars; the per-workgroup partial points go back to the host, which adds
+// the few dozen partials and compresses (microseconds on a CPU core, ~0.4 ms as a GPU tail).
+constexpr int kWideScalars = 32;  // scalars per workgroup
+__global__ __launch_bounds__(kMsmBlock) void msm_wide_kernel(const fq* __restrict__ S, size_t ncols,
+                                                             const ge_cached* __restrict__ table, size_t nb,
+                                                             fp* __restrict__ parts_xyzt) {
+  const size_t row = blockIdx.y;
+  const size_t j = (size_t)blockIdx.x * kWideScalars + (threadIdx.x >> 3);
+  const int grp = threadIdx.x & 7;  // windows [4*grp, 4*grp+4)
+  ge_ext acc = ge_identity();
+  if (j < ncols) {
+    fq s = fq_load(S + row * ncols + j);
+    if (!fq_is_zero(s)) {
+      s = fq_from_mont(s);
+      // signed-digit carry into window 4*grp: set iff the nearest lower byte != 0x80 is > 0x80
+      uint32_t carry = 0;
+      for (int w = 4 * grp - 1; w >= 0; w--) {
+        uint32_t byte = (s.v[w >> 2] >> ((w & 3) * 8)) & 0xffu;
+        if (byte != 128u) { carry = byte > 128u ? 1u : 0u; break; }
+      }
+      uint32_t limb = s.v[grp];
+#pragma unroll 1
+      for (int t = 0; t < 4; t++) {
+        uint32_t v = ((limb >> (8 * t)) & 0xffu) + carry;
+        bool neg = v > 128u;
+        uint32_t mag = neg ? 256u - v : v;
+        carry = neg ? 1u : 0u;
+        if (mag != 0) {
+          int w = 4 * grp + t;
+          ge_cached e = cached_load(table + ((size_t)w * nb + j) * kEntries + (mag - 1));
+          acc = ge_add_cached(acc, e, neg);
+        }
+      }
+    }
+  }
+  __shared__ ge_ext sh[kMsmBlock];
+  sh[threadIdx.x] = acc;
+  __syncthreads();
+  for (int st = kMsmBlock / 2; st >= 1; st >>= 1) {
+    if ((int)threadIdx.x < st) {
+      acc = ge_add(acc, sh[threadIdx.x + st]);
+      sh[threadIdx.x] = acc;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    fp* o = parts_xyzt + 4 * (row * gridDim.x + blockIdx.x);
+    fp_store(o, fp_freeze(acc.X)); fp_store(o + 1, fp_freeze(acc.Y)); fp_store(o + 2, fp_freeze(acc.Z)); fp_store(o + 3, fp_freeze(acc.T));
+  }
+}
+
 // out[row] = sum of the `chunks` partial points of that row
 __global__ __launch_bounds__(64) void ge_sum_chunks_kernel(const ge_ext* __restrict__ parts, size_t rows, int chunks,
                                                            ge_ext* __restrict__ out) {
@@ -314,6 +367,29 @@ int vpin_hyrax_commit_pair(vpin_ctx* c, const vpin_gens* g, const vpin_table* Za
   VPIN_HIP_TRY(hipMemcpyAsync(out_a, dout.p, L * 32, hipMemcpyDeviceToHost, c->stream));
   VPIN_HIP_TRY(hipMemcpyAsync(out_b, (uint8_t*)dout.p + L * 32, L * 32, hipMemcpyDeviceToHost, c->stream));
   VPIN_HIP_TRY(hipMemcpyAsync(out_sum, (uint8_t*)dout.p + 2 * L * 32, L * 32, hipMemcpyDeviceToHost, c->stream));
+  VPIN_HIP_TRY(hipStreamSynchronize(c->stream));
+  return VPIN_OK;
+}
+
+// partial points of few-row MSMs: parts_xyzt must hold rows * vpin_gens_msm_parts_count(ncols) * 128 bytes
+size_t vpin_gens_msm_parts_count(size_t ncols) { return (ncols + kWideScalars - 1) / kWideScalars; }
+
+int vpin_gens_msm_parts(vpin_ctx* c, const vpin_gens* g, const uint8_t* scalars_mont, size_t rows, size_t ncols,
+                        uint8_t* parts_xyzt) {
+  if (!c || !g || !scalars_mont || !parts_xyzt || rows == 0 || ncols == 0) return VPIN_EINVAL;
+  if (ncols > g->nb) return VPIN_ESHAPE;
+  (void)hipSetDevice(c->device);
+  const size_t nparts = vpin_gens_msm_parts_count(ncols);
+  DevBuf ds(c), dp(c);
+  if (ds.alloc(rows * ncols * 32) || dp.alloc(rows * nparts * 128)) return VPIN_ENOMEM;
+  VPIN_HIP_TRY(hipMemcpyAsync(ds.p, scalars_mont, rows * ncols * 32, hipMemcpyHostToDevice, c->stream));
+  {
+    ProfScope ps(c, VPIN_K_MSM, 32.0 * (double)rows * (double)ncols);
+    hipLaunchKernelGGL(msm_wide_kernel, dim3((unsigned)nparts, (unsigned)rows), dim3(kMsmBlock), 0, c->stream, (const fq*)ds.p,
+                       ncols, g->table, g->nb, (fp*)dp.p);
+  }
+  VPIN_HIP_TRY(hipGetLastError());
+  VPIN_HIP_TRY(hipMemcpyAsync(parts_xyzt, dp.p, rows * nparts * 128, hipMemcpyDeviceToHost, c->stream));
   VPIN_HIP_TRY(hipStreamSynchronize(c->stream));
   return VPIN_OK;
 }

@@ -25,6 +25,9 @@
 #include "host/transcript.h"
 
 extern "C" {
+size_t vpin_gens_msm_parts_count(size_t ncols);
+int vpin_gens_msm_parts(vpin_ctx* ctx, const vpin_gens* g, const uint8_t* scalars_mont, size_t rows, size_t ncols,
+                        uint8_t* parts_xyzt);
 int vpin_poly_bound(vpin_ctx* c, const vpin_table* Z, const uint8_t* Lvec, size_t L_size, uint8_t* out_LZ);
 void vpin_r1cs_dims(const vpin_r1cs_dev* d, size_t* num_cons, size_t* num_vars, size_t* num_inputs);
 }
@@ -141,6 +144,20 @@ static Point commit(const Fq* v, int n, const Fq& blind, const Mcg& g) {
   return acc;
 }
 static Point commit1(const Fq& x, const Fq& blind, const Mcg& g) { return commit(&x, 1, blind, g); }
+
+// few-row fixed-base MSM: GPU partial points, summed on the host (rows <= 2 here)
+static int msm_rows_host_sum(vpin_ctx* c, const SatGens* sg, const Fq* scalars, size_t rows, size_t ncols, Point* out) {
+  const size_t np = vpin_gens_msm_parts_count(ncols);
+  std::vector<uint8_t> parts(rows * np * 128);
+  int rc = vpin_gens_msm_parts(c, sg->dev, B(scalars), rows, ncols, parts.data());
+  if (rc) return rc;
+  for (size_t r = 0; r < rows; r++) {
+    Point acc = Point::from_xyzt(parts.data() + (r * np) * 128);
+    for (size_t k = 1; k < np; k++) acc = acc + Point::from_xyzt(parts.data() + (r * np + k) * 128);
+    out[r] = acc;
+  }
+  return VPIN_OK;
+}
 
 // ---- bincode writer ------------------------------------------------------------------------
 
@@ -593,7 +610,9 @@ static int sat_prove_core(vpin_ctx* c, const vpin_r1cs_dev* dinst, size_t nv, si
     memcpy(srow.data(), LZ.data(), R * 32);
     srow[R] = Fq::zero();
     srow[R + 1] = LZ_blind;
-    if ((rc = vpin_gens_msm(c, sg->dev, B(srow.data()), 1, ncols, Cx.b, nullptr))) return rc;
+    Point p;
+    if ((rc = msm_rows_host_sum(c, sg, srow.data(), 1, ncols, &p))) return rc;
+    Cx = compress(p);
   }
   tr.append_point("Cx", Cx.b);
   comm_vars_at_ry = compress(commit1(eval_vars_at_ry, blind_eval, sg->gens_1));
@@ -623,10 +642,10 @@ static int sat_prove_core(vpin_ctx* c, const vpin_r1cs_dev* dinst, size_t nv, si
     }
     sL[R] = cL * r_; sL[R + 1] = bv1[round];  // c_L * Q + blind_L * H,  Q = r * g[R]
     sR[R] = cR * r_; sR[R + 1] = bv2[round];
-    uint8_t lr[64];
-    if ((rc = vpin_gens_msm(c, sg->dev, B(srow.data()), 2, ncols, lr, nullptr))) return rc;
-    memcpy(Lvec[round].b, lr, 32);
-    memcpy(Rvec[round].b, lr + 32, 32);
+    Point lr[2];
+    if ((rc = msm_rows_host_sum(c, sg, srow.data(), 2, ncols, lr))) return rc;
+    Lvec[round] = compress(lr[0]);
+    Rvec[round] = compress(lr[1]);
     tr.append_point("L", Lvec[round].b);
     tr.append_point("R", Rvec[round].b);
     Fq u = tr.challenge_scalar("u"), u_inv = u.invert();
@@ -639,13 +658,12 @@ static int sat_prove_core(vpin_ctx* c, const vpin_r1cs_dev* dinst, size_t nv, si
   }
   Fq x_hat = av[0], a_hat = bvv[0], y_hat = x_hat * a_hat;
   // g_hat = sum_j s_j g_j
-  uint8_t ghat_xyzt[128], ghat_c[32];
+  Point g_hat;
   {
     std::vector<Fq> s1(ncols, Fq::zero());
     memcpy(s1.data(), sj.data(), R * 32);
-    if ((rc = vpin_gens_msm(c, sg->dev, B(s1.data()), 1, ncols, ghat_c, ghat_xyzt))) return rc;
+    if ((rc = msm_rows_host_sum(c, sg, s1.data(), 1, ncols, &g_hat))) return rc;
   }
-  Point g_hat = Point::from_xyzt(ghat_xyzt);
   CG dl_delta, dl_beta;
   {
     Point p = g_hat.mul(d_);  // d.commit(&r_delta, {G:[g_hat], h})

@@ -20,7 +20,7 @@
 namespace vpin {
 
 constexpr int kBlock = 256;
-constexpr int kMinWaves = 2;      // waves per SIMD asked of the register allocator (<=256 VGPRs)
+constexpr int kMinWaves = 3;      // waves per SIMD asked of the register allocator (<=168 VGPRs)
 constexpr int kMaxBlocks = 2048;  // 256 CUs x 8 blocks/CU, grid-stride beyond that
 
 // ---- per-pair evaluation -------------------------------------------------------------
@@ -49,6 +49,30 @@ struct Acc<4> {
 #pragma unroll
     for (int k = 0; k < 4; k++) p[k] = fq_add(p[k], d[k]);
     e[2] = fq_add(e[2], comb_cubic(p[0], p[1], p[2], p[3]));
+  }
+  // Staged form with a smaller live set: u[x] = B_x*C_x - D_x is built table by table, A is
+  // loaded last.  Each stage takes (p,d) of ONE table; the caller loads/folds that table just
+  // before the call, so at most two tables' values are live next to u[3] and e[3].
+  __device__ __forceinline__ void stage_bc(fq* u, fq pb, const fq& db, fq pc, const fq& dc) {
+    u[0] = fq_mul(pb, pc);
+    pb = fq_add(fq_add(pb, db), db); pc = fq_add(fq_add(pc, dc), dc);
+    u[1] = fq_mul(pb, pc);
+    pb = fq_add(pb, db); pc = fq_add(pc, dc);
+    u[2] = fq_mul(pb, pc);
+  }
+  __device__ __forceinline__ void stage_d(fq* u, fq pd, const fq& dd) {
+    u[0] = fq_sub(u[0], pd);
+    pd = fq_add(fq_add(pd, dd), dd);
+    u[1] = fq_sub(u[1], pd);
+    pd = fq_add(pd, dd);
+    u[2] = fq_sub(u[2], pd);
+  }
+  __device__ __forceinline__ void stage_a(const fq* u, fq pa, const fq& da) {
+    e[0] = fq_add(e[0], fq_mul(pa, u[0]));
+    pa = fq_add(fq_add(pa, da), da);
+    e[1] = fq_add(e[1], fq_mul(pa, u[1]));
+    pa = fq_add(pa, da);
+    e[2] = fq_add(e[2], fq_mul(pa, u[2]));
   }
 };
 
@@ -90,6 +114,23 @@ __device__ __forceinline__ void block_reduce_store(fq* e, fq* __restrict__ parti
   }
 }
 
+// (p, d) of one table's pair (i, i+half), unfolded
+__device__ __forceinline__ void load_pd(const fq* __restrict__ t, size_t i, size_t half, fq& p, fq& d) {
+  p = fq_load(t + i);
+  d = fq_sub(fq_load(t + half + i), p);
+}
+// fold one table's two pairs with r (dense_mlpoly.rs:232), store the folded values, return (p, d)
+__device__ __forceinline__ void fold_pd(fq* __restrict__ t, size_t i, size_t quarter, const fq& r, fq& p, fq& d) {
+  const size_t half = 2 * quarter;
+  fq a0 = fq_load(t + i), a1 = fq_load(t + half + i);
+  fq b0 = fq_load(t + quarter + i), b1 = fq_load(t + half + quarter + i);
+  p = fq_add(a0, fq_mul(r, fq_sub(a1, a0)));
+  fq hi = fq_add(b0, fq_mul(r, fq_sub(b1, b0)));
+  fq_store(t + i, p);
+  fq_store(t + quarter + i, hi);
+  d = fq_sub(hi, p);
+}
+
 // Round evaluation on tables of live length 2*half: pairs (i, i+half).
 template <int K>
 __global__ __launch_bounds__(kBlock, kMinWaves) void sc_eval_kernel(Tabs<K> tabs, size_t half,
@@ -97,13 +138,21 @@ __global__ __launch_bounds__(kBlock, kMinWaves) void sc_eval_kernel(Tabs<K> tabs
   Acc<K> acc;
   acc.init();
   for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < half; i += (size_t)gridDim.x * kBlock) {
-    fq p[K], d[K];
+    if constexpr (K == 4) {
+      fq u[3], p1, d1, p2, d2;
+      load_pd(tabs.t[1], i, half, p1, d1);
+      load_pd(tabs.t[2], i, half, p2, d2);
+      acc.stage_bc(u, p1, d1, p2, d2);
+      load_pd(tabs.t[3], i, half, p1, d1);
+      acc.stage_d(u, p1, d1);
+      load_pd(tabs.t[0], i, half, p1, d1);
+      acc.stage_a(u, p1, d1);
+    } else {
+      fq p[K], d[K];
 #pragma unroll
-    for (int k = 0; k < K; k++) {
-      p[k] = fq_load(tabs.t[k] + i);
-      d[k] = fq_sub(fq_load(tabs.t[k] + half + i), p[k]);
+      for (int k = 0; k < K; k++) load_pd(tabs.t[k], i, half, p[k], d[k]);
+      acc.add_pair(p, d);
     }
-    acc.add_pair(p, d);
   }
   block_reduce_store<Acc<K>::NE>(acc.e, partials);
 }
@@ -115,25 +164,75 @@ __global__ __launch_bounds__(kBlock, kMinWaves) void sc_bind_eval_kernel(Tabs<K>
                                                               fq* __restrict__ partials) {
   Acc<K> acc;
   acc.init();
-  const size_t half = 2 * quarter;
   for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < quarter; i += (size_t)gridDim.x * kBlock) {
-    fq p[K], d[K];
+    if constexpr (K == 4) {
+      fq u[3], p1, d1, p2, d2;
+      fold_pd(tabs.t[1], i, quarter, r, p1, d1);
+      fold_pd(tabs.t[2], i, quarter, r, p2, d2);
+      acc.stage_bc(u, p1, d1, p2, d2);
+      fold_pd(tabs.t[3], i, quarter, r, p1, d1);
+      acc.stage_d(u, p1, d1);
+      fold_pd(tabs.t[0], i, quarter, r, p1, d1);
+      acc.stage_a(u, p1, d1);
+    } else {
+      fq p[K], d[K];
 #pragma unroll
-    for (int k = 0; k < K; k++) {
-      fq a0 = fq_load(tabs.t[k] + i);
-      fq a1 = fq_load(tabs.t[k] + half + i);
-      fq b0 = fq_load(tabs.t[k] + quarter + i);
-      fq b1 = fq_load(tabs.t[k] + half + quarter + i);
-      // dense_mlpoly.rs:232: Z[i] = Z[i] + r * (Z[i+n] - Z[i])
-      p[k] = fq_add(a0, fq_mul(r, fq_sub(a1, a0)));
-      fq hi = fq_add(b0, fq_mul(r, fq_sub(b1, b0)));
-      fq_store(tabs.t[k] + i, p[k]);
-      fq_store(tabs.t[k] + quarter + i, hi);
-      d[k] = fq_sub(hi, p[k]);
+      for (int k = 0; k < K; k++) fold_pd(tabs.t[k], i, quarter, r, p[k], d[k]);
+      acc.add_pair(p, d);
+    }
+  }
+  block_reduce_store<Acc<K>::NE>(acc.e, partials);
+}
+
+// Tail rounds (tables of at most kSmallPairs pairs): one workgroup does the fold, the evaluation
+// and the whole reduction, and writes the 2-3 scalars straight to the pinned result buffer -- no
+// partials, no finisher launch.  These rounds are launch-latency bound, not bandwidth bound.
+constexpr int kSmallBlock = 512;
+constexpr size_t kSmallPairs = 512;
+
+template <int K, bool BIND>
+__global__ __launch_bounds__(kSmallBlock) void sc_tail_kernel(Tabs<K> tabs, size_t pairs, fq r, fq* __restrict__ out) {
+  Acc<K> acc;
+  acc.init();
+  const size_t i = threadIdx.x;
+  if (i < pairs) {
+    fq p[K], d[K];
+    if (BIND) {
+      const size_t quarter = pairs, half = 2 * pairs;
+#pragma unroll
+      for (int k = 0; k < K; k++) {
+        fq a0 = fq_load(tabs.t[k] + i), a1 = fq_load(tabs.t[k] + half + i);
+        fq b0 = fq_load(tabs.t[k] + quarter + i), b1 = fq_load(tabs.t[k] + half + quarter + i);
+        p[k] = fq_add(a0, fq_mul(r, fq_sub(a1, a0)));
+        fq hi = fq_add(b0, fq_mul(r, fq_sub(b1, b0)));
+        fq_store(tabs.t[k] + i, p[k]);
+        fq_store(tabs.t[k] + quarter + i, hi);
+        d[k] = fq_sub(hi, p[k]);
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < K; k++) {
+        p[k] = fq_load(tabs.t[k] + i);
+        d[k] = fq_sub(fq_load(tabs.t[k] + pairs + i), p[k]);
+      }
     }
     acc.add_pair(p, d);
   }
-  block_reduce_store<Acc<K>::NE>(acc.e, partials);
+  constexpr int NE = Acc<K>::NE;
+  __shared__ fq sh[kSmallBlock / 64][NE];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < NE; k++) {
+    fq s = fq_wave_sum(acc.e[k]);
+    if (lane == 0) sh[wave][k] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < NE) {
+    fq s = sh[0][threadIdx.x];
+#pragma unroll
+    for (int w = 1; w < kSmallBlock / 64; w++) s = fq_add(s, sh[w][threadIdx.x]);
+    fq_store(&out[threadIdx.x], s);
+  }
 }
 
 // Plain fold of K tables (live length 2*half).
@@ -214,9 +313,10 @@ static int check_tabs(vpin_ctx* c, const vpin_table* const* t, size_t min_len) {
 
 template <int NE>
 static int finish_launch(vpin_ctx* c, int nblocks) {
-  hipLaunchKernelGGL((sc_finish_kernel<NE>), dim3(1), dim3(kBlock), 0, c->stream, c->d_partials, nblocks, c->d_out);
+  // h_out is pinned host memory mapped into the device address space: the finisher writes the
+  // scalars where the host reads them after the stream sync (no memcpy node per round)
+  hipLaunchKernelGGL((sc_finish_kernel<NE>), dim3(1), dim3(kBlock), 0, c->stream, c->d_partials, nblocks, c->h_out);
   VPIN_HIP_TRY(hipGetLastError());
-  VPIN_HIP_TRY(hipMemcpyAsync(c->h_out, c->d_out, NE * sizeof(fq), hipMemcpyDeviceToHost, c->stream));
   return VPIN_OK;
 }
 
@@ -228,6 +328,12 @@ static int launch_eval(vpin_ctx* c, const vpin_table* const* t, int kclass) {
   Tabs<K> tabs;
   for (int k = 0; k < K; k++) tabs.t[k] = t[k]->d;
   size_t half = t[0]->len / 2;
+  if (half <= kSmallPairs) {
+    ProfScope ps(c, VPIN_K_SC_TAIL, (double)K * 32.0 * (double)t[0]->len);
+    hipLaunchKernelGGL((sc_tail_kernel<K, false>), dim3(1), dim3(kSmallBlock), 0, c->stream, tabs, half, fq{}, c->h_out);
+    VPIN_HIP_TRY(hipGetLastError());
+    return VPIN_OK;
+  }
   int grid = grid_for(half);
   {
     ProfScope ps(c, kclass, (double)K * 32.0 * (double)t[0]->len);
@@ -246,6 +352,16 @@ static int launch_bind_eval(vpin_ctx* c, vpin_table* const* t, const uint8_t* r,
   Tabs<K> tabs;
   for (int k = 0; k < K; k++) tabs.t[k] = t[k]->d;
   size_t len = t[0]->len, quarter = len / 4;
+  if (quarter <= kSmallPairs) {
+    {
+      ProfScope ps(c, VPIN_K_SC_TAIL, (double)K * 32.0 * ((double)len + (double)len / 2));
+      hipLaunchKernelGGL((sc_tail_kernel<K, true>), dim3(1), dim3(kSmallBlock), 0, c->stream, tabs, quarter, load_host_fq(r),
+                         c->h_out);
+    }
+    VPIN_HIP_TRY(hipGetLastError());
+    for (int k = 0; k < K; k++) t[k]->len = len / 2;
+    return VPIN_OK;
+  }
   int grid = grid_for(quarter);
   {
     // one read of every live element + one write of every folded element

@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-mult", type=int, default=18, help="point-mults in the CPU baseline sample")
     ap.add_argument("--cpu-sample-add", type=int, default=256)
+    ap.add_argument("--host-buffers", action="store_true",
+                    help="time vpin_sat_prove (instance + witness start in host memory: PCIe-inclusive; never the headline)")
     ap.add_argument("--pmc-traffic", type=float, default=None,
                     help="HBM bytes per launch of the roofline kernel from a separate rocprofv3 --pmc pass")
     return ap.parse_args()
@@ -95,8 +97,11 @@ def main():
 
     def step():
         out = []
-        for name, (di, tp, ti, tv, inp) in zip(("mult", "add"), resident):
-            out.append(ctx.sat_prove_resident(di, tp, ti, tv, inp, SEED_C, SEED_P))
+        for name, d, (di, tp, ti, tv, inp) in zip(("mult", "add"), insts, resident):
+            if args.host_buffers:
+                out.append(ctx.sat_prove(d, SEED_C, SEED_P))
+            else:
+                out.append(ctx.sat_prove_resident(di, tp, ti, tv, inp, SEED_C, SEED_P))
             last_spans[name] = ctx.sat_timings()
         return out
 
@@ -164,6 +169,13 @@ def main():
                        for name, v in stats.items()}
     line["spans_ms_last_step"] = {n: {kk: round(vv * 1e3, 3) for kk, vv in sp.items()} for n, sp in last_spans.items()}
     line["setup_s"] = round(setup_s, 3)
+    line["inputs"] = "host buffers (PCIe-inclusive, CSR/CSC built per proof)" if args.host_buffers else "resident in HBM"
+    # HBM traffic of the roofline kernel from the committed rocprofv3 --pmc passes (separate runs)
+    if "roofline" in line and line["roofline"]["traffic"] is None:
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        if os.path.exists(pmc):
+            with open(pmc) as f:
+                line["roofline"]["traffic"] = json.load(f).get("sc_bind_eval_kernel<4>", {}).get("hbm_bytes_per_launch")
 
     # ---- CPU baseline: the oracle on a bounded sample, rank 0, N=1 only ----
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -23,15 +23,21 @@ struct vpin_r1cs_dev {
   vpin::fq* csr_val[3] = {};
   uint32_t *colptr[3] = {}, *csc_row[3] = {};
   vpin::fq* csc_val[3] = {};
-  // long columns (> kLongCol entries), handled by one workgroup each
-  uint32_t* long_cols[3] = {};
-  size_t n_long[3] = {0, 0, 0};
+  // long columns (> kLongCol entries) are cut into chunks of kChunk entries; one workgroup per
+  // chunk, then one thread per long column adds its chunk partials
+  uint32_t* long_cols[3] = {};   // [n_long] column index
+  uint32_t* long_first[3] = {};  // [n_long+1] first chunk of each long column
+  uint32_t* chunk_k0[3] = {};    // [n_chunks] first entry of the chunk
+  uint32_t* chunk_k1[3] = {};    // [n_chunks] end entry
+  size_t n_long[3] = {0, 0, 0}, n_chunks[3] = {0, 0, 0};
+  vpin::fq* chunk_partials = nullptr;  // [max n_chunks]
 };
 
 namespace vpin {
 
 constexpr int kRB = 256;
 constexpr uint32_t kLongCol = 256;
+constexpr uint32_t kChunk = 2048;  // entries per workgroup for long columns
 
 __device__ __forceinline__ fq mul_special(const fq& val, const fq& x) {
   return fq_mul(val, x);
@@ -69,12 +75,11 @@ __global__ __launch_bounds__(kRB) void eval_table_kernel(const uint32_t* __restr
   fq_store(out + c, acc);
 }
 
-__global__ __launch_bounds__(kRB) void eval_table_long_kernel(const uint32_t* __restrict__ long_cols,
-                                                              const uint32_t* __restrict__ colptr, const uint32_t* __restrict__ row,
-                                                              const fq* __restrict__ val, const fq* __restrict__ rx, fq rc,
-                                                              int accumulate, fq* __restrict__ out) {
-  uint32_t c = long_cols[blockIdx.x];
-  uint32_t k0 = colptr[c], k1 = colptr[c + 1];
+// chunk partial: part[ch] = sum_{k in chunk} val[k] * rx[row[k]]
+__global__ __launch_bounds__(kRB) void long_chunk_kernel(const uint32_t* __restrict__ chunk_k0, const uint32_t* __restrict__ chunk_k1,
+                                                         const uint32_t* __restrict__ row, const fq* __restrict__ val,
+                                                         const fq* __restrict__ rx, fq* __restrict__ part) {
+  uint32_t k0 = chunk_k0[blockIdx.x], k1 = chunk_k1[blockIdx.x];
   fq acc = fq_zero();
   for (uint32_t k = k0 + threadIdx.x; k < k1; k += kRB) acc = fq_add(acc, fq_mul(fq_load(val + k), fq_load(rx + row[k])));
   __shared__ fq sh[kRB / 64];
@@ -84,10 +89,35 @@ __global__ __launch_bounds__(kRB) void eval_table_long_kernel(const uint32_t* __
   if (threadIdx.x == 0) {
     fq t = sh[0];
     for (int w = 1; w < kRB / 64; w++) t = fq_add(t, sh[w]);
-    t = fq_mul(t, rc);
-    if (accumulate) t = fq_add(t, fq_load(out + c));
-    fq_store(out + c, t);
+    fq_store(part + blockIdx.x, t);
   }
+}
+
+// one thread per long column: out[c] (+)= rc * sum of its chunk partials
+__global__ __launch_bounds__(64) void eval_table_long_finish_kernel(const uint32_t* __restrict__ long_cols,
+                                                                    const uint32_t* __restrict__ long_first, size_t n_long,
+                                                                    const fq* __restrict__ part, fq rc, int accumulate,
+                                                                    fq* __restrict__ out) {
+  size_t i = (size_t)blockIdx.x * 64 + threadIdx.x;
+  if (i >= n_long) return;
+  fq t = fq_zero();
+  for (uint32_t ch = long_first[i]; ch < long_first[i + 1]; ch++) t = fq_add(t, fq_load(part + ch));
+  t = fq_mul(t, rc);
+  uint32_t c = long_cols[i];
+  if (accumulate) t = fq_add(t, fq_load(out + c));
+  fq_store(out + c, t);
+}
+
+// one thread per long column: partials[i] = ry[c] * sum of its chunk partials
+__global__ __launch_bounds__(64) void evaluate_long_finish_kernel(const uint32_t* __restrict__ long_cols,
+                                                                  const uint32_t* __restrict__ long_first, size_t n_long,
+                                                                  const fq* __restrict__ part, const fq* __restrict__ ry,
+                                                                  fq* __restrict__ partials) {
+  size_t i = (size_t)blockIdx.x * 64 + threadIdx.x;
+  if (i >= n_long) return;
+  fq t = fq_zero();
+  for (uint32_t ch = long_first[i]; ch < long_first[i + 1]; ch++) t = fq_add(t, fq_load(part + ch));
+  fq_store(partials + i, fq_mul(t, fq_load(ry + long_cols[i])));
 }
 
 // partials[block] = sum_k rx[row[k]] * ry[col[k]] * val[k]   (CSR order: row index recovered by search)
@@ -111,25 +141,6 @@ __global__ __launch_bounds__(kRB) void evaluate_kernel(const uint32_t* __restric
     fq t = sh[0];
     for (int w = 1; w < kRB / 64; w++) t = fq_add(t, sh[w]);
     fq_store(partials + blockIdx.x, t);
-  }
-}
-
-__global__ __launch_bounds__(kRB) void evaluate_long_kernel(const uint32_t* __restrict__ long_cols, const uint32_t* __restrict__ colptr,
-                                                            const uint32_t* __restrict__ row, const fq* __restrict__ val,
-                                                            const fq* __restrict__ rx, const fq* __restrict__ ry,
-                                                            fq* __restrict__ partials) {
-  uint32_t c = long_cols[blockIdx.x];
-  uint32_t k0 = colptr[c], k1 = colptr[c + 1];
-  fq acc = fq_zero();
-  for (uint32_t k = k0 + threadIdx.x; k < k1; k += kRB) acc = fq_add(acc, fq_mul(fq_load(val + k), fq_load(rx + row[k])));
-  __shared__ fq sh[kRB / 64];
-  fq s = fq_wave_sum(acc);
-  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    fq t = sh[0];
-    for (int w = 1; w < kRB / 64; w++) t = fq_add(t, sh[w]);
-    fq_store(partials + blockIdx.x, fq_mul(t, fq_load(ry + c)));
   }
 }
 
@@ -180,10 +191,12 @@ void vpin_r1cs_free(vpin_ctx* c, vpin_r1cs_dev* d) {
   if (!d) return;
   if (c) { (void)hipSetDevice(c->device); (void)hipStreamSynchronize(c->stream); }
   for (int m = 0; m < 3; m++) {
-    void* ps[] = {d->rowptr[m], d->csr_col[m], d->csr_val[m], d->colptr[m], d->csc_row[m], d->csc_val[m], d->long_cols[m]};
+    void* ps[] = {d->rowptr[m], d->csr_col[m], d->csr_val[m], d->colptr[m], d->csc_row[m], d->csc_val[m], d->long_cols[m],
+                  d->long_first[m], d->chunk_k0[m], d->chunk_k1[m]};
     for (void* p : ps)
       if (p) (void)hipFree(p);
   }
+  if (d->chunk_partials) (void)hipFree(d->chunk_partials);
   delete d;
 }
 
@@ -216,16 +229,30 @@ int vpin_r1cs_upload(vpin_ctx* c, const vpin_r1cs* inst, vpin_r1cs_dev** out) {
       ccol[pr] = col[k]; rval[pr] = val[k];
       crow[pcn] = row[k]; cval[pcn] = val[k];
     }
-    std::vector<uint32_t> longs;
+    std::vector<uint32_t> longs, lfirst, ck0, ck1;
     for (size_t i = 0; i < ncols; i++)
-      if (colptr[i + 1] - colptr[i] > kLongCol) longs.push_back((uint32_t)i);
+      if (colptr[i + 1] - colptr[i] > kLongCol) {
+        longs.push_back((uint32_t)i);
+        lfirst.push_back((uint32_t)ck0.size());
+        for (uint32_t k = colptr[i]; k < colptr[i + 1]; k += kChunk) {
+          ck0.push_back(k);
+          ck1.push_back(std::min<uint32_t>(k + kChunk, colptr[i + 1]));
+        }
+      }
+    lfirst.push_back((uint32_t)ck0.size());
     d->n_long[m] = longs.size();
+    d->n_chunks[m] = ck0.size();
     if ((rc = up(c, &d->rowptr[m], rowptr.data(), nrows + 1)) || (rc = up(c, &d->csr_col[m], ccol.data(), nnz)) ||
         (rc = up(c, &d->csr_val[m], rval.data(), nnz)) || (rc = up(c, &d->colptr[m], colptr.data(), ncols + 1)) ||
         (rc = up(c, &d->csc_row[m], crow.data(), nnz)) || (rc = up(c, &d->csc_val[m], cval.data(), nnz)) ||
-        (rc = up(c, &d->long_cols[m], longs.data(), longs.size())))
+        (rc = up(c, &d->long_cols[m], longs.data(), longs.size())) || (rc = up(c, &d->long_first[m], lfirst.data(), lfirst.size())) ||
+        (rc = up(c, &d->chunk_k0[m], ck0.data(), ck0.size())) || (rc = up(c, &d->chunk_k1[m], ck1.data(), ck1.size())))
       break;
     if (hipStreamSynchronize(c->stream) != hipSuccess) rc = VPIN_EHIP;  // host vectors die at scope end
+  }
+  if (rc == VPIN_OK) {
+    size_t mx = std::max(d->n_chunks[0], std::max(d->n_chunks[1], d->n_chunks[2]));
+    if (hipMalloc((void**)&d->chunk_partials, (mx ? mx : 1) * sizeof(fq)) != hipSuccess) rc = VPIN_ENOMEM;
   }
   if (rc) { vpin_r1cs_free(c, d); return rc; }
   *out = d;
@@ -292,9 +319,12 @@ int vpin_r1cs_eval_table(vpin_ctx* c, const vpin_r1cs_dev* d, const vpin_table* 
     memcpy(rc_m.v, r_abc + 32 * m, 32);
     hipLaunchKernelGGL(eval_table_kernel, dim3((unsigned)((ncols + kRB - 1) / kRB)), dim3(kRB), 0, c->stream, d->colptr[m],
                        d->csc_row[m], d->csc_val[m], evals_rx->d, ncols, rc_m, 1, t->d);
-    if (d->n_long[m])
-      hipLaunchKernelGGL(eval_table_long_kernel, dim3((unsigned)d->n_long[m]), dim3(kRB), 0, c->stream, d->long_cols[m],
-                         d->colptr[m], d->csc_row[m], d->csc_val[m], evals_rx->d, rc_m, 1, t->d);
+    if (d->n_long[m]) {
+      hipLaunchKernelGGL(long_chunk_kernel, dim3((unsigned)d->n_chunks[m]), dim3(kRB), 0, c->stream, d->chunk_k0[m],
+                         d->chunk_k1[m], d->csc_row[m], d->csc_val[m], evals_rx->d, d->chunk_partials);
+      hipLaunchKernelGGL(eval_table_long_finish_kernel, dim3((unsigned)((d->n_long[m] + 63) / 64)), dim3(64), 0, c->stream,
+                         d->long_cols[m], d->long_first[m], d->n_long[m], d->chunk_partials, rc_m, 1, t->d);
+    }
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { set_last_error("eval_table", e); vpin_table_free(c, t); return VPIN_EHIP; }
@@ -318,9 +348,12 @@ int vpin_r1cs_evaluate(vpin_ctx* c, const vpin_r1cs_dev* d, const vpin_table* ev
     if ((size_t)nparts > c->partials_cap) return VPIN_ESHAPE;
     hipLaunchKernelGGL(evaluate_kernel, dim3(grid), dim3(kRB), 0, c->stream, d->colptr[m], d->csc_row[m], d->csc_val[m],
                        evals_rx->d, evals_ry->d, ncols, c->d_partials);
-    if (d->n_long[m])
-      hipLaunchKernelGGL(evaluate_long_kernel, dim3((unsigned)d->n_long[m]), dim3(kRB), 0, c->stream, d->long_cols[m],
-                         d->colptr[m], d->csc_row[m], d->csc_val[m], evals_rx->d, evals_ry->d, c->d_partials + grid);
+    if (d->n_long[m]) {
+      hipLaunchKernelGGL(long_chunk_kernel, dim3((unsigned)d->n_chunks[m]), dim3(kRB), 0, c->stream, d->chunk_k0[m],
+                         d->chunk_k1[m], d->csc_row[m], d->csc_val[m], evals_rx->d, d->chunk_partials);
+      hipLaunchKernelGGL(evaluate_long_finish_kernel, dim3((unsigned)((d->n_long[m] + 63) / 64)), dim3(64), 0, c->stream,
+                         d->long_cols[m], d->long_first[m], d->n_long[m], d->chunk_partials, evals_ry->d, c->d_partials + grid);
+    }
     hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(kRB), 0, c->stream, c->d_partials, nparts, d_out + m);
   }
   hipError_t e = hipGetLastError();

@@ -59,15 +59,12 @@ def main():
     import vpin_amd
     from vpin_amd import gadgets as G
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    dist = None
+    from vpin_amd.dist import Group, env_rank
+
+    rank, local_rank, world = env_rank()
     if world > 1:
-        import torch.distributed as dist_mod
-        dist = dist_mod
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    grp = Group(backend="nccl", device=torch.device("cuda", local_rank) if world > 1 else None)
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     # ---- synthetic workload (host side, outside the timed region) ----
@@ -82,8 +79,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
+        grp.barrier()
         torch.cuda.synchronize()
 
     # instance + the three assignments resident in HBM before the timed region (the PCIe-inclusive
@@ -122,10 +118,7 @@ def main():
     stats = ctx.prof_read()
     ctx.prof_enable(False)
 
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = grp.max_over_ranks(elapsed)
 
     total_cons = sum(cons) * args.steps * world
     value = total_cons / elapsed
@@ -203,8 +196,7 @@ def main():
     if rank == 0:
         print(json.dumps(line))
     ctx.close()
-    if dist is not None:
-        dist.destroy_process_group()
+    grp.close()
 
 
 if __name__ == "__main__":

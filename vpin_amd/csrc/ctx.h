@@ -38,6 +38,8 @@ struct vpin_table {
   bool owned = true;
 };
 
+struct vpin_gens;
+
 struct vpin_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -85,6 +87,13 @@ struct DevBuf {
   ~DevBuf() { if (p) dev_free(c, p); }
   int alloc(size_t bytes) { return dev_alloc(c, bytes, &p); }
 };
+
+// split-phase pair commitment (msm.hip)
+struct CommitPairState;
+int commit_pair_begin(vpin_ctx* c, const vpin_gens* g, const vpin_table* Za, const vpin_table* Zb, size_t L,
+                      CommitPairState** out);
+int commit_pair_finish(vpin_ctx* c, const vpin_gens* g, CommitPairState* st, const uint8_t* blinds_a, const uint8_t* blinds_b,
+                       size_t blind_base, uint8_t* out_a, uint8_t* out_b, uint8_t* out_sum);
 
 // asynchronous round launch / collect (sumcheck.hip), for the host prover's overlap
 int sc_round_launch(vpin_ctx* c, int K, vpin_table* const* tabs, const uint8_t* r);

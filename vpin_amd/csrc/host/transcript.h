@@ -19,21 +19,40 @@ inline void keccak_f1600(uint64_t a[25]) {
       0x0000000080008009ULL, 0x000000008000000aULL, 0x000000008000808bULL, 0x800000000000008bULL, 0x8000000000008089ULL,
       0x8000000000008003ULL, 0x8000000000008002ULL, 0x8000000000000080ULL, 0x000000000000800aULL, 0x800000008000000aULL,
       0x8000000080008081ULL, 0x8000000000008080ULL, 0x0000000080000001ULL, 0x8000000080008008ULL};
-  // rho offsets indexed [x + 5y]
-  static const int RHO[25] = {0, 1, 62, 28, 27, 36, 44, 6, 55, 20, 3, 10, 43, 25, 39, 41, 45, 15, 21, 8, 18, 2, 61, 56, 14};
-  auto rotl = [](uint64_t v, int n) { return n ? (v << n) | (v >> (64 - n)) : v; };
+#define VPIN_ROL(v, n) (((v) << (n)) | ((v) >> (64 - (n))))
+  // lanes indexed a[x + 5y]; one round fully unrolled (theta, rho+pi into b, chi, iota): the
+  // transcript makes one permutation per challenge, ~2000 of them per polynomial commitment
+  uint64_t a00 = a[0], a10 = a[1], a20 = a[2], a30 = a[3], a40 = a[4], a01 = a[5], a11 = a[6], a21 = a[7], a31 = a[8],
+           a41 = a[9], a02 = a[10], a12 = a[11], a22 = a[12], a32 = a[13], a42 = a[14], a03 = a[15], a13 = a[16],
+           a23 = a[17], a33 = a[18], a43 = a[19], a04 = a[20], a14 = a[21], a24 = a[22], a34 = a[23], a44 = a[24];
   for (int round = 0; round < 24; round++) {
-    uint64_t c[5], d[5], b[25];
-    for (int x = 0; x < 5; x++) c[x] = a[x] ^ a[x + 5] ^ a[x + 10] ^ a[x + 15] ^ a[x + 20];
-    for (int x = 0; x < 5; x++) d[x] = c[(x + 4) % 5] ^ rotl(c[(x + 1) % 5], 1);
-    for (int i = 0; i < 25; i++) a[i] ^= d[i % 5];
-    // rho + pi: B[y, 2x+3y] = rot(A[x,y])
-    for (int x = 0; x < 5; x++)
-      for (int y = 0; y < 5; y++) b[y + 5 * ((2 * x + 3 * y) % 5)] = rotl(a[x + 5 * y], RHO[x + 5 * y]);
-    for (int y = 0; y < 5; y++)
-      for (int x = 0; x < 5; x++) a[x + 5 * y] = b[x + 5 * y] ^ (~b[(x + 1) % 5 + 5 * y] & b[(x + 2) % 5 + 5 * y]);
-    a[0] ^= RC[round];
+    uint64_t c0 = a00 ^ a01 ^ a02 ^ a03 ^ a04, c1 = a10 ^ a11 ^ a12 ^ a13 ^ a14, c2 = a20 ^ a21 ^ a22 ^ a23 ^ a24,
+             c3 = a30 ^ a31 ^ a32 ^ a33 ^ a34, c4 = a40 ^ a41 ^ a42 ^ a43 ^ a44;
+    uint64_t d0 = c4 ^ VPIN_ROL(c1, 1), d1 = c0 ^ VPIN_ROL(c2, 1), d2 = c1 ^ VPIN_ROL(c3, 1), d3 = c2 ^ VPIN_ROL(c4, 1),
+             d4 = c3 ^ VPIN_ROL(c0, 1);
+    a00 ^= d0; a01 ^= d0; a02 ^= d0; a03 ^= d0; a04 ^= d0;
+    a10 ^= d1; a11 ^= d1; a12 ^= d1; a13 ^= d1; a14 ^= d1;
+    a20 ^= d2; a21 ^= d2; a22 ^= d2; a23 ^= d2; a24 ^= d2;
+    a30 ^= d3; a31 ^= d3; a32 ^= d3; a33 ^= d3; a34 ^= d3;
+    a40 ^= d4; a41 ^= d4; a42 ^= d4; a43 ^= d4; a44 ^= d4;
+    // rho + pi: B[y][2x+3y] = rot(A[x][y], r[x][y])
+    uint64_t b00 = a00, b13 = VPIN_ROL(a01, 36), b21 = VPIN_ROL(a02, 3), b34 = VPIN_ROL(a03, 41), b42 = VPIN_ROL(a04, 18);
+    uint64_t b02 = VPIN_ROL(a10, 1), b10 = VPIN_ROL(a11, 44), b23 = VPIN_ROL(a12, 10), b31 = VPIN_ROL(a13, 45), b44 = VPIN_ROL(a14, 2);
+    uint64_t b04 = VPIN_ROL(a20, 62), b12 = VPIN_ROL(a21, 6), b20 = VPIN_ROL(a22, 43), b33 = VPIN_ROL(a23, 15), b41 = VPIN_ROL(a24, 61);
+    uint64_t b01 = VPIN_ROL(a30, 28), b14 = VPIN_ROL(a31, 55), b22 = VPIN_ROL(a32, 25), b30 = VPIN_ROL(a33, 21), b43 = VPIN_ROL(a34, 56);
+    uint64_t b03 = VPIN_ROL(a40, 27), b11 = VPIN_ROL(a41, 20), b24 = VPIN_ROL(a42, 39), b32 = VPIN_ROL(a43, 8), b40 = VPIN_ROL(a44, 14);
+    // chi (names bXY = B[x][y])
+    a00 = b00 ^ (~b10 & b20); a10 = b10 ^ (~b20 & b30); a20 = b20 ^ (~b30 & b40); a30 = b30 ^ (~b40 & b00); a40 = b40 ^ (~b00 & b10);
+    a01 = b01 ^ (~b11 & b21); a11 = b11 ^ (~b21 & b31); a21 = b21 ^ (~b31 & b41); a31 = b31 ^ (~b41 & b01); a41 = b41 ^ (~b01 & b11);
+    a02 = b02 ^ (~b12 & b22); a12 = b12 ^ (~b22 & b32); a22 = b22 ^ (~b32 & b42); a32 = b32 ^ (~b42 & b02); a42 = b42 ^ (~b02 & b12);
+    a03 = b03 ^ (~b13 & b23); a13 = b13 ^ (~b23 & b33); a23 = b23 ^ (~b33 & b43); a33 = b33 ^ (~b43 & b03); a43 = b43 ^ (~b03 & b13);
+    a04 = b04 ^ (~b14 & b24); a14 = b14 ^ (~b24 & b34); a24 = b24 ^ (~b34 & b44); a34 = b34 ^ (~b44 & b04); a44 = b44 ^ (~b04 & b14);
+    a00 ^= RC[round];
   }
+#undef VPIN_ROL
+  a[0] = a00; a[1] = a10; a[2] = a20; a[3] = a30; a[4] = a40; a[5] = a01; a[6] = a11; a[7] = a21; a[8] = a31; a[9] = a41;
+  a[10] = a02; a[11] = a12; a[12] = a22; a[13] = a32; a[14] = a42; a[15] = a03; a[16] = a13; a[17] = a23; a[18] = a33;
+  a[19] = a43; a[20] = a04; a[21] = a14; a[22] = a24; a[23] = a34; a[24] = a44;
 }
 
 // SHAKE256 extendable output (FIPS 202)

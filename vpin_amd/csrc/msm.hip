@@ -15,6 +15,7 @@
 // vartime MSM.  One 256-thread workgroup per row; per-thread partial sums are combined by
 // an LDS tree.  Integer-ALU bound (~8 field multiplies per table add); no MFMA.
 #include <cstring>
+#include <memory>
 
 #include "ctx.h"
 #include "fp_dev.h"
@@ -393,6 +394,69 @@ int vpin_gens_msm_parts(vpin_ctx* c, const vpin_gens* g, const uint8_t* scalars_
   VPIN_HIP_TRY(hipStreamSynchronize(c->stream));
   return VPIN_OK;
 }
+
+}  // extern "C"
+
+// Split-phase form of vpin_hyrax_commit_pair for the host prover: `begin` enqueues the two big
+// row MSMs (which do not depend on the blinds), the host draws the 2L blinds from its RandomTape
+// while they run, `finish` adds blind_i * g[blind_base] per row, combines and compresses.
+namespace vpin {
+struct CommitPairState {
+  DevBuf pts;  // [5L] : M_a | M_b | blind_a*h | blind_b*h (reused for sums) | a+b
+  size_t L = 0;
+  explicit CommitPairState(vpin_ctx* c) : pts(c) {}
+};
+
+int commit_pair_begin(vpin_ctx* c, const vpin_gens* g, const vpin_table* Za, const vpin_table* Zb, size_t L,
+                      CommitPairState** out) {
+  if (!c || !g || !Za || !Zb || !out || L == 0) return VPIN_EINVAL;
+  if (Za->len != Zb->len || Za->len % L != 0) return VPIN_ESHAPE;
+  size_t R = Za->len / L;
+  if (R > g->nb) return VPIN_ESHAPE;
+  (void)hipSetDevice(c->device);
+  CommitPairState* st = new (std::nothrow) CommitPairState(c);
+  if (!st) return VPIN_ENOMEM;
+  st->L = L;
+  if (st->pts.alloc(5 * L * sizeof(ge_ext))) { delete st; return VPIN_ENOMEM; }
+  ge_ext* pts = (ge_ext*)st->pts.p;
+  int rc = msm_rows(c, g, Za->d, L, R, R, nullptr, 0, 0, pts);
+  if (!rc) rc = msm_rows(c, g, Zb->d, L, R, R, nullptr, 0, 0, pts + L);
+  if (rc) { delete st; return rc; }
+  *out = st;
+  return VPIN_OK;
+}
+
+int commit_pair_finish(vpin_ctx* c, const vpin_gens* g, CommitPairState* st, const uint8_t* blinds_a, const uint8_t* blinds_b,
+                       size_t blind_base, uint8_t* out_a, uint8_t* out_b, uint8_t* out_sum) {
+  if (!st) return VPIN_EINVAL;
+  std::unique_ptr<CommitPairState> guard(st);
+  if (!c || !g || !blinds_a || !blinds_b || !out_a || !out_b || !out_sum) return VPIN_EINVAL;
+  if (blind_base >= g->nb) return VPIN_ESHAPE;
+  const size_t L = st->L;
+  DevBuf dbl(c), dout(c);
+  if (dbl.alloc(2 * L * 32) || dout.alloc(3 * L * 32)) return VPIN_ENOMEM;
+  VPIN_HIP_TRY(hipMemcpyAsync(dbl.p, blinds_a, L * 32, hipMemcpyHostToDevice, c->stream));
+  VPIN_HIP_TRY(hipMemcpyAsync((uint8_t*)dbl.p + L * 32, blinds_b, L * 32, hipMemcpyHostToDevice, c->stream));
+  ge_ext* pts = (ge_ext*)st->pts.p;
+  // 2L one-scalar rows on the blind generator
+  int rc = msm_rows(c, g, (const fq*)dbl.p, 2 * L, 1, 0, (const fq*)dbl.p, 1, blind_base, pts + 2 * L);
+  if (rc) return rc;
+  const unsigned gb = (unsigned)((2 * L + 63) / 64);
+  hipLaunchKernelGGL(ge_add_rows_kernel, dim3(gb), dim3(64), 0, c->stream, pts, pts + 2 * L, 2 * L, pts + 2 * L);  // a, b
+  hipLaunchKernelGGL(ge_add_rows_kernel, dim3((unsigned)((L + 63) / 64)), dim3(64), 0, c->stream, pts + 2 * L, pts + 3 * L, L,
+                     pts + 4 * L);  // a + b
+  hipLaunchKernelGGL(ge_compress_kernel, dim3((unsigned)((3 * L + 63) / 64)), dim3(64), 0, c->stream,
+                     (const ge_ext*)(pts + 2 * L), 3 * L, (fp*)dout.p, (fp*)nullptr);
+  VPIN_HIP_TRY(hipGetLastError());
+  VPIN_HIP_TRY(hipMemcpyAsync(out_a, dout.p, L * 32, hipMemcpyDeviceToHost, c->stream));
+  VPIN_HIP_TRY(hipMemcpyAsync(out_b, (uint8_t*)dout.p + L * 32, L * 32, hipMemcpyDeviceToHost, c->stream));
+  VPIN_HIP_TRY(hipMemcpyAsync(out_sum, (uint8_t*)dout.p + 2 * L * 32, L * 32, hipMemcpyDeviceToHost, c->stream));
+  VPIN_HIP_TRY(hipStreamSynchronize(c->stream));
+  return VPIN_OK;
+}
+}  // namespace vpin
+
+extern "C" {
 
 int vpin_gens_msm(vpin_ctx* c, const vpin_gens* g, const uint8_t* scalars_mont, size_t rows, size_t ncols,
                   uint8_t* out_compressed, uint8_t* out_xyzt) {

@@ -19,8 +19,11 @@
 
 namespace vpin {
 
+#ifndef VPIN_SC_MIN_WAVES
+#define VPIN_SC_MIN_WAVES 3  // 164 VGPRs, no scratch (4 would need 128 VGPRs and spill ~150 B)
+#endif
 constexpr int kBlock = 256;
-constexpr int kMinWaves = 3;      // waves per SIMD asked of the register allocator (<=168 VGPRs)
+constexpr int kMinWaves = VPIN_SC_MIN_WAVES;  // waves per SIMD asked of the register allocator
 constexpr int kMaxBlocks = 2048;  // 256 CUs x 8 blocks/CU, grid-stride beyond that
 
 // ---- per-pair evaluation -------------------------------------------------------------

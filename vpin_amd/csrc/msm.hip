@@ -206,6 +206,52 @@ __global__ __launch_bounds__(kMsmBlock) void msm_wide_kernel(const fq* __restric
   }
 }
 
+// out[i] = s_i * g[base] for n scalars (the blind terms of the row commitments): 8 threads per
+// scalar, 4 windows each, 3-level LDS tree -- one wave handles 8 scalars
+__global__ __launch_bounds__(64) void single_base_mul_kernel(const fq* __restrict__ S, size_t n, const ge_cached* __restrict__ table,
+                                                             size_t nb, size_t base, ge_ext* __restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * 8 + (threadIdx.x >> 3);
+  const int grp = threadIdx.x & 7;
+  ge_ext acc = ge_identity();
+  if (i < n) {
+    fq s = fq_load(S + i);
+    if (!fq_is_zero(s)) {
+      s = fq_from_mont(s);
+      uint32_t carry = 0;
+      for (int w = 4 * grp - 1; w >= 0; w--) {
+        uint32_t byte = (s.v[w >> 2] >> ((w & 3) * 8)) & 0xffu;
+        if (byte != 128u) { carry = byte > 128u ? 1u : 0u; break; }
+      }
+      uint32_t limb = s.v[grp];
+#pragma unroll 1
+      for (int t = 0; t < 4; t++) {
+        uint32_t v = ((limb >> (8 * t)) & 0xffu) + carry;
+        bool neg = v > 128u;
+        uint32_t mag = neg ? 256u - v : v;
+        carry = neg ? 1u : 0u;
+        if (mag != 0) {
+          int w = 4 * grp + t;
+          acc = ge_add_cached(acc, cached_load(table + ((size_t)w * nb + base) * kEntries + (mag - 1)), neg);
+        }
+      }
+    }
+  }
+  __shared__ ge_ext sh[64];
+  sh[threadIdx.x] = acc;
+  __syncthreads();
+  for (int st = 4; st >= 1; st >>= 1) {
+    if (grp < st) {
+      acc = ge_add(acc, sh[threadIdx.x + st]);
+      sh[threadIdx.x] = acc;
+    }
+    __syncthreads();
+  }
+  if (grp == 0 && i < n) {
+    ge_ext* o = out + i;
+    fp_store(&o->X, acc.X); fp_store(&o->Y, acc.Y); fp_store(&o->Z, acc.Z); fp_store(&o->T, acc.T);
+  }
+}
+
 // out[row] = sum of the `chunks` partial points of that row
 __global__ __launch_bounds__(64) void ge_sum_chunks_kernel(const ge_ext* __restrict__ parts, size_t rows, int chunks,
                                                            ge_ext* __restrict__ out) {
@@ -438,9 +484,9 @@ int commit_pair_finish(vpin_ctx* c, const vpin_gens* g, CommitPairState* st, con
   VPIN_HIP_TRY(hipMemcpyAsync(dbl.p, blinds_a, L * 32, hipMemcpyHostToDevice, c->stream));
   VPIN_HIP_TRY(hipMemcpyAsync((uint8_t*)dbl.p + L * 32, blinds_b, L * 32, hipMemcpyHostToDevice, c->stream));
   ge_ext* pts = (ge_ext*)st->pts.p;
-  // 2L one-scalar rows on the blind generator
-  int rc = msm_rows(c, g, (const fq*)dbl.p, 2 * L, 1, 0, (const fq*)dbl.p, 1, blind_base, pts + 2 * L);
-  if (rc) return rc;
+  // 2L single-scalar multiples of the blind generator
+  hipLaunchKernelGGL(single_base_mul_kernel, dim3((unsigned)((2 * L + 7) / 8)), dim3(64), 0, c->stream, (const fq*)dbl.p, 2 * L,
+                     g->table, g->nb, blind_base, pts + 2 * L);
   const unsigned gb = (unsigned)((2 * L + 63) / 64);
   hipLaunchKernelGGL(ge_add_rows_kernel, dim3(gb), dim3(64), 0, c->stream, pts, pts + 2 * L, 2 * L, pts + 2 * L);  // a, b
   hipLaunchKernelGGL(ge_add_rows_kernel, dim3((unsigned)((L + 63) / 64)), dim3(64), 0, c->stream, pts + 2 * L, pts + 3 * L, L,

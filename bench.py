@@ -1,21 +1,27 @@
 #!/usr/bin/env python3
-"""bench.py -- Spartan sat-proof throughput of the MI355X hot path on vPIN's CNN-A trace shape.
+"""bench.py -- Spartan sat-proof throughput of the MI355X hot path on vPIN's LeNet trace.
 
 Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N>1 it is launched by
 torch.distributed.run with one rank per GPU.  Prints ONE JSON line on rank 0.
 
-A "step" is one pass of the hot path over one batch of synthetic input: the two R1CS
-satisfiability proofs vPIN produces for one trace (vPIN_proof_generation/src/main.rs:14-46):
-the point-multiplication instance and the point-addition instance of the configured network
-(default: CNN network A = BASELINE.json configs[1]: 178 point-mults -> 616,592 constraints
-(2^20 padded) and 2,144 point-adds -> 21,440 constraints (2^15 padded)).  The witness is
-synthetic (seeded SplitMix64 points on the curve E2, gadget-generated tables -- SURVEY.md 8(d)).
-value = unpadded R1CS constraints proven per second, whole job (all ranks).  Multi-GPU: the
-independent (trace) instances shard across ranks with no data-path collective -> weak scaling.
+Workload (BASELINE.json quotes its metric on the LeNet trace, and the satisfiability proofs of
+that trace fit one GPU): a "step" is one pass of the hot path over one LeNet inference trace =
+the 12 R1CS satisfiability proofs vPIN produces for it (vPIN_proof_generation/src/main.rs:14-46
+per layer: 7 point-addition instances, 5 point-multiplication instances; L5's has 6000
+point-mults = 20,784,000 constraints, 2^25 padded).  26.2 M unpadded constraints per step.  The
+witness is synthetic (seeded SplitMix64 points on the curve E2, gadget-generated tables --
+SURVEY.md 8(d)).  `--trace A` (BASELINE.json configs[1]; or 3_32, 7_256, E, L1..L7) times a
+single-network trace instead (2 instances).
+value = unpadded R1CS constraints proven per second, whole job (all ranks).  Multi-GPU: every
+rank proves its own trace -- independent instances, no data-path collective -> weak scaling.
+
+Schedule per rank: the point-mult instances are proven one after the other (largest first); the
+small, latency-bound point-add instances run on a second host thread / HIP stream once the
+largest instance is done, so that instance's kernels are timed undisturbed.
 
 Beside the headline value the line carries
-  roofline     : the fused sum-check round kernel (sc_cubic_fused), algorithmic bytes / HIP-event
-                 time over the timed region, against the 8 TB/s HBM3E peak;
+  roofline     : the fused sum-check round kernel (sc_bind_eval_kernel<4>), algorithmic bytes /
+                 HIP-event time over the timed region, against the 8 TB/s HBM3E peak;
   cpu_baseline : the CPU oracle (a C restatement of the reference prover, oracle/) timed on
                  this box's host cores on a bounded sample of the same workload.
 """
@@ -23,6 +29,7 @@ import argparse
 import json
 import os
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -38,15 +45,14 @@ SEED_P = bytes((7 * i + 3) % 256 for i in range(64))
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--label", default="A", help="trace label: 3_32, A, 7_256, E, L5")
-    ap.add_argument("--n-mult", type=int, default=0, help="override the number of point multiplications")
-    ap.add_argument("--n-add", type=int, default=0, help="override the number of point additions")
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--trace", default="lenet", help="lenet (L1..L7) or one label: 3_32, A, 7_256, E, L1..L7")
+    ap.add_argument("--label", default=None, help="alias of --trace for a single label")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-mult", type=int, default=18, help="point-mults in the CPU baseline sample")
     ap.add_argument("--cpu-sample-add", type=int, default=256)
-    ap.add_argument("--serial", action="store_true", help="prove the two instances one after the other")
+    ap.add_argument("--serial", action="store_true", help="one instance at a time, one host thread")
     ap.add_argument("--host-buffers", action="store_true",
                     help="time vpin_sat_prove (instance + witness start in host memory: PCIe-inclusive; never the headline)")
     ap.add_argument("--pmc-traffic", type=float, default=None,
@@ -59,7 +65,6 @@ def main():
     import torch
     import vpin_amd
     from vpin_amd import gadgets as G
-
     from vpin_amd.dist import Group, env_rank
 
     rank, local_rank, world = env_rank()
@@ -68,18 +73,27 @@ def main():
     grp = Group(backend="nccl", device=torch.device("cuda", local_rank) if world > 1 else None)
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
+    trace = args.label or args.trace
+    labels = list(G.LENET) if trace == "lenet" else [trace]
+
     # ---- synthetic workload (host side, outside the timed region) ----
     t0 = time.perf_counter()
-    mult = G.synthetic_mult_instance(args.label, args.n_mult or None)
-    add = G.synthetic_add_instance(args.label, args.n_add or None)
-    insts = [mult.as_dict(), add.as_dict()]
-    cons = [mult.num_cons_unpadded, add.num_cons_unpadded]
+    work = []  # (name, kind, Instance)
+    for lab in labels:
+        m = G.synthetic_mult_instance(lab)
+        if m is not None:
+            work.append((f"{lab}-mult", "mult", m))
+        work.append((f"{lab}-add", "add", G.synthetic_add_instance(lab)))
     setup_s = time.perf_counter() - t0
+    cons = {w[0]: w[2].num_cons_unpadded for w in work}
+    total_cons_step = sum(cons.values())
 
-    # one context (stream, pool, generator tables) per instance: the two proofs of a trace are
-    # independent, so they run concurrently on two host threads and share the GPU
-    ctxs = [vpin_amd.Context(local_rank) for _ in insts]
-    ctx = ctxs[0]
+    # lanes: mult instances largest first on lane 0; add instances on lane 1 (started after the
+    # largest mult instance unless --serial)
+    mults = sorted([w for w in work if w[1] == "mult"], key=lambda w: -w[2].num_cons_unpadded)
+    adds = [w for w in work if w[1] == "add"]
+    lanes = [mults + adds] if (args.serial or not mults) else [mults, adds]
+    ctxs = [vpin_amd.Context(local_rank) for _ in lanes]
 
     def barrier():
         torch.cuda.synchronize()
@@ -87,36 +101,56 @@ def main():
         torch.cuda.synchronize()
 
     # instance + the three assignments resident in HBM before the timed region (the PCIe-inclusive
-    # variant is vpin_sat_prove; its rate is noted in DESIGN.md)
-    resident = []
-    for cx, d in zip(ctxs, insts):
-        resident.append((cx.r1cs_upload(d), cx.upload(d["vars_para"]), cx.upload(d["vars_input"]),
-                         cx.upload(d["vars"]), d["inputs"]))
+    # variant is vpin_sat_prove / --host-buffers; its rate is noted in DESIGN.md)
+    resident, dicts = {}, {}
+    t0 = time.perf_counter()
+    for li, lane in enumerate(lanes):
+        for name, _, inst in lane:
+            d = inst.as_dict()
+            cx = ctxs[li]
+            if args.host_buffers:
+                dicts[name] = d
+            else:
+                resident[name] = (cx.r1cs_upload(d), cx.upload(d["vars_para"]), cx.upload(d["vars_input"]),
+                                  cx.upload(d["vars"]), d["inputs"])
+            inst.free()
+    upload_s = time.perf_counter() - t0
+    lane_names = [[w[0] for w in lane] for lane in lanes]
 
     last_spans = {}
-    names = ("mult", "add")
 
-    def prove_one(k):
-        cx, d, (di, tp, ti, tv, inp) = ctxs[k], insts[k], resident[k]
+    def prove(li, name):
+        cx = ctxs[li]
         if args.host_buffers:
-            r = cx.sat_prove(d, SEED_C, SEED_P)
+            r = cx.sat_prove(dicts[name], SEED_C, SEED_P)
         else:
+            di, tp, ti, tv, inp = resident[name]
             r = cx.sat_prove_resident(di, tp, ti, tv, inp, SEED_C, SEED_P)
-        last_spans[names[k]] = cx.sat_timings()  # thread-local in the library: read on the proving thread
-        return r
+        last_spans[name] = cx.sat_timings()  # thread-local in the library: read on the proving thread
+        return len(r["proof"])
 
-    from concurrent.futures import ThreadPoolExecutor
-    pool = ThreadPoolExecutor(max_workers=len(insts)) if not args.serial else None
+    def run_lane(li, gate):
+        if gate is not None:
+            gate.wait()
+        for name in lane_names[li]:
+            prove(li, name)
 
     def step():
-        if pool is None:
-            return [prove_one(k) for k in range(len(insts))]
-        return list(pool.map(prove_one, range(len(insts))))  # ctypes releases the GIL during the calls
+        if len(lanes) == 1:
+            run_lane(0, None)
+            return
+        gate = threading.Event()
+        t = threading.Thread(target=run_lane, args=(1, gate))
+        t.start()  # ctypes releases the GIL inside the library calls
+        for i, name in enumerate(lane_names[0]):
+            prove(0, name)
+            if i == 0:
+                gate.set()  # the add lane starts once the largest instance is proven
+        gate.set()
+        t.join()
 
     for _ in range(args.warmup):
-        proofs = step()
-    if args.warmup == 0:
-        proofs = None
+        step()
 
     for cx in ctxs:
         cx.prof_reset()
@@ -124,7 +158,7 @@ def main():
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        proofs = step()
+        step()
     for cx in ctxs:
         cx.sync()
     barrier()
@@ -138,9 +172,7 @@ def main():
         cx.prof_enable(False)
 
     elapsed = grp.max_over_ranks(elapsed)
-
-    total_cons = sum(cons) * args.steps * world
-    value = total_cons / elapsed
+    value = total_cons_step * args.steps * world / elapsed
 
     line = {
         "metric": "R1CS constraints/sec, Spartan sat proof (vPIN point-mult + point-add instances)",
@@ -156,13 +188,15 @@ def main():
         "dtype": "u256 (mod q = 2^252+..., mod p = 2^255-19; 32-bit limbs)",
         "data": "synthetic",
         "config": {
-            "workload": f"vPIN trace '{args.label}': sat proof of the point-mult instance + the point-add instance",
-            "label": args.label,
-            "point_mults": cons[0] // 3464, "point_adds": cons[1] // 10,
-            "constraints_unpadded": cons, "constraints_padded": [insts[0]["num_cons"], insts[1]["num_cons"]],
+            "workload": ("vPIN LeNet trace (layers L1..L7): 12 sat proofs per step" if trace == "lenet"
+                         else f"vPIN trace '{trace}': sat proofs of its point-mult and point-add instances"),
+            "instances": cons,
+            "constraints_unpadded_per_step": total_cons_step,
             "scope": "R1CSProof (commitments + both ZK sum-checks + evaluation proof); SPARK encode/eval proof not included",
-            "parallelism": f"instances sharded over {world} rank(s), no collective; per rank the two proofs of the trace run "
-                           + ("serially" if args.serial else "concurrently (2 host threads, 2 HIP streams)"),
+            "parallelism": f"one trace per rank x {world} rank(s), no collective; per rank "
+                           + ("instances proven serially" if len(lanes) == 1 else
+                              "mult instances serially, add instances on a second stream after the largest"),
+            "inputs": "host buffers (PCIe-inclusive, CSR/CSC built per proof)" if args.host_buffers else "resident in HBM",
         },
     }
 
@@ -170,10 +204,16 @@ def main():
     k = stats.get("sc_cubic_fused")
     if k and k["ms"] > 0:
         achieved = k["alg_bytes"] / (k["ms"] * 1e-3) / 1e9
+        traffic = args.pmc_traffic
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        if traffic is None and os.path.exists(pmc):
+            with open(pmc) as f:
+                ent = json.load(f).get("bench_default", {}).get("sc_bind_eval_kernel<4>", {})
+            traffic = ent.get("hbm_bytes_per_launch")
         line["roofline"] = {
-            "kernel": "sc_bind_eval_kernel<4> (fused fold + cubic round evaluation, phase 1)",
+            "kernel": "sc_bind_eval_kernel<4> (fused fold + cubic round evaluation, phase 1; rounds with > 512 pairs)",
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBPS, "traffic": args.pmc_traffic,
+            "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
             "launches": k["launches"], "avg_launch_us": k["ms"] * 1e3 / k["launches"],
             "alg_bytes_per_launch": k["alg_bytes"] / k["launches"],
         }
@@ -181,42 +221,35 @@ def main():
                               "GBps_alg": (v["alg_bytes"] / (v["ms"] * 1e-3) / 1e9) if v["ms"] else None}
                        for name, v in stats.items()}
     line["spans_ms_last_step"] = {n: {kk: round(vv * 1e3, 3) for kk, vv in sp.items()} for n, sp in last_spans.items()}
-    line["setup_s"] = round(setup_s, 3)
-    line["inputs"] = "host buffers (PCIe-inclusive, CSR/CSC built per proof)" if args.host_buffers else "resident in HBM"
-    # HBM traffic of the roofline kernel from the committed rocprofv3 --pmc passes (separate runs)
-    if "roofline" in line and line["roofline"]["traffic"] is None:
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-        if os.path.exists(pmc):
-            with open(pmc) as f:
-                line["roofline"]["traffic"] = json.load(f).get("sc_bind_eval_kernel<4>", {}).get("hbm_bytes_per_launch")
+    line["setup_s"] = {"gadgets_and_witness": round(setup_s, 3), "upload_and_csr": round(upload_s, 3)}
 
     # ---- CPU baseline: the oracle on a bounded sample, rank 0, N=1 only ----
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         import oracle_lib as O
         threads = min(os.cpu_count() or 1, 16)
-        sm = G.synthetic_mult_instance(args.label, min(args.cpu_sample_mult, cons[0] // 3464))
-        sa = G.synthetic_add_instance(args.label, min(args.cpu_sample_add, cons[1] // 10))
-        sample_cons = sm.num_cons_unpadded + sa.num_cons_unpadded
+        lab = "L1" if trace == "lenet" else trace
+        sm = G.synthetic_mult_instance(lab, args.cpu_sample_mult) if G.CONFIGS[lab]["n_mult"] else None
+        sa = G.synthetic_add_instance(lab, args.cpu_sample_add)
+        sample_cons = (sm.num_cons_unpadded if sm else 0) + sa.num_cons_unpadded
         t0 = time.perf_counter()
-        r1 = O.sat_prove(sm.as_dict(), SEED_C, SEED_P, threads=threads)
-        tm = O.sat_timings()
+        tm = {}
+        if sm:
+            r1 = O.sat_prove(sm.as_dict(), SEED_C, SEED_P, threads=threads)
+            tm = O.sat_timings()
+            assert len(r1["proof"])
         r2 = O.sat_prove(sa.as_dict(), SEED_C, SEED_P, threads=threads)
         cpu_s = time.perf_counter() - t0
-        assert len(r1["proof"]) and len(r2["proof"])
+        assert len(r2["proof"])
         line["cpu_baseline"] = {
             "value": sample_cons / cpu_s, "unit": "constraints/s", "cores": threads, "kind": "port",
-            "sample": f"first {sm.num_cons_unpadded // 3464} point-mults + first {sa.num_cons_unpadded // 10} point-adds of "
-                      f"the same trace ({sample_cons} constraints), C oracle, OpenMP rows in the commitment "
+            "sample": f"{args.cpu_sample_mult if sm else 0} point-mults + {sa.num_cons_unpadded // 10} point-adds drawn like layer {lab} "
+                      f"({sample_cons} constraints), C oracle (restated reference prover), OpenMP rows in the commitment "
                       f"(as rayon in the reference), single-threaded sum-checks; {cpu_s:.1f} s",
             "spans_ms_mult": {kk: round(vv * 1e3, 1) for kk, vv in tm.items()},
         }
-        sm.free()
-        sa.free()
 
     if rank == 0:
         print(json.dumps(line))
-    if pool is not None:
-        pool.shutdown()
     for cx in ctxs:
         cx.close()
     grp.close()

@@ -125,17 +125,32 @@ CONFIGS = {
     "A": dict(index=2, n_mult=178, n_add=2144, weights="wide", rz_one_every=300),
     "7_256": dict(index=3, n_mult=98, n_add=96, weights="conv7", rz_one_every=0),
     "E": dict(index=4, n_mult=658, n_add=2336, weights="wide", rz_one_every=300),
+    # LeNet layers (src/LeNet/Server.py:690-698,753-761): conv layers use the 5x5 diagonal filter
+    # {2,2,1,2,2} (Server.py:300), FC layers wide products; L2/L4 (pooling) have no point-mults
+    "L1": dict(index=11, n_mult=300, n_add=288, weights="conv5", rz_one_every=6),
+    "L2": dict(index=12, n_mult=0, n_add=7056, weights="conv5", rz_one_every=0),
+    "L3": dict(index=13, n_mult=800, n_add=768, weights="conv5", rz_one_every=6),
+    "L4": dict(index=14, n_mult=0, n_add=2400, weights="conv5", rz_one_every=0),
     "L5": dict(index=5, n_mult=6000, n_add=5760, weights="wide", rz_one_every=6),
+    "L6": dict(index=16, n_mult=240, n_add=406, weights="wide", rz_one_every=300),
+    "L7": dict(index=17, n_mult=168, n_add=186, weights="wide", rz_one_every=300),
 }
+
+LENET = ("L1", "L2", "L3", "L4", "L5", "L6", "L7")
 
 
 def synthetic_mult_instance(label, n_override=None):
     cfg = CONFIGS[label]
     n = n_override or cfg["n_mult"]
+    if n == 0:
+        return None
     x, y = synthetic_points(SEED + cfg["index"], n)
     if cfg["weights"] == "conv3":  # filter entries {1,0,1,2,0,2,1,0,1} x 2 (src/convolution/Server.py:453-455)
         base = [1, 0, 1, 2, 0, 2, 1, 0, 1]
         w = [base[i % 9] for i in range(n)]
+    elif cfg["weights"] == "conv5":  # 5x5 filter with {2,2,1,2,2} on the diagonal, zeros elsewhere
+        diag = {0: 2, 6: 2, 12: 1, 18: 2, 24: 2}
+        w = [diag.get(i % 25, 0) for i in range(n)]
     elif cfg["weights"] == "conv7":  # 6 non-zeros in {1,2} of 49 (Server.py:463-469)
         w = [(1 + (i % 2)) if (i % 49) % 8 == 0 and (i % 49) < 48 else 0 for i in range(n)]
     else:  # FC layers: ~2^120..2^128 products of HMAC prefixes and scaled weights; uniform in [0, 2^127)

@@ -142,6 +142,8 @@ def main():
         gate = threading.Event()
         t = threading.Thread(target=run_lane, args=(1, gate))
         t.start()  # ctypes releases the GIL inside the library calls
+        if len(lane_names[0]) == 1:
+            gate.set()  # single-network trace: nothing else would overlap the add instance
         for i, name in enumerate(lane_names[0]):
             prove(0, name)
             if i == 0:

@@ -119,6 +119,8 @@ constexpr int kMsmBlock = 256;
 
 // rows x (ncols scalars from Z with row stride `stride`) + optional extra scalars on bases
 // [extra_base0, extra_base0 + n_extra).  out[row] = sum_j s[row][j] * g_j  (extended coords)
+constexpr int kSeg = 8192;  // scalars per compaction segment (uint16 indices, 16 KiB of LDS)
+
 __global__ __launch_bounds__(kMsmBlock) void msm_rows_kernel(const fq* __restrict__ Z, size_t stride, size_t ncols,
                                                              const fq* __restrict__ extra, int n_extra, size_t extra_base0,
                                                              const ge_cached* __restrict__ table, size_t nb,
@@ -129,13 +131,31 @@ __global__ __launch_bounds__(kMsmBlock) void msm_rows_kernel(const fq* __restric
   // gridDim.y column chunks per row (few-row MSMs need more than `rows` workgroups)
   const size_t per = (total + gridDim.y - 1) / gridDim.y;
   const size_t j0 = (size_t)blockIdx.y * per, j1 = (j0 + per < total) ? j0 + per : total;
-  for (size_t j = j0 + threadIdx.x; j < j1; j += kMsmBlock) {
-    fq s;
-    size_t base;
-    if (j < ncols) { s = fq_load(Z + row * stride + j); base = j; }
-    else { s = fq_load(extra + row * (size_t)n_extra + (j - ncols)); base = extra_base0 + (j - ncols); }
-    if (fq_is_zero(s)) continue;  // vartime: skip zero scalars (padding, unset variables)
-    table_mul_acc(acc, fq_from_mont(s), table, nb, base);
+  // The witness is ~40% zeros in irregular positions; lanes that met a zero scalar would idle
+  // while their wave-mates do 32 table adds.  So each segment is first compacted: the indices
+  // of its non-zero scalars go to an LDS list (order is irrelevant: the group is commutative),
+  // then the threads stride over the dense list.
+  __shared__ uint16_t nz_list[kSeg];
+  __shared__ uint32_t nz_count;
+  for (size_t seg = j0; seg < j1; seg += kSeg) {
+    const size_t seg_end = (seg + kSeg < j1) ? seg + kSeg : j1;
+    if (threadIdx.x == 0) nz_count = 0;
+    __syncthreads();
+    for (size_t j = seg + threadIdx.x; j < seg_end; j += kMsmBlock) {
+      const fq* sp = (j < ncols) ? (Z + row * stride + j) : (extra + row * (size_t)n_extra + (j - ncols));
+      if (!fq_is_zero(fq_load(sp))) nz_list[atomicAdd(&nz_count, 1u)] = (uint16_t)(j - seg);
+    }
+    __syncthreads();
+    const uint32_t cnt = nz_count;
+    for (uint32_t k = threadIdx.x; k < cnt; k += kMsmBlock) {
+      const size_t j = seg + nz_list[k];
+      fq s;
+      size_t base;
+      if (j < ncols) { s = fq_load(Z + row * stride + j); base = j; }
+      else { s = fq_load(extra + row * (size_t)n_extra + (j - ncols)); base = extra_base0 + (j - ncols); }
+      table_mul_acc(acc, fq_from_mont(s), table, nb, base);
+    }
+    __syncthreads();
   }
   __shared__ ge_ext sh[kMsmBlock];
   sh[threadIdx.x] = acc;

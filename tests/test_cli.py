@@ -1,0 +1,78 @@
+"""vpin_prove: the reference binary's CLI / witness-file contract (VP/main.rs, load_data*.rs)."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import gadgets_model as GM
+import oracle_lib as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "vpin_amd", "bin", "vpin_prove")
+
+
+def write_witness(root, label, add_ops, mult_ops):
+    """the 8 JSON files exactly as src/convolution/Server.py:324-417 writes them"""
+    b32 = lambda v: list(int(v).to_bytes(32, "little"))
+    pa = os.path.join(root, "rust_files", label, "pointAdd")
+    pm = os.path.join(root, "rust_files", label, "pointMult")
+    os.makedirs(pa)
+    os.makedirs(pm)
+    for name, idx in (("px", 0), ("py", 1), ("rx", 2), ("ry", 3)):
+        json.dump([b32(o[idx]) for o in add_ops], open(os.path.join(pa, f"point_add_{name}_byte.json"), "w"))
+    json.dump([int(o[4]) for o in add_ops], open(os.path.join(pa, "point_add_rz_byte.json"), "w"))
+    json.dump([str(o[0]) for o in mult_ops], open(os.path.join(pm, "weight.json"), "w"))
+    json.dump([b32(o[1]) for o in mult_ops], open(os.path.join(pm, "point_mult_px_byte.json"), "w"))
+    json.dump([b32(o[2]) for o in mult_ops], open(os.path.join(pm, "point_mult_py_byte.json"), "w"))
+
+
+@pytest.fixture(scope="module")
+def built():
+    from vpin_amd import build as vbuild
+    vbuild.build()
+    assert os.path.exists(BIN)
+
+
+def test_missing_witness_files_fail_like_the_reference(built, tmp_path):
+    r = subprocess.run([BIN, "nope"], cwd=tmp_path, capture_output=True, text=True)
+    assert r.returncode == 101 and "Failed to open file" in r.stderr
+    assert r.stdout.startswith("network: nope")
+
+
+def test_malformed_json_is_rejected(built, tmp_path):
+    ops = GM.synthetic_add_ops(3, 2)
+    write_witness(tmp_path, "X", ops, GM.synthetic_mult_ops(4, 1))
+    with open(tmp_path / "rust_files" / "X" / "pointAdd" / "point_add_py_byte.json", "w") as f:
+        f.write("[[1,2,")
+    r = subprocess.run([BIN, "X"], cwd=tmp_path, capture_output=True, text=True)
+    assert r.returncode == 101 and "Failed to parse JSON" in r.stderr
+
+
+@pytest.mark.gpu
+def test_cli_proof_matches_oracle(built, tmp_path):
+    add_ops = GM.synthetic_add_ops(0x5650494E, 6, rz_one_every=3)
+    mult_ops = GM.synthetic_mult_ops(0x5650494E + 2, 1, weights=[(1 << 127) + 12345])
+    write_witness(tmp_path, "T", add_ops, mult_ops)
+    os.makedirs(tmp_path / "out")
+    seed_c, seed_p = bytes(range(64)), bytes((7 * i + 3) % 256 for i in range(64))
+    r = subprocess.run([BIN, "T", "--seed", (seed_c + seed_p).hex(), "--write-proof", "out"], cwd=tmp_path,
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    lines = r.stdout.splitlines()
+    assert lines[0] == "network: T"
+    assert lines[1:3] == ["Point Addition Gadget...", "Number of Point Additions: 6"]
+    assert "Point Multiplication Gadget..." in lines and "Number of Point Multiplications: 1" in lines
+    assert "Generating Proof..." in lines and "Still working on..." in lines
+    assert any(l.startswith("Total proof size: ") for l in lines)
+    for name, g in (("add", GM.build_point_add(add_ops)), ("mult", GM.build_point_mult(mult_ops))):
+        inst = GM.instance_new(g)
+        exp = O.sat_prove(inst, seed_c, seed_p)
+        got = open(tmp_path / "out" / f"T_{name}.proof", "rb").read()
+        assert got == exp["proof"]
+        assert f"Proof size: {len(got)} bytes" in lines
+        res = dict(exp, proof=got,
+                   comm_para=np.frombuffer(open(tmp_path / "out" / f"T_{name}.comm_para", "rb").read(), dtype=np.uint8).reshape(-1, 32).copy(),
+                   comm_input=np.frombuffer(open(tmp_path / "out" / f"T_{name}.comm_input", "rb").read(), dtype=np.uint8).reshape(-1, 32).copy())
+        assert O.sat_verify(inst, res) == 1

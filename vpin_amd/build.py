@@ -28,7 +28,7 @@ def sources():
 
 
 def deps():
-    return sources() + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "host", "*.h")) + [
+    return sources() + [os.path.join(CSRC, "cli", "vpin_prove.cpp")] + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "host", "*.h")) + [
         os.path.join(os.path.dirname(HERE), "include", "vpin_hip.h")]
 
 
@@ -65,7 +65,21 @@ def build(force=False, verbose=False):
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
+    build_cli(verbose)
     return LIB_PATH
+
+
+def build_cli(verbose=False):
+    """vpin_amd/bin/vpin_prove: the reference binary's CLI contract over the C ABI."""
+    src = os.path.join(CSRC, "cli", "vpin_prove.cpp")
+    out_dir = os.path.join(HERE, "bin")
+    os.makedirs(out_dir, exist_ok=True)
+    out = os.path.join(out_dir, "vpin_prove")
+    cmd = [hipcc(), "-O2", "-std=c++17", src, "-o", out, "-L", LIB_DIR, "-lvpin_hip", "-Wl,-rpath,$ORIGIN/../lib"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return out
 
 
 if __name__ == "__main__":

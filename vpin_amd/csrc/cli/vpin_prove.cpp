@@ -1,0 +1,252 @@
+// vpin_prove -- command-line prover with the reference binary's contract.
+//   reference: vPIN_proof_generation/src/main.rs:14-46 (`cargo run -- <label>`), witness files read by
+//   load_data.rs:5-63 and load_data_add.rs:5-103 from the cwd-relative directory rust_files/<label>/.
+// Usage: vpin_prove <label> [--seed <hex64bytes>] [--device N] [--write-proof <dir>]
+// Stdout follows the reference line for line (network / gadget banners / counts / proof size / times /
+// totals block).  Differences, all stated on stderr: the proof is the R1CS satisfiability proof only
+// (the SPARK eval proof is not part of this build), and verification is left to the verifier the
+// proof bytes are handed to (--write-proof dumps them with the two commitments and the claims).
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <random>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "../../../include/vpin_hip.h"
+
+namespace {
+
+[[noreturn]] void die(const std::string& msg) {
+  fprintf(stderr, "%s\n", msg.c_str());
+  exit(101);  // the reference panics (exit code 101) on every load/parse failure
+}
+
+std::string slurp(const std::string& path) {
+  std::ifstream f(path, std::ios::binary);
+  if (!f) die("Failed to open file: " + path);  // load_data.rs:14 expect("Failed to open file")
+  std::stringstream ss;
+  ss << f.rdbuf();
+  return ss.str();
+}
+
+// minimal JSON: arrays of integers, arrays of arrays of integers, arrays of strings
+struct Parser {
+  const std::string& s;
+  size_t i = 0;
+  explicit Parser(const std::string& str) : s(str) {}
+  void ws() { while (i < s.size() && (s[i] == ' ' || s[i] == '\n' || s[i] == '\t' || s[i] == '\r')) i++; }
+  bool eat(char c) { ws(); if (i < s.size() && s[i] == c) { i++; return true; } return false; }
+  void need(char c) { if (!eat(c)) die("Failed to parse JSON"); }
+  long long integer() {
+    ws();
+    size_t j = i;
+    if (j < s.size() && (s[j] == '-' || s[j] == '+')) j++;
+    while (j < s.size() && isdigit((unsigned char)s[j])) j++;
+    if (j == i) die("Failed to parse JSON");
+    long long v = atoll(s.substr(i, j - i).c_str());
+    i = j;
+    // tolerate "12.0"
+    if (i < s.size() && s[i] == '.') { i++; while (i < s.size() && isdigit((unsigned char)s[i])) i++; }
+    return v;
+  }
+  std::string str() {
+    need('"');
+    size_t j = s.find('"', i);
+    if (j == std::string::npos) die("Failed to parse JSON");
+    std::string r = s.substr(i, j - i);
+    i = j + 1;
+    return r;
+  }
+};
+
+// N x 32 byte matrix (point_*_byte.json): rows shorter than 32 are zero-extended like the reference's
+// fixed [u8;32] fill (point_mult.rs:355-361)
+std::vector<uint8_t> load_bytes32(const std::string& path, size_t* n_out) {
+  std::string txt = slurp(path);
+  Parser p(txt);
+  std::vector<uint8_t> out;
+  p.need('[');
+  size_t n = 0;
+  if (!p.eat(']')) {
+    do {
+      p.need('[');
+      uint8_t row[32] = {0};
+      size_t k = 0;
+      if (!p.eat(']')) {
+        do {
+          long long v = p.integer();
+          if (k < 32) row[k] = (uint8_t)v;
+          k++;
+        } while (p.eat(','));
+        p.need(']');
+      }
+      out.insert(out.end(), row, row + 32);
+      n++;
+    } while (p.eat(','));
+    p.need(']');
+  }
+  *n_out = n;
+  return out;
+}
+
+std::vector<uint8_t> load_flags(const std::string& path) {
+  std::string txt = slurp(path);
+  Parser p(txt);
+  std::vector<uint8_t> out;
+  p.need('[');
+  if (!p.eat(']')) {
+    do out.push_back(p.integer() != 0); while (p.eat(','));
+    p.need(']');
+  }
+  return out;
+}
+
+// weight.json: decimal strings parsed as u128 (load_data.rs:18-23)
+std::vector<uint8_t> load_weights(const std::string& path, size_t* n_out) {
+  std::string txt = slurp(path);
+  Parser p(txt);
+  std::vector<uint8_t> out;
+  size_t n = 0;
+  p.need('[');
+  if (!p.eat(']')) {
+    do {
+      std::string d = p.str();
+      unsigned __int128 v = 0;
+      if (d.empty()) die("Failed to parse weight");
+      for (char ch : d) {
+        if (!isdigit((unsigned char)ch)) die("Failed to parse weight");
+        unsigned __int128 nv = v * 10 + (unsigned)(ch - '0');
+        if (nv / 10 != v) die("Failed to parse weight");  // u128 overflow
+        v = nv;
+      }
+      uint8_t b[16];
+      memcpy(b, &v, 16);
+      out.insert(out.end(), b, b + 16);
+      n++;
+    } while (p.eat(','));
+    p.need(']');
+  }
+  *n_out = n;
+  return out;
+}
+
+using Clock = std::chrono::steady_clock;
+long long ms_since(Clock::time_point t0) {
+  return std::chrono::duration_cast<std::chrono::milliseconds>(Clock::now() - t0).count();
+}
+
+struct Result { size_t size = 0; long long gen_ms = 0, ver_ms = 0; };
+
+void check(int rc, const char* what) {
+  if (rc != 0) die(std::string(what) + ": " + vpin_strerror(rc) + " [" + vpin_last_error() + "]");
+}
+
+Result prove(vpin_ctx* ctx, vpin_instance* inst, const uint8_t seeds[128], const std::string& dump_prefix, Clock::time_point t0) {
+  if (vpin_instance_is_sat(inst) != 1) die("assertion failed: instance is not satisfied");  // point_mult.rs:650-651
+  const vpin_r1cs* r = vpin_instance_r1cs(inst);
+  size_t cap = vpin_sat_proof_max_bytes(r->num_cons, r->num_vars), len = 0;
+  size_t ell = 0;
+  while (((size_t)1 << ell) < r->num_vars) ell++;
+  size_t L = (size_t)1 << (ell / 2);
+  std::vector<uint8_t> proof(cap), cp(32 * L), ci(32 * L), ev(96);
+  check(vpin_sat_prove(ctx, r, vpin_instance_vars_para(inst), vpin_instance_vars_input(inst), vpin_instance_vars(inst),
+                       vpin_instance_inputs(inst), seeds, seeds + 64, proof.data(), cap, &len, cp.data(), ci.data(), ev.data(),
+                       nullptr, nullptr),
+        "vpin_sat_prove");
+  Result res;
+  res.size = len;
+  printf("Proof size: %zu bytes\n", len);
+  res.gen_ms = ms_since(t0);
+  printf("Proof generation time: %lld ms\n", res.gen_ms);
+  if (!dump_prefix.empty()) {
+    std::ofstream(dump_prefix + ".proof", std::ios::binary).write((const char*)proof.data(), (std::streamsize)len);
+    std::ofstream(dump_prefix + ".comm_para", std::ios::binary).write((const char*)cp.data(), (std::streamsize)cp.size());
+    std::ofstream(dump_prefix + ".comm_input", std::ios::binary).write((const char*)ci.data(), (std::streamsize)ci.size());
+    std::ofstream(dump_prefix + ".inst_evals", std::ios::binary).write((const char*)ev.data(), 96);
+  }
+  return res;
+}
+
+}  // namespace
+
+int main(int argc, char** argv) {
+  std::string network = argc > 1 ? argv[1] : "1";  // main.rs:16
+  std::string dump_dir;
+  int device = 0;
+  uint8_t seeds[128];
+  bool have_seed = false;
+  for (int i = 2; i < argc; i++) {
+    std::string a = argv[i];
+    if (a == "--device" && i + 1 < argc) device = atoi(argv[++i]);
+    else if (a == "--write-proof" && i + 1 < argc) dump_dir = argv[++i];
+    else if (a == "--seed" && i + 1 < argc) {
+      std::string h = argv[++i];  // hex, repeated cyclically to 128 bytes: commit seed | proof seed
+      size_t usable = h.size() & ~(size_t)1;
+      if (usable == 0) die("--seed needs hex bytes");
+      for (size_t k = 0; k < 128; k++) seeds[k] = (uint8_t)strtol(h.substr((2 * k) % usable, 2).c_str(), nullptr, 16);
+      have_seed = true;
+    }
+  }
+  if (!have_seed) {  // OsRng (Spartan/src/random.rs:17)
+    std::random_device rd;
+    for (auto& b : seeds) b = (uint8_t)rd();
+  }
+  fprintf(stderr, "vpin_prove: R1CS satisfiability proof only (no SPARK eval proof); proofs are not verified in-process\n");
+
+  printf("network: %s\n", network.c_str());
+  vpin_ctx* ctx = nullptr;
+  const std::string base = "rust_files/" + network + "/";
+
+  // ---- point addition (proof_point_add.rs) ----
+  auto t0 = Clock::now();
+  size_t n1 = 0, n2 = 0, n3 = 0, n4 = 0;
+  std::vector<uint8_t> apx = load_bytes32(base + "pointAdd/point_add_px_byte.json", &n1);
+  std::vector<uint8_t> apy = load_bytes32(base + "pointAdd/point_add_py_byte.json", &n2);
+  std::vector<uint8_t> arx = load_bytes32(base + "pointAdd/point_add_rx_byte.json", &n3);
+  std::vector<uint8_t> ary = load_bytes32(base + "pointAdd/point_add_ry_byte.json", &n4);
+  std::vector<uint8_t> arz = load_flags(base + "pointAdd/point_add_rz_byte.json");
+  if (n2 != n1 || n3 != n1 || n4 != n1 || arz.size() != n1) die("point addition witness files disagree on the number of operations");
+  printf("Point Addition Gadget...\n");
+  printf("Number of Point Additions: %zu\n", n1);
+  check(vpin_ctx_create(device, &ctx), "vpin_ctx_create");
+  vpin_instance* add = nullptr;
+  check(vpin_gadget_point_add(apx.data(), apy.data(), arx.data(), ary.data(), arz.data(), n1, &add), "vpin_gadget_point_add");
+  Result ra = prove(ctx, add, seeds, dump_dir.empty() ? "" : dump_dir + "/" + network + "_add", t0);
+  vpin_instance_free(add);
+  printf("\n");
+
+  // ---- point multiplication (proof_point_mult.rs); L2/L4 have none (main.rs:24-31) ----
+  Result rm;
+  if (network == "L2" || network == "L4") {
+    printf("Number of Point Multiplications: 0\n");
+    printf("Proof size: 0 bytes\n");
+    printf("Proof generation time: 0 ms\n");
+    printf("Proof verification time: 0 ms\n");
+  } else {
+    t0 = Clock::now();
+    size_t nw = 0, m1 = 0, m2 = 0;
+    std::vector<uint8_t> w = load_weights(base + "pointMult/weight.json", &nw);
+    std::vector<uint8_t> mpx = load_bytes32(base + "pointMult/point_mult_px_byte.json", &m1);
+    std::vector<uint8_t> mpy = load_bytes32(base + "pointMult/point_mult_py_byte.json", &m2);
+    if (m1 != nw || m2 != nw) die("point multiplication witness files disagree on the number of operations");
+    printf("Point Multiplication Gadget...\n");
+    printf("Number of Point Multiplications: %zu\n", nw);
+    printf("Generating Proof...\n");
+    vpin_instance* mult = nullptr;
+    check(vpin_gadget_point_mult(w.data(), mpx.data(), mpy.data(), nw, &mult), "vpin_gadget_point_mult");
+    printf("Still working on...\n");
+    rm = prove(ctx, mult, seeds, dump_dir.empty() ? "" : dump_dir + "/" + network + "_mult", t0);
+    vpin_instance_free(mult);
+  }
+  printf("\n====================================\n");
+  printf("Total proof size: %zu bytes\n", ra.size + rm.size);
+  printf("Total proof generation time: %lld ms\n", ra.gen_ms + rm.gen_ms);
+  printf("Total proof verification time: %lld ms\n", ra.ver_ms + rm.ver_ms);
+  printf("====================================\n");
+  vpin_ctx_destroy(ctx);
+  return 0;
+}

@@ -208,6 +208,12 @@ __device__ __noinline__ fp fp_pow_p58(const fp& z) {
   return fp_mul(fp_sqr_n(t1, 2), z);      // 2^252 - 3
 }
 
+// a^(p-2) = a^(2^255-21) = (a^(2^252-3))^8 * a^3
+__device__ __noinline__ fp fp_invert(const fp& a) {
+  fp t = fp_sqr_n(fp_pow_p58(a), 3);
+  return fp_mul(t, fp_mul(fp_sqr(a), a));
+}
+
 // ---- curve constants (little-endian 32-bit limbs), RFC 9496 section 4 ------------------------
 __device__ __forceinline__ fp fp_const(uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3, uint32_t a4, uint32_t a5,
                                        uint32_t a6, uint32_t a7) {
@@ -257,6 +263,23 @@ __device__ __forceinline__ ge_ext ge_add_cached(const ge_ext& p, const ge_cached
 }
 
 __device__ __forceinline__ ge_ext ge_add(const ge_ext& p, const ge_ext& q) { return ge_add_cached(p, ge_to_cached(q)); }
+
+// Affine table entry (y+x, y-x, 2dxy): 96 bytes, and a table add costs 7 multiplies (Z2 = 1)
+struct ge_niels { fp ypx, ymx, xy2d; };
+
+__device__ __forceinline__ ge_ext ge_add_niels(const ge_ext& p, const ge_niels& q, bool negate_q) {
+  fp qa = negate_q ? q.ymx : q.ypx, qb = negate_q ? q.ypx : q.ymx;
+  fp PP = fp_mul(fp_add(p.Y, p.X), qa);
+  fp MM = fp_mul(fp_sub(p.Y, p.X), qb);
+  fp TT = fp_mul(p.T, q.xy2d);
+  fp ZZ2 = fp_add(p.Z, p.Z);
+  fp E = fp_sub(PP, MM), H = fp_add(PP, MM);
+  fp G = negate_q ? fp_sub(ZZ2, TT) : fp_add(ZZ2, TT);
+  fp F = negate_q ? fp_add(ZZ2, TT) : fp_sub(ZZ2, TT);
+  ge_ext r;
+  r.X = fp_mul(E, F); r.Y = fp_mul(G, H); r.Z = fp_mul(F, G); r.T = fp_mul(E, H);
+  return r;
+}
 
 // dbl-2008-hwcd
 __device__ __forceinline__ ge_ext ge_double(const ge_ext& p) {

@@ -7,10 +7,11 @@
 //
 // MI355X-first design: every MSM of the sat proof is over the SAME generator stream
 // g[0..R+2) (MultiCommitGens::new, commitments.rs:20-38), so instead of per-row Pippenger
-// buckets we spend HBM (288 GB) on a window table  T[w][j][k] = (k+1) * 2^(8w) * g_j
-// (32 windows x 128 signed-digit multiples x 128 B "cached" points = 512 KiB per base) and
-// turn each row commitment into a pure gather-and-add: a non-zero scalar costs at most 32
-// table additions, no doublings, no bucket reduction, no atomics.  Zero scalars and zero
+// buckets we spend HBM (288 GB) on a window table  T[w][j][k] = (k+1) * 2^(c*w) * g_j  of
+// AFFINE points (y+x, y-x, 2dxy; 96 B) with c = 11 or 12 bit signed windows (W = 24 / 22
+// windows, 1024 / 2048 multiples each: 2.4-4.3 MB per generator, 9 GB for R = 2048, 19 GB for
+// R = 8192) and turn each row commitment into a pure gather-and-add: a non-zero scalar costs
+// at most W table additions of 7 field multiplies, no doublings, no bucket reduction, no atomics.  Zero scalars and zero
 // digits are skipped (the witness is ~40% zero padding and full of 0/1 bits), like dalek's
 // vartime MSM.  One 256-thread workgroup per row; per-thread partial sums are combined by
 // an LDS tree.  Integer-ALU bound (~8 field multiplies per table add); no MFMA.
@@ -21,56 +22,74 @@
 #include "fp_dev.h"
 
 struct vpin_gens {
-  vpin::ge_cached* table = nullptr;  // [32][nb][128]
-  vpin::ge_ext* shifts = nullptr;    // scratch [nb][32]: 2^(8w) * g_j
-  size_t nb = 0;                     // number of bases in the stream
+  vpin::ge_niels* table = nullptr;  // [W][nb][E]
+  size_t nb = 0;                    // number of bases in the stream
+  int c = 12, W = 22, E = 2048;     // window bits, windows, entries per window (= 2^(c-1))
 };
 
 namespace vpin {
 
-constexpr int kWin = 32;      // 8-bit windows
-constexpr int kEntries = 128; // multiples 1..128 per window (signed digits)
+struct TableView {
+  const ge_niels* t;
+  size_t nb;
+  int c, W, E;
+};
 
 // ---- table construction ---------------------------------------------------------------
 
-// one thread per base: shifts[j][w] = 2^(8w) * g_j
-__global__ __launch_bounds__(64) void gens_shift_kernel(const fp* __restrict__ xyzt, size_t nb, ge_ext* __restrict__ shifts) {
+// one thread per base: shifts[j][w] = 2^(c*w) * g_j
+__global__ __launch_bounds__(64) void gens_shift_kernel(const fp* __restrict__ xyzt, size_t nb, int W, int c,
+                                                        ge_ext* __restrict__ shifts) {
   size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= nb) return;
   ge_ext p;
   p.X = fp_load(xyzt + 4 * j); p.Y = fp_load(xyzt + 4 * j + 1); p.Z = fp_load(xyzt + 4 * j + 2); p.T = fp_load(xyzt + 4 * j + 3);
-  for (int w = 0; w < kWin; w++) {
-    ge_ext* o = shifts + j * kWin + w;
+  for (int w = 0; w < W; w++) {
+    ge_ext* o = shifts + j * W + w;
     fp_store(&o->X, p.X); fp_store(&o->Y, p.Y); fp_store(&o->Z, p.Z); fp_store(&o->T, p.T);
-    for (int k = 0; k < 8; k++) p = ge_double(p);
+    for (int k = 0; k < c; k++) p = ge_double(p);
   }
 }
 
-__device__ __forceinline__ void cached_store(ge_cached* o, const ge_cached& c) {
-  fp_store(&o->YpX, c.YpX); fp_store(&o->YmX, c.YmX); fp_store(&o->Z, c.Z); fp_store(&o->T2d, c.T2d);
-}
-__device__ __forceinline__ ge_cached cached_load(const ge_cached* o) {
-  ge_cached c;
-  c.YpX = fp_load(&o->YpX); c.YmX = fp_load(&o->YmX); c.Z = fp_load(&o->Z); c.T2d = fp_load(&o->T2d);
-  return c;
+__device__ __forceinline__ ge_niels niels_load(const ge_niels* o) {
+  ge_niels e;
+  e.ypx = fp_load(&o->ypx); e.ymx = fp_load(&o->ymx); e.xy2d = fp_load(&o->xy2d);
+  return e;
 }
 
-// one thread per (base, window): the 128 multiples of the shifted base
-__global__ __launch_bounds__(64) void gens_table_kernel(const ge_ext* __restrict__ shifts, size_t nb, ge_cached* __restrict__ table) {
+// one thread per (base, window): the E multiples of the shifted base, normalised to affine with
+// one inversion per thread (Montgomery's trick): forward pass stores X,Y,Z in the entry slots and
+// the running product of the Z's in `prefix`; the backward pass peels the inverses off.
+__global__ __launch_bounds__(64) void gens_table_kernel(const ge_ext* __restrict__ shifts, size_t nb, int W, int E,
+                                                        ge_niels* __restrict__ table, fp* __restrict__ prefix) {
   size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= nb * kWin) return;
-  size_t j = idx / kWin;
-  int w = (int)(idx % kWin);
-  const ge_ext* s = shifts + j * kWin + w;
+  if (idx >= nb * (size_t)W) return;
+  size_t j = idx / W;
+  int w = (int)(idx % W);
+  const ge_ext* s = shifts + j * W + w;
   ge_ext p;
   p.X = fp_load(&s->X); p.Y = fp_load(&s->Y); p.Z = fp_load(&s->Z); p.T = fp_load(&s->T);
   ge_cached pc = ge_to_cached(p);
-  ge_cached* out = table + ((size_t)w * nb + j) * kEntries;
+  ge_niels* out = table + ((size_t)w * nb + j) * E;
+  fp* pre = prefix + ((size_t)w * nb + j) * E;
   ge_ext q = p;
-  cached_store(out, pc);
-  for (int k = 1; k < kEntries; k++) {
-    q = ge_add_cached(q, pc);
-    cached_store(out + k, ge_to_cached(q));
+  fp run = fp_one();
+  for (int k = 0; k < E; k++) {
+    fp_store(&out[k].ypx, q.X); fp_store(&out[k].ymx, q.Y); fp_store(&out[k].xy2d, q.Z);
+    run = fp_mul(run, q.Z);
+    fp_store(pre + k, run);
+    if (k + 1 < E) q = ge_add_cached(q, pc);
+  }
+  fp acc = fp_invert(run);
+  const fp d2 = FP_D2();
+  for (int k = E - 1; k >= 0; k--) {
+    fp X = fp_load(&out[k].ypx), Y = fp_load(&out[k].ymx), Z = fp_load(&out[k].xy2d);
+    fp zinv = (k > 0) ? fp_mul(acc, fp_load(pre + k - 1)) : acc;
+    acc = fp_mul(acc, Z);
+    fp x = fp_mul(X, zinv), y = fp_mul(Y, zinv);
+    fp_store(&out[k].ypx, fp_add(y, x));
+    fp_store(&out[k].ymx, fp_sub(y, x));
+    fp_store(&out[k].xy2d, fp_mul(fp_mul(x, y), d2));
   }
 }
 
@@ -94,22 +113,55 @@ __device__ __forceinline__ fq fq_from_mont(const fq& a) {
 }
 
 // accumulate s * g_j into acc through the window table; s canonical, non-zero
-__device__ __forceinline__ void table_mul_acc(ge_ext& acc, fq s, const ge_cached* __restrict__ table, size_t nb, size_t j) {
+__device__ __forceinline__ void table_mul_acc(ge_ext& acc, fq s, const TableView& tv, size_t j) {
   uint32_t carry = 0;
+  const uint32_t mask = (1u << tv.c) - 1u, half = 1u << (tv.c - 1);
 #pragma unroll 1
-  for (int w = 0; w < kWin; w++) {
-    uint32_t v = (s.v[0] & 0xffu) + carry;
-    // shift the 256-bit scalar right by one byte (static register indices only)
+  for (int w = 0; w < tv.W; w++) {
+    uint32_t v = (s.v[0] & mask) + carry;
+    // shift the 256-bit scalar right by c bits (static register indices only)
 #pragma unroll
-    for (int i = 0; i < 7; i++) s.v[i] = __builtin_amdgcn_alignbyte(s.v[i + 1], s.v[i], 1);
-    s.v[7] >>= 8;
-    bool neg = v > 128u;
-    uint32_t mag = neg ? 256u - v : v;
+    for (int i = 0; i < 7; i++) s.v[i] = __builtin_amdgcn_alignbit(s.v[i + 1], s.v[i], tv.c);
+    s.v[7] >>= tv.c;
+    bool neg = v > half;
+    uint32_t mag = neg ? (mask + 1u) - v : v;
     carry = neg ? 1u : 0u;
     if (mag != 0) {
-      ge_cached e = cached_load(table + ((size_t)w * nb + j) * kEntries + (mag - 1));
-      acc = ge_add_cached(acc, e, neg);
+      ge_niels e = niels_load(tv.t + ((size_t)w * tv.nb + j) * tv.E + (mag - 1));
+      acc = ge_add_niels(acc, e, neg);
     }
+  }
+}
+
+// digit w (c bits) of a canonical scalar, for the kernels that split one scalar over several lanes
+__device__ __forceinline__ uint32_t scalar_digit(const fq& s, int w, int c) {
+  int off = w * c, word = off >> 5, sh = off & 31;
+  uint32_t lo = s.v[word], hi = (word + 1 < 8) ? s.v[word + 1] : 0u;
+  uint64_t both = ((uint64_t)hi << 32) | lo;
+  return (uint32_t)(both >> sh) & ((1u << c) - 1u);
+}
+
+// signed-digit carry into window w0: decided by the nearest lower digit that is not exactly 2^(c-1)
+__device__ __forceinline__ uint32_t carry_into(const fq& s, int w0, int c) {
+  const uint32_t half = 1u << (c - 1);
+  for (int w = w0 - 1; w >= 0; w--) {
+    uint32_t d = scalar_digit(s, w, c);
+    if (d != half) return d > half ? 1u : 0u;
+  }
+  return 0u;
+}
+
+// windows [w0, w1) of s * g_j
+__device__ __forceinline__ void table_mul_acc_range(ge_ext& acc, const fq& s, const TableView& tv, size_t j, int w0, int w1) {
+  uint32_t carry = carry_into(s, w0, tv.c);
+  const uint32_t full = 1u << tv.c, half = 1u << (tv.c - 1);
+#pragma unroll 1
+  for (int w = w0; w < w1; w++) {
+    uint32_t v = scalar_digit(s, w, tv.c) + carry;
+    bool neg = v > half;
+    uint32_t mag = neg ? full - v : v;
+    carry = neg ? 1u : 0u;
+    if (mag != 0) acc = ge_add_niels(acc, niels_load(tv.t + ((size_t)w * tv.nb + j) * tv.E + (mag - 1)), neg);
   }
 }
 
@@ -123,8 +175,7 @@ constexpr int kSeg = 8192;  // scalars per compaction segment (uint16 indices, 1
 
 __global__ __launch_bounds__(kMsmBlock) void msm_rows_kernel(const fq* __restrict__ Z, size_t stride, size_t ncols,
                                                              const fq* __restrict__ extra, int n_extra, size_t extra_base0,
-                                                             const ge_cached* __restrict__ table, size_t nb,
-                                                             ge_ext* __restrict__ out) {
+                                                             TableView tv, ge_ext* __restrict__ out) {
   const size_t row = blockIdx.x;
   ge_ext acc = ge_identity();
   const size_t total = ncols + (size_t)n_extra;
@@ -153,7 +204,7 @@ __global__ __launch_bounds__(kMsmBlock) void msm_rows_kernel(const fq* __restric
       size_t base;
       if (j < ncols) { s = fq_load(Z + row * stride + j); base = j; }
       else { s = fq_load(extra + row * (size_t)n_extra + (j - ncols)); base = extra_base0 + (j - ncols); }
-      table_mul_acc(acc, fq_from_mont(s), table, nb, base);
+      table_mul_acc(acc, fq_from_mont(s), tv, base);
     }
     __syncthreads();
   }
@@ -178,36 +229,17 @@ __global__ __launch_bounds__(kMsmBlock) void msm_rows_kernel(const fq* __restric
 // workgroup covers 32 scalars; the per-workgroup partial points go back to the host, which adds
 // the few dozen partials and compresses (microseconds on a CPU core, ~0.4 ms as a GPU tail).
 constexpr int kWideScalars = 32;  // scalars per workgroup
-__global__ __launch_bounds__(kMsmBlock) void msm_wide_kernel(const fq* __restrict__ S, size_t ncols,
-                                                             const ge_cached* __restrict__ table, size_t nb,
+__global__ __launch_bounds__(kMsmBlock) void msm_wide_kernel(const fq* __restrict__ S, size_t ncols, TableView tv,
                                                              fp* __restrict__ parts_xyzt) {
   const size_t row = blockIdx.y;
   const size_t j = (size_t)blockIdx.x * kWideScalars + (threadIdx.x >> 3);
-  const int grp = threadIdx.x & 7;  // windows [4*grp, 4*grp+4)
+  const int grp = threadIdx.x & 7, wpg = (tv.W + 7) / 8;  // this lane's windows [grp*wpg, (grp+1)*wpg)
   ge_ext acc = ge_identity();
   if (j < ncols) {
     fq s = fq_load(S + row * ncols + j);
     if (!fq_is_zero(s)) {
-      s = fq_from_mont(s);
-      // signed-digit carry into window 4*grp: set iff the nearest lower byte != 0x80 is > 0x80
-      uint32_t carry = 0;
-      for (int w = 4 * grp - 1; w >= 0; w--) {
-        uint32_t byte = (s.v[w >> 2] >> ((w & 3) * 8)) & 0xffu;
-        if (byte != 128u) { carry = byte > 128u ? 1u : 0u; break; }
-      }
-      uint32_t limb = s.v[grp];
-#pragma unroll 1
-      for (int t = 0; t < 4; t++) {
-        uint32_t v = ((limb >> (8 * t)) & 0xffu) + carry;
-        bool neg = v > 128u;
-        uint32_t mag = neg ? 256u - v : v;
-        carry = neg ? 1u : 0u;
-        if (mag != 0) {
-          int w = 4 * grp + t;
-          ge_cached e = cached_load(table + ((size_t)w * nb + j) * kEntries + (mag - 1));
-          acc = ge_add_cached(acc, e, neg);
-        }
-      }
+      int w0 = grp * wpg, w1 = (w0 + wpg < tv.W) ? w0 + wpg : tv.W;
+      if (w0 < w1) table_mul_acc_range(acc, fq_from_mont(s), tv, j, w0, w1);
     }
   }
   __shared__ ge_ext sh[kMsmBlock];
@@ -227,33 +259,17 @@ __global__ __launch_bounds__(kMsmBlock) void msm_wide_kernel(const fq* __restric
 }
 
 // out[i] = s_i * g[base] for n scalars (the blind terms of the row commitments): 8 threads per
-// scalar, 4 windows each, 3-level LDS tree -- one wave handles 8 scalars
-__global__ __launch_bounds__(64) void single_base_mul_kernel(const fq* __restrict__ S, size_t n, const ge_cached* __restrict__ table,
-                                                             size_t nb, size_t base, ge_ext* __restrict__ out) {
+// scalar, ceil(W/8) windows each, 3-level LDS tree -- one wave handles 8 scalars
+__global__ __launch_bounds__(64) void single_base_mul_kernel(const fq* __restrict__ S, size_t n, TableView tv, size_t base,
+                                                             ge_ext* __restrict__ out) {
   const size_t i = (size_t)blockIdx.x * 8 + (threadIdx.x >> 3);
-  const int grp = threadIdx.x & 7;
+  const int grp = threadIdx.x & 7, wpg = (tv.W + 7) / 8;
   ge_ext acc = ge_identity();
   if (i < n) {
     fq s = fq_load(S + i);
     if (!fq_is_zero(s)) {
-      s = fq_from_mont(s);
-      uint32_t carry = 0;
-      for (int w = 4 * grp - 1; w >= 0; w--) {
-        uint32_t byte = (s.v[w >> 2] >> ((w & 3) * 8)) & 0xffu;
-        if (byte != 128u) { carry = byte > 128u ? 1u : 0u; break; }
-      }
-      uint32_t limb = s.v[grp];
-#pragma unroll 1
-      for (int t = 0; t < 4; t++) {
-        uint32_t v = ((limb >> (8 * t)) & 0xffu) + carry;
-        bool neg = v > 128u;
-        uint32_t mag = neg ? 256u - v : v;
-        carry = neg ? 1u : 0u;
-        if (mag != 0) {
-          int w = 4 * grp + t;
-          acc = ge_add_cached(acc, cached_load(table + ((size_t)w * nb + base) * kEntries + (mag - 1)), neg);
-        }
-      }
+      int w0 = grp * wpg, w1 = (w0 + wpg < tv.W) ? w0 + wpg : tv.W;
+      if (w0 < w1) table_mul_acc_range(acc, fq_from_mont(s), tv, base, w0, w1);
     }
   }
   __shared__ ge_ext sh[64];
@@ -326,23 +342,34 @@ int vpin_gens_create(vpin_ctx* c, const uint8_t* gens_xyzt, size_t nb, vpin_gens
   vpin_gens* g = new (std::nothrow) vpin_gens();
   if (!g) return VPIN_ENOMEM;
   g->nb = nb;
+  // window width by table budget (<= ~24 GB): 12 bits up to ~2k generators, 11 above
+  g->c = (nb * (size_t)22 * 2048 * sizeof(ge_niels) <= ((size_t)24 << 30)) ? 12 : 11;
+  g->W = (254 + g->c - 1) / g->c;
+  g->E = 1 << (g->c - 1);
+  const size_t entries = nb * (size_t)g->W * g->E;
   DevBuf raw(c);
-  if (raw.alloc(nb * 128) != VPIN_OK || hipMalloc(&g->shifts, nb * kWin * sizeof(ge_ext)) != hipSuccess ||
-      hipMalloc(&g->table, nb * (size_t)kWin * kEntries * sizeof(ge_cached)) != hipSuccess) {
-    if (g->shifts) (void)hipFree(g->shifts);
+  ge_ext* shifts = nullptr;
+  fp* prefix = nullptr;
+  if (raw.alloc(nb * 128) != VPIN_OK || hipMalloc((void**)&shifts, nb * g->W * sizeof(ge_ext)) != hipSuccess ||
+      hipMalloc((void**)&prefix, entries * sizeof(fp)) != hipSuccess ||
+      hipMalloc((void**)&g->table, entries * sizeof(ge_niels)) != hipSuccess) {
+    if (shifts) (void)hipFree(shifts);
+    if (prefix) (void)hipFree(prefix);
     if (g->table) (void)hipFree(g->table);
     delete g;
     return VPIN_ENOMEM;
   }
   hipError_t e = hipMemcpyAsync(raw.p, gens_xyzt, nb * 128, hipMemcpyHostToDevice, c->stream);
   if (e == hipSuccess) {
-    hipLaunchKernelGGL(gens_shift_kernel, dim3((unsigned)((nb + 63) / 64)), dim3(64), 0, c->stream, (const fp*)raw.p, nb, g->shifts);
-    hipLaunchKernelGGL(gens_table_kernel, dim3((unsigned)((nb * kWin + 63) / 64)), dim3(64), 0, c->stream, g->shifts, nb, g->table);
+    hipLaunchKernelGGL(gens_shift_kernel, dim3((unsigned)((nb + 63) / 64)), dim3(64), 0, c->stream, (const fp*)raw.p, nb, g->W,
+                       g->c, shifts);
+    hipLaunchKernelGGL(gens_table_kernel, dim3((unsigned)((nb * g->W + 63) / 64)), dim3(64), 0, c->stream, shifts, nb, g->W,
+                       g->E, g->table, prefix);
     e = hipGetLastError();
   }
   if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-  (void)hipFree(g->shifts);
-  g->shifts = nullptr;
+  (void)hipFree(shifts);
+  (void)hipFree(prefix);
   if (e != hipSuccess) {
     set_last_error("vpin_gens_create", e);
     (void)hipFree(g->table);
@@ -363,6 +390,8 @@ void vpin_gens_free(vpin_ctx* c, vpin_gens* g) {
 size_t vpin_gens_count(const vpin_gens* g) { return g ? g->nb : 0; }
 
 // shared implementation: rows of scalars -> points (kept on device), then optional outputs
+static inline TableView view(const vpin_gens* g) { return TableView{g->table, g->nb, g->c, g->W, g->E}; }
+
 static int msm_rows(vpin_ctx* c, const vpin_gens* g, const fq* dZ, size_t rows, size_t stride, size_t ncols,
                     const fq* d_extra, int n_extra, size_t extra_base0, ge_ext* d_points) {
   double nz_est = (double)rows * ((double)ncols + n_extra);
@@ -381,7 +410,7 @@ static int msm_rows(vpin_ctx* c, const vpin_gens* g, const fq* dZ, size_t rows, 
   {
     ProfScope ps(c, VPIN_K_MSM, 32.0 * nz_est);
     hipLaunchKernelGGL(msm_rows_kernel, dim3((unsigned)rows, (unsigned)chunks), dim3(kMsmBlock), 0, c->stream, dZ, stride,
-                       ncols, d_extra, n_extra, extra_base0, g->table, g->nb, dst);
+                       ncols, d_extra, n_extra, extra_base0, view(g), dst);
   }
   if (chunks > 1)
     hipLaunchKernelGGL(ge_sum_chunks_kernel, dim3((unsigned)((rows + 63) / 64)), dim3(64), 0, c->stream, (const ge_ext*)dst,
@@ -453,7 +482,7 @@ int vpin_gens_msm_parts(vpin_ctx* c, const vpin_gens* g, const uint8_t* scalars_
   {
     ProfScope ps(c, VPIN_K_MSM, 32.0 * (double)rows * (double)ncols);
     hipLaunchKernelGGL(msm_wide_kernel, dim3((unsigned)nparts, (unsigned)rows), dim3(kMsmBlock), 0, c->stream, (const fq*)ds.p,
-                       ncols, g->table, g->nb, (fp*)dp.p);
+                       ncols, view(g), (fp*)dp.p);
   }
   VPIN_HIP_TRY(hipGetLastError());
   VPIN_HIP_TRY(hipMemcpyAsync(parts_xyzt, dp.p, rows * nparts * 128, hipMemcpyDeviceToHost, c->stream));
@@ -506,7 +535,7 @@ int commit_pair_finish(vpin_ctx* c, const vpin_gens* g, CommitPairState* st, con
   ge_ext* pts = (ge_ext*)st->pts.p;
   // 2L single-scalar multiples of the blind generator
   hipLaunchKernelGGL(single_base_mul_kernel, dim3((unsigned)((2 * L + 7) / 8)), dim3(64), 0, c->stream, (const fq*)dbl.p, 2 * L,
-                     g->table, g->nb, blind_base, pts + 2 * L);
+                     view(g), blind_base, pts + 2 * L);
   const unsigned gb = (unsigned)((2 * L + 63) / 64);
   hipLaunchKernelGGL(ge_add_rows_kernel, dim3(gb), dim3(64), 0, c->stream, pts, pts + 2 * L, 2 * L, pts + 2 * L);  // a, b
   hipLaunchKernelGGL(ge_add_rows_kernel, dim3((unsigned)((L + 63) / 64)), dim3(64), 0, c->stream, pts + 2 * L, pts + 3 * L, L,

@@ -149,6 +149,25 @@ int vpin_ctx_sync(vpin_ctx* c) {
   return VPIN_OK;
 }
 
+}  // extern "C"
+
+namespace vpin {
+// table whose every element the caller is about to overwrite: no zero fill (a 1 GiB memset per
+// table per proof is pure HBM traffic)
+int table_alloc_uninit(vpin_ctx* c, size_t len, vpin_table** out) {
+  if (!c || !out || !is_pow2(len)) return VPIN_EINVAL;
+  (void)hipSetDevice(c->device);
+  vpin_table* t = new (std::nothrow) vpin_table();
+  if (!t) return VPIN_ENOMEM;
+  if (dev_alloc(c, len * sizeof(fq), (void**)&t->d) != VPIN_OK) { delete t; return VPIN_ENOMEM; }
+  t->len = t->cap = len;
+  *out = t;
+  return VPIN_OK;
+}
+}  // namespace vpin
+
+extern "C" {
+
 int vpin_table_alloc(vpin_ctx* c, size_t len, vpin_table** out) {
   if (!c || !out || !is_pow2(len)) return VPIN_EINVAL;
   (void)hipSetDevice(c->device);

@@ -88,6 +88,8 @@ struct DevBuf {
   int alloc(size_t bytes) { return dev_alloc(c, bytes, &p); }
 };
 
+int table_alloc_uninit(vpin_ctx* c, size_t len, vpin_table** out);
+
 // split-phase pair commitment (msm.hip)
 struct CommitPairState;
 int commit_pair_begin(vpin_ctx* c, const vpin_gens* g, const vpin_table* Za, const vpin_table* Zb, size_t L,

@@ -265,7 +265,7 @@ int vpin_r1cs_build_z(vpin_ctx* c, const vpin_r1cs_dev* d, const vpin_table* var
   if (vars->len != d->num_vars) return VPIN_ESHAPE;
   (void)hipSetDevice(c->device);
   vpin_table* z = nullptr;
-  int rc = vpin_table_alloc(c, 2 * d->num_vars, &z);
+  int rc = table_alloc_uninit(c, 2 * d->num_vars, &z);  // lower half copied, upper half written by the kernel
   if (rc) return rc;
   DevBuf bin(c);
   fq* d_in = nullptr;
@@ -292,7 +292,7 @@ int vpin_r1cs_multiply_vec(vpin_ctx* c, const vpin_r1cs_dev* d, const vpin_table
   (void)hipSetDevice(c->device);
   vpin_table* t[3] = {nullptr, nullptr, nullptr};
   for (int m = 0; m < 3; m++) {
-    int rc = vpin_table_alloc(c, d->num_cons, &t[m]);
+    int rc = table_alloc_uninit(c, d->num_cons, &t[m]);  // spmv_kernel writes every row
     if (rc) { for (int k = 0; k < m; k++) vpin_table_free(c, t[k]); return rc; }
     hipLaunchKernelGGL(spmv_kernel, dim3((unsigned)((d->num_cons + kRB - 1) / kRB)), dim3(kRB), 0, c->stream, d->rowptr[m],
                        d->csr_col[m], d->csr_val[m], z->d, d->num_cons, t[m]->d);
@@ -312,18 +312,19 @@ int vpin_r1cs_eval_table(vpin_ctx* c, const vpin_r1cs_dev* d, const vpin_table* 
   (void)hipSetDevice(c->device);
   const size_t ncols = 2 * d->num_vars;
   vpin_table* t = nullptr;
-  int rc = vpin_table_alloc(c, ncols, &t);
+  int rc = table_alloc_uninit(c, ncols, &t);  // matrix A's pass writes every column, B and C accumulate
   if (rc) return rc;
   for (int m = 0; m < 3; m++) {
     fq rc_m;
     memcpy(rc_m.v, r_abc + 32 * m, 32);
+    const int accum = m > 0 ? 1 : 0;
     hipLaunchKernelGGL(eval_table_kernel, dim3((unsigned)((ncols + kRB - 1) / kRB)), dim3(kRB), 0, c->stream, d->colptr[m],
-                       d->csc_row[m], d->csc_val[m], evals_rx->d, ncols, rc_m, 1, t->d);
+                       d->csc_row[m], d->csc_val[m], evals_rx->d, ncols, rc_m, accum, t->d);
     if (d->n_long[m]) {
       hipLaunchKernelGGL(long_chunk_kernel, dim3((unsigned)d->n_chunks[m]), dim3(kRB), 0, c->stream, d->chunk_k0[m],
                          d->chunk_k1[m], d->csc_row[m], d->csc_val[m], evals_rx->d, d->chunk_partials);
       hipLaunchKernelGGL(eval_table_long_finish_kernel, dim3((unsigned)((d->n_long[m] + 63) / 64)), dim3(64), 0, c->stream,
-                         d->long_cols[m], d->long_first[m], d->n_long[m], d->chunk_partials, rc_m, 1, t->d);
+                         d->long_cols[m], d->long_first[m], d->n_long[m], d->chunk_partials, rc_m, accum, t->d);
     }
   }
   hipError_t e = hipGetLastError();

@@ -485,10 +485,10 @@ int vpin_eq_table(vpin_ctx* c, const uint8_t* r, int ell, vpin_table** out) {
   (void)hipSetDevice(c->device);
   size_t n = (size_t)1 << ell;
   vpin_table *a = nullptr, *b = nullptr;
-  int rc = vpin_table_alloc(c, n, &a);
+  int rc = table_alloc_uninit(c, n, &a);  // every element is written by the doubling steps
   if (rc) return rc;
   if (ell > 0) {
-    rc = vpin_table_alloc(c, n, &b);
+    rc = table_alloc_uninit(c, n, &b);
     if (rc) { vpin_table_free(c, a); return rc; }
   }
   // evals[0] = 1 (Montgomery R), then ell doubling steps, ping-ponging a <-> b

@@ -116,20 +116,32 @@ __device__ __forceinline__ fq fq_from_mont(const fq& a) {
 __device__ __forceinline__ void table_mul_acc(ge_ext& acc, fq s, const TableView& tv, size_t j) {
   uint32_t carry = 0;
   const uint32_t mask = (1u << tv.c) - 1u, half = 1u << (tv.c - 1);
+  // software pipeline: the (random, 96-byte) table entry of window w+1 is requested before the
+  // 7-multiply add of window w, so the gather latency hides behind arithmetic
+  ge_niels e_cur;
+  bool have_cur = false, neg_cur = false;
 #pragma unroll 1
-  for (int w = 0; w < tv.W; w++) {
-    uint32_t v = (s.v[0] & mask) + carry;
-    // shift the 256-bit scalar right by c bits (static register indices only)
+  for (int w = 0; w <= tv.W; w++) {
+    ge_niels e_next;
+    bool have_next = false, neg_next = false;
+    if (w < tv.W) {
+      uint32_t v = (s.v[0] & mask) + carry;
+      // shift the 256-bit scalar right by c bits (static register indices only)
 #pragma unroll
-    for (int i = 0; i < 7; i++) s.v[i] = __builtin_amdgcn_alignbit(s.v[i + 1], s.v[i], tv.c);
-    s.v[7] >>= tv.c;
-    bool neg = v > half;
-    uint32_t mag = neg ? (mask + 1u) - v : v;
-    carry = neg ? 1u : 0u;
-    if (mag != 0) {
-      ge_niels e = niels_load(tv.t + ((size_t)w * tv.nb + j) * tv.E + (mag - 1));
-      acc = ge_add_niels(acc, e, neg);
+      for (int i = 0; i < 7; i++) s.v[i] = __builtin_amdgcn_alignbit(s.v[i + 1], s.v[i], tv.c);
+      s.v[7] >>= tv.c;
+      neg_next = v > half;
+      uint32_t mag = neg_next ? (mask + 1u) - v : v;
+      carry = neg_next ? 1u : 0u;
+      if (mag != 0) {
+        e_next = niels_load(tv.t + ((size_t)w * tv.nb + j) * tv.E + (mag - 1));
+        have_next = true;
+      }
     }
+    if (have_cur) acc = ge_add_niels(acc, e_cur, neg_cur);
+    e_cur = e_next;
+    have_cur = have_next;
+    neg_cur = neg_next;
   }
 }
 
@@ -173,7 +185,7 @@ constexpr int kMsmBlock = 256;
 // [extra_base0, extra_base0 + n_extra).  out[row] = sum_j s[row][j] * g_j  (extended coords)
 constexpr int kSeg = 8192;  // scalars per compaction segment (uint16 indices, 16 KiB of LDS)
 
-__global__ __launch_bounds__(kMsmBlock) void msm_rows_kernel(const fq* __restrict__ Z, size_t stride, size_t ncols,
+__global__ __launch_bounds__(kMsmBlock, 3) void msm_rows_kernel(const fq* __restrict__ Z, size_t stride, size_t ncols,
                                                              const fq* __restrict__ extra, int n_extra, size_t extra_base0,
                                                              TableView tv, ge_ext* __restrict__ out) {
   const size_t row = blockIdx.x;

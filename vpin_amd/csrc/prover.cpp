@@ -638,7 +638,10 @@ static int sat_prove_core(vpin_ctx* c, const vpin_r1cs_dev* dinst, size_t nv, si
     Fq* sL = srow.data();
     Fq* sR = srow.data() + ncols;
     const size_t mask = 2 * n - 1;
-    for (size_t j = 0; j < R; j++) {
+    const int nthr = R >= 2048 ? host_threads() : 1;  // O(R) host work per round: worth a team only for large R
+#pragma omp parallel for schedule(static) num_threads(nthr)
+    for (long jj = 0; jj < (long)R; jj++) {
+      const size_t j = (size_t)jj;
       size_t pos = j & mask;
       if (pos >= n) { sL[j] = av[pos - n] * sj[j]; sR[j] = Fq::zero(); }  // a_L . G_R
       else { sL[j] = Fq::zero(); sR[j] = av[n + pos] * sj[j]; }           // a_R . G_L
@@ -656,7 +659,11 @@ static int sat_prove_core(vpin_ctx* c, const vpin_r1cs_dev* dinst, size_t nv, si
       av[i] = av[i] * u + u_inv * av[n + i];
       bvv[i] = bvv[i] * u_inv + u * bvv[n + i];
     }
-    for (size_t j = 0; j < R; j++) sj[j] = sj[j] * (((j & mask) < n) ? u_inv : u);
+#pragma omp parallel for schedule(static) num_threads(nthr)
+    for (long jj = 0; jj < (long)R; jj++) {
+      const size_t j = (size_t)jj;
+      sj[j] = sj[j] * (((j & mask) < n) ? u_inv : u);
+    }
     blind_fin = blind_fin + bv1[round] * u * u + bv2[round] * u_inv * u_inv;
   }
   Fq x_hat = av[0], a_hat = bvv[0], y_hat = x_hat * a_hat;

@@ -92,6 +92,18 @@ int vpin_sc_quad_bind_round(vpin_ctx* ctx, vpin_table* A, vpin_table* B, const u
 /* EqPolynomial::evals (dense_mlpoly.rs:78-94): r = ell x 32 B, result has 2^ell entries */
 int vpin_eq_table(vpin_ctx* ctx, const uint8_t* r, int ell, vpin_table** out);
 
+/* Eq-factored phase 1 (same e0,e2,e3 as vpin_sc_cubic_*, cheaper): the folded eq(tau,.) table of round j
+ * equals a scalar times the suffix table eq(tau_{j+1..}, .), so it is neither stored per round nor folded.
+ * vpin_eq_suffix_tables builds all suffix tables once (one table of 2^ell elements); the round calls take
+ * (Az,Bz,Cz) and level = j+1 and return the UNSCALED sums S_x = sum_i E[i]*(Az_x[i]*Bz_x[i] - Cz_x[i]) for
+ * x = 0, 2, 3 (the reference's comb is tau*(Az*Bz - Cz), r1csproof.rs:104-108); the caller multiplies by
+ * c_{j,x} = s_j*((1-tau_j) + x*(2*tau_j-1)) with s_j = prod_{i<j} eq1(tau_i, r_i) to get e0, e2, e3. */
+int vpin_eq_suffix_tables(vpin_ctx* ctx, const uint8_t* tau, int ell, vpin_table** out);
+int vpin_sc_cubic3_round(vpin_ctx* ctx, const vpin_table* pyramid, int ell, int level, vpin_table* Az,
+                         vpin_table* Bz, vpin_table* Cz, uint8_t out_S0_S2_S3[96]);
+int vpin_sc_cubic3_bind_round(vpin_ctx* ctx, const vpin_table* pyramid, int ell, int level, vpin_table* Az,
+                              vpin_table* Bz, vpin_table* Cz, const uint8_t r[32], uint8_t out_S0_S2_S3[96]);
+
 /* ---- Pedersen generators and fixed-base MSM ----------------------------------------- */
 /* The generator stream of MultiCommitGens::new (Spartan/src/commitments.rs:20-38):
  * nb points g[0..nb) as 128-byte X|Y|Z|T each.  Builds the device window table

@@ -182,3 +182,49 @@ def test_round_trip_property_large(ctx):
         hi = [ctx.upload(np.ascontiguousarray(np.concatenate([h, h]))) for h in his]
         e1 = M.table_to_ints(ctx.sc_cubic_round(*hi))[0]
         assert (e[0] + e1) % Q == claim
+
+
+@pytest.mark.parametrize("ell", [1, 2, 4, 9, 11, 14])
+def test_eq_factored_phase1_matches_reference_form(ctx, ell):
+    """vpin_eq_suffix_tables + vpin_sc_cubic3_* (no eq table folded) give the same e0,e2,e3 as the
+    4-table reference formulation on every round, and the same folded tables."""
+    import ctypes as C
+    import vpin_amd
+    L = vpin_amd.lib()
+    vp = C.c_void_p
+    L.vpin_eq_suffix_tables.argtypes = [vp, vp, C.c_int, C.POINTER(vp)]
+    L.vpin_sc_cubic3_round.argtypes = [vp, vp, C.c_int, C.c_int, vp, vp, vp, vp]
+    L.vpin_sc_cubic3_bind_round.argtypes = [vp, vp, C.c_int, C.c_int, vp, vp, vp, vp, vp]
+    rng = np.random.default_rng(5000 + ell)
+    n = 1 << ell
+    tau = rand_table(rng, ell)
+    host = [O.eq_evals(tau)] + [rand_table(rng, n, zero_frac=0.3) for _ in range(3)]
+    dev = [ctx.upload(t) for t in host[1:]]
+    pyr = vp()
+    assert L.vpin_eq_suffix_tables(ctx.h, tau.ctypes.data_as(vp), ell, C.byref(pyr)) == 0
+    tau_i = M.table_to_ints(tau)
+    s = 1
+    r = None
+    for j in range(ell):
+        out = np.zeros((3, 4), dtype=np.uint64)
+        if j == 0:
+            rc = L.vpin_sc_cubic3_round(ctx.h, pyr, ell, 1, dev[0].h, dev[1].h, dev[2].h, out.ctypes.data_as(vp))
+        else:
+            rc = L.vpin_sc_cubic3_bind_round(ctx.h, pyr, ell, j + 1, dev[0].h, dev[1].h, dev[2].h, r.ctypes.data_as(vp),
+                                             out.ctypes.data_as(vp))
+            host = [O.bound_top(t, r) for t in host]
+        assert rc == 0
+        S = M.table_to_ints(out)
+        t = tau_i[j]
+        got = [S[0] * s * (1 - t) % Q, S[1] * s * (3 * t - 1) % Q, S[2] * s * (5 * t - 2) % Q]
+        exp = M.table_to_ints(O.sc_cubic_round(*host))
+        assert got == exp, f"round {j}"
+        for d, h in zip(dev, host[1:]):
+            assert np.array_equal(d.read(), h)
+        r = rand_table(rng, 1)[0]
+        ri = M.table_to_ints(r.reshape(1, 4))[0]
+        s = s * (t * ri + (1 - t) * (1 - ri)) % Q
+    # after the last bind the eq table's single value is s
+    host = [O.bound_top(t, r) for t in host]
+    assert M.table_to_ints(host[0]) == [s]
+    L.vpin_table_free(ctx.h, pyr)

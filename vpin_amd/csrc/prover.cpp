@@ -300,10 +300,21 @@ static void write_zksc(Writer& w, const ZkSc& p) {
 //    rounds at once across the host cores;
 //  * round j+1's kernel is launched as soon as r_j is known and runs while the host finishes
 //    round j's dot-product proof.
+//
+// Phase 1 (K = 4) runs eq-factored when `tau`/`pyramid` are given: tabs = {Az,Bz,Cz}; the eq(tau,.)
+// table is never materialised per round.  After binding r_0..r_{j-1} it equals s_j * eq(tau_{j..}, .)
+// with s_j = prod_{i<j} eq1(tau_i, r_i), so its value at the round's evaluation point x is
+// s_j*((1-tau_j) + x*(2*tau_j-1)) * E_{j+1}[i]; the GPU returns sum_i E_{j+1}[i]*(Az_x Bz_x - Cz_x)[i] and
+// the three scale factors are applied here.  Exact field arithmetic: same e0,e2,e3, same proof bytes.
 static int zk_sumcheck(vpin_ctx* c, int K, vpin_table** tabs, const Fq& claim, const Fq& blind_claim, int rounds,
                        const Mcg& g1, const Mcg& gn, Transcript& tr, Transcript& tape, ZkSc& pf, std::vector<Fq>& r_out,
-                       Fq* final_claims, Fq& blind_last) {
+                       Fq* final_claims, Fq& blind_last, const std::vector<Fq>* tau = nullptr,
+                       const vpin_table* pyramid = nullptr) {
   const int nc = (K == 4) ? 4 : 3;
+  const bool factored = (K == 4 && tau != nullptr && pyramid != nullptr);
+  const int ntab = factored ? 3 : K;
+  Fq s_eq = Fq::one();
+  const Fq f_one = Fq::one(), f_two = Fq::from_u64(2), f_three = Fq::from_u64(3), f_five = Fq::from_u64(5);
   std::vector<Fq> blinds_poly = tape.challenge_vector("blinds_poly", rounds);
   std::vector<Fq> blinds_evals = tape.challenge_vector("blinds_evals", rounds);
   struct RoundRand { Fq d[4], r_delta, r_beta; };
@@ -325,12 +336,18 @@ static int zk_sumcheck(vpin_ctx* c, int K, vpin_table** tabs, const Fq& claim, c
   Fq claim_pr = claim;
   CG comm_claim = compress(commit1(claim_pr, blind_claim, g1));
   r_out.clear();
-  int rc = vpin::sc_round_launch(c, K, tabs, nullptr);
+  int rc = factored ? vpin::sc_cubic3_launch(c, tabs, pyramid, rounds, 1, nullptr) : vpin::sc_round_launch(c, K, tabs, nullptr);
   if (rc) return rc;
   Fq r_j = Fq::zero();
   for (int j = 0; j < rounds; j++) {
     Fq e[3];
     if ((rc = vpin::sc_round_wait(c, K, B(e)))) return rc;
+    if (factored) {
+      const Fq& t = (*tau)[j];
+      e[0] = e[0] * (s_eq * (f_one - t));
+      e[1] = e[1] * (s_eq * (f_three * t - f_one));
+      e[2] = e[2] * (s_eq * (f_five * t - f_two));
+    }
     Fq evals[4], coeffs[4];
     evals[0] = e[0]; evals[1] = claim_pr - e[0]; evals[2] = e[1];
     if (K == 4) evals[3] = e[2];
@@ -342,7 +359,14 @@ static int zk_sumcheck(vpin_ctx* c, int K, vpin_table** tabs, const Fq& claim, c
     pf.comm_polys.push_back(comm_poly);
     r_j = tr.challenge_scalar("challenge_nextround");
     // fold with r_j and evaluate the next round while the host finishes this one
-    if (j + 1 < rounds && (rc = vpin::sc_round_launch(c, K, tabs, B(&r_j)))) return rc;
+    if (j + 1 < rounds) {
+      rc = factored ? vpin::sc_cubic3_launch(c, tabs, pyramid, rounds, j + 2, B(&r_j)) : vpin::sc_round_launch(c, K, tabs, B(&r_j));
+      if (rc) return rc;
+    }
+    if (factored) {  // s_{j+1} = s_j * eq1(tau_j, r_j)
+      const Fq& t = (*tau)[j];
+      s_eq = s_eq * (t * r_j + (f_one - t) * (f_one - r_j));
+    }
     Fq eval = unipoly_eval(coeffs, nc, r_j);
     Point ce = P_be[j];
     g1.G[0]->mul_acc(ce, eval);
@@ -386,10 +410,11 @@ static int zk_sumcheck(vpin_ctx* c, int K, vpin_table** tabs, const Fq& claim, c
     pf.comm_evals.push_back(comm_eval);
   }
   // last fold (sumcheck.rs:673-676 of the final round), then the final claims P[0]
-  rc = vpin_sc_bind(c, tabs, K, B(&r_j));
+  rc = vpin_sc_bind(c, tabs, ntab, B(&r_j));
   if (rc) return rc;
-  for (int k = 0; k < K; k++) {
-    rc = vpin_table_read(c, tabs[k], 0, 1, B(&final_claims[k]));
+  if (factored) final_claims[0] = s_eq;  // tau(rx) = prod_i eq1(tau_i, r_i)
+  for (int k = 0; k < ntab; k++) {
+    rc = vpin_table_read(c, tabs[k], 0, 1, B(&final_claims[factored ? k + 1 : k]));
     if (rc) return rc;
   }
   blind_last = blinds_evals[rounds - 1];
@@ -513,9 +538,9 @@ static int sat_prove_core(vpin_ctx* c, const vpin_r1cs_dev* dinst, size_t nv, si
   tg.add(d_z);
   const int nrx = (int)log2z(ncons), nry = (int)log2z(zl);
   std::vector<Fq> tau = tr.challenge_vector("challenge_tau", nrx);
-  vpin_table* d_tau = nullptr;
-  if ((rc = vpin_eq_table(c, B(tau.data()), nrx, &d_tau))) return rc;
-  tg.add(d_tau);
+  vpin_table* d_pyr = nullptr;  // suffix tables eq(tau_{k..}, .), k = 1..nrx
+  if ((rc = vpin_eq_suffix_tables(c, B(tau.data()), nrx, &d_pyr))) return rc;
+  tg.add(d_pyr);
   const Fq one = Fq::one();
   vpin_table* d_abc[3] = {nullptr, nullptr, nullptr};
   auto t_spmv = Clock::now();
@@ -525,8 +550,9 @@ static int sat_prove_core(vpin_ctx* c, const vpin_r1cs_dev* dinst, size_t nv, si
   ZkSc sc1, sc2;
   std::vector<Fq> rx, ry;
   Fq claims1[4], blind_post1;
-  vpin_table* tabs1[4] = {d_tau, d_abc[0], d_abc[1], d_abc[2]};
-  rc = zk_sumcheck(c, 4, tabs1, Fq::zero(), Fq::zero(), nrx, sg->gens_1, sg->gens_4, tr, tape, sc1, rx, claims1, blind_post1);
+  vpin_table* tabs1[3] = {d_abc[0], d_abc[1], d_abc[2]};
+  rc = zk_sumcheck(c, 4, tabs1, Fq::zero(), Fq::zero(), nrx, sg->gens_1, sg->gens_4, tr, tape, sc1, rx, claims1, blind_post1,
+                   &tau, d_pyr);
   if (rc) return rc;
   g_timings[1] = secs(t0, Clock::now());
 

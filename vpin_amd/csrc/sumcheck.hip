@@ -70,6 +70,13 @@ struct Acc<4> {
     pd = fq_add(pd, dd);
     u[2] = fq_sub(u[2], pd);
   }
+  // eq-factored form: the folded eq(tau,.) table is a per-round scalar times the suffix table E, so
+  // A_x = c_x * E[i]; the kernel accumulates sum_i E[i]*u_x[i] and the host applies c_x
+  __device__ __forceinline__ void stage_e(const fq* u, const fq& E) {
+    e[0] = fq_add(e[0], fq_mul(E, u[0]));
+    e[1] = fq_add(e[1], fq_mul(E, u[1]));
+    e[2] = fq_add(e[2], fq_mul(E, u[2]));
+  }
   __device__ __forceinline__ void stage_a(const fq* u, fq pa, const fq& da) {
     e[0] = fq_add(e[0], fq_mul(pa, u[0]));
     pa = fq_add(fq_add(pa, da), da);
@@ -187,6 +194,27 @@ __global__ __launch_bounds__(kBlock, kMinWaves) void sc_bind_eval_kernel(Tabs<K>
   block_reduce_store<Acc<K>::NE>(acc.e, partials);
 }
 
+// Phase-1 kernel without the eq(tau,.) table: three foldable tables (Az,Bz,Cz) and the suffix table
+// E = eq(tau_{j+1..}, .) of this round (read-only, one element per pair).  12 Montgomery products
+// and 13 loads / 6 stores per pair instead of 14 / 16 / 8; the three sums are scaled by the host.
+template <bool BIND>
+__global__ __launch_bounds__(kBlock, kMinWaves) void sc_cubic3_kernel(Tabs<3> tabs, const fq* __restrict__ E, size_t pairs,
+                                                                      fq r, fq* __restrict__ partials) {
+  Acc<4> acc;
+  acc.init();
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < pairs; i += (size_t)gridDim.x * kBlock) {
+    fq u[3], p1, d1, p2, d2;
+    if (BIND) { fold_pd(tabs.t[0], i, pairs, r, p1, d1); fold_pd(tabs.t[1], i, pairs, r, p2, d2); }
+    else { load_pd(tabs.t[0], i, pairs, p1, d1); load_pd(tabs.t[1], i, pairs, p2, d2); }
+    acc.stage_bc(u, p1, d1, p2, d2);
+    if (BIND) fold_pd(tabs.t[2], i, pairs, r, p1, d1);
+    else load_pd(tabs.t[2], i, pairs, p1, d1);
+    acc.stage_d(u, p1, d1);
+    acc.stage_e(u, fq_load(E + i));
+  }
+  block_reduce_store<3>(acc.e, partials);
+}
+
 // Tail rounds (tables of at most kSmallPairs pairs): one workgroup does the fold, the evaluation
 // and the whole reduction, and writes the 2-3 scalars straight to the pinned result buffer -- no
 // partials, no finisher launch.  These rounds are launch-latency bound, not bandwidth bound.
@@ -235,6 +263,49 @@ __global__ __launch_bounds__(kSmallBlock) void sc_tail_kernel(Tabs<K> tabs, size
 #pragma unroll
     for (int w = 1; w < kSmallBlock / 64; w++) s = fq_add(s, sh[w][threadIdx.x]);
     fq_store(&out[threadIdx.x], s);
+  }
+}
+
+template <bool BIND>
+__global__ __launch_bounds__(kSmallBlock) void sc_tail3_kernel(Tabs<3> tabs, const fq* __restrict__ E, size_t pairs, fq r,
+                                                               fq* __restrict__ out) {
+  Acc<4> acc;
+  acc.init();
+  const size_t i = threadIdx.x;
+  if (i < pairs) {
+    fq u[3], p1, d1, p2, d2;
+    if (BIND) { fold_pd(tabs.t[0], i, pairs, r, p1, d1); fold_pd(tabs.t[1], i, pairs, r, p2, d2); }
+    else { load_pd(tabs.t[0], i, pairs, p1, d1); load_pd(tabs.t[1], i, pairs, p2, d2); }
+    acc.stage_bc(u, p1, d1, p2, d2);
+    if (BIND) fold_pd(tabs.t[2], i, pairs, r, p1, d1);
+    else load_pd(tabs.t[2], i, pairs, p1, d1);
+    acc.stage_d(u, p1, d1);
+    acc.stage_e(u, fq_load(E + i));
+  }
+  __shared__ fq sh[kSmallBlock / 64][3];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    fq s = fq_wave_sum(acc.e[k]);
+    if (lane == 0) sh[wave][k] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    fq s = sh[0][threadIdx.x];
+#pragma unroll
+    for (int w = 1; w < kSmallBlock / 64; w++) s = fq_add(s, sh[w][threadIdx.x]);
+    fq_store(&out[threadIdx.x], s);
+  }
+}
+
+// suffix-eq pyramid step: level k from level k+1 (m elements): dst[i] = (1-tau_k)*src[i], dst[m+i] = tau_k*src[i]
+__global__ __launch_bounds__(kBlock) void eq_pyramid_step_kernel(const fq* __restrict__ src, fq* __restrict__ dst, size_t m,
+                                                                 fq tau_k) {
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < m; i += (size_t)gridDim.x * kBlock) {
+    fq v = fq_load(src + i);
+    fq hi = fq_mul(v, tau_k);
+    fq_store(dst + i, fq_sub(v, hi));
+    fq_store(dst + m + i, hi);
   }
 }
 
@@ -406,6 +477,49 @@ int sc_round_launch(vpin_ctx* c, int K, vpin_table* const* tabs, const uint8_t* 
 }
 int sc_round_wait(vpin_ctx* c, int K, uint8_t* out) { return fetch(c, K == 4 ? 3 : 2, out); }
 
+// level k (k = 1..ell) of the suffix pyramid inside one table of 2^ell elements
+static inline size_t pyramid_offset(int ell, int k) { return ((size_t)1 << ell) - ((size_t)2 << (ell - k)); }
+
+// Phase-1 round on (Az,Bz,Cz) + the suffix table of level `level` (= round index + 1); r == nullptr
+// evaluates the tables as they are, otherwise binds them with r first.  Results: the three UNSCALED
+// sums  sum_i E[i]*(B_x C_x - D_x)[i]  for x = 0, 2, 3.
+int sc_cubic3_launch(vpin_ctx* c, vpin_table* const* t, const vpin_table* pyramid, int ell, int level, const uint8_t* r) {
+  int rc = check_tabs<3>(c, t, r ? 4 : 2);
+  if (rc) return rc;
+  if (!pyramid || level < 1 || level > ell || pyramid->len != ((size_t)1 << ell)) return VPIN_ESHAPE;
+  (void)hipSetDevice(c->device);
+  Tabs<3> tabs;
+  for (int k = 0; k < 3; k++) tabs.t[k] = t[k]->d;
+  const size_t len = t[0]->len, pairs = r ? len / 4 : len / 2;
+  if (pairs != ((size_t)1 << (ell - level))) return VPIN_ESHAPE;
+  const fq* E = pyramid->d + pyramid_offset(ell, level);
+  const fq rr = r ? load_host_fq(r) : fq{};
+  // algorithmic bytes stay those of the reference formulation (4 tables): SURVEY.md 8(d)
+  const double bytes = r ? 4 * 32.0 * ((double)len + (double)len / 2) : 4 * 32.0 * (double)len;
+  if (pairs <= kSmallPairs) {
+    {
+      ProfScope ps(c, VPIN_K_SC_TAIL, bytes);
+      if (r) hipLaunchKernelGGL((sc_tail3_kernel<true>), dim3(1), dim3(kSmallBlock), 0, c->stream, tabs, E, pairs, rr, c->h_out);
+      else hipLaunchKernelGGL((sc_tail3_kernel<false>), dim3(1), dim3(kSmallBlock), 0, c->stream, tabs, E, pairs, rr, c->h_out);
+    }
+    VPIN_HIP_TRY(hipGetLastError());
+  } else {
+    int grid = grid_for(pairs);
+    {
+      ProfScope ps(c, r ? VPIN_K_SC_CUBIC_FUSED : VPIN_K_SC_CUBIC, bytes);
+      if (r) hipLaunchKernelGGL((sc_cubic3_kernel<true>), dim3(grid), dim3(kBlock), 0, c->stream, tabs, E, pairs, rr, c->d_partials);
+      else hipLaunchKernelGGL((sc_cubic3_kernel<false>), dim3(grid), dim3(kBlock), 0, c->stream, tabs, E, pairs, rr, c->d_partials);
+    }
+    VPIN_HIP_TRY(hipGetLastError());
+    rc = finish_launch<3>(c, grid);
+    if (rc) return rc;
+  }
+  if (r)
+    for (int k = 0; k < 3; k++) t[k]->len = len / 2;
+  return VPIN_OK;
+}
+
+
 }  // namespace vpin
 
 using namespace vpin;
@@ -478,6 +592,49 @@ int vpin_sc_cubic_bind_round(vpin_ctx* c, vpin_table* tau, vpin_table* Az, vpin_
 int vpin_sc_quad_bind_round(vpin_ctx* c, vpin_table* A, vpin_table* B, const uint8_t r[32], uint8_t out[64]) {
   vpin_table* t[2] = {A, B};
   return run_bind_eval<2>(c, t, r, out, VPIN_K_SC_QUAD_FUSED);
+}
+
+// All suffix tables eq(tau_{k..ell-1}, .), k = 1..ell, in one table of 2^ell elements (level k holds
+// 2^(ell-k) elements at offset 2^ell - 2^(ell-k+1); the last element is unused).  Same doubling as
+// EqPolynomial::evals (dense_mlpoly.rs:78-94) run from the last variable, every intermediate kept.
+int vpin_eq_suffix_tables(vpin_ctx* c, const uint8_t* tau, int ell, vpin_table** out) {
+  if (!c || !out || !tau || ell < 1 || ell > 40) return VPIN_EINVAL;
+  (void)hipSetDevice(c->device);
+  vpin_table* t = nullptr;
+  int rc = table_alloc_uninit(c, (size_t)1 << ell, &t);
+  if (rc) return rc;
+  static const uint32_t kOne[8] = {0x8d98951du, 0xd6ec3174u, 0x737dcf70u, 0xc6ef5bf4u,
+                                   0xfffffffeu, 0xffffffffu, 0xffffffffu, 0x0fffffffu};
+  hipError_t e = hipMemcpyAsync(t->d + pyramid_offset(ell, ell), kOne, 32, hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) {
+    ProfScope ps(c, VPIN_K_EQ, 32.0 * 3.0 * (double)(((size_t)1 << (ell - 1)) - 1));
+    for (int k = ell - 1; k >= 1; k--) {  // level k from level k+1
+      size_t m = (size_t)1 << (ell - k - 1);
+      hipLaunchKernelGGL(eq_pyramid_step_kernel, dim3(grid_for(m)), dim3(kBlock), 0, c->stream,
+                         (const fq*)(t->d + pyramid_offset(ell, k + 1)), t->d + pyramid_offset(ell, k), m,
+                         load_host_fq(tau + 32 * (size_t)k));
+    }
+    e = hipGetLastError();
+  }
+  if (e != hipSuccess) { set_last_error("vpin_eq_suffix_tables", e); vpin_table_free(c, t); return VPIN_EHIP; }
+  *out = t;
+  return VPIN_OK;
+}
+
+// synchronous C-ABI forms of the eq-factored phase-1 round (unscaled sums, see sc_cubic3_launch)
+int vpin_sc_cubic3_round(vpin_ctx* c, const vpin_table* pyramid, int ell, int level, vpin_table* Az, vpin_table* Bz,
+                         vpin_table* Cz, uint8_t out[96]) {
+  if (!out) return VPIN_EINVAL;
+  vpin_table* t[3] = {Az, Bz, Cz};
+  int rc = sc_cubic3_launch(c, t, pyramid, ell, level, nullptr);
+  return rc ? rc : sc_round_wait(c, 4, out);
+}
+int vpin_sc_cubic3_bind_round(vpin_ctx* c, const vpin_table* pyramid, int ell, int level, vpin_table* Az, vpin_table* Bz,
+                              vpin_table* Cz, const uint8_t r[32], uint8_t out[96]) {
+  if (!out || !r) return VPIN_EINVAL;
+  vpin_table* t[3] = {Az, Bz, Cz};
+  int rc = sc_cubic3_launch(c, t, pyramid, ell, level, r);
+  return rc ? rc : sc_round_wait(c, 4, out);
 }
 
 int vpin_eq_table(vpin_ctx* c, const uint8_t* r, int ell, vpin_table** out) {

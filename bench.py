@@ -20,7 +20,7 @@ small, latency-bound point-add instances run on a second host thread / HIP strea
 largest instance is done, so that instance's kernels are timed undisturbed.
 
 Beside the headline value the line carries
-  roofline     : the fused sum-check round kernel (sc_bind_eval_kernel<4>), algorithmic bytes /
+  roofline     : the fused phase-1 sum-check round kernel (sc_cubic3_kernel<true>), algorithmic bytes /
                  HIP-event time over the timed region, against the 8 TB/s HBM3E peak;
   cpu_baseline : the CPU oracle (a C restatement of the reference prover, oracle/) timed on
                  this box's host cores on a bounded sample of the same workload.
@@ -210,10 +210,10 @@ def main():
         pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
         if traffic is None and os.path.exists(pmc):
             with open(pmc) as f:
-                ent = json.load(f).get("bench_default", {}).get("sc_bind_eval_kernel<4>", {})
+                ent = json.load(f).get("bench_default", {}).get("sc_cubic3_kernel<true>", {})
             traffic = ent.get("hbm_bytes_per_launch")
         line["roofline"] = {
-            "kernel": "sc_bind_eval_kernel<4> (fused fold + cubic round evaluation, phase 1; rounds with > 512 pairs)",
+            "kernel": "sc_cubic3_kernel<true> (fused fold + cubic round evaluation of phase 1, eq-factored; rounds with > 512 pairs)",
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
             "launches": k["launches"], "avg_launch_us": k["ms"] * 1e3 / k["launches"],

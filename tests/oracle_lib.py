@@ -266,3 +266,69 @@ def hyrax_commit(Z, Ls, blinds, gens, blind_index, threads=8):
                               ptr(np.ascontiguousarray(blinds, dtype=np.uint64)), gens, C.byref(gens[blind_index]),
                               threads)
     return out
+
+
+# ---- SPARK / whole SNARK ------------------------------------------------------------------------
+
+def _spark_decl(L):
+    L.oracle_spark_comm_bytes.restype = C.c_size_t
+    L.oracle_spark_comm_bytes.argtypes = [C.c_void_p]
+    L.oracle_snark_proof_max_bytes.restype = C.c_size_t
+    L.oracle_snark_proof_max_bytes.argtypes = [C.c_void_p]
+    L.oracle_spark_encode.restype = C.c_void_p
+    L.oracle_spark_encode.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]
+    L.oracle_spark_decomm_free.restype = None
+    L.oracle_spark_decomm_free.argtypes = [C.c_void_p]
+    L.oracle_vpin_snark_prove.restype = C.c_size_t
+    L.oracle_vpin_snark_prove.argtypes = [C.c_void_p] * 8 + [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+    L.oracle_vpin_snark_verify.restype = C.c_int
+    L.oracle_vpin_snark_verify.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
+                                           C.c_void_p, C.c_void_p]
+
+
+def snark_prove(inst, seed_commit, seed_proof, threads=8):
+    """SNARK::encode + the whole my_lib_prove: returns dict(proof, comm, comm_para, comm_input)."""
+    L = lib()
+    _spark_decl(L)
+    r = make_r1cs(inst)
+    ccap = L.oracle_spark_comm_bytes(C.byref(r))
+    comm = np.zeros(ccap, dtype=np.uint8)
+    clen = C.c_size_t(0)
+    dec = L.oracle_spark_encode(C.byref(r), threads, comm.ctypes.data_as(C.c_void_p), ccap, C.byref(clen))
+    assert dec, "oracle_spark_encode failed"
+    try:
+        nv = inst["num_vars"]
+        Lsz = 1 << (log2(nv) // 2)
+        cap = L.oracle_snark_proof_max_bytes(C.byref(r))
+        proof = np.zeros(cap, dtype=np.uint8)
+        comm_para = np.zeros((Lsz, 32), dtype=np.uint8)
+        comm_input = np.zeros((Lsz, 32), dtype=np.uint8)
+        sc = np.frombuffer(bytes(seed_commit), dtype=np.uint8).copy()
+        sp = np.frombuffer(bytes(seed_proof), dtype=np.uint8).copy()
+        inputs = np.ascontiguousarray(inst["inputs"])
+        n = L.oracle_vpin_snark_prove(C.byref(r), dec, ptr(inst["vars_para"]), ptr(inst["vars_input"]),
+                                      ptr(inst["vars"]), inputs.ctypes.data_as(C.c_void_p),
+                                      sc.ctypes.data_as(C.c_void_p), sp.ctypes.data_as(C.c_void_p), threads,
+                                      proof.ctypes.data_as(C.c_void_p), cap,
+                                      comm_para.ctypes.data_as(C.c_void_p), comm_input.ctypes.data_as(C.c_void_p))
+    finally:
+        L.oracle_spark_decomm_free(dec)
+    return dict(proof=bytes(proof[:n]), comm=bytes(comm[:clen.value]), comm_para=comm_para, comm_input=comm_input)
+
+
+def snark_verify(inst, res, proof=None, comm=None):
+    L = lib()
+    _spark_decl(L)
+    pb = np.frombuffer(proof if proof is not None else res["proof"], dtype=np.uint8).copy()
+    cb = np.frombuffer(comm if comm is not None else res["comm"], dtype=np.uint8).copy()
+    inputs = np.ascontiguousarray(inst["inputs"])
+    return L.oracle_vpin_snark_verify(pb.ctypes.data_as(C.c_void_p), len(pb), cb.ctypes.data_as(C.c_void_p), len(cb),
+                                      inputs.ctypes.data_as(C.c_void_p), inst["num_inputs"],
+                                      res["comm_para"].ctypes.data_as(C.c_void_p),
+                                      res["comm_input"].ctypes.data_as(C.c_void_p))
+
+
+def spark_timings():
+    out = (C.c_double * 7)()
+    lib().oracle_spark_last_timings(out)
+    return dict(zip(("encode", "sat", "derefs_commit", "network_build", "product_layer", "hash_layer", "total"), out))

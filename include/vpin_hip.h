@@ -197,6 +197,47 @@ size_t vpin_sat_proof_max_bytes(size_t num_cons, size_t num_vars);
  * [6] host SpMV share of [1]+[2]  [7] inst.evaluate */
 void vpin_sat_last_timings(double out[8]);
 
+/* ------------------------------------------------------------------------------------------------
+ * SPARK: the computation commitment and the sparse-polynomial evaluation proof that complete the
+ * reference's SNARK.
+ * ---------------------------------------------------------------------------------------------- */
+
+/* ComputationDecommitment (Spartan/src/lib.rs:70-73): MultiSparseMatPolynomialAsDense
+ * (Spartan/src/sparse_mlpoly.rs:285-292) resident in HBM. */
+typedef struct vpin_spark_decomm vpin_spark_decomm;
+
+/* bincode size of R1CSCommitment (Spartan/src/r1csinstance.rs:53-58) for this instance. */
+size_t vpin_spark_comm_bytes(const vpin_r1cs* inst);
+/* upper bound on bincode(SNARK) (Spartan/src/lib.rs:334-338) for this instance. */
+size_t vpin_snark_proof_max_bytes(const vpin_r1cs* inst);
+
+/* SNARK::encode (Spartan/src/lib.rs:347-359) = R1CSInstance::commit (r1csinstance.rs:309-322) =
+ * SparseMatPolynomial::multi_commit (sparse_mlpoly.rs:382-438,500-520): dense representation
+ * (ops_addr / read_ts / audit_ts / val), comb_ops and comb_mem committed row-wise under the
+ * b"gens_r1cs_eval" generators.  comm_out receives bincode(R1CSCommitment): num_cons, num_vars,
+ * num_inputs, batch_size = 3, num_ops, num_mem_cells, comm_comb_ops, comm_comb_mem.
+ * The generators are sized from the instance's own max nnz (the reference passes a hand-tuned
+ * num_non_zero_entries, point_mult.rs:67 / point_addition.rs:70, which must round to the same
+ * power of two or its commit asserts, commitments.rs:95). */
+int vpin_spark_encode(vpin_ctx* ctx, const vpin_r1cs* inst, vpin_spark_decomm** out, uint8_t* comm_out,
+                      size_t comm_cap, size_t* comm_len);
+void vpin_spark_decomm_free(vpin_ctx* ctx, vpin_spark_decomm* d);
+
+/* my_lib_prove in full (vPIN_proof_generation/src/commit_test.rs:59-133): the sat proof of
+ * vpin_sat_prove_resident, then inst_evals, then R1CSEvalProof::prove (r1csinstance.rs:330-354 ->
+ * sparse_mlpoly.rs:1466-1533) on the same transcript and RandomTape.  proof_out receives
+ * bincode(SNARK { r1cs_sat_proof, inst_evals, r1cs_eval_proof }) -- what proof_point_mult.rs:96
+ * measures as "Proof size". */
+int vpin_snark_prove_resident(vpin_ctx* ctx, const vpin_r1cs_dev* inst, const vpin_spark_decomm* decomm,
+                              const vpin_table* vars_para, const vpin_table* vars_input, const vpin_table* vars,
+                              const uint8_t* inputs, const uint8_t seed_commit64[64], const uint8_t seed_proof64[64],
+                              uint8_t* proof_out, size_t proof_cap, size_t* proof_len, uint8_t* comm_para_out,
+                              uint8_t* comm_input_out);
+/* wall-clock spans of the last encode / snark prove on this thread, seconds: [0] encode
+ * [1] derefs + commit  [2] network build  [3] product-layer proofs  [4] hash-layer proofs
+ * [5] sat part  [6] whole prove  [7] unused */
+void vpin_spark_last_timings(double out[8]);
+
 /* ---- gadgets: the R1CS instances vPIN proves (host, no GPU needed) ----------------------- */
 /* Owns the (A,B,C) triplets after Instance::new padding (Spartan/src/lib.rs:138-244) and the
  * three padded assignments vPIN commits to (para / input / all). */
@@ -242,6 +283,8 @@ int vpin_host_commit(const char* label, const uint8_t* v_mont, size_t n, const u
 #define VPIN_K_EQ 5
 #define VPIN_K_MSM 6
 #define VPIN_K_SC_TAIL 7 /* single-workgroup tail rounds (<= 512 pairs), latency bound */
+#define VPIN_K_SPARK_ROUND 8 /* batched cubic rounds of the product / dot-product circuits (SPARK) */
+#define VPIN_K_SPARK_BUILD 9 /* SPARK gathers, hash layer, product-tree levels, slice evaluations */
 #define VPIN_K_COUNT 16
 typedef struct {
   uint64_t launches;

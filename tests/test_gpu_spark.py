@@ -1,0 +1,69 @@
+"""GPU parity for the SPARK half: SNARK::encode's commitment and the whole SNARK (sat proof +
+inst_evals + R1CSEvalProof) produced through the C ABI must be byte-identical to the CPU oracle's
+for the same instance and RandomTape seeds, and the oracle's verifier must accept them."""
+import numpy as np
+import pytest
+
+import gadgets_model as GM
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+SEED_C = bytes(range(64))
+SEED_P = bytes((7 * i + 3) % 256 for i in range(64))
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import vpin_amd
+    c = vpin_amd.Context(0)
+    yield c
+    c.close()
+
+
+def check(ctx, inst, seeds=(SEED_C, SEED_P)):
+    got = ctx.snark_prove(inst, *seeds)
+    exp = O.snark_prove(inst, *seeds)
+    assert len(exp["proof"]) > 0
+    assert got["comm"] == exp["comm"]
+    assert np.array_equal(got["comm_para"], exp["comm_para"])
+    assert np.array_equal(got["comm_input"], exp["comm_input"])
+    if got["proof"] != exp["proof"]:
+        n = min(len(got["proof"]), len(exp["proof"]))
+        first = next((i for i in range(n) if got["proof"][i] != exp["proof"][i]), n)
+        sat_len = len(O.sat_prove(inst, *seeds)["proof"])
+        raise AssertionError(f"SNARK bytes differ at {first} (sat part is {sat_len} bytes; lengths "
+                             f"{len(got['proof'])} vs {len(exp['proof'])})")
+    assert O.snark_verify(inst, got) == 1
+    return got
+
+
+def test_encode_commitment_matches(ctx):
+    inst = GM.instance_new(GM.build_point_add(GM.synthetic_add_ops(0x5650494E, 6, rz_one_every=3)))
+    decomm, comm = ctx.spark_encode(inst)
+    decomm.free()
+    assert comm == O.snark_prove(inst, SEED_C, SEED_P)["comm"]
+
+
+def test_point_add_snark(ctx):
+    inst = GM.instance_new(GM.build_point_add(GM.synthetic_add_ops(0x5650494E, 6, rz_one_every=3)))
+    check(ctx, inst)
+
+
+def test_point_add_64_snark(ctx):
+    """64 additions: N = 2^10, so the ops forest has both host-proved and device-proved layers"""
+    inst = GM.instance_new(GM.build_point_add(GM.synthetic_add_ops(0x5650494E + 5, 64, rz_one_every=3)))
+    check(ctx, inst)
+
+
+def test_point_mult_snark(ctx):
+    inst = GM.instance_new(GM.build_point_mult(GM.synthetic_mult_ops(0x5650494E + 2, 1, weights=[(1 << 127) + 12345])))
+    got = check(ctx, inst)
+    got2 = ctx.snark_prove(inst, SEED_C, bytes(64))
+    assert got2["proof"] != got["proof"] and got2["comm"] == got["comm"]
+    assert O.snark_verify(inst, got2) == 1
+
+
+def test_point_mult_two_ops_snark(ctx):
+    inst = GM.instance_new(GM.build_point_mult(GM.synthetic_mult_ops(0x5650494E + 3, 2, weights=[5, (1 << 200) + 77])))
+    check(ctx, inst)

@@ -11,6 +11,7 @@ HEADER = os.path.join(ROOT, "include", "vpin_hip.h")
 
 KERNEL_CLASSES = {
     0: "sc_cubic", 1: "sc_quad", 2: "sc_bind", 3: "sc_cubic_fused", 4: "sc_quad_fused", 5: "eq", 6: "msm", 7: "sc_tail",
+    8: "spark_round", 9: "spark_build",
 }
 K_COUNT = 16
 
@@ -118,6 +119,16 @@ def lib():
     L.vpin_sat_proof_max_bytes.argtypes = [C.c_size_t, C.c_size_t]
     L.vpin_sat_proof_max_bytes.restype = C.c_size_t
     L.vpin_sat_last_timings.argtypes = [C.POINTER(C.c_double)]
+    L.vpin_spark_comm_bytes.restype = C.c_size_t
+    L.vpin_spark_comm_bytes.argtypes = [vp]
+    L.vpin_snark_proof_max_bytes.restype = C.c_size_t
+    L.vpin_snark_proof_max_bytes.argtypes = [vp]
+    L.vpin_spark_encode.argtypes = [vp, vp, C.POINTER(vp), vp, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.vpin_spark_decomm_free.restype = None
+    L.vpin_spark_decomm_free.argtypes = [vp, vp]
+    L.vpin_snark_prove_resident.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_size_t, C.POINTER(C.c_size_t), vp, vp]
+    L.vpin_spark_last_timings.restype = None
+    L.vpin_spark_last_timings.argtypes = [C.POINTER(C.c_double)]
     L.vpin_sat_last_timings.restype = None
     L.vpin_host_gens_derive.argtypes = [C.c_char_p, C.c_size_t, vp]
     L.vpin_host_merlin_kat.argtypes = [C.c_char_p, C.c_char_p, vp, C.c_size_t, C.c_char_p, vp, C.c_size_t]
@@ -181,6 +192,18 @@ class Table:
     def free(self):
         if self.h:
             lib().vpin_table_free(self.ctx.h, self.h)
+            self.h = None
+
+
+class SparkDecomm:
+    """ComputationDecommitment resident in HBM (vpin_spark_encode)."""
+
+    def __init__(self, ctx, h, proof_cap):
+        self.ctx, self.h, self.proof_cap = ctx, h, proof_cap
+
+    def free(self):
+        if self.h:
+            lib().vpin_spark_decomm_free(self.ctx.h, self.h)
             self.h = None
 
 
@@ -409,6 +432,57 @@ class Context:
                                            p(sc), p(sp), p(proof), cap, C.byref(n), p(cp), p(ci), p(ev), p(rx), p(ry)),
              "vpin_sat_prove_resident")
         return dict(proof=bytes(proof[:n.value]), comm_para=cp, comm_input=ci, inst_evals=ev, rx=rx, ry=ry)
+
+    # ---- SPARK / whole SNARK ----
+    def spark_encode(self, inst):
+        """SNARK::encode: returns (SparkDecomm, bincode(R1CSCommitment) bytes)."""
+        r = make_r1cs(inst)
+        cap = lib().vpin_spark_comm_bytes(C.byref(r))
+        comm = np.zeros(cap, dtype=np.uint8)
+        n = C.c_size_t(0)
+        h = C.c_void_p()
+        _chk(lib().vpin_spark_encode(self.h, C.byref(r), C.byref(h), comm.ctypes.data_as(C.c_void_p), cap, C.byref(n)),
+             "vpin_spark_encode")
+        return SparkDecomm(self, h, lib().vpin_snark_proof_max_bytes(C.byref(r))), bytes(comm[:n.value])
+
+    def snark_prove_resident(self, dinst, decomm, t_para, t_input, t_vars, inputs, seed_commit, seed_proof):
+        nv = dinst.num_vars
+        Ls = 1 << ((nv.bit_length() - 1) // 2)
+        cap = decomm.proof_cap
+        proof = np.zeros(cap, dtype=np.uint8)
+        n = C.c_size_t(0)
+        cp = np.zeros((Ls, 32), dtype=np.uint8)
+        ci = np.zeros((Ls, 32), dtype=np.uint8)
+        sc = np.frombuffer(bytes(seed_commit), dtype=np.uint8).copy()
+        sp = np.frombuffer(bytes(seed_proof), dtype=np.uint8).copy()
+        inp = np.ascontiguousarray(inputs, dtype=np.uint64)
+        p = lambda a: a.ctypes.data_as(C.c_void_p)
+        _chk(lib().vpin_snark_prove_resident(self.h, dinst.h, decomm.h, t_para.h, t_input.h, t_vars.h,
+                                             p(inp) if inp.size else None, p(sc), p(sp), p(proof), cap, C.byref(n),
+                                             p(cp), p(ci)), "vpin_snark_prove_resident")
+        return dict(proof=bytes(proof[:n.value]), comm_para=cp, comm_input=ci)
+
+    def snark_prove(self, inst, seed_commit, seed_proof):
+        """encode + prove from host buffers (test convenience): dict(proof, comm, comm_para, comm_input)."""
+        dinst = self.r1cs_upload(inst)
+        decomm, comm = self.spark_encode(inst)
+        tabs = [self.upload(inst[k]) for k in ("vars_para", "vars_input", "vars")]
+        try:
+            res = self.snark_prove_resident(dinst, decomm, tabs[0], tabs[1], tabs[2], inst["inputs"], seed_commit, seed_proof)
+        finally:
+            for t in tabs:
+                t.free()
+            decomm.free()
+            dinst.free()
+        res["comm"] = comm
+        return res
+
+    @staticmethod
+    def spark_timings():
+        out = (C.c_double * 8)()
+        lib().vpin_spark_last_timings(out)
+        names = ("encode", "derefs_commit", "network_build", "product_layer", "hash_layer", "sat", "total", "_")
+        return dict(zip(names, out))
 
     @staticmethod
     def sat_timings():

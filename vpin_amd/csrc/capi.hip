@@ -28,8 +28,11 @@ int dev_alloc(vpin_ctx* c, size_t bytes, void** out) {
   size_t cls = 256;
   while (cls < bytes) cls <<= 1;
   if (cls > (size_t)1 << 22) cls = (bytes + ((size_t)1 << 20) - 1) & ~(((size_t)1 << 20) - 1);  // MiB granularity above 4 MiB
-  auto it = c->pool_free_lists.find(cls);
-  if (it != c->pool_free_lists.end() && !it->second.empty()) {
+  // exact class first; for large requests any cached block up to 2x the size will do (proofs of
+  // different instance sizes would otherwise each leave their own multi-GB blocks in the pool)
+  for (auto it = c->pool_free_lists.lower_bound(cls); it != c->pool_free_lists.end(); ++it) {
+    if (it->first != cls && (cls < ((size_t)1 << 22) || it->first > 2 * cls)) break;
+    if (it->second.empty()) continue;
     *out = it->second.back();
     it->second.pop_back();
     return VPIN_OK;
@@ -129,6 +132,8 @@ void vpin_ctx_destroy(vpin_ctx* c) {
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->prover_cache_free) c->prover_cache_free(c);
+  if (c->spark_cache_free) c->spark_cache_free(c);
+  if (c->h_spark) (void)hipHostFree(c->h_spark);
   dev_pool_release(c);
   for (auto& kv : c->pool_sizes) (void)hipFree(kv.first);  // blocks still held by leaked handles
   c->pool_sizes.clear();

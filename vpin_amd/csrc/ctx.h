@@ -62,6 +62,10 @@ struct vpin_ctx {
   // host-side prover state (generator sets per polynomial size), owned by prover.cpp
   void* prover_cache = nullptr;
   void (*prover_cache_free)(vpin_ctx*) = nullptr;
+  // SPARK (spark.cpp / spark.hip): generator views per label, pinned staging for per-round results
+  void* spark_cache = nullptr;
+  void (*spark_cache_free)(vpin_ctx*) = nullptr;
+  vpin::fq* h_spark = nullptr;  // pinned, kSparkPinned fq
 };
 
 namespace vpin {

@@ -354,10 +354,13 @@ int vpin_gens_create(vpin_ctx* c, const uint8_t* gens_xyzt, size_t nb, vpin_gens
   vpin_gens* g = new (std::nothrow) vpin_gens();
   if (!g) return VPIN_ENOMEM;
   g->nb = nb;
-  // window width by table budget (<= ~24 GB): 12 bits up to ~2k generators, 11 above
-  g->c = (nb * (size_t)22 * 2048 * sizeof(ge_niels) <= ((size_t)24 << 30)) ? 12 : 11;
-  g->W = (254 + g->c - 1) / g->c;
-  g->E = 1 << (g->c - 1);
+  // window width by table budget (<= ~24 GB): 12 bits up to ~5k generators, 11 up to ~10k, ... 8 for
+  // the 32k-generator sets of the largest SPARK commitments
+  for (g->c = 12; g->c > 6; g->c--) {
+    g->W = (254 + g->c - 1) / g->c;
+    g->E = 1 << (g->c - 1);
+    if (nb * (size_t)g->W * (size_t)g->E * sizeof(ge_niels) <= ((size_t)24 << 30)) break;
+  }
   const size_t entries = nb * (size_t)g->W * g->E;
   DevBuf raw(c);
   ge_ext* shifts = nullptr;

@@ -12,68 +12,21 @@
 // The data-parallel work runs in the HIP kernels (sumcheck.hip, msm.hip, poly.hip); this file
 // owns the strictly sequential part: the Merlin transcript, the per-round <=5-term Pedersen
 // commitments, and proof serialisation (bincode layout).  It shares no code with the test-side checker.
-#include <omp.h>
-
-#include <chrono>
-#include <cstdlib>
-#include <map>
-#include <memory>
-#include <vector>
-
-#include "ctx.h"
-#include "host/curve.h"
-#include "host/transcript.h"
-
-extern "C" {
-size_t vpin_gens_msm_parts_count(size_t ncols);
-int vpin_gens_msm_parts(vpin_ctx* ctx, const vpin_gens* g, const uint8_t* scalars_mont, size_t rows, size_t ncols,
-                        uint8_t* parts_xyzt);
-int vpin_poly_bound(vpin_ctx* c, const vpin_table* Z, const uint8_t* Lvec, size_t L_size, uint8_t* out_LZ);
-void vpin_r1cs_dims(const vpin_r1cs_dev* d, size_t* num_cons, size_t* num_vars, size_t* num_inputs);
-}
+#include "host/prover_common.h"
 
 namespace {
 
 using namespace vpin_host;
-using Clock = std::chrono::steady_clock;
-static double secs(Clock::time_point a, Clock::time_point b) { return std::chrono::duration<double>(b - a).count(); }
-
-// Host worker threads for the few batched host loops (generator derivation, per-round blind
-// commitments).  OpenMP workers that spin after a parallel region burn a container's CPU quota and
-// get the whole process throttled, so waiting is made passive and the team is kept small.
-static int host_threads() {
-  static int n = [] {
-    setenv("KMP_BLOCKTIME", "0", 0);
-    setenv("OMP_WAIT_POLICY", "PASSIVE", 0);
-    int hw = omp_get_num_procs();
-    const char* e = getenv("VPIN_HOST_THREADS");
-    int want = e ? atoi(e) : 8;
-    if (want < 1) want = 1;
-    return want < hw ? want : hw;
-  }();
-  return n;
-}
-
-static size_t log2z(size_t n) { size_t l = 0; while (((size_t)1 << l) < n) l++; return l; }
-static const uint8_t* B(const Fq* p) { return reinterpret_cast<const uint8_t*>(p); }
-static uint8_t* B(Fq* p) { return reinterpret_cast<uint8_t*>(p); }
-
-struct CG { uint8_t b[32]; };
-static CG compress(const Point& p) { CG c; p.compress(c.b); return c; }
+using namespace vpin_prover;
 
 // ---- generators -------------------------------------------------------------------------
-
-struct Mcg {  // MultiCommitGens view over fixed-base tables
-  int n;
-  const FixedBase* G[4];
-  const FixedBase* h;
-};
 
 struct SatGens {
   size_t ell = 0, L = 0, R = 0, nb = 0;
   std::vector<Point> g;  // generator stream g[0..nb)
-  FixedBase fb[5], fb_gR, fb_h;
+  FixedBase fb[5];
   vpin_gens* dev = nullptr;
+  PcGens pc;                   // gens_pc (r1csproof.rs:76-89): fb_gR, fb_h, device table
   Mcg gens_1, gens_3, gens_4;  // R1CSSumcheckGens (r1csproof.rs:49-74); gens_1 also = gens_pc.gens.gens_1
 };
 
@@ -88,21 +41,6 @@ static void cache_free(vpin_ctx* c) {
     if (kv.second->dev) vpin_gens_free(c, kv.second->dev);
   delete pc;
   c->prover_cache = nullptr;
-}
-
-// MultiCommitGens::new (commitments.rs:20-38) stream under `label`
-static void derive_gens(std::vector<Point>& g, size_t nb, const char* label) {
-  uint8_t bc[32];
-  Point::basepoint().compress(bc);  // GROUP_BASEPOINT_COMPRESSED (group.rs:26-27)
-  Shake256 sh;
-  sh.absorb(reinterpret_cast<const uint8_t*>(label), strlen(label));
-  sh.absorb(bc, 32);
-  sh.finalize();
-  std::vector<uint8_t> stream(64 * nb);
-  sh.squeeze(stream.data(), stream.size());
-  g.resize(nb);
-#pragma omp parallel for schedule(static) num_threads(host_threads())
-  for (long i = 0; i < (long)nb; i++) g[i] = Point::from_uniform_bytes(stream.data() + 64 * i);
 }
 
 // R1CSGens::new(b"gens_r1cs_sat", _, num_vars) (r1csproof.rs:84-89, lib.rs:314)
@@ -121,158 +59,22 @@ static int get_gens(vpin_ctx* c, size_t num_vars, SatGens** out) {
 #pragma omp parallel for schedule(dynamic, 1) num_threads(host_threads())
   for (int i = 0; i < 7; i++) {
     if (i < 5) sg->fb[i] = FixedBase(sg->g[i]);
-    else if (i == 5) sg->fb_gR = FixedBase(sg->g[sg->R]);
-    else sg->fb_h = FixedBase(sg->g[sg->R + 1]);
+    else if (i == 5) sg->pc.fb_gR = FixedBase(sg->g[sg->R]);
+    else sg->pc.fb_h = FixedBase(sg->g[sg->R + 1]);
   }
-  sg->gens_1 = Mcg{1, {&sg->fb_gR, nullptr, nullptr, nullptr}, &sg->fb_h};
+  sg->pc.ell = sg->ell; sg->pc.L = sg->L; sg->pc.R = sg->R;
+  sg->pc.bind_views();
+  sg->gens_1 = sg->pc.gens_1;
   sg->gens_3 = Mcg{3, {&sg->fb[0], &sg->fb[1], &sg->fb[2], nullptr}, &sg->fb[3]};
   sg->gens_4 = Mcg{4, {&sg->fb[0], &sg->fb[1], &sg->fb[2], &sg->fb[3]}, &sg->fb[4]};
   std::vector<uint8_t> xyzt(128 * sg->nb);
   for (size_t i = 0; i < sg->nb; i++) sg->g[i].to_xyzt(xyzt.data() + 128 * i);
   int rc = vpin_gens_create(c, xyzt.data(), sg->nb, &sg->dev);
   if (rc) return rc;
+  sg->pc.dev = sg->dev;
   *out = sg.get();
   pc->by_nv[num_vars] = std::move(sg);
   return VPIN_OK;
-}
-
-// Commitments for Scalar / [Scalar] over at most 4 generators (commitments.rs:85-98)
-static Point commit(const Fq* v, int n, const Fq& blind, const Mcg& g) {
-  Point acc = Point::identity();
-  for (int i = 0; i < n; i++) g.G[i]->mul_acc(acc, v[i]);
-  g.h->mul_acc(acc, blind);
-  return acc;
-}
-static Point commit1(const Fq& x, const Fq& blind, const Mcg& g) { return commit(&x, 1, blind, g); }
-
-// few-row fixed-base MSM: GPU partial points, summed on the host (rows <= 2 here)
-static int msm_rows_host_sum(vpin_ctx* c, const SatGens* sg, const Fq* scalars, size_t rows, size_t ncols, Point* out) {
-  const size_t np = vpin_gens_msm_parts_count(ncols);
-  std::vector<uint8_t> parts(rows * np * 128);
-  int rc = vpin_gens_msm_parts(c, sg->dev, B(scalars), rows, ncols, parts.data());
-  if (rc) return rc;
-  for (size_t r = 0; r < rows; r++) {
-    Point acc = Point::from_xyzt(parts.data() + (r * np) * 128);
-    for (size_t k = 1; k < np; k++) acc = acc + Point::from_xyzt(parts.data() + (r * np + k) * 128);
-    out[r] = acc;
-  }
-  return VPIN_OK;
-}
-
-// ---- bincode writer ------------------------------------------------------------------------
-
-struct Writer {
-  std::vector<uint8_t> buf;
-  void bytes(const void* p, size_t n) { const uint8_t* b = (const uint8_t*)p; buf.insert(buf.end(), b, b + n); }
-  void u64(uint64_t v) { bytes(&v, 8); }
-  void scalar(const Fq& s) { bytes(s.l, 32); }  // Montgomery limbs, as derive(Serialize) on Scalar([u64;4])
-  void point(const CG& c) { bytes(c.b, 32); }
-};
-
-// ---- sigma protocols -----------------------------------------------------------------------
-
-struct DotProof { CG delta, beta; std::vector<Fq> z; Fq z_delta, z_beta; };
-
-// DotProductProof::prove (nizk/mod.rs:315-374).  Cx is known to the caller (it is the round's
-// comm_poly), so it is passed in instead of being recomputed.
-[[maybe_unused]] static void dotproduct_prove(DotProof& pf, const Mcg& g1, const Mcg& gn, Transcript& tr, Transcript& tape, const Fq* x,
-                             const Fq& blind_x, const Fq* a, const Fq& y, const Fq& blind_y, int n, const CG& Cx) {
-  tr.append_protocol_name("dot product proof");
-  std::vector<Fq> d = tape.challenge_vector("d_vec", n);
-  Fq r_delta = tape.challenge_scalar("r_delta"), r_beta = tape.challenge_scalar("r_beta");
-  (void)blind_x;
-  tr.append_point("Cx", Cx.b);
-  CG Cy = compress(commit1(y, blind_y, g1));
-  tr.append_point("Cy", Cy.b);
-  tr.append_scalars("a", a, n);
-  pf.delta = compress(commit(d.data(), n, r_delta, gn));
-  tr.append_point("delta", pf.delta.b);
-  Fq ad = Fq::zero();
-  for (int i = 0; i < n; i++) ad = ad + a[i] * d[i];
-  pf.beta = compress(commit1(ad, r_beta, g1));
-  tr.append_point("beta", pf.beta.b);
-  Fq c = tr.challenge_scalar("c");
-  pf.z.resize(n);
-  for (int i = 0; i < n; i++) pf.z[i] = c * x[i] + d[i];
-  pf.z_delta = c * blind_x + r_delta;
-  pf.z_beta = c * blind_y + r_beta;
-}
-
-struct KnowProof { CG alpha; Fq z1, z2; };
-static CG knowledge_prove(KnowProof& pf, const Mcg& g, Transcript& tr, Transcript& tape, const Fq& x, const Fq& r) {
-  tr.append_protocol_name("knowledge proof");
-  Fq t1 = tape.challenge_scalar("t1"), t2 = tape.challenge_scalar("t2");
-  CG C = compress(commit1(x, r, g));
-  tr.append_point("C", C.b);
-  pf.alpha = compress(commit1(t1, t2, g));
-  tr.append_point("alpha", pf.alpha.b);
-  Fq c = tr.challenge_scalar("c");
-  pf.z1 = x * c + t1;
-  pf.z2 = r * c + t2;
-  return C;
-}
-
-struct EqProof { CG alpha; Fq z; };
-static void equality_prove(EqProof& pf, const Mcg& g, Transcript& tr, Transcript& tape, const Fq& v1, const Fq& s1,
-                           const Fq& v2, const Fq& s2) {
-  tr.append_protocol_name("equality proof");
-  Fq r = tape.challenge_scalar("r");
-  CG C1 = compress(commit1(v1, s1, g));
-  tr.append_point("C1", C1.b);
-  CG C2 = compress(commit1(v2, s2, g));
-  tr.append_point("C2", C2.b);
-  pf.alpha = compress(g.h->mul(r));
-  tr.append_point("alpha", pf.alpha.b);
-  Fq c = tr.challenge_scalar("c");
-  pf.z = c * (s1 - s2) + r;
-}
-
-struct ProdProof { CG alpha, beta, delta; Fq z[5]; };
-static void product_prove(ProdProof& pf, const Mcg& g, Transcript& tr, Transcript& tape, const Fq& x, const Fq& rX,
-                          const Fq& y, const Fq& rY, const Fq& z, const Fq& rZ, CG& X, CG& Y, CG& Z) {
-  tr.append_protocol_name("product proof");
-  Fq b1 = tape.challenge_scalar("b1"), b2 = tape.challenge_scalar("b2"), b3 = tape.challenge_scalar("b3"),
-     b4 = tape.challenge_scalar("b4"), b5 = tape.challenge_scalar("b5");
-  Point Xp = commit1(x, rX, g);
-  X = compress(Xp); tr.append_point("X", X.b);
-  Y = compress(commit1(y, rY, g)); tr.append_point("Y", Y.b);
-  Z = compress(commit1(z, rZ, g)); tr.append_point("Z", Z.b);
-  pf.alpha = compress(commit1(b1, b2, g)); tr.append_point("alpha", pf.alpha.b);
-  pf.beta = compress(commit1(b3, b4, g)); tr.append_point("beta", pf.beta.b);
-  // delta = b3 * X + b5 * h  (gens_X = {G: [X], h}); X re-derived from its encoding as the reference does
-  Point Xd;
-  Point::decompress(Xd, X.b);
-  Point dl = Xd.mul(b3);
-  g.h->mul_acc(dl, b5);
-  pf.delta = compress(dl); tr.append_point("delta", pf.delta.b);
-  Fq c = tr.challenge_scalar("c");
-  pf.z[0] = b1 + c * x;
-  pf.z[1] = b2 + c * rX;
-  pf.z[2] = b3 + c * y;
-  pf.z[3] = b4 + c * rY;
-  pf.z[4] = b5 + c * (rZ - rX * y);
-}
-
-// UniPoly::from_evals / evaluate (unipoly.rs:23-54,72-80)
-static void unipoly_from_evals(const Fq* e, int n, Fq* coeffs) {
-  static const Fq two_inv = Fq::from_u64(2).invert(), six_inv = Fq::from_u64(6).invert();
-  if (n == 3) {
-    Fq c = e[0];
-    Fq a = two_inv * (e[2] - e[1] - e[1] + c);
-    Fq b = e[1] - c - a;
-    coeffs[0] = c; coeffs[1] = b; coeffs[2] = a;
-  } else {
-    Fq d = e[0];
-    Fq a = six_inv * (e[3] - e[2] - e[2] - e[2] + e[1] + e[1] + e[1] - e[0]);
-    Fq b = two_inv * (e[0] + e[0] - e[1] - e[1] - e[1] - e[1] - e[1] + e[2] + e[2] + e[2] + e[2] - e[3]);
-    Fq c = e[1] - d - a - b;
-    coeffs[0] = d; coeffs[1] = c; coeffs[2] = b; coeffs[3] = a;
-  }
-}
-static Fq unipoly_eval(const Fq* coeffs, int n, const Fq& r) {
-  Fq eval = coeffs[0], power = r;
-  for (int i = 1; i < n; i++) { eval = eval + power * coeffs[i]; power = power * r; }
-  return eval;
 }
 
 // ---- ZK sum-check over device tables -------------------------------------------------------
@@ -430,14 +232,6 @@ static int zk_sumcheck(vpin_ctx* c, int K, vpin_table** tabs, const Fq& claim, c
   else dst = dst + val * x;
 }
 
-struct TableGuard {
-  vpin_ctx* c;
-  std::vector<vpin_table*> t;
-  explicit TableGuard(vpin_ctx* c_) : c(c_) {}
-  ~TableGuard() { for (auto* p : t) vpin_table_free(c, p); }
-  vpin_table* add(vpin_table* p) { t.push_back(p); return p; }
-};
-
 static thread_local double g_timings[8];  // per host thread: concurrent proofs on separate contexts
 
 }  // namespace
@@ -487,11 +281,15 @@ size_t vpin_sat_proof_max_bytes(size_t num_cons, size_t num_vars) {
 
 }  // extern "C"
 
-static int sat_prove_core(vpin_ctx* c, const vpin_r1cs_dev* dinst, size_t nv, size_t ncons, size_t ni,
-                          const vpin_table* d_para, const vpin_table* d_input, const vpin_table* d_vars, const uint8_t* inputs,
-                          const uint8_t seed_commit64[64], const uint8_t seed_proof64[64], uint8_t* proof_out, size_t proof_cap,
-                          size_t* proof_len, uint8_t* comm_para_out, uint8_t* comm_input_out, uint8_t inst_evals_out[96],
-                          uint8_t* rx_out, uint8_t* ry_out) {
+namespace vpin_prover {
+
+// my_lib_prove up to and including the Ar/Br/Cr claims.  tr_out / tape_out (optional) receive the
+// transcript and the RandomTape as they stand afterwards, for R1CSEvalProof::prove (spark.cpp).
+int sat_prove_core(vpin_ctx* c, const vpin_r1cs_dev* dinst, size_t nv, size_t ncons, size_t ni,
+                   const vpin_table* d_para, const vpin_table* d_input, const vpin_table* d_vars, const uint8_t* inputs,
+                   const uint8_t seed_commit64[64], const uint8_t seed_proof64[64], uint8_t* proof_out, size_t proof_cap,
+                   size_t* proof_len, uint8_t* comm_para_out, uint8_t* comm_input_out, uint8_t inst_evals_out[96],
+                   uint8_t* rx_out, uint8_t* ry_out, vpin_host::Transcript* tr_out, vpin_host::Transcript* tape_out) {
   auto t_begin = Clock::now();
   memset(g_timings, 0, sizeof g_timings);
   (void)hipSetDevice(c->device);
@@ -601,18 +399,6 @@ static int sat_prove_core(vpin_ctx* c, const vpin_r1cs_dev* dinst, size_t nv, si
   t0 = Clock::now();
   const size_t left = sg->ell / 2, right = sg->ell - left;
   std::vector<Fq> Lv(L), Rv(R), LZ(R);
-  auto host_eq = [](const Fq* r, size_t ell, Fq* out) {  // EqPolynomial::evals (dense_mlpoly.rs:78-94)
-    out[0] = Fq::one();
-    size_t size = 1;
-    for (size_t j = 0; j < ell; j++) {
-      for (size_t i = size; i-- > 0;) {
-        Fq s = out[i];
-        out[2 * i + 1] = s * r[j];
-        out[2 * i] = s - out[2 * i + 1];
-      }
-      size *= 2;
-    }
-  };
   host_eq(ry.data() + 1, left, Lv.data());
   host_eq(ry.data() + 1 + left, right, Rv.data());
   if ((rc = vpin_poly_bound(c, d_vars, B(Lv.data()), L, B(LZ.data())))) return rc;
@@ -624,96 +410,8 @@ static int sat_prove_core(vpin_ctx* c, const vpin_r1cs_dev* dinst, size_t nv, si
   Fq LZ_blind = Fq::zero();
   for (size_t i = 0; i < L; i++) LZ_blind = LZ_blind + blind_vars[i] * Lv[i];
 
-  // DotProductProofLog::prove (nizk/mod.rs:447-531)
-  tr.append_protocol_name("dot product proof (log)");
-  Fq d_ = tape.challenge_scalar("d");
-  Fq r_delta = tape.challenge_scalar("r_delta");
-  Fq r_beta = tape.challenge_scalar("r_delta");  // sic: the reference draws r_beta under the label "r_delta"
-  const size_t lgR = log2z(R);
-  std::vector<Fq> bv1 = tape.challenge_vector("blinds_vec_1", 2 * lgR);
-  std::vector<Fq> bv2 = tape.challenge_vector("blinds_vec_2", 2 * lgR);
-  const size_t ncols = R + 2;  // scalars over g[0..R) | g[R] | g[R+1]=h
-  std::vector<Fq> srow(2 * ncols, Fq::zero());
-  CG Cx, comm_vars_at_ry;
-  {
-    memcpy(srow.data(), LZ.data(), R * 32);
-    srow[R] = Fq::zero();
-    srow[R + 1] = LZ_blind;
-    Point p;
-    if ((rc = msm_rows_host_sum(c, sg, srow.data(), 1, ncols, &p))) return rc;
-    Cx = compress(p);
-  }
-  tr.append_point("Cx", Cx.b);
-  comm_vars_at_ry = compress(commit1(eval_vars_at_ry, blind_eval, sg->gens_1));
-  tr.append_point("Cy", comm_vars_at_ry.b);
-  tr.append_scalars("a", Rv.data(), R);
-  Fq r_ = tr.challenge_scalar("r");
-  // gens_1_scaled.G[0] = r * g[R]; every use below multiplies g[R] by r times something
-  Fq blind_Gamma = LZ_blind + r_ * blind_eval;
-  // BulletReductionProof::prove (nizk/bullet.rs:32-132).  G is never folded explicitly: the folded
-  // generator G_k[i] = sum_{j = i mod n} s_j g_j for known coefficients s_j, so every L/R of the
-  // reduction (and g_hat) is a fixed-base MSM over the original stream -> one GPU call per round.
-  std::vector<Fq> av(LZ), bvv(Rv), sj(R, Fq::one());
-  std::vector<CG> Lvec(lgR), Rvec(lgR);
-  Fq blind_fin = blind_Gamma;
-  size_t n = R;
-  for (size_t round = 0; round < lgR; round++) {
-    n /= 2;
-    Fq cL = Fq::zero(), cR = Fq::zero();
-    for (size_t i = 0; i < n; i++) { cL = cL + av[i] * bvv[n + i]; cR = cR + av[n + i] * bvv[i]; }
-    Fq* sL = srow.data();
-    Fq* sR = srow.data() + ncols;
-    const size_t mask = 2 * n - 1;
-    const int nthr = R >= 2048 ? host_threads() : 1;  // O(R) host work per round: worth a team only for large R
-#pragma omp parallel for schedule(static) num_threads(nthr)
-    for (long jj = 0; jj < (long)R; jj++) {
-      const size_t j = (size_t)jj;
-      size_t pos = j & mask;
-      if (pos >= n) { sL[j] = av[pos - n] * sj[j]; sR[j] = Fq::zero(); }  // a_L . G_R
-      else { sL[j] = Fq::zero(); sR[j] = av[n + pos] * sj[j]; }           // a_R . G_L
-    }
-    sL[R] = cL * r_; sL[R + 1] = bv1[round];  // c_L * Q + blind_L * H,  Q = r * g[R]
-    sR[R] = cR * r_; sR[R + 1] = bv2[round];
-    Point lr[2];
-    if ((rc = msm_rows_host_sum(c, sg, srow.data(), 2, ncols, lr))) return rc;
-    Lvec[round] = compress(lr[0]);
-    Rvec[round] = compress(lr[1]);
-    tr.append_point("L", Lvec[round].b);
-    tr.append_point("R", Rvec[round].b);
-    Fq u = tr.challenge_scalar("u"), u_inv = u.invert();
-    for (size_t i = 0; i < n; i++) {
-      av[i] = av[i] * u + u_inv * av[n + i];
-      bvv[i] = bvv[i] * u_inv + u * bvv[n + i];
-    }
-#pragma omp parallel for schedule(static) num_threads(nthr)
-    for (long jj = 0; jj < (long)R; jj++) {
-      const size_t j = (size_t)jj;
-      sj[j] = sj[j] * (((j & mask) < n) ? u_inv : u);
-    }
-    blind_fin = blind_fin + bv1[round] * u * u + bv2[round] * u_inv * u_inv;
-  }
-  Fq x_hat = av[0], a_hat = bvv[0], y_hat = x_hat * a_hat;
-  // g_hat = sum_j s_j g_j
-  Point g_hat;
-  {
-    std::vector<Fq> s1(ncols, Fq::zero());
-    memcpy(s1.data(), sj.data(), R * 32);
-    if ((rc = msm_rows_host_sum(c, sg, s1.data(), 1, ncols, &g_hat))) return rc;
-  }
-  CG dl_delta, dl_beta;
-  {
-    Point p = g_hat.mul(d_);  // d.commit(&r_delta, {G:[g_hat], h})
-    sg->fb_h.mul_acc(p, r_delta);
-    dl_delta = compress(p);
-    tr.append_point("delta", dl_delta.b);
-    Point q = sg->fb_gR.mul(d_ * r_);  // d.commit(&r_beta, gens_1_scaled)
-    sg->fb_h.mul_acc(q, r_beta);
-    dl_beta = compress(q);
-    tr.append_point("beta", dl_beta.b);
-  }
-  Fq c_ = tr.challenge_scalar("c");
-  Fq dl_z1 = d_ + c_ * y_hat;
-  Fq dl_z2 = a_hat * (c_ * blind_fin + r_beta) + r_delta;
+  DpLog pe;
+  if ((rc = dplog_prove(c, sg->pc, tr, tape, LZ, LZ_blind, Rv, eval_vars_at_ry, blind_eval, pe))) return rc;
   g_timings[3] = secs(t0, Clock::now());
 
   Fq blind_eval_Z = (one - ry[0]) * blind_eval;
@@ -748,19 +446,21 @@ static int sat_prove_core(vpin_ctx* c, const vpin_r1cs_dev* dinst, size_t nv, si
   for (int i = 0; i < 5; i++) w.scalar(pprod.z[i]);
   w.point(eq1.alpha); w.scalar(eq1.z);
   write_zksc(w, sc2);
-  w.point(comm_vars_at_ry);
-  w.u64(lgR); for (auto& p : Lvec) w.point(p);
-  w.u64(lgR); for (auto& p : Rvec) w.point(p);
-  w.point(dl_delta); w.point(dl_beta); w.scalar(dl_z1); w.scalar(dl_z2);
+  w.point(pe.Cy);  // comm_vars_at_ry
+  write_dplog(w, pe);
   w.point(eq2.alpha); w.scalar(eq2.z);
   if (w.buf.size() > proof_cap) return VPIN_ESHAPE;
   memcpy(proof_out, w.buf.data(), w.buf.size());
   *proof_len = w.buf.size();
   if (rx_out) memcpy(rx_out, rx.data(), rx.size() * 32);
   if (ry_out) memcpy(ry_out, ry.data(), ry.size() * 32);
+  if (tr_out) *tr_out = tr;
+  if (tape_out) *tape_out = tape;
   g_timings[4] = secs(t_begin, Clock::now());
   return VPIN_OK;
 }
+
+}  // namespace vpin_prover
 
 extern "C" {
 
@@ -775,8 +475,9 @@ int vpin_sat_prove_resident(vpin_ctx* c, const vpin_r1cs_dev* dinst, const vpin_
   size_t nv, ncons, ni;
   vpin_r1cs_dims(dinst, &ncons, &nv, &ni);
   if (vars_para->len != nv || vars_input->len != nv || vars->len != nv || (ni && !inputs)) return VPIN_ESHAPE;
-  return sat_prove_core(c, dinst, nv, ncons, ni, vars_para, vars_input, vars, inputs, seed_commit64, seed_proof64, proof_out,
-                        proof_cap, proof_len, comm_para_out, comm_input_out, inst_evals_out, rx_out, ry_out);
+  return vpin_prover::sat_prove_core(c, dinst, nv, ncons, ni, vars_para, vars_input, vars, inputs, seed_commit64, seed_proof64,
+                                     proof_out, proof_cap, proof_len, comm_para_out, comm_input_out, inst_evals_out, rx_out,
+                                     ry_out, nullptr, nullptr);
 }
 
 int vpin_sat_prove(vpin_ctx* c, const vpin_r1cs* inst, const uint8_t* vars_para, const uint8_t* vars_input,

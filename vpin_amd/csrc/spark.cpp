@@ -1,0 +1,636 @@
+// spark.cpp -- host orchestration of the SPARK half of vPIN's Spartan SNARK on one MI355X:
+// the computation commitment and the sparse-polynomial evaluation proof that follow the sat proof
+// on the same transcript.
+//
+// C++ counterpart of (names mirror the reference):
+//   Spartan/src/lib.rs:294-359                    SNARKGens::new, SNARK::encode
+//   Spartan/src/r1csinstance.rs:29-49,309-372     R1CSCommitmentGens, R1CSInstance::commit, R1CSEvalProof
+//   Spartan/src/sparse_mlpoly.rs:42-1572          Derefs, AddrTimestamps, multi_commit, Layers,
+//                                                 ProductLayerProof, HashLayerProof, PolyEvalNetworkProof,
+//                                                 SparseMatPolyEvalProof
+//   Spartan/src/product_tree.rs:258-385           ProductCircuitEvalProofBatched::prove
+//   Spartan/src/sumcheck.rs:248-425               SumcheckInstanceProof::prove_cubic_batched
+//   vPIN_proof_generation/src/commit_test.rs:59-133  my_lib_prove (whole)
+// The gathers, the hash layer, the product trees, every sum-check round, the slice evaluations and the
+// commitments run in spark.hip / msm.hip / poly.hip; this file owns the transcript, the per-round
+// scalars and the bincode image.  It shares no code with the test-side checker.
+#include "host/prover_common.h"
+#include "spark_dev.h"
+
+namespace {
+
+using namespace vpin_host;
+using namespace vpin_prover;
+
+// ---- generators: one stream under b"gens_r1cs_eval", three PolyCommitmentGens views -----------
+
+struct SparkGens {
+  size_t nb = 0;
+  std::vector<Point> g;
+  vpin_gens* dev = nullptr;
+  std::map<size_t, std::unique_ptr<PcGens>> views;  // by num_vars of the committed polynomial
+};
+
+static void spark_cache_free(vpin_ctx* c) {
+  auto* sg = static_cast<SparkGens*>(c->spark_cache);
+  if (!sg) return;
+  if (sg->dev) vpin_gens_free(c, sg->dev);
+  delete sg;
+  c->spark_cache = nullptr;
+}
+
+// PolyCommitmentGens::new(ell, b"gens_r1cs_eval") (dense_mlpoly.rs:26-33; lib.rs:315-321)
+static int get_view(vpin_ctx* c, size_t ell, const PcGens** out) {
+  if (!c->spark_cache) { c->spark_cache = new SparkGens(); c->spark_cache_free = spark_cache_free; }
+  auto* sg = static_cast<SparkGens*>(c->spark_cache);
+  const size_t left = ell / 2, R = (size_t)1 << (ell - left);
+  if (sg->nb < R + 2) {
+    // every MultiCommitGens::new(n, label) is a prefix of the same SHAKE stream: keep the longest
+    if (sg->dev) { vpin_gens_free(c, sg->dev); sg->dev = nullptr; }
+    sg->views.clear();
+    sg->nb = R + 2;
+    derive_gens(sg->g, sg->nb, "gens_r1cs_eval");
+    std::vector<uint8_t> xyzt(128 * sg->nb);
+#pragma omp parallel for schedule(static) num_threads(host_threads())
+    for (long i = 0; i < (long)sg->nb; i++) sg->g[i].to_xyzt(xyzt.data() + 128 * (size_t)i);
+    int rc = vpin_gens_create(c, xyzt.data(), sg->nb, &sg->dev);
+    if (rc) { sg->nb = 0; return rc; }
+  }
+  auto it = sg->views.find(ell);
+  if (it == sg->views.end()) {
+    std::unique_ptr<PcGens> v(new PcGens());
+    v->ell = ell; v->L = (size_t)1 << left; v->R = R; v->dev = sg->dev;
+    v->fb_gR = FixedBase(sg->g[R]);
+    v->fb_h = FixedBase(sg->g[R + 1]);
+    v->bind_views();
+    it = sg->views.emplace(ell, std::move(v)).first;
+  }
+  *out = it->second.get();
+  return VPIN_OK;
+}
+
+struct Shape { size_t nx, ny, N, M, v_ops, v_mem, v_derefs; };
+
+static size_t next_pow2(size_t n) { size_t p = 1; while (p < n) p <<= 1; return p; }
+
+static Shape shape_of(size_t num_cons, size_t num_vars, const size_t nnz[3]) {
+  Shape s;
+  s.nx = log2z(num_cons);
+  s.ny = log2z(2 * num_vars);
+  s.N = 1;
+  for (int m = 0; m < 3; m++) s.N = std::max(s.N, next_pow2(nnz[m]));  // get_num_nz_entries (sparse_mlpoly.rs:364)
+  s.M = (size_t)1 << std::max(s.nx, s.ny);
+  // SparseMatPolyCommitmentGens::new (sparse_mlpoly.rs:300-329), batch_size = 3
+  s.v_ops = log2z(s.N) + 4;
+  s.v_mem = std::max(s.nx, s.ny) + 1;
+  s.v_derefs = log2z(s.N) + 3;
+  return s;
+}
+
+// DensePolynomial::commit(gens, None) (dense_mlpoly.rs:193-218): zero blinds
+static int commit_noblind(vpin_ctx* c, const PcGens* pc, const vpin_table* Z, std::vector<CG>& out) {
+  std::vector<uint8_t> zeros(pc->L * 32, 0);
+  out.resize(pc->L);
+  return vpin_hyrax_commit(c, pc->dev, Z, zeros.data(), pc->L, pc->R + 1, out[0].b);
+}
+
+static void append_polycomm(Transcript& tr, const char* label, const std::vector<CG>& C) {
+  // PolyCommitment::append_to_transcript (dense_mlpoly.rs:305-313)
+  tr.append_message(label, "poly_commitment_begin");
+  for (auto& p : C) tr.append_point("poly_commitment_share", p.b);
+  tr.append_message(label, "poly_commitment_end");
+}
+
+static void append_unipoly(Transcript& tr, const Fq* coeffs, int n) {
+  // AppendToTranscript for UniPoly (unipoly.rs:112-120)
+  tr.append_message("poly", "UniPoly_begin");
+  for (int i = 0; i < n; i++) tr.append_scalar("coeff", coeffs[i]);
+  tr.append_message("poly", "UniPoly_end");
+}
+
+static void w_scalars(Writer& w, const Fq* v, size_t n) { w.u64(n); for (size_t i = 0; i < n; i++) w.scalar(v[i]); }
+
+// fold 2^k evaluations with bound_poly_var_bot in reverse challenge order (sparse_mlpoly.rs:104-109)
+static Fq combine_bot(std::vector<Fq> e, const std::vector<Fq>& ch) {
+  size_t n = e.size();
+  for (size_t ii = ch.size(); ii-- > 0;) {
+    n /= 2;
+    for (size_t i = 0; i < n; i++) e[i] = e[2 * i] + ch[ii] * (e[2 * i + 1] - e[2 * i]);
+  }
+  return e[0];
+}
+
+// PolyEvalProof::prove with blinds None, blind_Zr None (dense_mlpoly.rs:326-379)
+static int polyeval_prove_plain(vpin_ctx* c, const PcGens& pc, const vpin_table* Z, const std::vector<Fq>& r, const Fq& Zr,
+                                Transcript& tr, Transcript& tape, DpLog& out) {
+  if (r.size() != pc.ell || Z->len != ((size_t)1 << pc.ell)) return VPIN_ESHAPE;
+  tr.append_protocol_name("polynomial evaluation proof");
+  const size_t left = pc.ell / 2, right = pc.ell - left;
+  std::vector<Fq> Lv(pc.L), Rv(pc.R), LZ(pc.R);
+  host_eq(r.data(), left, Lv.data());
+  host_eq(r.data() + left, right, Rv.data());
+  int rc = vpin_poly_bound(c, Z, B(Lv.data()), pc.L, B(LZ.data()));
+  if (rc) return rc;
+  return dplog_prove(c, pc, tr, tape, LZ, Fq::zero(), Rv, Zr, Fq::zero(), out);
+}
+
+// ---- ProductCircuitEvalProofBatched::prove (product_tree.rs:258-385) ------------------------------
+
+struct Batched {
+  std::vector<std::vector<Fq>> polys, claims_left, claims_right;  // per layer, top layer first
+  std::vector<Fq> dotp[3];
+};
+
+static void write_batched(Writer& w, const Batched& b) {
+  w.u64(b.polys.size());
+  for (size_t l = 0; l < b.polys.size(); l++) {
+    w.u64(b.polys[l].size() / 3);  // SumcheckInstanceProof.compressed_polys
+    for (size_t j = 0; j < b.polys[l].size() / 3; j++) w_scalars(w, &b.polys[l][3 * j], 3);
+    w_scalars(w, b.claims_left[l].data(), b.claims_left[l].size());
+    w_scalars(w, b.claims_right[l].data(), b.claims_right[l].size());
+  }
+  for (int k = 0; k < 3; k++) w_scalars(w, b.dotp[k].data(), b.dotp[k].size());
+}
+
+static inline size_t pyramid_offset(int ell, int k) { return ((size_t)1 << ell) - ((size_t)2 << (ell - k)); }
+
+struct DotpCtx {  // the six DotProductCircuit halves ride along on layer 0 of the ops forest
+  const vpin_spark_decomm* d;
+  const vpin::fq* comb_derefs;
+  vpin::fq* scratch;
+  Fq claims[6];  // their evaluations (claim_eval_dotp_left/right per matrix)
+};
+
+static int batched_prove(vpin_ctx* c, vpin::SparkForest& f, DotpCtx* dotp, Transcript& tr, Batched& out, std::vector<Fq>& rand) {
+  const int npc = f.ncirc, ndotp = dotp ? 6 : 0;
+  const int num_layers = (int)log2z(f.n);
+  int rc;
+  // host copies of the small top levels
+  const size_t cnt = std::min<size_t>(2 * vpin::kSparkHostTop, f.stride());
+  if ((rc = vpin::spark_fetch_tops(c, &f, cnt))) return rc;
+  std::vector<Fq> tops((size_t)npc * cnt);
+  memcpy(tops.data(), c->h_spark, tops.size() * 32);
+
+  out.polys.assign(num_layers, {});
+  out.claims_left.assign(num_layers, {});
+  out.claims_right.assign(num_layers, {});
+  std::vector<Fq> claims(npc + ndotp), coeffs;
+  for (int t = 0; t < npc; t++) claims[t] = tops[(size_t)t * cnt + cnt - 2];  // the root: ProductCircuit::evaluate
+  rand.clear();
+  TableGuard tg(c);
+  const Fq one = Fq::one();
+
+  for (int layer_id = num_layers - 1, o = 0; layer_id >= 0; layer_id--, o++) {
+    const size_t h = f.n >> (layer_id + 1);  // entries of left_vec[layer_id]
+    const int k = (int)log2z(h);             // rounds; rand.size() == k
+    const bool with_dotp = (layer_id == 0 && ndotp > 0);
+    int nclaims = npc;
+    if (with_dotp) {
+      for (int i = 0; i < 6; i++) claims[npc + i] = dotp->claims[i];
+      nclaims += 6;
+    }
+    coeffs = tr.challenge_vector("rand_coeffs_next_layer", nclaims);
+    Fq e = Fq::zero();
+    for (int i = 0; i < nclaims; i++) e = e + claims[i] * coeffs[i];
+    std::vector<Fq> r(k);
+    std::vector<Fq>& polys = out.polys[o];
+    polys.resize(3 * (size_t)k);
+    std::vector<Fq> cl(npc), cr(npc);
+    const bool on_host = (2 * h <= vpin::kSparkHostTop) && layer_id != 0;
+
+    if (on_host) {
+      // prove_cubic_batched (sumcheck.rs:248-425) as written, on <= 16-entry tables
+      std::vector<Fq> C(h), A((size_t)npc * h), Bv((size_t)npc * h);
+      host_eq(rand.data(), (size_t)k, C.data());
+      for (int t = 0; t < npc; t++) {
+        const Fq* lvl = &tops[(size_t)t * cnt + cnt - 4 * h];  // level of 2h entries
+        memcpy(&A[(size_t)t * h], lvl, h * 32);
+        memcpy(&Bv[(size_t)t * h], lvl + h, h * 32);
+      }
+      size_t len = h;
+      for (int j = 0; j < k; j++) {
+        const size_t half = len / 2;
+        Fq c0 = Fq::zero(), c2 = Fq::zero(), c3 = Fq::zero();
+        for (int t = 0; t < npc; t++) {
+          const Fq* a = &A[(size_t)t * h];
+          const Fq* b = &Bv[(size_t)t * h];
+          Fq e0 = Fq::zero(), e2 = Fq::zero(), e3 = Fq::zero();
+          for (size_t i = 0; i < half; i++) {
+            e0 = e0 + a[i] * b[i] * C[i];
+            Fq a2 = a[half + i] + a[half + i] - a[i], b2 = b[half + i] + b[half + i] - b[i], c2p = C[half + i] + C[half + i] - C[i];
+            e2 = e2 + a2 * b2 * c2p;
+            Fq a3 = a2 + a[half + i] - a[i], b3 = b2 + b[half + i] - b[i], c3p = c2p + C[half + i] - C[i];
+            e3 = e3 + a3 * b3 * c3p;
+          }
+          c0 = c0 + e0 * coeffs[t]; c2 = c2 + e2 * coeffs[t]; c3 = c3 + e3 * coeffs[t];
+        }
+        Fq evals[4] = {c0, e - c0, c2, c3}, cf[4];
+        unipoly_from_evals(evals, 4, cf);
+        append_unipoly(tr, cf, 4);
+        Fq rj = tr.challenge_scalar("challenge_nextround");
+        r[j] = rj;
+        for (int t = 0; t < npc; t++) {
+          Fq* a = &A[(size_t)t * h];
+          Fq* b = &Bv[(size_t)t * h];
+          for (size_t i = 0; i < half; i++) { a[i] = a[i] + rj * (a[half + i] - a[i]); b[i] = b[i] + rj * (b[half + i] - b[i]); }
+        }
+        for (size_t i = 0; i < half; i++) C[i] = C[i] + rj * (C[half + i] - C[i]);
+        e = unipoly_eval(cf, 4, rj);
+        polys[3 * j] = cf[0]; polys[3 * j + 1] = cf[2]; polys[3 * j + 2] = cf[3];
+        len = half;
+      }
+      for (int t = 0; t < npc; t++) { cl[t] = A[(size_t)t * h]; cr[t] = Bv[(size_t)t * h]; }
+    } else {
+      // eq-factored rounds on the device: poly_C = eq(rand, .) folded with r_0..r_{j-1} equals
+      // s_j * eq(rand_{j..}, .), s_j = prod_{i<j} eq1(rand_i, r_i); at the round's evaluation point x it is
+      // s_j*((1-rand_j) + x*(2 rand_j - 1)) * E_{j+1}[i].  The kernel returns sum_i E_{j+1}[i]*(A_x B_x)[i].
+      if (k < 1) return VPIN_ESHAPE;
+      vpin_table* pyr = nullptr;
+      if ((rc = vpin_eq_suffix_tables(c, B(rand.data()), k, &pyr))) return rc;
+      tg.add(pyr);
+      Fq s = one;
+      for (int j = 0; j < k; j++) {
+        const size_t len = j == 0 ? h : (h >> (j - 1));  // live length before this round's launch
+        const vpin::fq* E = pyr->d + pyramid_offset(k, j + 1);
+        const uint8_t* rprev = j ? B(&r[j - 1]) : nullptr;
+        if ((rc = vpin::spark_prod_round(c, &f, layer_id, len, E, rprev))) return rc;
+        if (with_dotp && (rc = vpin::spark_dotp_round(c, dotp->d, dotp->comb_derefs, dotp->scratch, len, j == 1, rprev))) return rc;
+        if ((rc = vpin::spark_wait(c))) return rc;
+        const Fq* res = reinterpret_cast<const Fq*>(c->h_spark);
+        Fq S0 = Fq::zero(), S2 = Fq::zero(), S3 = Fq::zero();
+        for (int t = 0; t < npc; t++) { S0 = S0 + res[3 * t] * coeffs[t]; S2 = S2 + res[3 * t + 1] * coeffs[t]; S3 = S3 + res[3 * t + 2] * coeffs[t]; }
+        const Fq rho = rand[j], omr = one - rho;
+        const Fq two_rho = rho + rho;
+        Fq c0 = s * omr * S0;
+        Fq c2 = s * (two_rho + rho - one) * S2;                       // (1-rho) + 2(2rho-1) = 3rho - 1
+        Fq c3 = s * (two_rho + two_rho + rho - one - one) * S3;       // (1-rho) + 3(2rho-1) = 5rho - 2
+        if (with_dotp)
+          for (int i = 0; i < 6; i++) {
+            const Fq* q = res + 3 * (12 + i);
+            c0 = c0 + q[0] * coeffs[npc + i]; c2 = c2 + q[1] * coeffs[npc + i]; c3 = c3 + q[2] * coeffs[npc + i];
+          }
+        Fq evals[4] = {c0, e - c0, c2, c3}, cf[4];
+        unipoly_from_evals(evals, 4, cf);
+        append_unipoly(tr, cf, 4);
+        Fq rj = tr.challenge_scalar("challenge_nextround");
+        r[j] = rj;
+        e = unipoly_eval(cf, 4, rj);
+        s = s * (rho * rj + omr * (one - rj));
+        polys[3 * j] = cf[0]; polys[3 * j + 1] = cf[2]; polys[3 * j + 2] = cf[3];
+      }
+      // final fold of the two live entries per table with r_{k-1}
+      if ((rc = vpin::spark_collect_prod(c, &f, layer_id))) return rc;
+      const Fq* res = reinterpret_cast<const Fq*>(c->h_spark);
+      const Fq rl = r[k - 1];
+      for (int t = 0; t < npc; t++) {
+        cl[t] = res[4 * t] + rl * (res[4 * t + 1] - res[4 * t]);
+        cr[t] = res[4 * t + 2] + rl * (res[4 * t + 3] - res[4 * t + 2]);
+      }
+      if (with_dotp) {
+        if ((rc = vpin::spark_collect_dotp(c, dotp->d, dotp->comb_derefs, dotp->scratch, k >= 2))) return rc;
+        const Fq* q = reinterpret_cast<const Fq*>(c->h_spark) + 64;
+        for (int t = 0; t < 3; t++) out.dotp[t].resize(6);
+        for (int i = 0; i < 6; i++)
+          for (int t = 0; t < 3; t++) out.dotp[t][i] = q[6 * i + 2 * t] + rl * (q[6 * i + 2 * t + 1] - q[6 * i + 2 * t]);
+      }
+    }
+
+    for (int t = 0; t < npc; t++) {
+      tr.append_scalar("claim_prod_left", cl[t]);
+      tr.append_scalar("claim_prod_right", cr[t]);
+    }
+    if (with_dotp)
+      for (int i = 0; i < 6; i++) {
+        tr.append_scalar("claim_dotp_left", out.dotp[0][i]);
+        tr.append_scalar("claim_dotp_right", out.dotp[1][i]);
+        tr.append_scalar("claim_dotp_weight", out.dotp[2][i]);
+      }
+    Fq r_layer = tr.challenge_scalar("challenge_r_layer");
+    for (int t = 0; t < npc; t++) claims[t] = cl[t] + r_layer * (cr[t] - cl[t]);
+    out.claims_left[o] = cl;
+    out.claims_right[o] = cr;
+    std::vector<Fq> ext;
+    ext.reserve(k + 1);
+    ext.push_back(r_layer);
+    ext.insert(ext.end(), r.begin(), r.end());
+    rand.swap(ext);
+  }
+  return VPIN_OK;
+}
+
+static thread_local double g_spark_timings[8];
+
+// SparseMatPolyEvalProof::prove (sparse_mlpoly.rs:1466-1533) -> bincode(R1CSEvalProof) appended to w
+static int spark_prove(vpin_ctx* c, const vpin_spark_decomm* d, const std::vector<Fq>& rx, const std::vector<Fq>& ry,
+                       const Fq evals[3], Transcript& tr, Transcript& tape, Writer& w) {
+  const size_t N = d->N, M = d->M, lgN = log2z(N), lgM = log2z(M);
+  if (N < 4 || M < 4 || rx.size() != d->nx || ry.size() != d->ny) return VPIN_ESHAPE;
+  int rc;
+  const Shape sh{d->nx, d->ny, N, M, lgN + 4, std::max(d->nx, d->ny) + 1, lgN + 3};
+  const PcGens *g_ops = nullptr, *g_mem = nullptr, *g_derefs = nullptr;
+  // the longest stream first: a later, longer request would rebuild the table and drop earlier views
+  if ((rc = get_view(c, std::max(sh.v_ops, sh.v_mem), &g_ops)) || (rc = get_view(c, sh.v_ops, &g_ops)) ||
+      (rc = get_view(c, sh.v_mem, &g_mem)) || (rc = get_view(c, sh.v_derefs, &g_derefs)))
+    return rc;
+  TableGuard tg(c);
+  auto t0 = Clock::now();
+
+  tr.append_protocol_name("Sparse polynomial evaluation proof");
+  // equalize (sparse_mlpoly.rs:1448-1465) + the two memories eq(rx_ext, .), eq(ry_ext, .)
+  const size_t nm = std::max(d->nx, d->ny);
+  std::vector<Fq> rx_ext(nm, Fq::zero()), ry_ext(nm, Fq::zero());
+  std::copy(rx.begin(), rx.end(), rx_ext.begin() + (nm - d->nx));
+  std::copy(ry.begin(), ry.end(), ry_ext.begin() + (nm - d->ny));
+  vpin_table *mem_rx = nullptr, *mem_ry = nullptr, *comb = nullptr;
+  if ((rc = vpin_eq_table(c, B(rx_ext.data()), (int)nm, &mem_rx))) return rc;
+  tg.add(mem_rx);
+  if ((rc = vpin_eq_table(c, B(ry_ext.data()), (int)nm, &mem_ry))) return rc;
+  tg.add(mem_ry);
+  // Derefs (sparse_mlpoly.rs:525-531,56-71) and their commitment
+  if ((rc = vpin::table_alloc_uninit(c, 8 * N, &comb))) return rc;
+  tg.add(comb);
+  if ((rc = vpin::spark_gather_derefs(c, d, mem_rx->d, mem_ry->d, comb->d))) return rc;
+  std::vector<CG> comm_derefs;
+  if ((rc = commit_noblind(c, g_derefs, comb, comm_derefs))) return rc;
+  tr.append_message("derefs_commitment", "begin_derefs_commitment");  // DerefsCommitment::append_to_transcript (:216-222)
+  append_polycomm(tr, "comm_poly_row_col_ops_val", comm_derefs);
+  tr.append_message("derefs_commitment", "end_derefs_commitment");
+  g_spark_timings[1] = secs(t0, Clock::now());
+
+  // ---- PolyEvalNetwork::new (sparse_mlpoly.rs:681-696) ----
+  t0 = Clock::now();
+  std::vector<Fq> r_mem_check = tr.challenge_vector("challenge_r_hash", 2);
+  const Fq r_hash = r_mem_check[0], gamma = r_mem_check[1], r_hash_sqr = r_hash * r_hash, r2_boost = r_hash_sqr * Fq::r2();
+  vpin::SparkForest f_ops, f_mem;
+  vpin::DevBuf b_ops(c), b_mem(c), b_scr(c);
+  if (b_ops.alloc(12 * 2 * N * 32) || b_mem.alloc(4 * 2 * M * 32) || b_scr.alloc(18 * (N / 4) * 32)) return VPIN_ENOMEM;
+  f_ops.base = (vpin::fq*)b_ops.p; f_ops.n = N; f_ops.ncirc = 12;
+  f_mem.base = (vpin::fq*)b_mem.p; f_mem.n = M; f_mem.ncirc = 4;
+  if ((rc = vpin::spark_build_forests(c, d, comb->d, mem_rx->d, mem_ry->d, B(&r_hash), B(&r_hash_sqr), B(&r2_boost), B(&gamma),
+                                      &f_ops, &f_mem)))
+    return rc;
+  if ((rc = vpin::spark_wait(c))) return rc;
+  g_spark_timings[2] = secs(t0, Clock::now());
+
+  // ---- PolyEvalNetworkProof::prove / ProductLayerProof::prove (:1336-1370, :1049-1227) ----
+  t0 = Clock::now();
+  tr.append_protocol_name("Sparse polynomial evaluation proof");
+  tr.append_protocol_name("Sparse polynomial product layer proof");
+  // roots of the 16 circuits
+  Fq pl[2][8];  // per side: init, read[3], write[3], audit
+  {
+    if ((rc = vpin::spark_fetch_tops(c, &f_ops, 2))) return rc;
+    const Fq* t = reinterpret_cast<const Fq*>(c->h_spark);
+    for (int s = 0; s < 2; s++)
+      for (int m = 0; m < 3; m++) { pl[s][1 + m] = t[2 * (s * 6 + m)]; pl[s][4 + m] = t[2 * (s * 6 + 3 + m)]; }
+    if ((rc = vpin::spark_fetch_tops(c, &f_mem, 2))) return rc;
+    for (int s = 0; s < 2; s++) { pl[s][0] = t[2 * (2 * s)]; pl[s][7] = t[2 * (2 * s + 1)]; }
+  }
+  static const char* lab[2][4] = {{"claim_row_eval_init", "claim_row_eval_read", "claim_row_eval_write", "claim_row_eval_audit"},
+                                  {"claim_col_eval_init", "claim_col_eval_read", "claim_col_eval_write", "claim_col_eval_audit"}};
+  for (int s = 0; s < 2; s++) {
+    Fq ws = Fq::one(), rs = Fq::one();
+    for (int m = 0; m < 3; m++) { rs = rs * pl[s][1 + m]; ws = ws * pl[s][4 + m]; }
+    if (!(pl[s][0] * ws == rs * pl[s][7])) return VPIN_ESHAPE;  // assert_eq!(row_eval_init * ws, rs * row_eval_audit)
+    tr.append_scalar(lab[s][0], pl[s][0]);
+    tr.append_scalars(lab[s][1], &pl[s][1], 3);
+    tr.append_scalars(lab[s][2], &pl[s][4], 3);
+    tr.append_scalar(lab[s][3], pl[s][7]);
+  }
+  DotpCtx dotp{d, comb->d, (vpin::fq*)b_scr.p, {}};
+  Fq dotp_left[3], dotp_right[3];
+  {
+    // DotProductCircuit::evaluate (product_tree.rs:87-91) of the six halves
+    if ((rc = vpin::spark_triple_sums(c, d, comb->d))) return rc;
+    for (int i = 0; i < 6; i++) dotp.claims[i] = reinterpret_cast<const Fq*>(c->h_spark)[3 * i];
+    for (int m = 0; m < 3; m++) {
+      dotp_left[m] = dotp.claims[2 * m];
+      dotp_right[m] = dotp.claims[2 * m + 1];
+      tr.append_scalar("claim_eval_dotp_left", dotp_left[m]);
+      tr.append_scalar("claim_eval_dotp_right", dotp_right[m]);
+      if (!(dotp_left[m] + dotp_right[m] == evals[m])) return VPIN_ESHAPE;  // assert_eq!(left + right, eval[i])
+    }
+  }
+  Batched pf_ops, pf_mem;
+  std::vector<Fq> rand_ops, rand_mem;
+  if ((rc = batched_prove(c, f_ops, &dotp, tr, pf_ops, rand_ops))) return rc;
+  if ((rc = batched_prove(c, f_mem, nullptr, tr, pf_mem, rand_mem))) return rc;
+  g_spark_timings[3] = secs(t0, Clock::now());
+
+  // ---- HashLayerProof::prove (:740-849) ----
+  t0 = Clock::now();
+  tr.append_protocol_name("Sparse polynomial hash layer proof");
+  vpin_table *eq_ops = nullptr, *eq_mem = nullptr;
+  if ((rc = vpin_eq_table(c, B(rand_ops.data()), (int)lgN, &eq_ops))) return rc;
+  tg.add(eq_ops);
+  if ((rc = vpin_eq_table(c, B(rand_mem.data()), (int)lgM, &eq_mem))) return rc;
+  tg.add(eq_mem);
+  Fq ev_derefs[6], ev_ops[15], ev_mem[2];
+  const Fq* hs = reinterpret_cast<const Fq*>(c->h_spark);
+  if ((rc = vpin::spark_slice_evals(c, comb->d, N, 6, eq_ops->d))) return rc;
+  for (int i = 0; i < 6; i++) ev_derefs[i] = hs[3 * i];
+  DpLog pe_derefs, pe_ops, pe_mem;
+  {
+    // DerefsEvalProof::prove (:137-158, :90-135)
+    tr.append_protocol_name("Derefs evaluation proof");
+    std::vector<Fq> e8(8, Fq::zero());
+    for (int i = 0; i < 6; i++) e8[i] = ev_derefs[i];
+    tr.append_scalars("evals_ops_val", e8.data(), 8);
+    std::vector<Fq> ch = tr.challenge_vector("challenge_combine_n_to_one", 3);
+    Fq joint = combine_bot(e8, ch);
+    std::vector<Fq> rj(ch);
+    rj.insert(rj.end(), rand_ops.begin(), rand_ops.end());
+    tr.append_scalar("joint_claim_eval", joint);
+    if ((rc = polyeval_prove_plain(c, *g_derefs, comb, rj, joint, tr, tape, pe_derefs))) return rc;
+  }
+  if ((rc = vpin::spark_slice_evals(c, d->comb_ops->d, N, 15, eq_ops->d))) return rc;
+  for (int i = 0; i < 15; i++) ev_ops[i] = hs[3 * i];
+  if ((rc = vpin::spark_slice_evals(c, d->comb_mem->d, M, 2, eq_mem->d))) return rc;
+  for (int i = 0; i < 2; i++) ev_mem[i] = hs[3 * i];
+  {
+    std::vector<Fq> e16(16, Fq::zero());
+    for (int i = 0; i < 15; i++) e16[i] = ev_ops[i];  // row addr, row read_ts, col addr, col read_ts, val (comb_ops order)
+    tr.append_scalars("claim_evals_ops", e16.data(), 16);
+    std::vector<Fq> ch = tr.challenge_vector("challenge_combine_n_to_one", 4);
+    Fq joint = combine_bot(e16, ch);
+    std::vector<Fq> rj(ch);
+    rj.insert(rj.end(), rand_ops.begin(), rand_ops.end());
+    tr.append_scalar("joint_claim_eval_ops", joint);
+    if ((rc = polyeval_prove_plain(c, *g_ops, d->comb_ops, rj, joint, tr, tape, pe_ops))) return rc;
+  }
+  {
+    std::vector<Fq> e2 = {ev_mem[0], ev_mem[1]};
+    tr.append_scalars("claim_evals_mem", e2.data(), 2);
+    std::vector<Fq> ch = tr.challenge_vector("challenge_combine_two_to_one", 1);
+    Fq joint = combine_bot(e2, ch);
+    std::vector<Fq> rj(ch);
+    rj.insert(rj.end(), rand_mem.begin(), rand_mem.end());
+    tr.append_scalar("joint_claim_eval_mem", joint);
+    if ((rc = polyeval_prove_plain(c, *g_mem, d->comb_mem, rj, joint, tr, tape, pe_mem))) return rc;
+  }
+  g_spark_timings[4] = secs(t0, Clock::now());
+
+  // ---- bincode(R1CSEvalProof) (r1csinstance.rs:326-328; sparse_mlpoly.rs:1438-1441,1326-1329,1036-1042,698-707) ----
+  w.u64(comm_derefs.size());
+  for (auto& p : comm_derefs) w.point(p);
+  for (int s = 0; s < 2; s++) { w.scalar(pl[s][0]); w_scalars(w, &pl[s][1], 3); w_scalars(w, &pl[s][4], 3); w.scalar(pl[s][7]); }
+  w_scalars(w, dotp_left, 3);
+  w_scalars(w, dotp_right, 3);
+  write_batched(w, pf_mem);
+  write_batched(w, pf_ops);
+  w_scalars(w, &ev_ops[0], 3); w_scalars(w, &ev_ops[3], 3); w.scalar(ev_mem[0]);  // eval_row: addr, read_ts, audit_ts
+  w_scalars(w, &ev_ops[6], 3); w_scalars(w, &ev_ops[9], 3); w.scalar(ev_mem[1]);  // eval_col
+  w_scalars(w, &ev_ops[12], 3);                                                   // eval_val
+  w_scalars(w, &ev_derefs[0], 3); w_scalars(w, &ev_derefs[3], 3);                 // eval_derefs
+  write_dplog(w, pe_ops);
+  write_dplog(w, pe_mem);
+  write_dplog(w, pe_derefs);
+  return VPIN_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t vpin_spark_comm_bytes(const vpin_r1cs* inst) {
+  if (!inst) return 0;
+  Shape s = shape_of(inst->num_cons, inst->num_vars, inst->nnz);
+  return 8 * 6 + 8 + 32 * ((size_t)1 << (s.v_ops / 2)) + 8 + 32 * ((size_t)1 << (s.v_mem / 2));
+}
+
+size_t vpin_snark_proof_max_bytes(const vpin_r1cs* inst) {
+  if (!inst) return 0;
+  Shape s = shape_of(inst->num_cons, inst->num_vars, inst->nnz);
+  const size_t lgN = log2z(s.N), lgM = log2z(s.M);
+  size_t b = vpin_sat_proof_max_bytes(inst->num_cons, inst->num_vars) + 96;
+  b += 8 + 32 * ((size_t)1 << (s.v_derefs / 2)) + 64 * 32;
+  b += lgN * (lgN * 104 + 64 + 24 * 32 + 64) + 18 * 32 + 64;
+  b += lgM * (lgM * 104 + 64 + 8 * 32 + 64) + 64;
+  b += 3 * (16 + 64 * 40 + 128 + 64) + 40 * 32 + 1024;
+  return b;
+}
+
+void vpin_spark_decomm_free(vpin_ctx* c, vpin_spark_decomm* d) {
+  if (!d) return;
+  if (c) {
+    (void)hipSetDevice(c->device);
+    if (d->idx) vpin::dev_free(c, d->idx);
+    if (d->comb_ops) vpin_table_free(c, d->comb_ops);
+    if (d->comb_mem) vpin_table_free(c, d->comb_mem);
+  }
+  delete d;
+}
+
+// SNARK::encode (lib.rs:347-359) = R1CSInstance::commit (r1csinstance.rs:309-322) =
+// SparseMatPolynomial::multi_commit (sparse_mlpoly.rs:500-520)
+int vpin_spark_encode(vpin_ctx* c, const vpin_r1cs* inst, vpin_spark_decomm** out, uint8_t* comm_out, size_t comm_cap,
+                      size_t* comm_len) {
+  if (!c || !inst || !out || !comm_out || !comm_len) return VPIN_EINVAL;
+  if (!vpin::is_pow2(inst->num_cons) || !vpin::is_pow2(inst->num_vars) || inst->num_inputs >= inst->num_vars) return VPIN_ESHAPE;
+  auto t0 = Clock::now();
+  (void)hipSetDevice(c->device);
+  const Shape s = shape_of(inst->num_cons, inst->num_vars, inst->nnz);
+  const size_t N = s.N, M = s.M;
+  if (N < 4 || M < 4 || M > ((size_t)1 << 32) || N > ((size_t)1 << 31)) return VPIN_ESHAPE;
+  if (comm_cap < vpin_spark_comm_bytes(inst)) return VPIN_ESHAPE;
+  for (int m = 0; m < 3; m++)
+    if (inst->nnz[m] && (!inst->row[m] || !inst->col[m] || !inst->val[m])) return VPIN_EINVAL;
+  std::unique_ptr<vpin_spark_decomm> d(new vpin_spark_decomm());
+  d->num_cons = inst->num_cons; d->num_vars = inst->num_vars; d->num_inputs = inst->num_inputs;
+  d->nx = s.nx; d->ny = s.ny; d->N = N; d->M = M;
+  auto fail = [&](int rc) { vpin_spark_decomm_free(c, d.release()); return rc; };
+
+  // sparse_to_dense_vecs (:368-380) + AddrTimestamps::new (:232-265) on the host: the timestamps are a
+  // sequential memory trace (audit_ts runs on across A, B, C), O(N) integer work done once per circuit
+  std::vector<uint32_t> idx(12 * N + 2 * M, 0);
+  for (int m = 0; m < 3; m++) {
+    for (size_t k = 0; k < inst->nnz[m]; k++) {
+      if (inst->row[m][k] >= inst->num_cons || inst->col[m][k] >= 2 * inst->num_vars) return fail(VPIN_ESHAPE);
+      idx[(size_t)m * N + k] = inst->row[m][k];
+      idx[(size_t)(6 + m) * N + k] = inst->col[m][k];
+    }
+  }
+#pragma omp parallel for schedule(static) num_threads(2)
+  for (int side = 0; side < 2; side++) {
+    uint32_t* audit = idx.data() + 12 * N + (size_t)side * M;
+    for (int m = 0; m < 3; m++) {
+      const uint32_t* addr = idx.data() + (size_t)(side * 6 + m) * N;
+      uint32_t* ts = idx.data() + (size_t)(side * 6 + 3 + m) * N;
+      for (size_t i = 0; i < N; i++) ts[i] = audit[addr[i]]++;
+    }
+  }
+  int rc;
+  if ((rc = vpin::dev_alloc(c, idx.size() * 4, (void**)&d->idx))) return fail(rc);
+  if (hipMemcpyAsync(d->idx, idx.data(), idx.size() * 4, hipMemcpyHostToDevice, c->stream) != hipSuccess) return fail(VPIN_EHIP);
+  // comb_ops = merge(row.ops_addr, row.read_ts, col.ops_addr, col.read_ts, val) padded to 16N (:418-426);
+  // comb_mem = row.audit_ts ++ col.audit_ts (:427-428)
+  if ((rc = vpin::table_alloc_uninit(c, 16 * N, &d->comb_ops))) return fail(rc);
+  if ((rc = vpin::table_alloc_uninit(c, 2 * M, &d->comb_mem))) return fail(rc);
+  if ((rc = vpin::spark_u32_to_fq(c, d->idx, d->comb_ops->d, 12 * N))) return fail(rc);
+  if ((rc = vpin::spark_u32_to_fq(c, d->idx + 12 * N, d->comb_mem->d, 2 * M))) return fail(rc);
+  if (hipMemsetAsync(d->comb_ops->d + 12 * N, 0, 4 * N * 32, c->stream) != hipSuccess) return fail(VPIN_EHIP);
+  for (int m = 0; m < 3; m++)
+    if (inst->nnz[m] && hipMemcpyAsync(d->comb_ops->d + (size_t)(12 + m) * N, inst->val[m], inst->nnz[m] * 32, hipMemcpyHostToDevice,
+                                       c->stream) != hipSuccess)
+      return fail(VPIN_EHIP);
+  if (hipStreamSynchronize(c->stream) != hipSuccess) return fail(VPIN_EHIP);
+
+  const PcGens *g_ops = nullptr, *g_mem = nullptr;
+  if ((rc = get_view(c, std::max(s.v_ops, s.v_mem), &g_ops)) || (rc = get_view(c, s.v_ops, &g_ops)) ||
+      (rc = get_view(c, s.v_mem, &g_mem)))
+    return fail(rc);
+  std::vector<CG> c_ops, c_mem;
+  if ((rc = commit_noblind(c, g_ops, d->comb_ops, c_ops)) || (rc = commit_noblind(c, g_mem, d->comb_mem, c_mem))) return fail(rc);
+  // bincode(R1CSCommitment) (r1csinstance.rs:53-58, sparse_mlpoly.rs:332-338)
+  Writer w;
+  w.u64(inst->num_cons); w.u64(inst->num_vars); w.u64(inst->num_inputs);
+  w.u64(3); w.u64(N); w.u64(M);
+  w.u64(c_ops.size()); for (auto& p : c_ops) w.point(p);
+  w.u64(c_mem.size()); for (auto& p : c_mem) w.point(p);
+  if (w.buf.size() > comm_cap) return fail(VPIN_ESHAPE);
+  memcpy(comm_out, w.buf.data(), w.buf.size());
+  *comm_len = w.buf.size();
+  *out = d.release();
+  g_spark_timings[0] = secs(t0, Clock::now());
+  return VPIN_OK;
+}
+
+// my_lib_prove (commit_test.rs:59-133) in full: R1CSProof, inst_evals, R1CSEvalProof -> bincode(SNARK)
+int vpin_snark_prove_resident(vpin_ctx* c, const vpin_r1cs_dev* dinst, const vpin_spark_decomm* decomm,
+                              const vpin_table* vars_para, const vpin_table* vars_input, const vpin_table* vars,
+                              const uint8_t* inputs, const uint8_t seed_commit64[64], const uint8_t seed_proof64[64],
+                              uint8_t* proof_out, size_t proof_cap, size_t* proof_len, uint8_t* comm_para_out,
+                              uint8_t* comm_input_out) {
+  if (!c || !dinst || !decomm || !vars_para || !vars_input || !vars || !seed_commit64 || !seed_proof64 || !proof_out ||
+      !proof_len || !comm_para_out || !comm_input_out)
+    return VPIN_EINVAL;
+  size_t nv, ncons, ni;
+  vpin_r1cs_dims(dinst, &ncons, &nv, &ni);
+  if (vars_para->len != nv || vars_input->len != nv || vars->len != nv || (ni && !inputs)) return VPIN_ESHAPE;
+  if (decomm->num_cons != ncons || decomm->num_vars != nv || decomm->num_inputs != ni) return VPIN_ESHAPE;
+  auto t0 = Clock::now();
+  Transcript tr("snark_example"), tape("snark_example");
+  uint8_t ie[96];
+  std::vector<Fq> rx(log2z(ncons)), ry(log2z(2 * nv));
+  size_t sat_len = 0;
+  int rc = sat_prove_core(c, dinst, nv, ncons, ni, vars_para, vars_input, vars, inputs, seed_commit64, seed_proof64, proof_out,
+                          proof_cap, &sat_len, comm_para_out, comm_input_out, ie, B(rx.data()), B(ry.data()), &tr, &tape);
+  if (rc) return rc;
+  g_spark_timings[5] = secs(t0, Clock::now());
+  Writer w;
+  w.bytes(ie, 96);  // SNARK.inst_evals (lib.rs:334-338)
+  Fq evals[3];
+  memcpy(evals, ie, 96);
+  if ((rc = spark_prove(c, decomm, rx, ry, evals, tr, tape, w))) return rc;
+  if (sat_len + w.buf.size() > proof_cap) return VPIN_ESHAPE;
+  memcpy(proof_out + sat_len, w.buf.data(), w.buf.size());
+  *proof_len = sat_len + w.buf.size();
+  g_spark_timings[6] = secs(t0, Clock::now());
+  return VPIN_OK;
+}
+
+// [0] encode, [1] derefs + commit, [2] network build, [3] product-layer proofs, [4] hash-layer proofs,
+// [5] sat part, [6] whole prove
+void vpin_spark_last_timings(double out[8]) { memcpy(out, g_spark_timings, sizeof g_spark_timings); }
+
+}  // extern "C"

@@ -1,0 +1,498 @@
+// spark.hip -- device kernels of the SPARK half (computation commitment + sparse-polynomial
+// evaluation proof) for gfx950.
+//
+// Replaces the data-parallel loops of
+//   Spartan/src/sparse_mlpoly.rs:267-283,525-531  AddrTimestamps::deref (gather)
+//   Spartan/src/sparse_mlpoly.rs:547-622          Layers::build_hash_layer
+//   Spartan/src/product_tree.rs:18-56             ProductCircuit::new (pairwise-product tree)
+//   Spartan/src/sumcheck.rs:273-330,346-370       prove_cubic_batched round evaluation + folds
+//   Spartan/src/dense_mlpoly.rs:249-255           DensePolynomial::evaluate of the dense slices
+//
+// Layout.  A product circuit over n leaves is ONE array of 2n field elements: level l (n>>l entries)
+// at offset 2n - (2n>>l); the reference's left_vec[l] / right_vec[l] are its two halves, and level
+// l+1 is the element-wise product of those halves, so building a level is a unit-stride stream
+// (2 loads, 1 store, 1 Montgomery product per output).  The 12 "ops" circuits (and the 4 "mem"
+// circuits) of a proof have equal size and are proven in lock-step, so they sit in one allocation
+// and every kernel takes the circuit index from blockIdx.y: one launch per round for all of them.
+//
+// Round kernel.  The third factor of every product-circuit sum-check is eq(rand, .), so the rounds
+// run eq-factored exactly like phase 1 of the sat proof (sumcheck.hip): the kernel returns
+// sum_i E[i]*(A_x*B_x)[i] for x = 0,2,3 with E the read-only suffix table of the round, and the
+// host applies the per-round scalar.  Per pair: fold 2 tables (4 products), 3 products A_x*B_x,
+// 3 products by E: 10 Montgomery products, 9 loads, 4 stores.  HBM-streaming integer work.
+#include "sc_dev.h"
+#include "spark_dev.h"
+
+namespace vpin {
+
+// R^2 mod q (ristretto255.rs:309-314): fq_mul(raw, kR2) = raw in Montgomery form
+__device__ __forceinline__ fq fq_r2() {
+  fq r;
+  r.v[0] = 0x449c0f01u; r.v[1] = 0xa40611e3u; r.v[2] = 0x68859347u; r.v[3] = 0xd00e1ba7u;
+  r.v[4] = 0x17f5be65u; r.v[5] = 0xceec73d2u; r.v[6] = 0x7c309a3du; r.v[7] = 0x0399411bu;
+  return r;
+}
+__device__ __forceinline__ fq fq_raw_u32(uint32_t x) {
+  fq r = fq_zero();
+  r.v[0] = x;
+  return r;
+}
+
+__global__ __launch_bounds__(kBlock) void u32_to_fq_kernel(const uint32_t* __restrict__ src, fq* __restrict__ dst, size_t n) {
+  const fq r2 = fq_r2();
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
+    uint32_t x = src[i];
+    fq_store(dst + i, x ? fq_mul(fq_raw_u32(x), r2) : fq_zero());
+  }
+}
+
+// blockIdx.y = slice 0..7: 0..2 row derefs of A,B,C, 3..5 col derefs, 6..7 zero padding
+__global__ __launch_bounds__(kBlock) void gather_derefs_kernel(const uint32_t* __restrict__ idx, size_t N,
+                                                               const fq* __restrict__ mem_rx, const fq* __restrict__ mem_ry,
+                                                               fq* __restrict__ comb) {
+  const int s = blockIdx.y;
+  fq* dst = comb + (size_t)s * N;
+  if (s >= 6) {
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < N; i += (size_t)gridDim.x * kBlock) fq_store(dst + i, fq_zero());
+    return;
+  }
+  const uint32_t* a = idx + (size_t)(s < 3 ? s : 3 + s) * N;  // idx slices 0..2 = row, 6..8 = col
+  const fq* mem = s < 3 ? mem_rx : mem_ry;
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < N; i += (size_t)gridDim.x * kBlock)
+    fq_store(dst + i, fq_load(mem + a[i]));
+}
+
+// hash_func(addr, val, ts) - r_multiset_check = ts*r^2 + val*r + addr - gamma  (sparse_mlpoly.rs:557-560).
+// r2_boost = r^2 * R (Montgomery form of the Montgomery image), so fq_mul(raw ts, r2_boost) is ts*r^2
+// in Montgomery form without a separate conversion of ts.
+struct HashParams { fq r, r2, r2_boost, gamma; };
+
+// blockIdx.y = side*3 + m.  Writes level 0 of read circuit (side*6 + m) and write circuit (side*6 + 3 + m).
+__global__ __launch_bounds__(kBlock) void hash_ops_kernel(const uint32_t* __restrict__ idx, const fq* __restrict__ derefs, size_t N,
+                                                          HashParams hp, fq* __restrict__ forest) {
+  const int side = blockIdx.y / 3, m = blockIdx.y % 3;
+  const uint32_t* addr = idx + (size_t)(side * 6 + m) * N;
+  const uint32_t* ts = idx + (size_t)(side * 6 + 3 + m) * N;
+  const fq* val = derefs + (size_t)(side * 3 + m) * N;
+  fq* rd = forest + (size_t)(side * 6 + m) * 2 * N;
+  fq* wr = forest + (size_t)(side * 6 + 3 + m) * 2 * N;
+  const fq r2c = fq_r2();
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < N; i += (size_t)gridDim.x * kBlock) {
+    fq h = fq_sub(fq_mul(fq_load(val + i), hp.r), hp.gamma);
+    uint32_t a = addr[i], t = ts[i];
+    if (a) h = fq_add(h, fq_mul(fq_raw_u32(a), r2c));
+    if (t) h = fq_add(h, fq_mul(fq_raw_u32(t), hp.r2_boost));
+    fq_store(rd + i, h);
+    fq_store(wr + i, fq_add(h, hp.r2));  // write timestamp = read timestamp + 1
+  }
+}
+
+// blockIdx.y = side.  Level 0 of init circuit (2*side) and audit circuit (2*side + 1).
+__global__ __launch_bounds__(kBlock) void hash_mem_kernel(const uint32_t* __restrict__ audit_ts, const fq* __restrict__ mem_rx,
+                                                          const fq* __restrict__ mem_ry, size_t M, HashParams hp,
+                                                          fq* __restrict__ forest) {
+  const int side = blockIdx.y;
+  const fq* mem = side ? mem_ry : mem_rx;
+  const uint32_t* ts = audit_ts + (size_t)side * M;
+  fq* init = forest + (size_t)(2 * side) * 2 * M;
+  fq* audit = forest + (size_t)(2 * side + 1) * 2 * M;
+  const fq r2c = fq_r2();
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < M; i += (size_t)gridDim.x * kBlock) {
+    fq h = fq_sub(fq_mul(fq_load(mem + i), hp.r), hp.gamma);
+    if (i) h = fq_add(h, fq_mul(fq_raw_u32((uint32_t)i), r2c));
+    fq_store(init + i, h);
+    uint32_t t = ts[i];
+    if (t) h = fq_add(h, fq_mul(fq_raw_u32(t), hp.r2_boost));
+    fq_store(audit + i, h);
+  }
+}
+
+// next level of every tree: dst[i] = src[i] * src[i + h], i < h  (product_tree.rs:18-35)
+__global__ __launch_bounds__(kBlock) void tree_level_kernel(fq* __restrict__ forest, size_t stride, size_t src_off, size_t dst_off,
+                                                            size_t h) {
+  fq* t = forest + (size_t)blockIdx.y * stride;
+  const fq* src = t + src_off;
+  fq* dst = t + dst_off;
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < h; i += (size_t)gridDim.x * kBlock)
+    fq_store(dst + i, fq_mul(fq_load(src + i), fq_load(src + h + i)));
+}
+
+// the top of every tree in one workgroup: levels from `h0` outputs down to 1 (h0 <= 1024)
+constexpr int kTopBlock = 1024;
+__global__ __launch_bounds__(kTopBlock) void tree_top_kernel(fq* __restrict__ forest, size_t stride, size_t n2, size_t h0) {
+  fq* t = forest + (size_t)blockIdx.x * stride;
+  for (size_t h = h0; h >= 1; h >>= 1) {
+    // level with h entries is built from the level with 2h entries
+    const fq* src = t + (n2 - 4 * h);
+    fq* dst = t + (n2 - 2 * h);
+    if (threadIdx.x < h) fq_store(dst + threadIdx.x, fq_mul(fq_load(src + threadIdx.x), fq_load(src + h + threadIdx.x)));
+    __syncthreads();
+  }
+}
+
+// ---- batched cubic rounds ------------------------------------------------------------------
+
+// unit-stride fold with separate source and destination (the first fold of the dot-product tables
+// must not overwrite the committed polynomials)
+__device__ __forceinline__ void fold_pd2(const fq* src, fq* dst, size_t i, size_t q, const fq& r, fq& p, fq& d) {
+  fq a0 = fq_load(src + i), a1 = fq_load(src + 2 * q + i);
+  fq b0 = fq_load(src + q + i), b1 = fq_load(src + 3 * q + i);
+  p = fq_add(a0, fq_mul(r, fq_sub(a1, a0)));
+  fq hi = fq_add(b0, fq_mul(r, fq_sub(b1, b0)));
+  fq_store(dst + i, p);
+  fq_store(dst + q + i, hi);
+  d = fq_sub(hi, p);
+}
+
+template <bool BIND>
+__global__ __launch_bounds__(kBlock, kMinWaves) void prod_round_kernel(fq* __restrict__ forest, size_t stride, size_t off, size_t h,
+                                                                       const fq* __restrict__ E, size_t pairs, fq r,
+                                                                       fq* __restrict__ partials) {
+  fq* A = forest + (size_t)blockIdx.y * stride + off;
+  fq* B = A + h;
+  Acc<4> acc;
+  acc.init();
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < pairs; i += (size_t)gridDim.x * kBlock) {
+    fq u[3], p1, d1, p2, d2;
+    if (BIND) { fold_pd(A, i, pairs, r, p1, d1); fold_pd(B, i, pairs, r, p2, d2); }
+    else { load_pd(A, i, pairs, p1, d1); load_pd(B, i, pairs, p2, d2); }
+    acc.stage_bc(u, p1, d1, p2, d2);
+    acc.stage_e(u, fq_load(E + i));
+  }
+  block_reduce_store<3>(acc.e, partials + (size_t)blockIdx.y * gridDim.x * 3);
+}
+
+struct DotpPtrs { const fq* src[3]; fq* dst[3]; size_t src_stride[3]; };
+
+// MODE 0: evaluate src as is; 1: fold src -> dst, evaluate; (dst == src for the in-place rounds)
+template <bool BIND>
+__global__ __launch_bounds__(kBlock, kMinWaves) void dotp_round_kernel(const fq* __restrict__ derefs, const fq* __restrict__ vals,
+                                                                       size_t N, fq* __restrict__ scratch, bool from_scratch,
+                                                                       size_t pairs, fq r, fq* __restrict__ partials) {
+  const int k = blockIdx.y, m = k >> 1, half = k & 1;
+  const size_t hN = N / 2, q4 = N / 4;
+  const fq* src[3];
+  fq* dst[3];
+#pragma unroll
+  for (int t = 0; t < 3; t++) dst[t] = scratch + (size_t)(3 * k + t) * q4;
+  if (from_scratch) {
+#pragma unroll
+    for (int t = 0; t < 3; t++) src[t] = dst[t];
+  } else {
+    src[0] = derefs + (size_t)m * N + (size_t)half * hN;
+    src[1] = derefs + (size_t)(3 + m) * N + (size_t)half * hN;
+    src[2] = vals + (size_t)m * N + (size_t)half * hN;
+  }
+  Acc<4> acc;
+  acc.init();
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < pairs; i += (size_t)gridDim.x * kBlock) {
+    fq u[3], p1, d1, p2, d2;
+    if (BIND) { fold_pd2(src[0], dst[0], i, pairs, r, p1, d1); fold_pd2(src[1], dst[1], i, pairs, r, p2, d2); }
+    else { load_pd(src[0], i, pairs, p1, d1); load_pd(src[1], i, pairs, p2, d2); }
+    acc.stage_bc(u, p1, d1, p2, d2);
+    if (BIND) fold_pd2(src[2], dst[2], i, pairs, r, p1, d1);
+    else load_pd(src[2], i, pairs, p1, d1);
+    acc.stage_a(u, p1, d1);
+  }
+  block_reduce_store<3>(acc.e, partials + (size_t)blockIdx.y * gridDim.x * 3);
+}
+
+// per-instance finisher: out[3*(inst0 + y) + k] = sum over the instance's block partials
+__global__ __launch_bounds__(kBlock) void inst_finish_kernel(const fq* __restrict__ partials, int nblocks, int inst0,
+                                                             fq* __restrict__ out) {
+  const fq* p = partials + (size_t)blockIdx.x * nblocks * 3;
+  fq e[3] = {fq_zero(), fq_zero(), fq_zero()};
+  for (int b = threadIdx.x; b < nblocks; b += kBlock)
+#pragma unroll
+    for (int k = 0; k < 3; k++) e[k] = fq_add(e[k], fq_load(&p[(size_t)b * 3 + k]));
+  __shared__ fq sh[kBlock / 64][3];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    fq s = fq_wave_sum(e[k]);
+    if (lane == 0) sh[wave][k] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    fq s = sh[0][threadIdx.x];
+#pragma unroll
+    for (int w = 1; w < kBlock / 64; w++) s = fq_add(s, sh[w][threadIdx.x]);
+    fq_store(&out[3 * (size_t)(inst0 + blockIdx.x) + threadIdx.x], s);
+  }
+}
+
+__global__ __launch_bounds__(64) void collect_prod_kernel(const fq* __restrict__ forest, size_t stride, size_t off, size_t h,
+                                                          int ncirc, fq* __restrict__ out) {
+  int t = threadIdx.x >> 2, w = threadIdx.x & 3;  // w: A[0], A[1], B[0], B[1]
+  if (t < ncirc) {
+    const fq* A = forest + (size_t)t * stride + off;
+    fq_store(out + 4 * t + w, fq_load(A + (w >> 1) * h + (w & 1)));
+  }
+}
+
+__global__ __launch_bounds__(64) void collect_dotp_kernel(const fq* __restrict__ derefs, const fq* __restrict__ vals, size_t N,
+                                                          const fq* __restrict__ scratch, bool from_scratch, fq* __restrict__ out) {
+  int idx = threadIdx.x;
+  if (idx >= 36) return;
+  int k = idx / 6, t = (idx % 6) >> 1, e = idx & 1, m = k >> 1, half = k & 1;
+  const size_t hN = N / 2;
+  const fq* src;
+  if (from_scratch) src = scratch + (size_t)(3 * k + t) * (N / 4);
+  else src = (t == 0 ? derefs + (size_t)m * N : t == 1 ? derefs + (size_t)(3 + m) * N : vals + (size_t)m * N) + (size_t)half * hN;
+  fq_store(out + idx, fq_load(src + e));
+}
+
+__global__ __launch_bounds__(kBlock) void fetch_tops_kernel(const fq* __restrict__ forest, size_t stride, size_t cnt, int ncirc,
+                                                            fq* __restrict__ out) {
+  size_t total = cnt * (size_t)ncirc;
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (size_t)gridDim.x * kBlock) {
+    size_t t = i / cnt, j = i % cnt;
+    fq_store(out + i, fq_load(forest + t * stride + (stride - cnt) + j));
+  }
+}
+
+// blockIdx.y = slice: partial sums of <table[slice], eq>
+__global__ __launch_bounds__(kBlock) void slice_dot_kernel(const fq* __restrict__ table, size_t len, const fq* __restrict__ eq,
+                                                           fq* __restrict__ partials) {
+  const fq* t = table + (size_t)blockIdx.y * len;
+  fq acc = fq_zero();
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < len; i += (size_t)gridDim.x * kBlock) {
+    fq v = fq_load(t + i);
+    if (!fq_is_zero(v)) acc = fq_add(acc, fq_mul(v, fq_load(eq + i)));
+  }
+  fq e[3] = {acc, fq_zero(), fq_zero()};
+  block_reduce_store<3>(e, partials + (size_t)blockIdx.y * gridDim.x * 3);
+}
+
+// blockIdx.y = dot-product circuit half k: partial sums of L*R*W
+__global__ __launch_bounds__(kBlock) void triple_sum_kernel(const fq* __restrict__ derefs, const fq* __restrict__ vals, size_t N,
+                                                            fq* __restrict__ partials) {
+  const int k = blockIdx.y, m = k >> 1, half = k & 1;
+  const size_t hN = N / 2;
+  const fq* L = derefs + (size_t)m * N + (size_t)half * hN;
+  const fq* R = derefs + (size_t)(3 + m) * N + (size_t)half * hN;
+  const fq* W = vals + (size_t)m * N + (size_t)half * hN;
+  fq acc = fq_zero();
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < hN; i += (size_t)gridDim.x * kBlock) {
+    fq w = fq_load(W + i);
+    if (!fq_is_zero(w)) acc = fq_add(acc, fq_mul(fq_mul(fq_load(L + i), fq_load(R + i)), w));
+  }
+  fq e[3] = {acc, fq_zero(), fq_zero()};
+  block_reduce_store<3>(e, partials + (size_t)blockIdx.y * gridDim.x * 3);
+}
+
+// ---- launchers -------------------------------------------------------------------------------
+
+int spark_pinned(vpin_ctx* c) {
+  if (c->h_spark) return VPIN_OK;
+  (void)hipSetDevice(c->device);
+  VPIN_HIP_TRY(hipHostMalloc((void**)&c->h_spark, kSparkPinned * sizeof(fq), hipHostMallocDefault));
+  return VPIN_OK;
+}
+
+int spark_wait(vpin_ctx* c) {
+  VPIN_HIP_TRY(hipStreamSynchronize(c->stream));
+  return VPIN_OK;
+}
+
+int spark_u32_to_fq(vpin_ctx* c, const uint32_t* src, fq* dst, size_t n) {
+  ProfScope ps(c, VPIN_K_SPARK_BUILD, 36.0 * (double)n);
+  hipLaunchKernelGGL(u32_to_fq_kernel, dim3(grid_for(n)), dim3(kBlock), 0, c->stream, src, dst, n);
+  VPIN_HIP_TRY(hipGetLastError());
+  return VPIN_OK;
+}
+
+int spark_gather_derefs(vpin_ctx* c, const vpin_spark_decomm* d, const fq* mem_rx, const fq* mem_ry, fq* comb) {
+  ProfScope ps(c, VPIN_K_SPARK_BUILD, (double)d->N * (6 * 68.0 + 2 * 32.0));
+  hipLaunchKernelGGL(gather_derefs_kernel, dim3(grid_for(d->N), 8), dim3(kBlock), 0, c->stream, (const uint32_t*)d->idx, d->N,
+                     mem_rx, mem_ry, comb);
+  VPIN_HIP_TRY(hipGetLastError());
+  return VPIN_OK;
+}
+
+static int build_levels(vpin_ctx* c, SparkForest* f) {
+  const size_t n2 = 2 * f->n;
+  size_t h = f->n / 2;  // entries of the level being built
+  int l = 0;
+  while (h > (size_t)kTopBlock) {
+    hipLaunchKernelGGL(tree_level_kernel, dim3(grid_for(h), f->ncirc), dim3(kBlock), 0, c->stream, f->base, f->stride(),
+                       f->level_off(l), f->level_off(l + 1), h);
+    h >>= 1;
+    l++;
+  }
+  if (h >= 1) hipLaunchKernelGGL(tree_top_kernel, dim3(f->ncirc), dim3(kTopBlock), 0, c->stream, f->base, f->stride(), n2, h);
+  VPIN_HIP_TRY(hipGetLastError());
+  return VPIN_OK;
+}
+
+int spark_build_forests(vpin_ctx* c, const vpin_spark_decomm* d, const fq* comb_derefs, const fq* mem_rx, const fq* mem_ry,
+                        const uint8_t r_hash[32], const uint8_t r_hash_sqr[32], const uint8_t r_hash_sqr_boost[32],
+                        const uint8_t gamma[32], SparkForest* ops, SparkForest* mem) {
+  if (!c || !d || !ops || !mem || !ops->base || !mem->base) return VPIN_EINVAL;
+  if (ops->n != d->N || mem->n != d->M || ops->ncirc != 12 || mem->ncirc != 4 || d->N < 2 || d->M < 2) return VPIN_ESHAPE;
+  (void)hipSetDevice(c->device);
+  HashParams hp;
+  hp.r = load_host_fq(r_hash);
+  hp.r2 = load_host_fq(r_hash_sqr);
+  hp.r2_boost = load_host_fq(r_hash_sqr_boost);
+  hp.gamma = load_host_fq(gamma);
+  {
+    // leaves: 6 gathers of (addr, ts, val) -> 12 N leaves; 2 x (ts, mem) -> 4 M leaves; then 1 product per inner node
+    ProfScope ps(c, VPIN_K_SPARK_BUILD, (double)d->N * (6 * (8.0 + 32.0) + 12 * 32.0 + 12 * 64.0) + (double)d->M * (2 * 36.0 + 4 * 32.0 + 4 * 64.0));
+    hipLaunchKernelGGL(hash_ops_kernel, dim3(grid_for(d->N), 6), dim3(kBlock), 0, c->stream, (const uint32_t*)d->idx, comb_derefs,
+                       d->N, hp, ops->base);
+    hipLaunchKernelGGL(hash_mem_kernel, dim3(grid_for(d->M), 2), dim3(kBlock), 0, c->stream,
+                       (const uint32_t*)(d->idx + 12 * d->N), mem_rx, mem_ry, d->M, hp, mem->base);
+    VPIN_HIP_TRY(hipGetLastError());
+    int rc = build_levels(c, ops);
+    if (!rc) rc = build_levels(c, mem);
+    if (rc) return rc;
+  }
+  return VPIN_OK;
+}
+
+int spark_fetch_tops(vpin_ctx* c, const SparkForest* f, size_t cnt) {
+  if (cnt * (size_t)f->ncirc > kSparkPinned || cnt > f->stride()) return VPIN_ESHAPE;
+  int rc = spark_pinned(c);
+  if (rc) return rc;
+  hipLaunchKernelGGL(fetch_tops_kernel, dim3(grid_for(cnt * f->ncirc)), dim3(kBlock), 0, c->stream, (const fq*)f->base, f->stride(),
+                     cnt, f->ncirc, c->h_spark);
+  VPIN_HIP_TRY(hipGetLastError());
+  return spark_wait(c);
+}
+
+// block partial scratch for up to kSparkMaxInst instances x kRoundBlocks blocks
+constexpr int kRoundBlocks = 512;
+
+static int round_partials(vpin_ctx* c, fq** out) {
+  // reuse the context's partial buffer when large enough (8192*4 fq = 18 x 512 x 3 fits)
+  static_assert((size_t)kSparkMaxInst * kRoundBlocks * 3 <= 8192 * 4, "partials buffer too small");
+  if (c->partials_cap < (size_t)kSparkMaxInst * kRoundBlocks * 3) return VPIN_ENOMEM;
+  *out = c->d_partials;
+  return VPIN_OK;
+}
+
+static inline int round_grid(size_t pairs) {
+  size_t b = (pairs + kBlock - 1) / kBlock;
+  if (b < 1) b = 1;
+  if (b > (size_t)kRoundBlocks) b = kRoundBlocks;
+  return (int)b;
+}
+
+int spark_prod_round(vpin_ctx* c, const SparkForest* f, int level, size_t len, const fq* E, const uint8_t* r) {
+  if (!c || !f || !f->base || !E) return VPIN_EINVAL;
+  const size_t h = f->n >> (level + 1);
+  if (h == 0 || len > h || !is_pow2(len) || len < (r ? 4u : 2u) || f->ncirc > 12) return VPIN_ESHAPE;
+  int rc = spark_pinned(c);
+  if (rc) return rc;
+  (void)hipSetDevice(c->device);
+  fq* partials = nullptr;
+  if ((rc = round_partials(c, &partials))) return rc;
+  const size_t pairs = r ? len / 4 : len / 2;
+  const int grid = round_grid(pairs);
+  const fq rr = r ? load_host_fq(r) : fq{};
+  {
+    // algorithmic bytes of the reference formulation: 3 tables (A, B and the shared eq table counted once
+    // per circuit as the reference folds it once) read, folded halves written
+    const double bytes = (double)f->ncirc * 2 * 32.0 * (r ? (double)len * 1.5 : (double)len) + 32.0 * (r ? (double)len * 1.5 : (double)len);
+    ProfScope ps(c, VPIN_K_SPARK_ROUND, bytes);
+    if (r)
+      hipLaunchKernelGGL((prod_round_kernel<true>), dim3(grid, f->ncirc), dim3(kBlock), 0, c->stream, f->base, f->stride(),
+                         f->level_off(level), h, E, pairs, rr, partials);
+    else
+      hipLaunchKernelGGL((prod_round_kernel<false>), dim3(grid, f->ncirc), dim3(kBlock), 0, c->stream, f->base, f->stride(),
+                         f->level_off(level), h, E, pairs, rr, partials);
+  }
+  hipLaunchKernelGGL(inst_finish_kernel, dim3(f->ncirc), dim3(kBlock), 0, c->stream, (const fq*)partials, grid, 0, c->h_spark);
+  VPIN_HIP_TRY(hipGetLastError());
+  return VPIN_OK;
+}
+
+int spark_dotp_round(vpin_ctx* c, const vpin_spark_decomm* d, const fq* comb_derefs, fq* scratch, size_t len, bool first_fold,
+                     const uint8_t* r) {
+  if (!c || !d || !comb_derefs || !scratch) return VPIN_EINVAL;
+  if (len > d->N / 2 || !is_pow2(len) || len < (r ? 4u : 2u) || (first_fold && (!r || len != d->N / 2))) return VPIN_ESHAPE;
+  int rc = spark_pinned(c);
+  if (rc) return rc;
+  (void)hipSetDevice(c->device);
+  fq* partials = nullptr;
+  if ((rc = round_partials(c, &partials))) return rc;
+  partials += (size_t)12 * kRoundBlocks * 3;  // behind the product circuits' partials (same stream, but keep them apart)
+  const size_t pairs = r ? len / 4 : len / 2;
+  const int grid = round_grid(pairs);
+  const fq rr = r ? load_host_fq(r) : fq{};
+  const fq* vals = d->comb_ops->d + 12 * d->N;
+  const bool from_scratch = r && !first_fold;
+  {
+    const double bytes = 6 * 3 * 32.0 * (r ? (double)len * 1.5 : (double)len);
+    ProfScope ps(c, VPIN_K_SPARK_ROUND, bytes);
+    if (r)
+      hipLaunchKernelGGL((dotp_round_kernel<true>), dim3(grid, 6), dim3(kBlock), 0, c->stream, comb_derefs, vals, d->N, scratch,
+                         from_scratch, pairs, rr, partials);
+    else
+      hipLaunchKernelGGL((dotp_round_kernel<false>), dim3(grid, 6), dim3(kBlock), 0, c->stream, comb_derefs, vals, d->N, scratch,
+                         false, pairs, rr, partials);
+  }
+  hipLaunchKernelGGL(inst_finish_kernel, dim3(6), dim3(kBlock), 0, c->stream, (const fq*)partials, grid, 12, c->h_spark);
+  VPIN_HIP_TRY(hipGetLastError());
+  return VPIN_OK;
+}
+
+int spark_collect_prod(vpin_ctx* c, const SparkForest* f, int level) {
+  if (!c || !f || !f->base || f->ncirc > 12) return VPIN_EINVAL;
+  int rc = spark_pinned(c);
+  if (rc) return rc;
+  const size_t h = f->n >> (level + 1);
+  if (h < 2) return VPIN_ESHAPE;  // a 1-entry half has no second element; the host handles those layers
+  hipLaunchKernelGGL(collect_prod_kernel, dim3(1), dim3(64), 0, c->stream, (const fq*)f->base, f->stride(), f->level_off(level), h,
+                     f->ncirc, c->h_spark);
+  VPIN_HIP_TRY(hipGetLastError());
+  return spark_wait(c);
+}
+
+int spark_collect_dotp(vpin_ctx* c, const vpin_spark_decomm* d, const fq* comb_derefs, const fq* scratch, bool folded) {
+  if (!c || !d || !comb_derefs || !scratch) return VPIN_EINVAL;
+  int rc = spark_pinned(c);
+  if (rc) return rc;
+  hipLaunchKernelGGL(collect_dotp_kernel, dim3(1), dim3(64), 0, c->stream, comb_derefs, (const fq*)(d->comb_ops->d + 12 * d->N), d->N,
+                     scratch, folded, c->h_spark + 64);
+  VPIN_HIP_TRY(hipGetLastError());
+  return spark_wait(c);
+}
+
+int spark_triple_sums(vpin_ctx* c, const vpin_spark_decomm* d, const fq* comb_derefs) {
+  if (!c || !d || !comb_derefs) return VPIN_EINVAL;
+  int rc = spark_pinned(c);
+  if (rc) return rc;
+  (void)hipSetDevice(c->device);
+  fq* partials = nullptr;
+  if ((rc = round_partials(c, &partials))) return rc;
+  const int grid = round_grid(d->N / 2);
+  {
+    ProfScope ps(c, VPIN_K_SPARK_BUILD, 9.0 * 32.0 * (double)d->N);
+    hipLaunchKernelGGL(triple_sum_kernel, dim3(grid, 6), dim3(kBlock), 0, c->stream, comb_derefs,
+                       (const fq*)(d->comb_ops->d + 12 * d->N), d->N, partials);
+  }
+  hipLaunchKernelGGL(inst_finish_kernel, dim3(6), dim3(kBlock), 0, c->stream, (const fq*)partials, grid, 0, c->h_spark);
+  VPIN_HIP_TRY(hipGetLastError());
+  return spark_wait(c);
+}
+
+int spark_slice_evals(vpin_ctx* c, const fq* table, size_t len, int nslices, const fq* eq) {
+  if (!c || !table || !eq || nslices < 1 || nslices > kSparkMaxInst) return VPIN_EINVAL;
+  int rc = spark_pinned(c);
+  if (rc) return rc;
+  (void)hipSetDevice(c->device);
+  fq* partials = nullptr;
+  if ((rc = round_partials(c, &partials))) return rc;
+  const int grid = round_grid(len);
+  {
+    ProfScope ps(c, VPIN_K_SPARK_BUILD, (double)nslices * 32.0 * (double)len + 32.0 * (double)len);
+    hipLaunchKernelGGL(slice_dot_kernel, dim3(grid, nslices), dim3(kBlock), 0, c->stream, table, len, eq, partials);
+  }
+  hipLaunchKernelGGL(inst_finish_kernel, dim3(nslices), dim3(kBlock), 0, c->stream, (const fq*)partials, grid, 0, c->h_spark);
+  VPIN_HIP_TRY(hipGetLastError());
+  return spark_wait(c);
+}
+
+}  // namespace vpin

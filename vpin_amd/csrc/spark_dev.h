@@ -1,0 +1,89 @@
+// spark_dev.h -- device-side state and launchers of the SPARK half (spark.hip), driven by spark.cpp
+#pragma once
+#include "ctx.h"
+
+// ComputationDecommitment (lib.rs:70-73): MultiSparseMatPolynomialAsDense (sparse_mlpoly.rs:285-292)
+// resident in HBM.  Index / timestamp vectors stay as u32 next to their field-element images
+// inside comb_ops / comb_mem.
+struct vpin_spark_decomm {
+  size_t num_cons = 0, num_vars = 0, num_inputs = 0;
+  size_t nx = 0, ny = 0, N = 0, M = 0;
+  // u32 [row A,B,C | row_read_ts A,B,C | col A,B,C | col_read_ts A,B,C] (12 x N, the order of
+  // comb_ops), then row_audit_ts (M), col_audit_ts (M)
+  uint32_t* idx = nullptr;
+  vpin_table* comb_ops = nullptr;  // 16N: slices as idx (0..11), val A,B,C (12..14), zero (15)
+  vpin_table* comb_mem = nullptr;  // 2M: row_audit_ts | col_audit_ts
+};
+
+namespace vpin {
+
+constexpr size_t kSparkPinned = 8192;  // fq elements of pinned staging (ctx->h_spark)
+constexpr int kSparkMaxInst = 18;      // 12 product circuits + 6 dot-product circuits
+constexpr size_t kSparkHostTop = 32;   // tree levels of at most this many entries are proven on the host
+
+int spark_pinned(vpin_ctx* c);  // allocate ctx->h_spark on first use
+
+// dst[i] = Scalar::from(src[i]) (Montgomery form)
+int spark_u32_to_fq(vpin_ctx* c, const uint32_t* src, fq* dst, size_t n);
+
+// Derefs (sparse_mlpoly.rs:267-283,525-531): comb[m*N+i] = mem_rx[row_m[i]], comb[(3+m)*N+i] =
+// mem_ry[col_m[i]], comb[6N..8N) = 0
+int spark_gather_derefs(vpin_ctx* c, const vpin_spark_decomm* d, const fq* mem_rx, const fq* mem_ry, fq* comb);
+
+// Product-circuit forest: `ncirc` trees of `n` leaves; tree t lives at base + t*2n, level l (n>>l
+// entries) at offset 2n - (2n>>l) inside it.  ProductCircuit.left_vec[l] / right_vec[l] are the two
+// halves of level l (product_tree.rs:18-56).
+struct SparkForest {
+  fq* base = nullptr;
+  size_t n = 0;
+  int ncirc = 0;
+  size_t stride() const { return 2 * n; }
+  size_t level_off(int l) const { return 2 * n - ((2 * n) >> l); }
+};
+
+// Layers::build_hash_layer (sparse_mlpoly.rs:547-622) for both sides, written as level 0 of the
+// forests: ops = [row read A,B,C | row write A,B,C | col read A,B,C | col write A,B,C] (n = N),
+// mem = [row init, row audit, col init, col audit] (n = M); then every upper level.
+// r_hash_sqr = r_hash^2; r_hash_sqr_boost = r_hash^2 * R (its Montgomery image taken to Montgomery form
+// once more), which lets the kernel multiply RAW u32 timestamps straight into Montgomery form.
+int spark_build_forests(vpin_ctx* c, const vpin_spark_decomm* d, const fq* comb_derefs, const fq* mem_rx, const fq* mem_ry,
+                        const uint8_t r_hash[32], const uint8_t r_hash_sqr[32], const uint8_t r_hash_sqr_boost[32],
+                        const uint8_t gamma[32], SparkForest* ops, SparkForest* mem);
+
+// the last `cnt` entries of every tree (the levels of <= cnt/2 entries), to ctx->h_spark
+// [tree][cnt]; synchronises
+int spark_fetch_tops(vpin_ctx* c, const SparkForest* f, size_t cnt);
+
+// One round of prove_cubic_batched (sumcheck.rs:273-302) for the `ncirc` product circuits of forest
+// level `level`, eq-factored: returns per circuit the three sums  sum_i E[i] * (A_x B_x)[i], x = 0,2,3
+// with A/B = left/right halves (live length len) and E the suffix table of this round (len/2 or,
+// when r != nullptr and the tables are first folded with r, len/4 entries).  Results land in
+// ctx->h_spark[3*t + k] after spark_wait.  `len` is the live length BEFORE this call.
+int spark_prod_round(vpin_ctx* c, const SparkForest* f, int level, size_t len, const fq* E, const uint8_t* r);
+
+// Same for the 6 DotProductCircuit halves of layer 0 (comb = A*B*C, three foldable tables each,
+// sumcheck.rs:304-330).  src tables: left = comb_derefs row slices, right = col slices, weight =
+// comb_ops val slices, each cut in two halves of N/2 (sparse_mlpoly.rs:1103-1125).  The first fold
+// writes into `scratch` (18 x N/4 entries) so the committed polynomials stay intact.
+// round 0: r == nullptr, len = N/2.  Results at ctx->h_spark[3*(12+k) + x].
+int spark_dotp_round(vpin_ctx* c, const vpin_spark_decomm* d, const fq* comb_derefs, fq* scratch, size_t len, bool first_fold,
+                     const uint8_t* r);
+
+// after the last round: the two live entries of every table, for the host to bind with the final
+// challenge: h_spark[4*t + {0,1,2,3}] = A[0], A[1], B[0], B[1] per product circuit; synchronises
+int spark_collect_prod(vpin_ctx* c, const SparkForest* f, int level);
+// h_spark[64 + 6*k + {0..5}] = L[0], L[1], R[0], R[1], W[0], W[1] per dot-product circuit (from scratch, or
+// from the source tables when N/2 == 2 and no fold has happened); synchronises
+int spark_collect_dotp(vpin_ctx* c, const vpin_spark_decomm* d, const fq* comb_derefs, const fq* scratch, bool folded);
+
+// DotProductCircuit::evaluate (product_tree.rs:87-91) of the six halves: h_spark[3*k] = sum_i L[i]*R[i]*W[i]
+// over the N/2 entries of half k; synchronises
+int spark_triple_sums(vpin_ctx* c, const vpin_spark_decomm* d, const fq* comb_derefs);
+
+int spark_wait(vpin_ctx* c);  // stream sync
+
+// out[s] = sum_i table[s*len + i] * eq[i], s < nslices (DensePolynomial::evaluate of every slice at
+// the point whose eq table is `eq`); results in ctx->h_spark[3*s]; synchronises
+int spark_slice_evals(vpin_ctx* c, const fq* table, size_t len, int nslices, const fq* eq);
+
+}  // namespace vpin

@@ -55,6 +55,10 @@ def parse():
     ap.add_argument("--serial", action="store_true", help="one instance at a time, one host thread")
     ap.add_argument("--host-buffers", action="store_true",
                     help="time vpin_sat_prove (instance + witness start in host memory: PCIe-inclusive; never the headline)")
+    ap.add_argument("--snark", action="store_true",
+                    help="time the whole SNARK (sat proof + inst_evals + SPARK R1CSEvalProof, my_lib_prove in full) instead of "
+                         "the sat proof; SNARK::encode runs once per instance before the timed region and is reported beside it")
+    ap.add_argument("--no-prof", action="store_true", help="no HIP-event bracketing of kernels (no roofline object)")
     ap.add_argument("--pmc-traffic", type=float, default=None,
                     help="HBM bytes per launch of the roofline kernel from a separate rocprofv3 --pmc pass")
     return ap.parse_args()
@@ -93,6 +97,10 @@ def main():
     mults = sorted([w for w in work if w[1] == "mult"], key=lambda w: -w[2].num_cons_unpadded)
     adds = [w for w in work if w[1] == "add"]
     lanes = [mults + adds] if (args.serial or not mults) else [mults, adds]
+    if args.snark and not args.serial and len(mults) > 2:
+        # whole SNARKs are long enough to be worth three host threads / streams: the largest instance
+        # alone, the other point-mult instances, the point-add instances; no gating (throughput run)
+        lanes = [mults[:1], mults[1:], adds]
     ctxs = [vpin_amd.Context(local_rank) for _ in lanes]
 
     def barrier():
@@ -102,7 +110,7 @@ def main():
 
     # instance + the three assignments resident in HBM before the timed region (the PCIe-inclusive
     # variant is vpin_sat_prove / --host-buffers; its rate is noted in DESIGN.md)
-    resident, dicts = {}, {}
+    resident, dicts, decomms, encode_ms, comm_bytes = {}, {}, {}, {}, {}
     t0 = time.perf_counter()
     for li, lane in enumerate(lanes):
         for name, _, inst in lane:
@@ -113,20 +121,35 @@ def main():
             else:
                 resident[name] = (cx.r1cs_upload(d), cx.upload(d["vars_para"]), cx.upload(d["vars_input"]),
                                   cx.upload(d["vars"]), d["inputs"])
+            if args.snark:
+                # SNARK::encode: once per circuit, outside the timed region (the computation commitment
+                # does not depend on the witness); first call also builds the generator table
+                cx.spark_encode(d)[0].free()
+                te = time.perf_counter()
+                decomms[name], comm = cx.spark_encode(d)
+                encode_ms[name] = round((time.perf_counter() - te) * 1e3, 3)
+                comm_bytes[name] = len(comm)
             inst.free()
     upload_s = time.perf_counter() - t0
     lane_names = [[w[0] for w in lane] for lane in lanes]
 
-    last_spans = {}
+    last_spans, proof_bytes = {}, {}
 
     def prove(li, name):
         cx = ctxs[li]
+        if args.snark:
+            di, tp, ti, tv, inp = resident[name]
+            r = cx.snark_prove_resident(di, decomms[name], tp, ti, tv, inp, SEED_C, SEED_P)
+            last_spans[name] = dict(cx.sat_timings(), **{"spark_" + k: v for k, v in cx.spark_timings().items() if k != "_"})
+            proof_bytes[name] = len(r["proof"])
+            return len(r["proof"])
         if args.host_buffers:
             r = cx.sat_prove(dicts[name], SEED_C, SEED_P)
         else:
             di, tp, ti, tv, inp = resident[name]
             r = cx.sat_prove_resident(di, tp, ti, tv, inp, SEED_C, SEED_P)
         last_spans[name] = cx.sat_timings()  # thread-local in the library: read on the proving thread
+        proof_bytes[name] = len(r["proof"])
         return len(r["proof"])
 
     def run_lane(li, gate):
@@ -138,6 +161,14 @@ def main():
     def step():
         if len(lanes) == 1:
             run_lane(0, None)
+            return
+        if len(lanes) == 3:
+            ts = [threading.Thread(target=run_lane, args=(li, None)) for li in (1, 2)]
+            for t in ts:
+                t.start()
+            run_lane(0, None)
+            for t in ts:
+                t.join()
             return
         gate = threading.Event()
         t = threading.Thread(target=run_lane, args=(1, gate))
@@ -156,7 +187,7 @@ def main():
 
     for cx in ctxs:
         cx.prof_reset()
-        cx.prof_enable(True)
+        cx.prof_enable(not args.no_prof)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -177,7 +208,8 @@ def main():
     value = total_cons_step * args.steps * world / elapsed
 
     line = {
-        "metric": "R1CS constraints/sec, Spartan sat proof (vPIN point-mult + point-add instances)",
+        "metric": ("R1CS constraints/sec, whole Spartan SNARK (sat proof + SPARK evaluation proof; vPIN point-mult + point-add instances)"
+                   if args.snark else "R1CS constraints/sec, Spartan sat proof (vPIN point-mult + point-add instances)"),
         "value": value,
         "unit": "constraints/s",
         "n_gpus": world,
@@ -194,7 +226,9 @@ def main():
                          else f"vPIN trace '{trace}': sat proofs of its point-mult and point-add instances"),
             "instances": cons,
             "constraints_unpadded_per_step": total_cons_step,
-            "scope": "R1CSProof (commitments + both ZK sum-checks + evaluation proof); SPARK encode/eval proof not included",
+            "scope": ("my_lib_prove in full: R1CSProof + inst_evals + R1CSEvalProof (SPARK); SNARK::encode once per circuit "
+                      "outside the timed region (encode_ms)" if args.snark else
+                      "R1CSProof (commitments + both ZK sum-checks + evaluation proof); SPARK encode/eval proof not included"),
             "parallelism": f"one trace per rank x {world} rank(s), no collective; per rank "
                            + ("instances proven serially" if len(lanes) == 1 else
                               "mult instances serially, add instances on a second stream after the largest"),
@@ -224,6 +258,10 @@ def main():
                        for name, v in stats.items()}
     line["spans_ms_last_step"] = {n: {kk: round(vv * 1e3, 3) for kk, vv in sp.items()} for n, sp in last_spans.items()}
     line["setup_s"] = {"gadgets_and_witness": round(setup_s, 3), "upload_and_csr": round(upload_s, 3)}
+    line["proof_bytes"] = proof_bytes
+    if args.snark:
+        line["encode_ms"] = encode_ms
+        line["comm_bytes"] = comm_bytes
 
     # ---- CPU baseline: the oracle on a bounded sample, rank 0, N=1 only ----
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -235,12 +273,17 @@ def main():
         sample_cons = (sm.num_cons_unpadded if sm else 0) + sa.num_cons_unpadded
         t0 = time.perf_counter()
         tm = {}
+        cpu_prove = (lambda dd: O.snark_prove(dd, SEED_C, SEED_P, threads=threads)) if args.snark else \
+                    (lambda dd: O.sat_prove(dd, SEED_C, SEED_P, threads=threads))
+        enc_s = 0.0
         if sm:
-            r1 = O.sat_prove(sm.as_dict(), SEED_C, SEED_P, threads=threads)
-            tm = O.sat_timings()
+            r1 = cpu_prove(sm.as_dict())
+            tm = dict(O.sat_timings(), **({"spark_" + k: v for k, v in O.spark_timings().items()} if args.snark else {}))
+            enc_s += O.spark_timings()["encode"] if args.snark else 0.0
             assert len(r1["proof"])
-        r2 = O.sat_prove(sa.as_dict(), SEED_C, SEED_P, threads=threads)
-        cpu_s = time.perf_counter() - t0
+        r2 = cpu_prove(sa.as_dict())
+        enc_s += O.spark_timings()["encode"] if args.snark else 0.0
+        cpu_s = time.perf_counter() - t0 - enc_s  # SNARK::encode excluded on both sides
         assert len(r2["proof"])
         line["cpu_baseline"] = {
             "value": sample_cons / cpu_s, "unit": "constraints/s", "cores": threads, "kind": "port",

@@ -114,6 +114,8 @@ typedef struct vpin_gens vpin_gens;
 int vpin_gens_create(vpin_ctx* ctx, const uint8_t* gens_xyzt, size_t nb, vpin_gens** out);
 void vpin_gens_free(vpin_ctx* ctx, vpin_gens* g);
 size_t vpin_gens_count(const vpin_gens* g);
+/* bytes per window-table entry (affine Niels point, possibly padded to a cache line) */
+size_t vpin_gens_entry_bytes(void);
 /* DensePolynomial::commit_inner (Spartan/src/dense_mlpoly.rs:160-175): Z viewed as L rows
  * of R = len/L scalars; out[i] = compress( sum_j Z[iR+j]*g[j] + blinds[i]*g[blind_base] ).
  * blinds = L x 32 B Montgomery scalars on the host. */

@@ -54,7 +54,7 @@ def build(force=False, verbose=False):
         if not force and os.path.exists(obj) and os.path.getmtime(obj) >= newest_dep:
             continue
         cmd = [hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-fopenmp", "-c", src, "-o", obj,
-               "-I", os.path.join(os.path.dirname(HERE), "include")]
+               "-I", os.path.join(os.path.dirname(HERE), "include")] + os.environ.get("VPIN_HIPCC_FLAGS", "").split()
         if verbose:
             print(" ".join(cmd))
         procs.append((src, subprocess.Popen(cmd)))

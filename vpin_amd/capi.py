@@ -100,6 +100,8 @@ def lib():
     L.vpin_gens_free.argtypes = [vp, vp]
     L.vpin_gens_free.restype = None
     L.vpin_gens_count.argtypes = [vp]
+    L.vpin_gens_entry_bytes.restype = C.c_size_t
+    L.vpin_gens_entry_bytes.argtypes = []
     L.vpin_gens_count.restype = C.c_size_t
     L.vpin_hyrax_commit.argtypes = [vp, vp, vp, vp, C.c_size_t, C.c_size_t, vp]
     L.vpin_hyrax_commit_pair.argtypes = [vp, vp, vp, vp, vp, vp, C.c_size_t, C.c_size_t, vp, vp, vp]

@@ -45,56 +45,41 @@ __device__ __forceinline__ void fp_store(fp* __restrict__ p, const fp& a) {
   q[1] = make_uint4(a.v[4], a.v[5], a.v[6], a.v[7]);
 }
 
+// Carry chains are written with clang's add/sub-with-carry builtins: they lower to
+// v_add_co_u32 / v_addc_co_u32 links (one VALU instruction per limb, the compiler fills the
+// VCC wait states), where the earlier 64-bit-per-limb formulation cost ~100 instructions per add.
+
 // fold a small carry c (value c * 2^256 = 38c) back in; result again in [0, 2^256)
 __device__ __forceinline__ fp fp_fold(fp t, uint32_t c) {
-  // two rounds: after the first the carry-out can only be 0/1 and then the low limb is tiny
+  unsigned cy = 0;
+  t.v[0] = __builtin_addc(t.v[0], c * 38u, 0u, &cy);
 #pragma unroll
-  for (int round = 0; round < 2; round++) {
-    uint64_t k = (uint64_t)c * 38u;
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-      k += t.v[i];
-      t.v[i] = (uint32_t)k;
-      k >>= 32;
-    }
-    c = (uint32_t)k;
-  }
+  for (int i = 1; i < 8; i++) t.v[i] = __builtin_addc(t.v[i], 0u, cy, &cy);
+  // a second wrap leaves a value below 38*c in limb 0 and zeros above it: no chain needed
+  t.v[0] += cy ? 38u : 0u;
   return t;
 }
 
 __device__ __forceinline__ fp fp_add(const fp& a, const fp& b) {
   fp t;
-  uint64_t k = 0;
+  unsigned cy = 0;
 #pragma unroll
-  for (int i = 0; i < 8; i++) {
-    k += (uint64_t)a.v[i] + b.v[i];
-    t.v[i] = (uint32_t)k;
-    k >>= 32;
-  }
-  return fp_fold(t, (uint32_t)k);
+  for (int i = 0; i < 8; i++) t.v[i] = __builtin_addc(a.v[i], b.v[i], cy, &cy);
+  return fp_fold(t, cy);
 }
 
 __device__ __forceinline__ fp fp_sub(const fp& a, const fp& b) {
-  // a - b + 2^256*borrow, and -2^256 = -38: subtract 38 per borrow (twice at most)
+  // a - b + 2^256*borrow, and -2^256 = -38: subtract 38 per borrow (twice at most; after a second
+  // wrap the limbs above limb 0 are all ones and limb 0 >= 2^32 - 38, so it ends there)
   fp t;
-  int64_t k = 0;
+  unsigned bw = 0;
 #pragma unroll
-  for (int i = 0; i < 8; i++) {
-    k += (int64_t)a.v[i] - (int64_t)b.v[i];
-    t.v[i] = (uint32_t)k;
-    k >>= 32;
-  }
+  for (int i = 0; i < 8; i++) t.v[i] = __builtin_subc(a.v[i], b.v[i], bw, &bw);
+  unsigned b2 = 0;
+  t.v[0] = __builtin_subc(t.v[0], bw ? 38u : 0u, 0u, &b2);
 #pragma unroll
-  for (int round = 0; round < 2; round++) {
-    int64_t c = k * 38;  // k is 0 or -1
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-      c += (int64_t)t.v[i];
-      t.v[i] = (uint32_t)c;
-      c >>= 32;
-    }
-    k = c;
-  }
+  for (int i = 1; i < 8; i++) t.v[i] = __builtin_subc(t.v[i], 0u, b2, &b2);
+  t.v[0] -= b2 ? 38u : 0u;
   return t;
 }
 

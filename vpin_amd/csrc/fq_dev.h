@@ -72,55 +72,41 @@ __device__ __forceinline__ bool fq_is_zero(const fq& a) {
   return o == 0;
 }
 
+// Carry chains use clang's add/sub-with-carry builtins: they lower to v_add_co_u32 / v_addc_co_u32
+// links (one VALU instruction per limb), a quarter of what the 64-bit-per-limb formulation cost.
+
 // r = (t >= q) ? t - q : t      (t < 2q)
 __device__ __forceinline__ fq fq_cond_sub_q(const fq& t) {
   fq d;
-  int64_t c = 0;
+  unsigned bw = 0;
 #pragma unroll
-  for (int i = 0; i < 8; i++) {
-    c += (int64_t)t.v[i] - (int64_t)fq_modulus_limb(i);
-    d.v[i] = (uint32_t)c;
-    c >>= 32;  // arithmetic shift: borrow propagates as -1
-  }
-  bool ge = (c == 0);
+  for (int i = 0; i < 8; i++) d.v[i] = __builtin_subc(t.v[i], fq_modulus_limb(i), bw, &bw);
   fq r;
 #pragma unroll
-  for (int i = 0; i < 8; i++) r.v[i] = ge ? d.v[i] : t.v[i];
+  for (int i = 0; i < 8; i++) r.v[i] = bw ? t.v[i] : d.v[i];
   return r;
 }
 
 // ristretto255.rs:746-757
 __device__ __forceinline__ fq fq_add(const fq& a, const fq& b) {
   fq t;
-  uint64_t c = 0;
+  unsigned cy = 0;
 #pragma unroll
-  for (int i = 0; i < 8; i++) {
-    c += (uint64_t)a.v[i] + b.v[i];
-    t.v[i] = (uint32_t)c;
-    c >>= 32;
-  }
+  for (int i = 0; i < 8; i++) t.v[i] = __builtin_addc(a.v[i], b.v[i], cy, &cy);
   return fq_cond_sub_q(t);  // a+b < 2q < 2^254: no carry out of limb 7
 }
 
 // ristretto255.rs:729-743
 __device__ __forceinline__ fq fq_sub(const fq& a, const fq& b) {
   fq d;
-  int64_t c = 0;
+  unsigned bw = 0;
 #pragma unroll
-  for (int i = 0; i < 8; i++) {
-    c += (int64_t)a.v[i] - (int64_t)b.v[i];
-    d.v[i] = (uint32_t)c;
-    c >>= 32;
-  }
-  uint32_t mask = (uint32_t)c;  // 0xffffffff on underflow
-  uint64_t k = 0;
+  for (int i = 0; i < 8; i++) d.v[i] = __builtin_subc(a.v[i], b.v[i], bw, &bw);
+  // add q back on underflow
   fq r;
+  unsigned cy = 0;
 #pragma unroll
-  for (int i = 0; i < 8; i++) {
-    k += (uint64_t)d.v[i] + (fq_modulus_limb(i) & mask);
-    r.v[i] = (uint32_t)k;
-    k >>= 32;
-  }
+  for (int i = 0; i < 8; i++) r.v[i] = __builtin_addc(d.v[i], bw ? fq_modulus_limb(i) : 0u, cy, &cy);
   return r;
 }
 
@@ -177,9 +163,11 @@ __device__ __forceinline__ void mac2(acc96& c, uint32_t a0, uint32_t b0, uint32_
 
 // c += x (64-bit) with carry into hi
 __device__ __forceinline__ void acc_add64(acc96& c, uint64_t x) {
-  uint64_t t = c.lo + x;
-  c.hi += (t < x) ? 1u : 0u;
-  c.lo = t;
+  unsigned cy = 0;
+  uint32_t l = __builtin_addc((uint32_t)c.lo, (uint32_t)x, 0u, &cy);
+  uint32_t h = __builtin_addc((uint32_t)(c.lo >> 32), (uint32_t)(x >> 32), cy, &cy);
+  c.hi = __builtin_addc(c.hi, 0u, cy, &cy);
+  c.lo = (uint64_t)l | ((uint64_t)h << 32);
 }
 
 // next column: drop the low 32 bits

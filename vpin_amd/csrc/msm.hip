@@ -21,8 +21,16 @@
 #include "ctx.h"
 #include "fp_dev.h"
 
+#ifndef VPIN_NIELS_SLOT
+#define VPIN_NIELS_SLOT 96  // bytes per table entry: 96 (packed) or 128 (one entry per 128-byte line)
+#endif
+namespace vpin {
+struct alignas(VPIN_NIELS_SLOT == 128 ? 128 : 32) niels_slot : ge_niels {};
+static_assert(sizeof(niels_slot) == VPIN_NIELS_SLOT, "table entry size");
+}  // namespace vpin
+
 struct vpin_gens {
-  vpin::ge_niels* table = nullptr;  // [W][nb][E]
+  vpin::niels_slot* table = nullptr;  // [W][nb][E]
   size_t nb = 0;                    // number of bases in the stream
   int c = 12, W = 22, E = 2048;     // window bits, windows, entries per window (= 2^(c-1))
 };
@@ -30,7 +38,7 @@ struct vpin_gens {
 namespace vpin {
 
 struct TableView {
-  const ge_niels* t;
+  const niels_slot* t;
   size_t nb;
   int c, W, E;
 };
@@ -51,7 +59,7 @@ __global__ __launch_bounds__(64) void gens_shift_kernel(const fp* __restrict__ x
   }
 }
 
-__device__ __forceinline__ ge_niels niels_load(const ge_niels* o) {
+__device__ __forceinline__ ge_niels niels_load(const niels_slot* o) {
   ge_niels e;
   e.ypx = fp_load(&o->ypx); e.ymx = fp_load(&o->ymx); e.xy2d = fp_load(&o->xy2d);
   return e;
@@ -61,7 +69,7 @@ __device__ __forceinline__ ge_niels niels_load(const ge_niels* o) {
 // one inversion per thread (Montgomery's trick): forward pass stores X,Y,Z in the entry slots and
 // the running product of the Z's in `prefix`; the backward pass peels the inverses off.
 __global__ __launch_bounds__(64) void gens_table_kernel(const ge_ext* __restrict__ shifts, size_t nb, int W, int E,
-                                                        ge_niels* __restrict__ table, fp* __restrict__ prefix) {
+                                                        niels_slot* __restrict__ table, fp* __restrict__ prefix) {
   size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= nb * (size_t)W) return;
   size_t j = idx / W;
@@ -70,7 +78,7 @@ __global__ __launch_bounds__(64) void gens_table_kernel(const ge_ext* __restrict
   ge_ext p;
   p.X = fp_load(&s->X); p.Y = fp_load(&s->Y); p.Z = fp_load(&s->Z); p.T = fp_load(&s->T);
   ge_cached pc = ge_to_cached(p);
-  ge_niels* out = table + ((size_t)w * nb + j) * E;
+  niels_slot* out = table + ((size_t)w * nb + j) * E;
   fp* pre = prefix + ((size_t)w * nb + j) * E;
   ge_ext q = p;
   fp run = fp_one();
@@ -359,7 +367,7 @@ int vpin_gens_create(vpin_ctx* c, const uint8_t* gens_xyzt, size_t nb, vpin_gens
   for (g->c = 12; g->c > 6; g->c--) {
     g->W = (254 + g->c - 1) / g->c;
     g->E = 1 << (g->c - 1);
-    if (nb * (size_t)g->W * (size_t)g->E * sizeof(ge_niels) <= ((size_t)24 << 30)) break;
+    if (nb * (size_t)g->W * (size_t)g->E * sizeof(niels_slot) <= ((size_t)24 << 30)) break;
   }
   const size_t entries = nb * (size_t)g->W * g->E;
   DevBuf raw(c);
@@ -367,7 +375,7 @@ int vpin_gens_create(vpin_ctx* c, const uint8_t* gens_xyzt, size_t nb, vpin_gens
   fp* prefix = nullptr;
   if (raw.alloc(nb * 128) != VPIN_OK || hipMalloc((void**)&shifts, nb * g->W * sizeof(ge_ext)) != hipSuccess ||
       hipMalloc((void**)&prefix, entries * sizeof(fp)) != hipSuccess ||
-      hipMalloc((void**)&g->table, entries * sizeof(ge_niels)) != hipSuccess) {
+      hipMalloc((void**)&g->table, entries * sizeof(niels_slot)) != hipSuccess) {
     if (shifts) (void)hipFree(shifts);
     if (prefix) (void)hipFree(prefix);
     if (g->table) (void)hipFree(g->table);
@@ -403,6 +411,7 @@ void vpin_gens_free(vpin_ctx* c, vpin_gens* g) {
 }
 
 size_t vpin_gens_count(const vpin_gens* g) { return g ? g->nb : 0; }
+size_t vpin_gens_entry_bytes(void) { return sizeof(niels_slot); }
 
 // shared implementation: rows of scalars -> points (kept on device), then optional outputs
 static inline TableView view(const vpin_gens* g) { return TableView{g->table, g->nb, g->c, g->W, g->E}; }

@@ -1,23 +1,30 @@
 #!/usr/bin/env python3
-"""bench.py -- Spartan sat-proof throughput of the MI355X hot path on vPIN's LeNet trace.
+"""bench.py -- Spartan proof throughput of the MI355X path on vPIN's LeNet trace.
 
 Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N>1 it is launched by
 torch.distributed.run with one rank per GPU.  Prints ONE JSON line on rank 0.
 
-Workload (BASELINE.json quotes its metric on the LeNet trace, and the satisfiability proofs of
-that trace fit one GPU): a "step" is one pass of the hot path over one LeNet inference trace =
-the 12 R1CS satisfiability proofs vPIN produces for it (vPIN_proof_generation/src/main.rs:14-46
-per layer: 7 point-addition instances, 5 point-multiplication instances; L5's has 6000
-point-mults = 20,784,000 constraints, 2^25 padded).  26.2 M unpadded constraints per step.  The
-witness is synthetic (seeded SplitMix64 points on the curve E2, gadget-generated tables --
-SURVEY.md 8(d)).  `--trace A` (BASELINE.json configs[1]; or 3_32, 7_256, E, L1..L7) times a
-single-network trace instead (2 instances).
+Workload (BASELINE.json quotes its metric on the LeNet trace, and the whole trace fits one GPU): a
+"step" is one pass over one LeNet inference trace = the 12 proofs vPIN produces for it
+(vPIN_proof_generation/src/main.rs:14-46 per layer: 7 point-addition instances, 5
+point-multiplication instances; L5's has 6000 point-mults = 20,784,000 constraints, 2^25 padded).
+26.2 M unpadded constraints per step.  The witness is synthetic (seeded SplitMix64 points on the
+curve E2, gadget-generated tables -- SURVEY.md 8(d)).  `--trace A` (BASELINE.json configs[1]; or
+3_32, 7_256, E, L1..L7) times a single-network trace instead (2 instances).
+
+What is proven per instance (default): the WHOLE SNARK the reference's my_lib_prove produces
+(commit_test.rs:59-133): R1CSProof (two commitments, both ZK sum-checks, evaluation proof) +
+inst_evals + R1CSEvalProof (SPARK: derefs commitment, 16 product circuits with batched cubic
+sum-checks, hash-layer evaluation proofs).  SNARK::encode (the computation commitment, a function
+of the circuit only) runs once per instance before the timed region; its time is reported as
+encode_ms.  `--sat-only` times the R1CS satisfiability proof alone.
 value = unpadded R1CS constraints proven per second, whole job (all ranks).  Multi-GPU: every
 rank proves its own trace -- independent instances, no data-path collective -> weak scaling.
 
-Schedule per rank: the point-mult instances are proven one after the other (largest first); the
-small, latency-bound point-add instances run on a second host thread / HIP stream once the
-largest instance is done, so that instance's kernels are timed undisturbed.
+Schedule per rank: three host threads / HIP streams -- the largest instance; the other
+point-mult instances; the point-add instances.  The second and third start when the largest
+instance's sat part is done, so its sum-check kernels are timed undisturbed (--sat-only: two
+lanes, the add lane starts after the largest instance).  `--serial`: one instance at a time.
 
 Beside the headline value the line carries
   roofline     : the fused phase-1 sum-check round kernel (sc_cubic3_kernel<true>), algorithmic bytes /
@@ -55,9 +62,10 @@ def parse():
     ap.add_argument("--serial", action="store_true", help="one instance at a time, one host thread")
     ap.add_argument("--host-buffers", action="store_true",
                     help="time vpin_sat_prove (instance + witness start in host memory: PCIe-inclusive; never the headline)")
-    ap.add_argument("--snark", action="store_true",
-                    help="time the whole SNARK (sat proof + inst_evals + SPARK R1CSEvalProof, my_lib_prove in full) instead of "
-                         "the sat proof; SNARK::encode runs once per instance before the timed region and is reported beside it")
+    ap.add_argument("--sat-only", action="store_true",
+                    help="time only the R1CS satisfiability proof (SURVEY.md 8(a) rows H1-H10) instead of the whole SNARK")
+    ap.add_argument("--snark", action="store_true", help="(default) whole SNARK: sat proof + inst_evals + SPARK R1CSEvalProof, "
+                    "my_lib_prove in full; SNARK::encode runs once per instance before the timed region and is reported beside it")
     ap.add_argument("--no-prof", action="store_true", help="no HIP-event bracketing of kernels (no roofline object)")
     ap.add_argument("--pmc-traffic", type=float, default=None,
                     help="HBM bytes per launch of the roofline kernel from a separate rocprofv3 --pmc pass")
@@ -66,6 +74,7 @@ def parse():
 
 def main():
     args = parse()
+    args.snark = not args.sat_only and not args.host_buffers
     import torch
     import vpin_amd
     from vpin_amd import gadgets as G
@@ -99,7 +108,8 @@ def main():
     lanes = [mults + adds] if (args.serial or not mults) else [mults, adds]
     if args.snark and not args.serial and len(mults) > 2:
         # whole SNARKs are long enough to be worth three host threads / streams: the largest instance
-        # alone, the other point-mult instances, the point-add instances; no gating (throughput run)
+        # alone, the other point-mult instances, the point-add instances; lanes 1 and 2 start when the
+        # largest instance's sat part is done, so its sum-check kernels are timed undisturbed
         lanes = [mults[:1], mults[1:], adds]
     ctxs = [vpin_amd.Context(local_rank) for _ in lanes]
 
@@ -134,6 +144,10 @@ def main():
     lane_names = [[w[0] for w in lane] for lane in lanes]
 
     last_spans, proof_bytes = {}, {}
+    import numpy as np
+    progress = np.zeros(4, dtype=np.int32)
+    if args.snark and len(lanes) == 3:
+        ctxs[0].set_progress_flag(progress)
 
     def prove(li, name):
         cx = ctxs[li]
@@ -163,10 +177,18 @@ def main():
             run_lane(0, None)
             return
         if len(lanes) == 3:
-            ts = [threading.Thread(target=run_lane, args=(li, None)) for li in (1, 2)]
+            progress[0] = 0
+            gate = threading.Event()
+
+            def watch():
+                while progress[0] == 0 and not gate.is_set():
+                    time.sleep(0.0005)
+                gate.set()
+            ts = [threading.Thread(target=run_lane, args=(li, gate)) for li in (1, 2)] + [threading.Thread(target=watch)]
             for t in ts:
                 t.start()
             run_lane(0, None)
+            gate.set()
             for t in ts:
                 t.join()
             return
@@ -196,9 +218,12 @@ def main():
         cx.sync()
     barrier()
     elapsed = time.perf_counter() - t0
-    stats = {}
-    for cx in ctxs:
-        for name, v in cx.prof_read().items():
+    stats, stats_lane0 = {}, {}
+    for ci, cx in enumerate(ctxs):
+        per_ctx = cx.prof_read()
+        if ci == 0:
+            stats_lane0 = {n: dict(v) for n, v in per_ctx.items()}
+        for name, v in per_ctx.items():
             a = stats.setdefault(name, {"launches": 0, "ms": 0.0, "alg_bytes": 0.0})
             for kk in a:
                 a[kk] += v[kk]
@@ -222,8 +247,8 @@ def main():
         "dtype": "u256 (mod q = 2^252+..., mod p = 2^255-19; 32-bit limbs)",
         "data": "synthetic",
         "config": {
-            "workload": ("vPIN LeNet trace (layers L1..L7): 12 sat proofs per step" if trace == "lenet"
-                         else f"vPIN trace '{trace}': sat proofs of its point-mult and point-add instances"),
+            "workload": (("vPIN LeNet trace (layers L1..L7): 12 " + ("SNARKs" if args.snark else "sat proofs") + " per step") if trace == "lenet"
+                         else f"vPIN trace '{trace}': " + ("SNARKs" if args.snark else "sat proofs") + " of its point-mult and point-add instances"),
             "instances": cons,
             "constraints_unpadded_per_step": total_cons_step,
             "scope": ("my_lib_prove in full: R1CSProof + inst_evals + R1CSEvalProof (SPARK); SNARK::encode once per circuit "
@@ -231,13 +256,19 @@ def main():
                       "R1CSProof (commitments + both ZK sum-checks + evaluation proof); SPARK encode/eval proof not included"),
             "parallelism": f"one trace per rank x {world} rank(s), no collective; per rank "
                            + ("instances proven serially" if len(lanes) == 1 else
+                              "3 streams: largest instance | other mult instances | add instances (2nd, 3rd start after the largest's sat part)"
+                              if len(lanes) == 3 else
                               "mult instances serially, add instances on a second stream after the largest"),
             "inputs": "host buffers (PCIe-inclusive, CSR/CSC built per proof)" if args.host_buffers else "resident in HBM",
         },
     }
 
     # ---- roofline of the fused sum-check round kernel ----
-    k = stats.get("sc_cubic_fused")
+    # with several streams the event time of a kernel on one stream includes waiting for CUs taken by the
+    # other streams' kernels; lane 0 (the largest instance) runs its sat part before the other lanes
+    # start, so the roofline is taken over lane 0's launches only
+    k = (stats_lane0 if len(lanes) > 1 else stats).get("sc_cubic_fused")
+    k_all = stats.get("sc_cubic_fused")
     if k and k["ms"] > 0:
         achieved = k["alg_bytes"] / (k["ms"] * 1e-3) / 1e9
         traffic = args.pmc_traffic
@@ -252,6 +283,9 @@ def main():
             "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
             "launches": k["launches"], "avg_launch_us": k["ms"] * 1e3 / k["launches"],
             "alg_bytes_per_launch": k["alg_bytes"] / k["launches"],
+            "scope": (f"launches of the largest instance ({lane_names[0][0]}) only: {k['launches']} of {k_all['launches']} launches, "
+                      f"{100.0 * k['alg_bytes'] / k_all['alg_bytes']:.1f}% of the kernel's algorithmic bytes in the timed region; the other "
+                      "instances run concurrently on other streams" if len(lanes) > 1 else "all launches in the timed region"),
         }
     line["kernels"] = {name: {"launches": v["launches"], "ms": round(v["ms"], 4),
                               "GBps_alg": (v["alg_bytes"] / (v["ms"] * 1e-3) / 1e9) if v["ms"] else None}

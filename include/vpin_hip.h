@@ -52,6 +52,10 @@ int vpin_ctx_create(int device, vpin_ctx** out);
 void vpin_ctx_destroy(vpin_ctx* ctx);
 /* hipStream_t the ctx launches on (as void*), for callers that time with HIP events */
 void* vpin_ctx_stream(vpin_ctx* ctx);
+/* Optional progress word in host memory: vpin_snark_prove_resident stores 1 to it when the sat part of
+ * the proof is complete (bench.py starts its other lanes then, so the largest instance's sum-check
+ * kernels are timed undisturbed).  NULL disables. */
+int vpin_ctx_set_progress_flag(vpin_ctx* ctx, int* flag);
 int vpin_ctx_sync(vpin_ctx* ctx);
 
 /* ---- tables: device-resident Vec<Scalar> ---------------------------------------- */
@@ -235,6 +239,13 @@ int vpin_snark_prove_resident(vpin_ctx* ctx, const vpin_r1cs_dev* inst, const vp
                               const uint8_t* inputs, const uint8_t seed_commit64[64], const uint8_t seed_proof64[64],
                               uint8_t* proof_out, size_t proof_cap, size_t* proof_len, uint8_t* comm_para_out,
                               uint8_t* comm_input_out);
+/* proof_point_mult.rs:38-94 from host buffers (instance triplets + the three assignments in host memory):
+ * SNARK::encode, then my_lib_prove in full.  comm_out receives bincode(R1CSCommitment). */
+int vpin_snark_prove(vpin_ctx* ctx, const vpin_r1cs* inst, const uint8_t* vars_para, const uint8_t* vars_input,
+                     const uint8_t* vars, const uint8_t* inputs, const uint8_t seed_commit64[64],
+                     const uint8_t seed_proof64[64], uint8_t* proof_out, size_t proof_cap, size_t* proof_len,
+                     uint8_t* comm_out, size_t comm_cap, size_t* comm_len, uint8_t* comm_para_out,
+                     uint8_t* comm_input_out);
 /* wall-clock spans of the last encode / snark prove on this thread, seconds: [0] encode
  * [1] derefs + commit  [2] network build  [3] product-layer proofs  [4] hash-layer proofs
  * [5] sat part  [6] whole prove  [7] unused */

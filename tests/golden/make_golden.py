@@ -61,7 +61,27 @@ def proof_vectors():
     return out
 
 
+def snark_vectors():
+    """whole-SNARK and computation-commitment digests of the same instances, from the C oracle"""
+    seed_c, seed_p = bytes(range(64)), bytes((7 * i + 3) % 256 for i in range(64))
+    out = {"_source": "oracle/spark.c + oracle/sat.c (C restatement of my_lib_prove incl. SPARK) on instances from "
+                      "tests/gadgets_model.py; seed_commit = bytes(range(64)), seed_proof = bytes((7*i+3)%256)",
+           "cases": []}
+    cases = [("add6", GM.build_point_add(GM.synthetic_add_ops(0x5650494E, 6, rz_one_every=3))),
+             ("mult1", GM.build_point_mult(GM.synthetic_mult_ops(0x5650494E + 2, 1, weights=[(1 << 127) + 12345])))]
+    for name, g in cases:
+        inst = GM.instance_new(g)
+        res = O.snark_prove(inst, seed_c, seed_p)
+        assert O.snark_verify(inst, res) == 1
+        out["cases"].append({"name": name, "snark_len": len(res["proof"]),
+                             "snark_sha256": hashlib.sha256(res["proof"]).hexdigest(),
+                             "comm_len": len(res["comm"]), "comm_sha256": hashlib.sha256(res["comm"]).hexdigest()})
+    return out
+
+
 if __name__ == "__main__":
+    with open(os.path.join(HERE, "snark_digests.json"), "w") as f:
+        json.dump(snark_vectors(), f, indent=1)
     with open(os.path.join(HERE, "sumcheck_vectors.json"), "w") as f:
         json.dump(sumcheck_vectors(), f, indent=1)
     with open(os.path.join(HERE, "sat_proof_digests.json"), "w") as f:

@@ -68,11 +68,19 @@ def test_cli_proof_matches_oracle(built, tmp_path):
     assert any(l.startswith("Total proof size: ") for l in lines)
     for name, g in (("add", GM.build_point_add(add_ops)), ("mult", GM.build_point_mult(mult_ops))):
         inst = GM.instance_new(g)
-        exp = O.sat_prove(inst, seed_c, seed_p)
+        exp = O.snark_prove(inst, seed_c, seed_p)  # the CLI proves the whole SNARK, like the reference binary
         got = open(tmp_path / "out" / f"T_{name}.proof", "rb").read()
         assert got == exp["proof"]
+        assert open(tmp_path / "out" / f"T_{name}.comm", "rb").read() == exp["comm"]
         assert f"Proof size: {len(got)} bytes" in lines
         res = dict(exp, proof=got,
                    comm_para=np.frombuffer(open(tmp_path / "out" / f"T_{name}.comm_para", "rb").read(), dtype=np.uint8).reshape(-1, 32).copy(),
                    comm_input=np.frombuffer(open(tmp_path / "out" / f"T_{name}.comm_input", "rb").read(), dtype=np.uint8).reshape(-1, 32).copy())
-        assert O.sat_verify(inst, res) == 1
+        assert O.snark_verify(inst, res) == 1
+    # --sat-only: the R1CS satisfiability proof alone
+    os.makedirs(tmp_path / "out2")
+    r = subprocess.run([BIN, "T", "--seed", (seed_c + seed_p).hex(), "--write-proof", "out2", "--sat-only"], cwd=tmp_path,
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    inst = GM.instance_new(GM.build_point_add(add_ops))
+    assert open(tmp_path / "out2" / "T_add.proof", "rb").read() == O.sat_prove(inst, seed_c, seed_p)["proof"]

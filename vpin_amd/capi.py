@@ -79,6 +79,7 @@ def lib():
     L.vpin_ctx_stream.argtypes = [vp]
     L.vpin_ctx_stream.restype = vp
     L.vpin_ctx_sync.argtypes = [vp]
+    L.vpin_ctx_set_progress_flag.argtypes = [vp, vp]
     L.vpin_table_upload.argtypes = [vp, vp, C.c_size_t, C.POINTER(vp)]
     L.vpin_table_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
     L.vpin_table_wrap.argtypes = [vp, vp, C.c_size_t, C.POINTER(vp)]
@@ -129,6 +130,7 @@ def lib():
     L.vpin_spark_decomm_free.restype = None
     L.vpin_spark_decomm_free.argtypes = [vp, vp]
     L.vpin_snark_prove_resident.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_size_t, C.POINTER(C.c_size_t), vp, vp]
+    L.vpin_snark_prove.argtypes = [vp] * 9 + [C.c_size_t, C.POINTER(C.c_size_t), vp, C.c_size_t, C.POINTER(C.c_size_t), vp, vp]
     L.vpin_spark_last_timings.restype = None
     L.vpin_spark_last_timings.argtypes = [C.POINTER(C.c_double)]
     L.vpin_sat_last_timings.restype = None
@@ -434,6 +436,11 @@ class Context:
                                            p(sc), p(sp), p(proof), cap, C.byref(n), p(cp), p(ci), p(ev), p(rx), p(ry)),
              "vpin_sat_prove_resident")
         return dict(proof=bytes(proof[:n.value]), comm_para=cp, comm_input=ci, inst_evals=ev, rx=rx, ry=ry)
+
+    def set_progress_flag(self, arr):
+        """arr: np.int32 array of length >= 1 kept alive by the caller, or None."""
+        _chk(lib().vpin_ctx_set_progress_flag(self.h, arr.ctypes.data_as(C.c_void_p) if arr is not None else None),
+             "vpin_ctx_set_progress_flag")
 
     # ---- SPARK / whole SNARK ----
     def spark_encode(self, inst):

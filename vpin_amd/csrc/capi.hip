@@ -134,6 +134,7 @@ void vpin_ctx_destroy(vpin_ctx* c) {
   if (c->prover_cache_free) c->prover_cache_free(c);
   if (c->spark_cache_free) c->spark_cache_free(c);
   if (c->h_spark) (void)hipHostFree(c->h_spark);
+  if (c->d_spark_cnt) (void)hipFree(c->d_spark_cnt);
   dev_pool_release(c);
   for (auto& kv : c->pool_sizes) (void)hipFree(kv.first);  // blocks still held by leaked handles
   c->pool_sizes.clear();
@@ -147,6 +148,12 @@ void vpin_ctx_destroy(vpin_ctx* c) {
 }
 
 void* vpin_ctx_stream(vpin_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
+int vpin_ctx_set_progress_flag(vpin_ctx* c, int* flag) {
+  if (!c) return VPIN_EINVAL;
+  c->progress_flag = flag;
+  return VPIN_OK;
+}
 
 int vpin_ctx_sync(vpin_ctx* c) {
   if (!c) return VPIN_EINVAL;

@@ -1,7 +1,7 @@
 // vpin_prove -- command-line prover with the reference binary's contract.
 //   reference: vPIN_proof_generation/src/main.rs:14-46 (`cargo run -- <label>`), witness files read by
 //   load_data.rs:5-63 and load_data_add.rs:5-103 from the cwd-relative directory rust_files/<label>/.
-// Usage: vpin_prove <label> [--seed <hex64bytes>] [--device N] [--write-proof <dir>]
+// Usage: vpin_prove <label> [--seed <hex64bytes>] [--device N] [--write-proof <dir>] [--sat-only]
 // Stdout follows the reference line for line (network / gadget banners / counts / proof size / times /
 // totals block).  Differences, all stated on stderr: the proof is the R1CS satisfiability proof only
 // (the SPARK eval proof is not part of this build), and verification is left to the verifier the
@@ -145,18 +145,27 @@ void check(int rc, const char* what) {
   if (rc != 0) die(std::string(what) + ": " + vpin_strerror(rc) + " [" + vpin_last_error() + "]");
 }
 
+bool g_sat_only = false;
+
 Result prove(vpin_ctx* ctx, vpin_instance* inst, const uint8_t seeds[128], const std::string& dump_prefix, Clock::time_point t0) {
   if (vpin_instance_is_sat(inst) != 1) die("assertion failed: instance is not satisfied");  // point_mult.rs:650-651
   const vpin_r1cs* r = vpin_instance_r1cs(inst);
-  size_t cap = vpin_sat_proof_max_bytes(r->num_cons, r->num_vars), len = 0;
+  size_t cap = g_sat_only ? vpin_sat_proof_max_bytes(r->num_cons, r->num_vars) : vpin_snark_proof_max_bytes(r), len = 0;
   size_t ell = 0;
   while (((size_t)1 << ell) < r->num_vars) ell++;
   size_t L = (size_t)1 << (ell / 2);
-  std::vector<uint8_t> proof(cap), cp(32 * L), ci(32 * L), ev(96);
-  check(vpin_sat_prove(ctx, r, vpin_instance_vars_para(inst), vpin_instance_vars_input(inst), vpin_instance_vars(inst),
-                       vpin_instance_inputs(inst), seeds, seeds + 64, proof.data(), cap, &len, cp.data(), ci.data(), ev.data(),
-                       nullptr, nullptr),
-        "vpin_sat_prove");
+  std::vector<uint8_t> proof(cap), cp(32 * L), ci(32 * L), ev(96), comm(g_sat_only ? 0 : vpin_spark_comm_bytes(r));
+  size_t comm_len = 0;
+  if (g_sat_only)
+    check(vpin_sat_prove(ctx, r, vpin_instance_vars_para(inst), vpin_instance_vars_input(inst), vpin_instance_vars(inst),
+                         vpin_instance_inputs(inst), seeds, seeds + 64, proof.data(), cap, &len, cp.data(), ci.data(), ev.data(),
+                         nullptr, nullptr),
+          "vpin_sat_prove");
+  else  // SNARK::encode + my_lib_prove (proof_point_mult.rs:38-94): what the reference's "Proof size" measures
+    check(vpin_snark_prove(ctx, r, vpin_instance_vars_para(inst), vpin_instance_vars_input(inst), vpin_instance_vars(inst),
+                           vpin_instance_inputs(inst), seeds, seeds + 64, proof.data(), cap, &len, comm.data(), comm.size(),
+                           &comm_len, cp.data(), ci.data()),
+          "vpin_snark_prove");
   Result res;
   res.size = len;
   printf("Proof size: %zu bytes\n", len);
@@ -166,7 +175,8 @@ Result prove(vpin_ctx* ctx, vpin_instance* inst, const uint8_t seeds[128], const
     std::ofstream(dump_prefix + ".proof", std::ios::binary).write((const char*)proof.data(), (std::streamsize)len);
     std::ofstream(dump_prefix + ".comm_para", std::ios::binary).write((const char*)cp.data(), (std::streamsize)cp.size());
     std::ofstream(dump_prefix + ".comm_input", std::ios::binary).write((const char*)ci.data(), (std::streamsize)ci.size());
-    std::ofstream(dump_prefix + ".inst_evals", std::ios::binary).write((const char*)ev.data(), 96);
+    if (g_sat_only) std::ofstream(dump_prefix + ".inst_evals", std::ios::binary).write((const char*)ev.data(), 96);
+    else std::ofstream(dump_prefix + ".comm", std::ios::binary).write((const char*)comm.data(), (std::streamsize)comm_len);
   }
   return res;
 }
@@ -183,6 +193,7 @@ int main(int argc, char** argv) {
     std::string a = argv[i];
     if (a == "--device" && i + 1 < argc) device = atoi(argv[++i]);
     else if (a == "--write-proof" && i + 1 < argc) dump_dir = argv[++i];
+    else if (a == "--sat-only") g_sat_only = true;
     else if (a == "--seed" && i + 1 < argc) {
       std::string h = argv[++i];  // hex, repeated cyclically to 128 bytes: commit seed | proof seed
       size_t usable = h.size() & ~(size_t)1;
@@ -195,7 +206,8 @@ int main(int argc, char** argv) {
     std::random_device rd;
     for (auto& b : seeds) b = (uint8_t)rd();
   }
-  fprintf(stderr, "vpin_prove: R1CS satisfiability proof only (no SPARK eval proof); proofs are not verified in-process\n");
+  fprintf(stderr, g_sat_only ? "vpin_prove: R1CS satisfiability proof only (--sat-only); proofs are not verified in-process\n"
+                             : "vpin_prove: whole SNARK (sat proof + SPARK evaluation proof); proofs are not verified in-process\n");
 
   printf("network: %s\n", network.c_str());
   vpin_ctx* ctx = nullptr;

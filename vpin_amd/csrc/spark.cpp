@@ -253,9 +253,9 @@ static int batched_prove(vpin_ctx* c, vpin::SparkForest& f, DotpCtx* dotp, Trans
         const size_t len = j == 0 ? h : (h >> (j - 1));  // live length before this round's launch
         const vpin::fq* E = pyr->d + pyramid_offset(k, j + 1);
         const uint8_t* rprev = j ? B(&r[j - 1]) : nullptr;
-        if ((rc = vpin::spark_prod_round(c, &f, layer_id, len, E, rprev))) return rc;
+        if ((rc = vpin::spark_prod_round(c, &f, layer_id, len, E, rprev, with_dotp))) return rc;
         if (with_dotp && (rc = vpin::spark_dotp_round(c, dotp->d, dotp->comb_derefs, dotp->scratch, len, j == 1, rprev))) return rc;
-        if ((rc = vpin::spark_wait(c))) return rc;
+        if ((rc = vpin::spark_wait_flag(c))) return rc;
         const Fq* res = reinterpret_cast<const Fq*>(c->h_spark);
         Fq S0 = Fq::zero(), S2 = Fq::zero(), S3 = Fq::zero();
         for (int t = 0; t < npc; t++) { S0 = S0 + res[3 * t] * coeffs[t]; S2 = S2 + res[3 * t + 1] * coeffs[t]; S3 = S3 + res[3 * t + 2] * coeffs[t]; }
@@ -279,7 +279,9 @@ static int batched_prove(vpin_ctx* c, vpin::SparkForest& f, DotpCtx* dotp, Trans
         polys[3 * j] = cf[0]; polys[3 * j + 1] = cf[2]; polys[3 * j + 2] = cf[3];
       }
       // final fold of the two live entries per table with r_{k-1}
-      if ((rc = vpin::spark_collect_prod(c, &f, layer_id))) return rc;
+      if ((rc = vpin::spark_collect(c, &f, layer_id, with_dotp ? dotp->d : nullptr, with_dotp ? dotp->comb_derefs : nullptr,
+                                    with_dotp ? dotp->scratch : nullptr, with_dotp, k >= 2)))
+        return rc;
       const Fq* res = reinterpret_cast<const Fq*>(c->h_spark);
       const Fq rl = r[k - 1];
       for (int t = 0; t < npc; t++) {
@@ -287,7 +289,6 @@ static int batched_prove(vpin_ctx* c, vpin::SparkForest& f, DotpCtx* dotp, Trans
         cr[t] = res[4 * t + 2] + rl * (res[4 * t + 3] - res[4 * t + 2]);
       }
       if (with_dotp) {
-        if ((rc = vpin::spark_collect_dotp(c, dotp->d, dotp->comb_derefs, dotp->scratch, k >= 2))) return rc;
         const Fq* q = reinterpret_cast<const Fq*>(c->h_spark) + 64;
         for (int t = 0; t < 3; t++) out.dotp[t].resize(6);
         for (int i = 0; i < 6; i++)
@@ -616,6 +617,7 @@ int vpin_snark_prove_resident(vpin_ctx* c, const vpin_r1cs_dev* dinst, const vpi
   int rc = sat_prove_core(c, dinst, nv, ncons, ni, vars_para, vars_input, vars, inputs, seed_commit64, seed_proof64, proof_out,
                           proof_cap, &sat_len, comm_para_out, comm_input_out, ie, B(rx.data()), B(ry.data()), &tr, &tape);
   if (rc) return rc;
+  if (c->progress_flag) *c->progress_flag = 1;
   g_spark_timings[5] = secs(t0, Clock::now());
   Writer w;
   w.bytes(ie, 96);  // SNARK.inst_evals (lib.rs:334-338)
@@ -627,6 +629,34 @@ int vpin_snark_prove_resident(vpin_ctx* c, const vpin_r1cs_dev* dinst, const vpi
   *proof_len = sat_len + w.buf.size();
   g_spark_timings[6] = secs(t0, Clock::now());
   return VPIN_OK;
+}
+
+// proof_point_mult.rs:38-94 from host buffers: SNARK::encode, then my_lib_prove in full
+int vpin_snark_prove(vpin_ctx* c, const vpin_r1cs* inst, const uint8_t* vars_para, const uint8_t* vars_input,
+                     const uint8_t* vars, const uint8_t* inputs, const uint8_t seed_commit64[64], const uint8_t seed_proof64[64],
+                     uint8_t* proof_out, size_t proof_cap, size_t* proof_len, uint8_t* comm_out, size_t comm_cap, size_t* comm_len,
+                     uint8_t* comm_para_out, uint8_t* comm_input_out) {
+  if (!c || !inst || !vars_para || !vars_input || !vars) return VPIN_EINVAL;
+  const size_t nv = inst->num_vars;
+  if (!vpin::is_pow2(nv) || !vpin::is_pow2(inst->num_cons) || inst->num_inputs >= nv) return VPIN_ESHAPE;
+  vpin_r1cs_dev* dinst = nullptr;
+  vpin_spark_decomm* decomm = nullptr;
+  int rc = vpin_r1cs_upload(c, inst, &dinst);
+  if (rc) return rc;
+  TableGuard tg(c);
+  vpin_table *d_para = nullptr, *d_input = nullptr, *d_vars = nullptr;
+  rc = vpin_spark_encode(c, inst, &decomm, comm_out, comm_cap, comm_len);
+  if (!rc) rc = vpin_table_upload(c, vars_para, nv, &d_para);
+  if (!rc) { tg.add(d_para); rc = vpin_table_upload(c, vars_input, nv, &d_input); }
+  if (!rc) { tg.add(d_input); rc = vpin_table_upload(c, vars, nv, &d_vars); }
+  if (!rc) {
+    tg.add(d_vars);
+    rc = vpin_snark_prove_resident(c, dinst, decomm, d_para, d_input, d_vars, inputs, seed_commit64, seed_proof64, proof_out,
+                                   proof_cap, proof_len, comm_para_out, comm_input_out);
+  }
+  vpin_spark_decomm_free(c, decomm);
+  vpin_r1cs_free(c, dinst);
+  return rc;
 }
 
 // [0] encode, [1] derefs + commit, [2] network build, [3] product-layer proofs, [4] hash-layer proofs,

@@ -130,6 +130,78 @@ __global__ __launch_bounds__(kTopBlock) void tree_top_kernel(fq* __restrict__ fo
   }
 }
 
+
+// ---- fused finisher -----------------------------------------------------------------------
+// Every round kernel ends with the "last block done" pattern instead of a second launch: a block
+// stores its 3 partial sums, bumps its instance's counter, and the block that finds it was the last
+// one sums the instance's partials and writes the three scalars to pinned host memory; the last
+// instance to finish (global counter) then publishes the launch group's sequence number in the
+// pinned flag word the host is spinning on (no hipStreamSynchronize on the round path: ~7 us
+// instead of ~14 us per round on MI355X, tools/ubench_sync.hip).  Counters reset themselves.
+struct Finisher {
+  fq* partials;        // [inst][nblocks][3]
+  uint32_t* counters;  // [kSparkMaxInst] per instance, [kSparkMaxInst] global
+  fq* out;             // pinned: out[3*(inst0 + y) + k]
+  uint32_t* flag;      // pinned
+  uint32_t seq;
+  int inst0;           // first instance index of this launch
+  int total_inst;      // instances in the launch group (all kernels flagged with the same seq)
+};
+
+// block-wide sums of e[0..2]: valid in threads 0..2 (thread k holds sum k)
+__device__ __forceinline__ fq block_sum3(fq* e) {
+  __shared__ fq sh[kBlock / 64][3];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    fq t = fq_wave_sum(e[k]);
+    if (lane == 0) sh[wave][k] = t;
+  }
+  __syncthreads();
+  fq t = fq_zero();
+  if (threadIdx.x < 3) {
+    t = sh[0][threadIdx.x];
+#pragma unroll
+    for (int w = 1; w < kBlock / 64; w++) t = fq_add(t, sh[w][threadIdx.x]);
+  }
+  __syncthreads();  // sh is reused by a second call
+  return t;
+}
+
+// called by every thread of the block after the per-thread accumulators e[3] are final
+__device__ __forceinline__ void finish_block(fq* e, const Finisher& f) {
+  fq t = block_sum3(e);
+  if (gridDim.x > 1) {
+    fq* mine = f.partials + (size_t)blockIdx.y * gridDim.x * 3;
+    if (threadIdx.x < 3) fq_store(&mine[(size_t)blockIdx.x * 3 + threadIdx.x], t);
+    __shared__ bool is_last;
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) is_last = (atomicAdd(&f.counters[f.inst0 + blockIdx.y], 1u) == gridDim.x - 1);
+    __syncthreads();
+    if (!is_last) return;
+    __threadfence();  // acquire: the other blocks' partials (never read before by this CU in this kernel)
+    fq s[3] = {fq_zero(), fq_zero(), fq_zero()};
+    for (int b = threadIdx.x; b < (int)gridDim.x; b += kBlock)
+#pragma unroll
+      for (int k = 0; k < 3; k++) s[k] = fq_add(s[k], fq_load(&mine[(size_t)b * 3 + k]));
+    t = block_sum3(s);
+  }
+  if (threadIdx.x < 3) {
+    fq_store(&f.out[3 * (size_t)(f.inst0 + blockIdx.y) + threadIdx.x], t);
+    __threadfence_system();
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (gridDim.x > 1) f.counters[f.inst0 + blockIdx.y] = 0;
+    if (atomicAdd(&f.counters[kSparkMaxInst], 1u) == (uint32_t)f.total_inst - 1) {
+      f.counters[kSparkMaxInst] = 0;
+      __threadfence_system();
+      *(volatile uint32_t*)f.flag = f.seq;
+    }
+  }
+}
+
 // ---- batched cubic rounds ------------------------------------------------------------------
 
 // unit-stride fold with separate source and destination (the first fold of the dot-product tables
@@ -146,8 +218,7 @@ __device__ __forceinline__ void fold_pd2(const fq* src, fq* dst, size_t i, size_
 
 template <bool BIND>
 __global__ __launch_bounds__(kBlock, kMinWaves) void prod_round_kernel(fq* __restrict__ forest, size_t stride, size_t off, size_t h,
-                                                                       const fq* __restrict__ E, size_t pairs, fq r,
-                                                                       fq* __restrict__ partials) {
+                                                                       const fq* __restrict__ E, size_t pairs, fq r, Finisher fin) {
   fq* A = forest + (size_t)blockIdx.y * stride + off;
   fq* B = A + h;
   Acc<4> acc;
@@ -159,7 +230,7 @@ __global__ __launch_bounds__(kBlock, kMinWaves) void prod_round_kernel(fq* __res
     acc.stage_bc(u, p1, d1, p2, d2);
     acc.stage_e(u, fq_load(E + i));
   }
-  block_reduce_store<3>(acc.e, partials + (size_t)blockIdx.y * gridDim.x * 3);
+  finish_block(acc.e, fin);
 }
 
 struct DotpPtrs { const fq* src[3]; fq* dst[3]; size_t src_stride[3]; };
@@ -168,7 +239,7 @@ struct DotpPtrs { const fq* src[3]; fq* dst[3]; size_t src_stride[3]; };
 template <bool BIND>
 __global__ __launch_bounds__(kBlock, kMinWaves) void dotp_round_kernel(const fq* __restrict__ derefs, const fq* __restrict__ vals,
                                                                        size_t N, fq* __restrict__ scratch, bool from_scratch,
-                                                                       size_t pairs, fq r, fq* __restrict__ partials) {
+                                                                       size_t pairs, fq r, Finisher fin) {
   const int k = blockIdx.y, m = k >> 1, half = k & 1;
   const size_t hN = N / 2, q4 = N / 4;
   const fq* src[3];
@@ -194,7 +265,7 @@ __global__ __launch_bounds__(kBlock, kMinWaves) void dotp_round_kernel(const fq*
     else load_pd(src[2], i, pairs, p1, d1);
     acc.stage_a(u, p1, d1);
   }
-  block_reduce_store<3>(acc.e, partials + (size_t)blockIdx.y * gridDim.x * 3);
+  finish_block(acc.e, fin);
 }
 
 // per-instance finisher: out[3*(inst0 + y) + k] = sum over the instance's block partials
@@ -221,25 +292,31 @@ __global__ __launch_bounds__(kBlock) void inst_finish_kernel(const fq* __restric
   }
 }
 
-__global__ __launch_bounds__(64) void collect_prod_kernel(const fq* __restrict__ forest, size_t stride, size_t off, size_t h,
-                                                          int ncirc, fq* __restrict__ out) {
-  int t = threadIdx.x >> 2, w = threadIdx.x & 3;  // w: A[0], A[1], B[0], B[1]
-  if (t < ncirc) {
-    const fq* A = forest + (size_t)t * stride + off;
-    fq_store(out + 4 * t + w, fq_load(A + (w >> 1) * h + (w & 1)));
+// The collectors gather both groups' live entries in ONE single-workgroup launch and flag completion.
+__global__ __launch_bounds__(128) void collect_kernel(const fq* __restrict__ forest, size_t stride, size_t off, size_t h, int ncirc,
+                                                      const fq* __restrict__ derefs, const fq* __restrict__ vals, size_t N,
+                                                      const fq* __restrict__ scratch, bool with_dotp, bool from_scratch,
+                                                      fq* __restrict__ out, uint32_t* flag, uint32_t seq) {
+  if (threadIdx.x < 64) {
+    int t = threadIdx.x >> 2, w = threadIdx.x & 3;  // w: A[0], A[1], B[0], B[1]
+    if (t < ncirc) {
+      const fq* A = forest + (size_t)t * stride + off;
+      fq_store(out + 4 * t + w, fq_load(A + (w >> 1) * h + (w & 1)));
+    }
+  } else if (with_dotp) {
+    int idx = threadIdx.x - 64;
+    if (idx < 36) {
+      int k = idx / 6, t = (idx % 6) >> 1, e = idx & 1, m = k >> 1, half = k & 1;
+      const size_t hN = N / 2;
+      const fq* src;
+      if (from_scratch) src = scratch + (size_t)(3 * k + t) * (N / 4);
+      else src = (t == 0 ? derefs + (size_t)m * N : t == 1 ? derefs + (size_t)(3 + m) * N : vals + (size_t)m * N) + (size_t)half * hN;
+      fq_store(out + 64 + idx, fq_load(src + e));
+    }
   }
-}
-
-__global__ __launch_bounds__(64) void collect_dotp_kernel(const fq* __restrict__ derefs, const fq* __restrict__ vals, size_t N,
-                                                          const fq* __restrict__ scratch, bool from_scratch, fq* __restrict__ out) {
-  int idx = threadIdx.x;
-  if (idx >= 36) return;
-  int k = idx / 6, t = (idx % 6) >> 1, e = idx & 1, m = k >> 1, half = k & 1;
-  const size_t hN = N / 2;
-  const fq* src;
-  if (from_scratch) src = scratch + (size_t)(3 * k + t) * (N / 4);
-  else src = (t == 0 ? derefs + (size_t)m * N : t == 1 ? derefs + (size_t)(3 + m) * N : vals + (size_t)m * N) + (size_t)half * hN;
-  fq_store(out + idx, fq_load(src + e));
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) *(volatile uint32_t*)flag = seq;
 }
 
 __global__ __launch_bounds__(kBlock) void fetch_tops_kernel(const fq* __restrict__ forest, size_t stride, size_t cnt, int ncirc,
@@ -287,6 +364,27 @@ int spark_pinned(vpin_ctx* c) {
   if (c->h_spark) return VPIN_OK;
   (void)hipSetDevice(c->device);
   VPIN_HIP_TRY(hipHostMalloc((void**)&c->h_spark, kSparkPinned * sizeof(fq), hipHostMallocDefault));
+  memset(c->h_spark, 0, kSparkPinned * sizeof(fq));
+  VPIN_HIP_TRY(hipMalloc((void**)&c->d_spark_cnt, 2 * kSparkMaxInst * sizeof(uint32_t)));
+  VPIN_HIP_TRY(hipMemset(c->d_spark_cnt, 0, 2 * kSparkMaxInst * sizeof(uint32_t)));
+  c->spark_seq = 0;
+  return VPIN_OK;
+}
+
+static inline uint32_t* flag_ptr(vpin_ctx* c) { return reinterpret_cast<uint32_t*>(c->h_spark + (kSparkPinned - 1)); }
+
+// Wait for the launch group that carries the current sequence number: spin briefly on the pinned flag
+// word (the kernels' results are fenced before it), then fall back to an ordinary stream sync --
+// tools that intercept dispatches (rocprofv3) may hold a launch back until the host synchronises.
+int spark_wait_flag(vpin_ctx* c) {
+  volatile uint32_t* f = flag_ptr(c);
+  const uint32_t want = c->spark_seq;
+  for (int spins = 0; spins < 20000; spins++) {  // ~100-200 us
+    if (*f == want) return VPIN_OK;
+    __builtin_ia32_pause();
+  }
+  VPIN_HIP_TRY(hipStreamSynchronize(c->stream));
+  if (*f != want) { set_last_error("spark_wait_flag: launch group did not publish its flag", hipErrorUnknown); return VPIN_EHIP; }
   return VPIN_OK;
 }
 
@@ -379,7 +477,19 @@ static inline int round_grid(size_t pairs) {
   return (int)b;
 }
 
-int spark_prod_round(vpin_ctx* c, const SparkForest* f, int level, size_t len, const fq* E, const uint8_t* r) {
+static Finisher make_finisher(vpin_ctx* c, fq* partials, int inst0, int total_inst) {
+  Finisher f;
+  f.partials = partials;
+  f.counters = c->d_spark_cnt;
+  f.out = c->h_spark;
+  f.flag = flag_ptr(c);
+  f.seq = c->spark_seq;
+  f.inst0 = inst0;
+  f.total_inst = total_inst;
+  return f;
+}
+
+int spark_prod_round(vpin_ctx* c, const SparkForest* f, int level, size_t len, const fq* E, const uint8_t* r, bool with_dotp) {
   if (!c || !f || !f->base || !E) return VPIN_EINVAL;
   const size_t h = f->n >> (level + 1);
   if (h == 0 || len > h || !is_pow2(len) || len < (r ? 4u : 2u) || f->ncirc > 12) return VPIN_ESHAPE;
@@ -391,19 +501,20 @@ int spark_prod_round(vpin_ctx* c, const SparkForest* f, int level, size_t len, c
   const size_t pairs = r ? len / 4 : len / 2;
   const int grid = round_grid(pairs);
   const fq rr = r ? load_host_fq(r) : fq{};
+  c->spark_seq++;  // a new launch group: this kernel (+ the dot-product kernel that follows when with_dotp)
+  Finisher fin = make_finisher(c, partials, 0, f->ncirc + (with_dotp ? 6 : 0));
   {
-    // algorithmic bytes of the reference formulation: 3 tables (A, B and the shared eq table counted once
-    // per circuit as the reference folds it once) read, folded halves written
+    // algorithmic bytes of the reference formulation: A and B of every circuit and the shared eq table read,
+    // folded halves written
     const double bytes = (double)f->ncirc * 2 * 32.0 * (r ? (double)len * 1.5 : (double)len) + 32.0 * (r ? (double)len * 1.5 : (double)len);
     ProfScope ps(c, VPIN_K_SPARK_ROUND, bytes);
     if (r)
       hipLaunchKernelGGL((prod_round_kernel<true>), dim3(grid, f->ncirc), dim3(kBlock), 0, c->stream, f->base, f->stride(),
-                         f->level_off(level), h, E, pairs, rr, partials);
+                         f->level_off(level), h, E, pairs, rr, fin);
     else
       hipLaunchKernelGGL((prod_round_kernel<false>), dim3(grid, f->ncirc), dim3(kBlock), 0, c->stream, f->base, f->stride(),
-                         f->level_off(level), h, E, pairs, rr, partials);
+                         f->level_off(level), h, E, pairs, rr, fin);
   }
-  hipLaunchKernelGGL(inst_finish_kernel, dim3(f->ncirc), dim3(kBlock), 0, c->stream, (const fq*)partials, grid, 0, c->h_spark);
   VPIN_HIP_TRY(hipGetLastError());
   return VPIN_OK;
 }
@@ -417,47 +528,40 @@ int spark_dotp_round(vpin_ctx* c, const vpin_spark_decomm* d, const fq* comb_der
   (void)hipSetDevice(c->device);
   fq* partials = nullptr;
   if ((rc = round_partials(c, &partials))) return rc;
-  partials += (size_t)12 * kRoundBlocks * 3;  // behind the product circuits' partials (same stream, but keep them apart)
   const size_t pairs = r ? len / 4 : len / 2;
   const int grid = round_grid(pairs);
   const fq rr = r ? load_host_fq(r) : fq{};
   const fq* vals = d->comb_ops->d + 12 * d->N;
   const bool from_scratch = r && !first_fold;
+  // same launch group as the product circuits' kernel just issued: instances 12..17 of 18
+  Finisher fin = make_finisher(c, partials + (size_t)12 * kRoundBlocks * 3, 12, 18);
   {
     const double bytes = 6 * 3 * 32.0 * (r ? (double)len * 1.5 : (double)len);
     ProfScope ps(c, VPIN_K_SPARK_ROUND, bytes);
     if (r)
       hipLaunchKernelGGL((dotp_round_kernel<true>), dim3(grid, 6), dim3(kBlock), 0, c->stream, comb_derefs, vals, d->N, scratch,
-                         from_scratch, pairs, rr, partials);
+                         from_scratch, pairs, rr, fin);
     else
       hipLaunchKernelGGL((dotp_round_kernel<false>), dim3(grid, 6), dim3(kBlock), 0, c->stream, comb_derefs, vals, d->N, scratch,
-                         false, pairs, rr, partials);
+                         false, pairs, rr, fin);
   }
-  hipLaunchKernelGGL(inst_finish_kernel, dim3(6), dim3(kBlock), 0, c->stream, (const fq*)partials, grid, 12, c->h_spark);
   VPIN_HIP_TRY(hipGetLastError());
   return VPIN_OK;
 }
 
-int spark_collect_prod(vpin_ctx* c, const SparkForest* f, int level) {
-  if (!c || !f || !f->base || f->ncirc > 12) return VPIN_EINVAL;
+int spark_collect(vpin_ctx* c, const SparkForest* f, int level, const vpin_spark_decomm* d, const fq* comb_derefs,
+                  const fq* scratch, bool with_dotp, bool folded) {
+  if (!c || !f || !f->base || f->ncirc > 12 || (with_dotp && (!d || !comb_derefs || !scratch))) return VPIN_EINVAL;
   int rc = spark_pinned(c);
   if (rc) return rc;
   const size_t h = f->n >> (level + 1);
   if (h < 2) return VPIN_ESHAPE;  // a 1-entry half has no second element; the host handles those layers
-  hipLaunchKernelGGL(collect_prod_kernel, dim3(1), dim3(64), 0, c->stream, (const fq*)f->base, f->stride(), f->level_off(level), h,
-                     f->ncirc, c->h_spark);
+  c->spark_seq++;
+  hipLaunchKernelGGL(collect_kernel, dim3(1), dim3(128), 0, c->stream, (const fq*)f->base, f->stride(), f->level_off(level), h,
+                     f->ncirc, comb_derefs, with_dotp ? (const fq*)(d->comb_ops->d + 12 * d->N) : (const fq*)nullptr,
+                     with_dotp ? d->N : (size_t)0, scratch, with_dotp, folded, c->h_spark, flag_ptr(c), c->spark_seq);
   VPIN_HIP_TRY(hipGetLastError());
-  return spark_wait(c);
-}
-
-int spark_collect_dotp(vpin_ctx* c, const vpin_spark_decomm* d, const fq* comb_derefs, const fq* scratch, bool folded) {
-  if (!c || !d || !comb_derefs || !scratch) return VPIN_EINVAL;
-  int rc = spark_pinned(c);
-  if (rc) return rc;
-  hipLaunchKernelGGL(collect_dotp_kernel, dim3(1), dim3(64), 0, c->stream, comb_derefs, (const fq*)(d->comb_ops->d + 12 * d->N), d->N,
-                     scratch, folded, c->h_spark + 64);
-  VPIN_HIP_TRY(hipGetLastError());
-  return spark_wait(c);
+  return spark_wait_flag(c);
 }
 
 int spark_triple_sums(vpin_ctx* c, const vpin_spark_decomm* d, const fq* comb_derefs) {

@@ -58,23 +58,28 @@ int spark_fetch_tops(vpin_ctx* c, const SparkForest* f, size_t cnt);
 // level `level`, eq-factored: returns per circuit the three sums  sum_i E[i] * (A_x B_x)[i], x = 0,2,3
 // with A/B = left/right halves (live length len) and E the suffix table of this round (len/2 or,
 // when r != nullptr and the tables are first folded with r, len/4 entries).  Results land in
-// ctx->h_spark[3*t + k] after spark_wait.  `len` is the live length BEFORE this call.
-int spark_prod_round(vpin_ctx* c, const SparkForest* f, int level, size_t len, const fq* E, const uint8_t* r);
+// ctx->h_spark[3*t + k] once spark_wait_flag returns.  `len` is the live length BEFORE this call.
+// Starts a new launch group; with_dotp announces that spark_dotp_round follows in the same group.
+int spark_prod_round(vpin_ctx* c, const SparkForest* f, int level, size_t len, const fq* E, const uint8_t* r, bool with_dotp);
 
 // Same for the 6 DotProductCircuit halves of layer 0 (comb = A*B*C, three foldable tables each,
 // sumcheck.rs:304-330).  src tables: left = comb_derefs row slices, right = col slices, weight =
 // comb_ops val slices, each cut in two halves of N/2 (sparse_mlpoly.rs:1103-1125).  The first fold
 // writes into `scratch` (18 x N/4 entries) so the committed polynomials stay intact.
-// round 0: r == nullptr, len = N/2.  Results at ctx->h_spark[3*(12+k) + x].
+// round 0: r == nullptr, len = N/2.  Results at ctx->h_spark[3*(12+k) + x].  Call right after
+// spark_prod_round(..., with_dotp = true).
 int spark_dotp_round(vpin_ctx* c, const vpin_spark_decomm* d, const fq* comb_derefs, fq* scratch, size_t len, bool first_fold,
                      const uint8_t* r);
 
+// completion of the current launch group: spins on the pinned flag word the last block publishes
+int spark_wait_flag(vpin_ctx* c);
+
 // after the last round: the two live entries of every table, for the host to bind with the final
-// challenge: h_spark[4*t + {0,1,2,3}] = A[0], A[1], B[0], B[1] per product circuit; synchronises
-int spark_collect_prod(vpin_ctx* c, const SparkForest* f, int level);
-// h_spark[64 + 6*k + {0..5}] = L[0], L[1], R[0], R[1], W[0], W[1] per dot-product circuit (from scratch, or
-// from the source tables when N/2 == 2 and no fold has happened); synchronises
-int spark_collect_dotp(vpin_ctx* c, const vpin_spark_decomm* d, const fq* comb_derefs, const fq* scratch, bool folded);
+// challenge: h_spark[4*t + {0,1,2,3}] = A[0], A[1], B[0], B[1] per product circuit and, with_dotp,
+// h_spark[64 + 6*k + {0..5}] = L[0], L[1], R[0], R[1], W[0], W[1] per dot-product circuit (from scratch when
+// `folded`, else from the source tables: N/2 == 2, no fold has happened); waits for completion
+int spark_collect(vpin_ctx* c, const SparkForest* f, int level, const vpin_spark_decomm* d, const fq* comb_derefs,
+                  const fq* scratch, bool with_dotp, bool folded);
 
 // DotProductCircuit::evaluate (product_tree.rs:87-91) of the six halves: h_spark[3*k] = sum_i L[i]*R[i]*W[i]
 // over the N/2 entries of half k; synchronises

@@ -188,6 +188,27 @@ __global__ __launch_bounds__(kBlock) void eq_pyramid_step_kernel(const fq* __res
   }
 }
 
+// The small end of the pyramid in one workgroup: level ell (the single 1) down to level k_lo, every level
+// of at most 512 elements.  taus.t[k - k_lo] = tau_k.
+struct TauPack { fq t[10]; };
+__global__ __launch_bounds__(512) void eq_pyramid_top_kernel(fq* __restrict__ base, int ell, int k_lo, TauPack taus) {
+  const size_t n = (size_t)1 << ell;
+  if (threadIdx.x == 0) fq_store(base + (n - 2), fq_one());  // level ell
+  __syncthreads();
+  for (int k = ell - 1; k >= k_lo; k--) {  // level k from level k+1
+    const size_t m = (size_t)1 << (ell - k - 1);
+    const fq* src = base + (n - ((size_t)2 << (ell - k - 1)));
+    fq* dst = base + (n - ((size_t)2 << (ell - k)));
+    if (threadIdx.x < m) {
+      fq v = fq_load(src + threadIdx.x);
+      fq hi = fq_mul(v, taus.t[k - k_lo]);
+      fq_store(dst + threadIdx.x, fq_sub(v, hi));
+      fq_store(dst + m + threadIdx.x, hi);
+    }
+    __syncthreads();
+  }
+}
+
 // Plain fold of K tables (live length 2*half).
 template <int K>
 __global__ __launch_bounds__(kBlock) void sc_bind_kernel(Tabs<K> tabs, size_t half, fq r) {
@@ -443,12 +464,15 @@ int vpin_eq_suffix_tables(vpin_ctx* c, const uint8_t* tau, int ell, vpin_table**
   vpin_table* t = nullptr;
   int rc = table_alloc_uninit(c, (size_t)1 << ell, &t);
   if (rc) return rc;
-  static const uint32_t kOne[8] = {0x8d98951du, 0xd6ec3174u, 0x737dcf70u, 0xc6ef5bf4u,
-                                   0xfffffffeu, 0xffffffffu, 0xffffffffu, 0x0fffffffu};
-  hipError_t e = hipMemcpyAsync(t->d + pyramid_offset(ell, ell), kOne, 32, hipMemcpyHostToDevice, c->stream);
-  if (e == hipSuccess) {
+  hipError_t e = hipSuccess;
+  {
     ProfScope ps(c, VPIN_K_EQ, 32.0 * 3.0 * (double)(((size_t)1 << (ell - 1)) - 1));
-    for (int k = ell - 1; k >= 1; k--) {  // level k from level k+1
+    // levels of up to 512 elements (k >= ell-9) in one launch, the larger ones one launch each
+    const int k_lo = ell - 9 > 1 ? ell - 9 : 1;
+    TauPack tp;
+    for (int k = k_lo; k <= ell - 1; k++) tp.t[k - k_lo] = load_host_fq(tau + 32 * (size_t)k);
+    hipLaunchKernelGGL(eq_pyramid_top_kernel, dim3(1), dim3(512), 0, c->stream, t->d, ell, k_lo, tp);
+    for (int k = k_lo - 1; k >= 1; k--) {  // level k from level k+1
       size_t m = (size_t)1 << (ell - k - 1);
       hipLaunchKernelGGL(eq_pyramid_step_kernel, dim3(grid_for(m)), dim3(kBlock), 0, c->stream,
                          (const fq*)(t->d + pyramid_offset(ell, k + 1)), t->d + pyramid_offset(ell, k), m,

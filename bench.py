@@ -66,6 +66,7 @@ def parse():
                     help="time only the R1CS satisfiability proof (SURVEY.md 8(a) rows H1-H10) instead of the whole SNARK")
     ap.add_argument("--snark", action="store_true", help="(default) whole SNARK: sat proof + inst_evals + SPARK R1CSEvalProof, "
                     "my_lib_prove in full; SNARK::encode runs once per instance before the timed region and is reported beside it")
+    ap.add_argument("--only", choices=["mult", "add"], default=None, help="keep only the point-mult / point-add instances of the trace")
     ap.add_argument("--no-prof", action="store_true", help="no HIP-event bracketing of kernels (no roofline object)")
     ap.add_argument("--pmc-traffic", type=float, default=None,
                     help="HBM bytes per launch of the roofline kernel from a separate rocprofv3 --pmc pass")
@@ -97,6 +98,8 @@ def main():
         if m is not None:
             work.append((f"{lab}-mult", "mult", m))
         work.append((f"{lab}-add", "add", G.synthetic_add_instance(lab)))
+    if args.only:
+        work = [w for w in work if w[1] == args.only]
     setup_s = time.perf_counter() - t0
     cons = {w[0]: w[2].num_cons_unpadded for w in work}
     total_cons_step = sum(cons.values())

@@ -116,6 +116,15 @@ int vpin_sc_cubic3_bind_round(vpin_ctx* ctx, const vpin_table* pyramid, int ell,
  * gens_1.G[0] = g[R], h = g[R+1]; gens_3 / gens_4 are prefixes with h = g[3] / g[4]. */
 typedef struct vpin_gens vpin_gens;
 int vpin_gens_create(vpin_ctx* ctx, const uint8_t* gens_xyzt, size_t nb, vpin_gens** out);
+/* Shared form: one immutable table per (device, label), holding the longest prefix of the label's
+ * generator stream requested so far -- MultiCommitGens::new(n, label) for every n is a prefix of the same
+ * SHAKE256 stream (Spartan/src/commitments.rs:20-38), so all contexts / streams / polynomial sizes of a
+ * label share it.  gens_xyzt (nb points) is only read when a new table has to be built.  budget_gb = 0:
+ * default table budget.  The returned handle is owned by the registry (never pass it to vpin_gens_free). */
+int vpin_gens_shared(vpin_ctx* ctx, const char* label, const uint8_t* gens_xyzt, size_t nb, size_t budget_gb,
+                     const vpin_gens** out);
+/* frees every shared table; only when no context uses them any more */
+void vpin_gens_shared_clear(void);
 void vpin_gens_free(vpin_ctx* ctx, vpin_gens* g);
 size_t vpin_gens_count(const vpin_gens* g);
 /* bytes per window-table entry (affine Niels point, possibly padded to a cache line) */
@@ -197,6 +206,9 @@ int vpin_sat_prove_resident(vpin_ctx* ctx, const vpin_r1cs_dev* inst, const vpin
                             size_t proof_cap, size_t* proof_len, uint8_t* comm_para_out, uint8_t* comm_input_out,
                             uint8_t inst_evals_out[96], uint8_t* rx_out, uint8_t* ry_out);
 size_t vpin_sat_proof_max_bytes(size_t num_cons, size_t num_vars);
+/* R1CSGens::new (Spartan/src/r1csproof.rs:84-89) for this polynomial size ahead of the first proof: host
+ * fixed-base tables + the shared device window table (built on demand by the prove calls otherwise). */
+int vpin_sat_prepare(vpin_ctx* ctx, size_t num_vars);
 /* wall-clock spans of the last vpin_sat_prove call on this thread's process, seconds:
  * [0] polycommit (uploads + 2 commits + combine)  [1] prove_sc_phase_one (eq table, SpMV, 4 uploads, rounds)
  * [2] prove_sc_phase_two  [3] polyeval  [4] total  [5] generators (0 when cached)

@@ -48,7 +48,7 @@ def main():
         st = ctx.prof_read()["msm"]
         ctx.prof_enable(False)
         ms = st["ms"] / st["launches"]
-        c = next(c for c in range(12, 6, -1) if nb * ((254 + c - 1) // c) * (1 << (c - 1)) * capi.lib().vpin_gens_entry_bytes() <= (24 << 30))
+        c = next(c for c in range(12, 6, -1) if nb * ((254 + c - 1) // c) * (1 << (c - 1)) * capi.lib().vpin_gens_entry_bytes() <= (int(os.environ.get('VPIN_GENS_BUDGET_GB', '24')) << 30))
         W = (254 + c - 1) // c
         print(f"nb={nb} c={c} W={W} table={nb * W * (1 << (c - 1)) * capi.lib().vpin_gens_entry_bytes() / 2**30:.1f} GiB build={t_build:.2f}s  "
               f"L={L} R={R}: {ms:.2f} ms  {L * R / ms / 1e6:.3f} G scalars/s  {L * R * W / ms / 1e6:.2f} G adds/s", flush=True)

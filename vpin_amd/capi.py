@@ -122,6 +122,10 @@ def lib():
     L.vpin_sat_proof_max_bytes.argtypes = [C.c_size_t, C.c_size_t]
     L.vpin_sat_proof_max_bytes.restype = C.c_size_t
     L.vpin_sat_last_timings.argtypes = [C.POINTER(C.c_double)]
+    L.vpin_sat_prepare.argtypes = [vp, C.c_size_t]
+    L.vpin_gens_shared.argtypes = [vp, C.c_char_p, vp, C.c_size_t, C.c_size_t, C.POINTER(vp)]
+    L.vpin_gens_shared_clear.restype = None
+    L.vpin_gens_shared_clear.argtypes = []
     L.vpin_spark_comm_bytes.restype = C.c_size_t
     L.vpin_spark_comm_bytes.argtypes = [vp]
     L.vpin_snark_proof_max_bytes.restype = C.c_size_t
@@ -441,6 +445,9 @@ class Context:
         """arr: np.int32 array of length >= 1 kept alive by the caller, or None."""
         _chk(lib().vpin_ctx_set_progress_flag(self.h, arr.ctypes.data_as(C.c_void_p) if arr is not None else None),
              "vpin_ctx_set_progress_flag")
+
+    def sat_prepare(self, num_vars):
+        _chk(lib().vpin_sat_prepare(self.h, num_vars), "vpin_sat_prepare")
 
     # ---- SPARK / whole SNARK ----
     def spark_encode(self, inst):

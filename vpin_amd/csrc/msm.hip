@@ -15,8 +15,12 @@
 // digits are skipped (the witness is ~40% zero padding and full of 0/1 bits), like dalek's
 // vartime MSM.  One 256-thread workgroup per row; per-thread partial sums are combined by
 // an LDS tree.  Integer-ALU bound (~8 field multiplies per table add); no MFMA.
+#include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
 
 #include "ctx.h"
 #include "fp_dev.h"
@@ -356,7 +360,7 @@ using namespace vpin;
 
 extern "C" {
 
-int vpin_gens_create(vpin_ctx* c, const uint8_t* gens_xyzt, size_t nb, vpin_gens** out) {
+static int gens_build(vpin_ctx* c, const uint8_t* gens_xyzt, size_t nb, size_t budget, vpin_gens** out) {
   if (!c || !gens_xyzt || !out || nb == 0) return VPIN_EINVAL;
   (void)hipSetDevice(c->device);
   vpin_gens* g = new (std::nothrow) vpin_gens();
@@ -367,7 +371,7 @@ int vpin_gens_create(vpin_ctx* c, const uint8_t* gens_xyzt, size_t nb, vpin_gens
   for (g->c = 12; g->c > 6; g->c--) {
     g->W = (254 + g->c - 1) / g->c;
     g->E = 1 << (g->c - 1);
-    if (nb * (size_t)g->W * (size_t)g->E * sizeof(niels_slot) <= ((size_t)24 << 30)) break;
+    if (nb * (size_t)g->W * (size_t)g->E * sizeof(niels_slot) <= budget) break;
   }
   const size_t entries = nb * (size_t)g->W * g->E;
   DevBuf raw(c);
@@ -401,6 +405,57 @@ int vpin_gens_create(vpin_ctx* c, const uint8_t* gens_xyzt, size_t nb, vpin_gens
   }
   *out = g;
   return VPIN_OK;
+}
+
+static size_t default_budget() {
+  static const size_t budget = [] {
+    const char* e = getenv("VPIN_GENS_BUDGET_GB");
+    size_t gb = e ? (size_t)atoi(e) : 24;
+    return (gb ? gb : 24) << 30;
+  }();
+  return budget;
+}
+
+int vpin_gens_create(vpin_ctx* c, const uint8_t* gens_xyzt, size_t nb, vpin_gens** out) {
+  return gens_build(c, gens_xyzt, nb, default_budget(), out);
+}
+
+// Process-wide registry of window tables by (device, label): every MultiCommitGens::new(n, label) is a
+// prefix of one SHAKE stream (commitments.rs:20-38), so one table of the longest prefix requested so
+// far serves every context, stream and polynomial size of that label.  Tables are immutable once
+// built; superseded (shorter) ones stay alive because other contexts may still hold them.
+namespace {
+struct RegEntry { int device; std::string label; vpin_gens* g; };
+std::mutex g_reg_mu;
+std::vector<RegEntry> g_reg;
+}  // namespace
+
+int vpin_gens_shared(vpin_ctx* c, const char* label, const uint8_t* gens_xyzt, size_t nb, size_t budget_gb,
+                     const vpin_gens** out) {
+  if (!c || !label || !out || nb == 0) return VPIN_EINVAL;
+  std::lock_guard<std::mutex> lock(g_reg_mu);
+  const vpin_gens* best = nullptr;
+  for (auto& e : g_reg)
+    if (e.device == c->device && e.label == label && e.g->nb >= nb && (!best || e.g->nb < best->nb)) best = e.g;
+  if (best) { *out = best; return VPIN_OK; }
+  if (!gens_xyzt) return VPIN_EINVAL;
+  vpin_gens* g = nullptr;
+  int rc = gens_build(c, gens_xyzt, nb, budget_gb ? (budget_gb << 30) : default_budget(), &g);
+  if (rc) return rc;
+  g_reg.push_back(RegEntry{c->device, label, g});
+  *out = g;
+  return VPIN_OK;
+}
+
+void vpin_gens_shared_clear(void) {
+  std::lock_guard<std::mutex> lock(g_reg_mu);
+  for (auto& e : g_reg) {
+    (void)hipSetDevice(e.device);
+    (void)hipDeviceSynchronize();
+    if (e.g->table) (void)hipFree(e.g->table);
+    delete e.g;
+  }
+  g_reg.clear();
 }
 
 void vpin_gens_free(vpin_ctx* c, vpin_gens* g) {

@@ -25,7 +25,7 @@ struct SatGens {
   size_t ell = 0, L = 0, R = 0, nb = 0;
   std::vector<Point> g;  // generator stream g[0..nb)
   FixedBase fb[5];
-  vpin_gens* dev = nullptr;
+  const vpin_gens* dev = nullptr;  // shared per (device, label): vpin_gens_shared
   PcGens pc;                   // gens_pc (r1csproof.rs:76-89): fb_gR, fb_h, device table
   Mcg gens_1, gens_3, gens_4;  // R1CSSumcheckGens (r1csproof.rs:49-74); gens_1 also = gens_pc.gens.gens_1
 };
@@ -37,9 +37,7 @@ struct ProverCache {
 static void cache_free(vpin_ctx* c) {
   auto* pc = static_cast<ProverCache*>(c->prover_cache);
   if (!pc) return;
-  for (auto& kv : pc->by_nv)
-    if (kv.second->dev) vpin_gens_free(c, kv.second->dev);
-  delete pc;
+  delete pc;  // the device tables belong to the shared registry
   c->prover_cache = nullptr;
 }
 
@@ -67,9 +65,12 @@ static int get_gens(vpin_ctx* c, size_t num_vars, SatGens** out) {
   sg->gens_1 = sg->pc.gens_1;
   sg->gens_3 = Mcg{3, {&sg->fb[0], &sg->fb[1], &sg->fb[2], nullptr}, &sg->fb[3]};
   sg->gens_4 = Mcg{4, {&sg->fb[0], &sg->fb[1], &sg->fb[2], &sg->fb[3]}, &sg->fb[4]};
-  std::vector<uint8_t> xyzt(128 * sg->nb);
-  for (size_t i = 0; i < sg->nb; i++) sg->g[i].to_xyzt(xyzt.data() + 128 * i);
-  int rc = vpin_gens_create(c, xyzt.data(), sg->nb, &sg->dev);
+  int rc = vpin_gens_shared(c, "gens_r1cs_sat", nullptr, sg->nb, 0, &sg->dev);
+  if (rc == VPIN_EINVAL) {  // no table of this label covers nb generators yet: build one
+    std::vector<uint8_t> xyzt(128 * sg->nb);
+    for (size_t i = 0; i < sg->nb; i++) sg->g[i].to_xyzt(xyzt.data() + 128 * i);
+    rc = vpin_gens_shared(c, "gens_r1cs_sat", xyzt.data(), sg->nb, 0, &sg->dev);
+  }
   if (rc) return rc;
   sg->pc.dev = sg->dev;
   *out = sg.get();
@@ -463,6 +464,14 @@ int sat_prove_core(vpin_ctx* c, const vpin_r1cs_dev* dinst, size_t nv, size_t nc
 }  // namespace vpin_prover
 
 extern "C" {
+
+// R1CSGens::new for this polynomial size, ahead of the first proof (host fixed-base tables + the
+// shared device window table); proofs build them on demand otherwise
+int vpin_sat_prepare(vpin_ctx* c, size_t num_vars) {
+  if (!c || !vpin::is_pow2(num_vars)) return VPIN_EINVAL;
+  SatGens* sg = nullptr;
+  return get_gens(c, num_vars, &sg);
+}
 
 int vpin_sat_prove_resident(vpin_ctx* c, const vpin_r1cs_dev* dinst, const vpin_table* vars_para, const vpin_table* vars_input,
                             const vpin_table* vars, const uint8_t* inputs, const uint8_t seed_commit64[64],

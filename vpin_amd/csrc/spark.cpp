@@ -25,41 +25,51 @@ using namespace vpin_prover;
 // ---- generators: one stream under b"gens_r1cs_eval", three PolyCommitmentGens views -----------
 
 struct SparkGens {
-  size_t nb = 0;
-  std::vector<Point> g;
-  vpin_gens* dev = nullptr;
+  std::vector<Point> g;                              // host copy of the stream prefix derived so far
   std::map<size_t, std::unique_ptr<PcGens>> views;  // by num_vars of the committed polynomial
 };
 
 static void spark_cache_free(vpin_ctx* c) {
   auto* sg = static_cast<SparkGens*>(c->spark_cache);
   if (!sg) return;
-  if (sg->dev) vpin_gens_free(c, sg->dev);
-  delete sg;
+  delete sg;  // the device tables belong to the shared registry
   c->spark_cache = nullptr;
+}
+
+// table budget for the b"gens_r1cs_eval" stream: its largest user (the derefs commitment, 6N full-width
+// scalars per proof) is the single most expensive step of a SNARK, and every window bit saves ~8 % of
+// it, so on a 288 GB part the table gets up to 80 GB (11-bit windows for 32 770 generators)
+static size_t spark_budget_gb(vpin_ctx* c) {
+  static const size_t gb = [c] {
+    const char* e = getenv("VPIN_SPARK_GENS_BUDGET_GB");
+    if (e && atoi(e) > 0) return (size_t)atoi(e);
+    size_t free_b = 0, total_b = 0;
+    (void)hipSetDevice(c->device);
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return (size_t)24;
+    return total_b >= ((size_t)200 << 30) ? (size_t)80 : (size_t)24;
+  }();
+  return gb;
 }
 
 // PolyCommitmentGens::new(ell, b"gens_r1cs_eval") (dense_mlpoly.rs:26-33; lib.rs:315-321)
 static int get_view(vpin_ctx* c, size_t ell, const PcGens** out) {
   if (!c->spark_cache) { c->spark_cache = new SparkGens(); c->spark_cache_free = spark_cache_free; }
   auto* sg = static_cast<SparkGens*>(c->spark_cache);
-  const size_t left = ell / 2, R = (size_t)1 << (ell - left);
-  if (sg->nb < R + 2) {
-    // every MultiCommitGens::new(n, label) is a prefix of the same SHAKE stream: keep the longest
-    if (sg->dev) { vpin_gens_free(c, sg->dev); sg->dev = nullptr; }
-    sg->views.clear();
-    sg->nb = R + 2;
-    derive_gens(sg->g, sg->nb, "gens_r1cs_eval");
-    std::vector<uint8_t> xyzt(128 * sg->nb);
-#pragma omp parallel for schedule(static) num_threads(host_threads())
-    for (long i = 0; i < (long)sg->nb; i++) sg->g[i].to_xyzt(xyzt.data() + 128 * (size_t)i);
-    int rc = vpin_gens_create(c, xyzt.data(), sg->nb, &sg->dev);
-    if (rc) { sg->nb = 0; return rc; }
-  }
   auto it = sg->views.find(ell);
   if (it == sg->views.end()) {
+    const size_t left = ell / 2, R = (size_t)1 << (ell - left), nb = R + 2;
+    // every MultiCommitGens::new(n, label) is a prefix of the same SHAKE stream
+    if (sg->g.size() < nb) derive_gens(sg->g, nb, "gens_r1cs_eval");
     std::unique_ptr<PcGens> v(new PcGens());
-    v->ell = ell; v->L = (size_t)1 << left; v->R = R; v->dev = sg->dev;
+    v->ell = ell; v->L = (size_t)1 << left; v->R = R;
+    int rc = vpin_gens_shared(c, "gens_r1cs_eval", nullptr, nb, 0, &v->dev);
+    if (rc == VPIN_EINVAL) {
+      std::vector<uint8_t> xyzt(128 * nb);
+#pragma omp parallel for schedule(static) num_threads(host_threads())
+      for (long i = 0; i < (long)nb; i++) sg->g[i].to_xyzt(xyzt.data() + 128 * (size_t)i);
+      rc = vpin_gens_shared(c, "gens_r1cs_eval", xyzt.data(), nb, spark_budget_gb(c), &v->dev);
+    }
+    if (rc) return rc;
     v->fb_gR = FixedBase(sg->g[R]);
     v->fb_h = FixedBase(sg->g[R + 1]);
     v->bind_views();

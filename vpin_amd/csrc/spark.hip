@@ -20,6 +20,8 @@
 // sum_i E[i]*(A_x*B_x)[i] for x = 0,2,3 with E the read-only suffix table of the round, and the
 // host applies the per-round scalar.  Per pair: fold 2 tables (4 products), 3 products A_x*B_x,
 // 3 products by E: 10 Montgomery products, 9 loads, 4 stores.  HBM-streaming integer work.
+#include <cstdlib>
+
 #include "sc_dev.h"
 #include "spark_dev.h"
 
@@ -471,7 +473,8 @@ static int round_partials(vpin_ctx* c, fq** out) {
 }
 
 static inline int round_grid(size_t pairs) {
-  size_t b = (pairs + kBlock - 1) / kBlock;
+  static const size_t per_thread = [] { const char* e = getenv("VPIN_SPARK_PAIRS_PER_THREAD"); size_t v = e ? (size_t)atoi(e) : 2; return v ? v : 2; }();
+  size_t b = (pairs + kBlock * per_thread - 1) / (kBlock * per_thread);
   if (b < 1) b = 1;
   if (b > (size_t)kRoundBlocks) b = kRoundBlocks;
   return (int)b;

@@ -282,6 +282,23 @@ __global__ __launch_bounds__(kMsmBlock) void msm_wide_kernel(const fq* __restric
   }
 }
 
+// second stage for long rows: out[row][p] = sum of parts p, p+P, p+2P, ... of that row (frozen X|Y|Z|T)
+__global__ __launch_bounds__(64) void parts_reduce_kernel(const fp* __restrict__ in, size_t rows, size_t nraw, int P,
+                                                          fp* __restrict__ out) {
+  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= rows * (size_t)P) return;
+  const size_t row = t / P, p = t % P;
+  ge_ext acc = ge_identity();
+  for (size_t k = p; k < nraw; k += P) {
+    const fp* q = in + 4 * (row * nraw + k);
+    ge_ext e;
+    e.X = fp_load(q); e.Y = fp_load(q + 1); e.Z = fp_load(q + 2); e.T = fp_load(q + 3);
+    acc = ge_add(acc, e);
+  }
+  fp* o = out + 4 * t;
+  fp_store(o, fp_freeze(acc.X)); fp_store(o + 1, fp_freeze(acc.Y)); fp_store(o + 2, fp_freeze(acc.Z)); fp_store(o + 3, fp_freeze(acc.T));
+}
+
 // out[i] = s_i * g[base] for n scalars (the blind terms of the row commitments): 8 threads per
 // scalar, ceil(W/8) windows each, 3-level LDS tree -- one wave handles 8 scalars
 __global__ __launch_bounds__(64) void single_base_mul_kernel(const fq* __restrict__ S, size_t n, TableView tv, size_t base,
@@ -547,24 +564,34 @@ int vpin_hyrax_commit_pair(vpin_ctx* c, const vpin_gens* g, const vpin_table* Za
 }
 
 // partial points of few-row MSMs: parts_xyzt must hold rows * vpin_gens_msm_parts_count(ncols) * 128 bytes
-size_t vpin_gens_msm_parts_count(size_t ncols) { return (ncols + kWideScalars - 1) / kWideScalars; }
+// at most kMaxParts per row: longer rows get a second, on-device summation stage (the host would
+// otherwise add a thousand points per row for the 32k-generator evaluation proofs)
+constexpr size_t kMaxParts = 32;
+static inline size_t raw_parts(size_t ncols) { return (ncols + kWideScalars - 1) / kWideScalars; }
+size_t vpin_gens_msm_parts_count(size_t ncols) { size_t n = raw_parts(ncols); return n < kMaxParts ? n : kMaxParts; }
 
 int vpin_gens_msm_parts(vpin_ctx* c, const vpin_gens* g, const uint8_t* scalars_mont, size_t rows, size_t ncols,
                         uint8_t* parts_xyzt) {
   if (!c || !g || !scalars_mont || !parts_xyzt || rows == 0 || ncols == 0) return VPIN_EINVAL;
   if (ncols > g->nb) return VPIN_ESHAPE;
   (void)hipSetDevice(c->device);
-  const size_t nparts = vpin_gens_msm_parts_count(ncols);
-  DevBuf ds(c), dp(c);
-  if (ds.alloc(rows * ncols * 32) || dp.alloc(rows * nparts * 128)) return VPIN_ENOMEM;
+  const size_t nraw = raw_parts(ncols), nparts = vpin_gens_msm_parts_count(ncols);
+  DevBuf ds(c), dp(c), dr(c);
+  if (ds.alloc(rows * ncols * 32) || dp.alloc(rows * nraw * 128) || (nraw > nparts && dr.alloc(rows * nparts * 128))) return VPIN_ENOMEM;
   VPIN_HIP_TRY(hipMemcpyAsync(ds.p, scalars_mont, rows * ncols * 32, hipMemcpyHostToDevice, c->stream));
   {
     ProfScope ps(c, VPIN_K_MSM, 32.0 * (double)rows * (double)ncols);
-    hipLaunchKernelGGL(msm_wide_kernel, dim3((unsigned)nparts, (unsigned)rows), dim3(kMsmBlock), 0, c->stream, (const fq*)ds.p,
+    hipLaunchKernelGGL(msm_wide_kernel, dim3((unsigned)nraw, (unsigned)rows), dim3(kMsmBlock), 0, c->stream, (const fq*)ds.p,
                        ncols, view(g), (fp*)dp.p);
   }
+  const void* src = dp.p;
+  if (nraw > nparts) {
+    hipLaunchKernelGGL(parts_reduce_kernel, dim3((unsigned)((rows * nparts + 63) / 64)), dim3(64), 0, c->stream, (const fp*)dp.p, rows,
+                       nraw, (int)nparts, (fp*)dr.p);
+    src = dr.p;
+  }
   VPIN_HIP_TRY(hipGetLastError());
-  VPIN_HIP_TRY(hipMemcpyAsync(parts_xyzt, dp.p, rows * nparts * 128, hipMemcpyDeviceToHost, c->stream));
+  VPIN_HIP_TRY(hipMemcpyAsync(parts_xyzt, src, rows * nparts * 128, hipMemcpyDeviceToHost, c->stream));
   VPIN_HIP_TRY(hipStreamSynchronize(c->stream));
   return VPIN_OK;
 }

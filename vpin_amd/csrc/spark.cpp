@@ -14,6 +14,8 @@
 // The gathers, the hash layer, the product trees, every sum-check round, the slice evaluations and the
 // commitments run in spark.hip / msm.hip / poly.hip; this file owns the transcript, the per-round
 // scalars and the bincode image.  It shares no code with the test-side checker.
+#include <cstdio>
+
 #include "host/prover_common.h"
 #include "spark_dev.h"
 
@@ -21,6 +23,14 @@ namespace {
 
 using namespace vpin_host;
 using namespace vpin_prover;
+
+// VPIN_SPARK_TRACE=1: finer spans of one proof on stderr (development aid)
+static bool spark_trace() { static const bool on = getenv("VPIN_SPARK_TRACE") != nullptr; return on; }
+struct TraceSpan {
+  const char* name; Clock::time_point t0;
+  explicit TraceSpan(const char* n) : name(n), t0(Clock::now()) {}
+  ~TraceSpan() { if (spark_trace()) fprintf(stderr, "[spark] %-28s %8.3f ms\n", name, secs(t0, Clock::now()) * 1e3); }
+};
 
 // ---- generators: one stream under b"gens_r1cs_eval", three PolyCommitmentGens views -----------
 
@@ -139,8 +149,13 @@ static int polyeval_prove_plain(vpin_ctx* c, const PcGens& pc, const vpin_table*
   std::vector<Fq> Lv(pc.L), Rv(pc.R), LZ(pc.R);
   host_eq(r.data(), left, Lv.data());
   host_eq(r.data() + left, right, Rv.data());
-  int rc = vpin_poly_bound(c, Z, B(Lv.data()), pc.L, B(LZ.data()));
+  int rc;
+  {
+    TraceSpan ts("  poly_bound");
+    rc = vpin_poly_bound(c, Z, B(Lv.data()), pc.L, B(LZ.data()));
+  }
   if (rc) return rc;
+  TraceSpan ts("  dplog");
   return dplog_prove(c, pc, tr, tape, LZ, Fq::zero(), Rv, Zr, Fq::zero(), out);
 }
 
@@ -424,21 +439,33 @@ static int spark_prove(vpin_ctx* c, const vpin_spark_decomm* d, const std::vecto
   }
   Batched pf_ops, pf_mem;
   std::vector<Fq> rand_ops, rand_mem;
-  if ((rc = batched_prove(c, f_ops, &dotp, tr, pf_ops, rand_ops))) return rc;
-  if ((rc = batched_prove(c, f_mem, nullptr, tr, pf_mem, rand_mem))) return rc;
+  {
+    TraceSpan ts("product: ops forest");
+    if ((rc = batched_prove(c, f_ops, &dotp, tr, pf_ops, rand_ops))) return rc;
+  }
+  {
+    TraceSpan ts("product: mem forest");
+    if ((rc = batched_prove(c, f_mem, nullptr, tr, pf_mem, rand_mem))) return rc;
+  }
   g_spark_timings[3] = secs(t0, Clock::now());
 
   // ---- HashLayerProof::prove (:740-849) ----
   t0 = Clock::now();
   tr.append_protocol_name("Sparse polynomial hash layer proof");
   vpin_table *eq_ops = nullptr, *eq_mem = nullptr;
-  if ((rc = vpin_eq_table(c, B(rand_ops.data()), (int)lgN, &eq_ops))) return rc;
-  tg.add(eq_ops);
-  if ((rc = vpin_eq_table(c, B(rand_mem.data()), (int)lgM, &eq_mem))) return rc;
-  tg.add(eq_mem);
+  {
+    TraceSpan ts("hash: eq tables");
+    if ((rc = vpin_eq_table(c, B(rand_ops.data()), (int)lgN, &eq_ops))) return rc;
+    tg.add(eq_ops);
+    if ((rc = vpin_eq_table(c, B(rand_mem.data()), (int)lgM, &eq_mem))) return rc;
+    tg.add(eq_mem);
+  }
   Fq ev_derefs[6], ev_ops[15], ev_mem[2];
   const Fq* hs = reinterpret_cast<const Fq*>(c->h_spark);
-  if ((rc = vpin::spark_slice_evals(c, comb->d, N, 6, eq_ops->d))) return rc;
+  {
+    TraceSpan ts("hash: derefs slice evals");
+    if ((rc = vpin::spark_slice_evals(c, comb->d, N, 6, eq_ops->d))) return rc;
+  }
   for (int i = 0; i < 6; i++) ev_derefs[i] = hs[3 * i];
   DpLog pe_derefs, pe_ops, pe_mem;
   {
@@ -452,12 +479,16 @@ static int spark_prove(vpin_ctx* c, const vpin_spark_decomm* d, const std::vecto
     std::vector<Fq> rj(ch);
     rj.insert(rj.end(), rand_ops.begin(), rand_ops.end());
     tr.append_scalar("joint_claim_eval", joint);
+    TraceSpan ts("hash: polyeval derefs");
     if ((rc = polyeval_prove_plain(c, *g_derefs, comb, rj, joint, tr, tape, pe_derefs))) return rc;
   }
-  if ((rc = vpin::spark_slice_evals(c, d->comb_ops->d, N, 15, eq_ops->d))) return rc;
-  for (int i = 0; i < 15; i++) ev_ops[i] = hs[3 * i];
-  if ((rc = vpin::spark_slice_evals(c, d->comb_mem->d, M, 2, eq_mem->d))) return rc;
-  for (int i = 0; i < 2; i++) ev_mem[i] = hs[3 * i];
+  {
+    TraceSpan ts("hash: ops+mem slice evals");
+    if ((rc = vpin::spark_slice_evals(c, d->comb_ops->d, N, 15, eq_ops->d))) return rc;
+    for (int i = 0; i < 15; i++) ev_ops[i] = hs[3 * i];
+    if ((rc = vpin::spark_slice_evals(c, d->comb_mem->d, M, 2, eq_mem->d))) return rc;
+    for (int i = 0; i < 2; i++) ev_mem[i] = hs[3 * i];
+  }
   {
     std::vector<Fq> e16(16, Fq::zero());
     for (int i = 0; i < 15; i++) e16[i] = ev_ops[i];  // row addr, row read_ts, col addr, col read_ts, val (comb_ops order)
@@ -467,6 +498,7 @@ static int spark_prove(vpin_ctx* c, const vpin_spark_decomm* d, const std::vecto
     std::vector<Fq> rj(ch);
     rj.insert(rj.end(), rand_ops.begin(), rand_ops.end());
     tr.append_scalar("joint_claim_eval_ops", joint);
+    TraceSpan ts("hash: polyeval ops");
     if ((rc = polyeval_prove_plain(c, *g_ops, d->comb_ops, rj, joint, tr, tape, pe_ops))) return rc;
   }
   {
@@ -477,6 +509,7 @@ static int spark_prove(vpin_ctx* c, const vpin_spark_decomm* d, const std::vecto
     std::vector<Fq> rj(ch);
     rj.insert(rj.end(), rand_mem.begin(), rand_mem.end());
     tr.append_scalar("joint_claim_eval_mem", joint);
+    TraceSpan ts("hash: polyeval mem");
     if ((rc = polyeval_prove_plain(c, *g_mem, d->comb_mem, rj, joint, tr, tape, pe_mem))) return rc;
   }
   g_spark_timings[4] = secs(t0, Clock::now());

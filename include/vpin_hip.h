@@ -37,6 +37,7 @@ extern "C" {
 #define VPIN_ENOMEM (-3)  /* device or host allocation failed */
 #define VPIN_EHIP (-4)    /* a HIP runtime call failed; see vpin_last_error() */
 #define VPIN_ESHAPE (-5)  /* operand shapes do not match (the reference would assert) */
+#define VPIN_EVERIFY (-6) /* a verifier rejected the proof (ProofVerifyError / a failed assert in the reference) */
 
 typedef struct vpin_ctx vpin_ctx;
 typedef struct vpin_table vpin_table;
@@ -258,6 +259,17 @@ int vpin_snark_prove(vpin_ctx* ctx, const vpin_r1cs* inst, const uint8_t* vars_p
                      const uint8_t seed_proof64[64], uint8_t* proof_out, size_t proof_cap, size_t* proof_len,
                      uint8_t* comm_out, size_t comm_cap, size_t* comm_len, uint8_t* comm_para_out,
                      uint8_t* comm_input_out);
+/* Verifiers (host C++; the evaluation proofs' fixed-base MSMs run on the device tables).  VPIN_OK = accept,
+ * VPIN_EVERIFY = reject.
+ * vpin_sat_verify   = my_r1csproof_verify (vPIN_proof_generation/src/commit_test.rs:340-496) with claimed inst_evals;
+ * vpin_snark_verify = my_lib_verify (commit_test.rs:498-548): sat part, inst_evals, R1CSEvalProof::verify
+ *                     (Spartan/src/r1csinstance.rs:356-372 -> sparse_mlpoly.rs:1535-1571) against
+ *                     comm = bincode(R1CSCommitment) from vpin_spark_encode. */
+int vpin_sat_verify(vpin_ctx* ctx, const uint8_t* proof, size_t proof_len, size_t num_cons, size_t num_vars,
+                    const uint8_t* inputs, size_t num_inputs, const uint8_t inst_evals[96], const uint8_t* comm_para,
+                    const uint8_t* comm_input);
+int vpin_snark_verify(vpin_ctx* ctx, const uint8_t* proof, size_t proof_len, const uint8_t* comm, size_t comm_len,
+                      const uint8_t* inputs, size_t num_inputs, const uint8_t* comm_para, const uint8_t* comm_input);
 /* wall-clock spans of the last encode / snark prove on this thread, seconds: [0] encode
  * [1] derefs + commit  [2] network build  [3] product-layer proofs  [4] hash-layer proofs
  * [5] sat part  [6] whole prove  [7] unused */

@@ -66,6 +66,7 @@ def test_cli_proof_matches_oracle(built, tmp_path):
     assert "Point Multiplication Gadget..." in lines and "Number of Point Multiplications: 1" in lines
     assert "Generating Proof..." in lines and "Still working on..." in lines
     assert any(l.startswith("Total proof size: ") for l in lines)
+    assert lines.count("Proof verification successful!") == 2 and any(l.startswith("Proof verification time: ") for l in lines)
     for name, g in (("add", GM.build_point_add(add_ops)), ("mult", GM.build_point_mult(mult_ops))):
         inst = GM.instance_new(g)
         exp = O.snark_prove(inst, seed_c, seed_p)  # the CLI proves the whole SNARK, like the reference binary

@@ -67,3 +67,40 @@ def test_point_mult_snark(ctx):
 def test_point_mult_two_ops_snark(ctx):
     inst = GM.instance_new(GM.build_point_mult(GM.synthetic_mult_ops(0x5650494E + 3, 2, weights=[5, (1 << 200) + 77])))
     check(ctx, inst)
+
+
+def test_product_verifier_accepts_and_rejects(ctx):
+    """vpin_snark_verify / vpin_sat_verify (my_lib_verify / my_r1csproof_verify in the product) accept the
+    library's and the oracle's proofs and reject tampering in every section, like the oracle's verifier"""
+    inst = GM.instance_new(GM.build_point_add(GM.synthetic_add_ops(0x5650494E + 5, 64, rz_one_every=3)))
+    got = ctx.snark_prove(inst, SEED_C, SEED_P)
+    assert ctx.snark_verify(inst, got)
+    exp = O.snark_prove(inst, SEED_C, SEED_P)
+    assert ctx.snark_verify(inst, exp)
+    sat = ctx.sat_prove(inst, SEED_C, SEED_P)
+    assert ctx.sat_verify(inst, sat)
+    n_sat, p = len(sat["proof"]), got["proof"]
+    for pos in (10, n_sat // 2, n_sat + 5, n_sat + 96 + 20, n_sat + 96 + 8 + 32 * 8 + 40, (n_sat + len(p)) // 2, len(p) - 2000, len(p) - 40):
+        bad = bytearray(p)
+        bad[pos] ^= 1
+        assert not ctx.snark_verify(inst, got, proof=bytes(bad)), pos
+        assert O.snark_verify(inst, got, proof=bytes(bad)) == 0, pos
+    badc = bytearray(got["comm"])
+    badc[-7] ^= 1
+    assert not ctx.snark_verify(inst, got, comm=bytes(badc))
+    assert not ctx.snark_verify(inst, got, proof=p[:-1])
+    bad = bytearray(sat["proof"])
+    bad[len(bad) // 3] ^= 4
+    assert not ctx.sat_verify(inst, sat, proof=bytes(bad))
+    other = dict(got)
+    cp = got["comm_para"].copy()
+    cp[0], cp[1] = got["comm_para"][1].copy(), got["comm_para"][0].copy()
+    other["comm_para"] = cp
+    assert not ctx.snark_verify(inst, other)
+
+
+def test_product_verifier_mult(ctx):
+    inst = GM.instance_new(GM.build_point_mult(GM.synthetic_mult_ops(0x5650494E + 2, 1, weights=[(1 << 127) + 12345])))
+    got = ctx.snark_prove(inst, SEED_C, SEED_P)
+    assert ctx.snark_verify(inst, got)
+    assert ctx.snark_verify(inst, O.snark_prove(inst, SEED_C, bytes(64)))

@@ -135,6 +135,8 @@ def lib():
     L.vpin_spark_decomm_free.argtypes = [vp, vp]
     L.vpin_snark_prove_resident.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_size_t, C.POINTER(C.c_size_t), vp, vp]
     L.vpin_snark_prove.argtypes = [vp] * 9 + [C.c_size_t, C.POINTER(C.c_size_t), vp, C.c_size_t, C.POINTER(C.c_size_t), vp, vp]
+    L.vpin_sat_verify.argtypes = [vp, vp, C.c_size_t, C.c_size_t, C.c_size_t, vp, C.c_size_t, vp, vp, vp]
+    L.vpin_snark_verify.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, vp, C.c_size_t, vp, vp]
     L.vpin_spark_last_timings.restype = None
     L.vpin_spark_last_timings.argtypes = [C.POINTER(C.c_double)]
     L.vpin_sat_last_timings.restype = None
@@ -492,6 +494,30 @@ class Context:
             dinst.free()
         res["comm"] = comm
         return res
+
+    def snark_verify(self, inst, res, proof=None, comm=None):
+        """my_lib_verify: True = accept, False = rejected by the verifier."""
+        pb = np.frombuffer(proof if proof is not None else res["proof"], dtype=np.uint8).copy()
+        cb = np.frombuffer(comm if comm is not None else res["comm"], dtype=np.uint8).copy()
+        inp = np.ascontiguousarray(inst["inputs"], dtype=np.uint64)
+        p = lambda a: a.ctypes.data_as(C.c_void_p)
+        rc = lib().vpin_snark_verify(self.h, p(pb), len(pb), p(cb), len(cb), p(inp) if inp.size else None, inst["num_inputs"],
+                                     p(np.ascontiguousarray(res["comm_para"])), p(np.ascontiguousarray(res["comm_input"])))
+        if rc not in (0, -6):
+            _chk(rc, "vpin_snark_verify")
+        return rc == 0
+
+    def sat_verify(self, inst, res, proof=None):
+        pb = np.frombuffer(proof if proof is not None else res["proof"], dtype=np.uint8).copy()
+        inp = np.ascontiguousarray(inst["inputs"], dtype=np.uint64)
+        ev = np.ascontiguousarray(res["inst_evals"], dtype=np.uint64)
+        p = lambda a: a.ctypes.data_as(C.c_void_p)
+        rc = lib().vpin_sat_verify(self.h, p(pb), len(pb), inst["num_cons"], inst["num_vars"], p(inp) if inp.size else None,
+                                   inst["num_inputs"], p(ev), p(np.ascontiguousarray(res["comm_para"])),
+                                   p(np.ascontiguousarray(res["comm_input"])))
+        if rc not in (0, -6):
+            _chk(rc, "vpin_sat_verify")
+        return rc == 0
 
     @staticmethod
     def spark_timings():

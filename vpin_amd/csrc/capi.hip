@@ -91,6 +91,7 @@ const char* vpin_strerror(int code) {
     case VPIN_ENOMEM: return "out of memory";
     case VPIN_EHIP: return "HIP runtime error";
     case VPIN_ESHAPE: return "operand shapes do not match";
+    case VPIN_EVERIFY: return "proof rejected by the verifier";
     default: return "unknown error";
   }
 }

@@ -171,6 +171,18 @@ Result prove(vpin_ctx* ctx, vpin_instance* inst, const uint8_t seeds[128], const
   printf("Proof size: %zu bytes\n", len);
   res.gen_ms = ms_since(t0);
   printf("Proof generation time: %lld ms\n", res.gen_ms);
+  {
+    // proof_point_mult.rs:103-111: verify in-process, assert, report
+    auto t1 = Clock::now();
+    int vrc = g_sat_only ? vpin_sat_verify(ctx, proof.data(), len, r->num_cons, r->num_vars, vpin_instance_inputs(inst), r->num_inputs,
+                                           ev.data(), cp.data(), ci.data())
+                         : vpin_snark_verify(ctx, proof.data(), len, comm.data(), comm_len, vpin_instance_inputs(inst), r->num_inputs,
+                                             cp.data(), ci.data());
+    if (vrc != 0) die(std::string("assertion failed: proof verification: ") + vpin_strerror(vrc));
+    printf("Proof verification successful!\n");
+    res.ver_ms = ms_since(t1);
+    printf("Proof verification time: %lld ms\n", res.ver_ms);
+  }
   if (!dump_prefix.empty()) {
     std::ofstream(dump_prefix + ".proof", std::ios::binary).write((const char*)proof.data(), (std::streamsize)len);
     std::ofstream(dump_prefix + ".comm_para", std::ios::binary).write((const char*)cp.data(), (std::streamsize)cp.size());
@@ -206,8 +218,8 @@ int main(int argc, char** argv) {
     std::random_device rd;
     for (auto& b : seeds) b = (uint8_t)rd();
   }
-  fprintf(stderr, g_sat_only ? "vpin_prove: R1CS satisfiability proof only (--sat-only); proofs are not verified in-process\n"
-                             : "vpin_prove: whole SNARK (sat proof + SPARK evaluation proof); proofs are not verified in-process\n");
+  fprintf(stderr, g_sat_only ? "vpin_prove: R1CS satisfiability proof only (--sat-only)\n"
+                             : "vpin_prove: whole SNARK (sat proof + SPARK evaluation proof)\n");
 
   printf("network: %s\n", network.c_str());
   vpin_ctx* ctx = nullptr;

@@ -11,7 +11,7 @@
 //   Spartan/src/sparse_mlpoly.rs:160-214,851-1032,1229-1322,1372-1434,1535-1571   SPARK verifiers
 //   Spartan/src/product_tree.rs:387-485               ProductCircuitEvalProofBatched::verify
 // It exists so that `vpin_prove` can close the reference binary's loop ("Proof verification
-// successful!"); it shares no code with the test-side checker under oracle/.
+// successful!"); it shares no code with the test-side checker.
 #include "host/prover_common.h"
 
 namespace {

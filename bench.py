@@ -114,7 +114,10 @@ def main():
         # alone, the other point-mult instances, the point-add instances; lanes 1 and 2 start when the
         # largest instance's sat part is done, so its sum-check kernels are timed undisturbed
         lanes = [mults[:1], mults[1:], adds]
-    ctxs = [vpin_amd.Context(local_rank) for _ in lanes]
+    # the lanes of small, latency-bound instances get high-priority streams: their one-workgroup round
+    # kernels are then dispatched ahead of the large instance's queued workgroups instead of behind them
+    prios = [0] + [-1] * (len(lanes) - 1) if not os.environ.get("VPIN_BENCH_NO_PRIO") else [0] * len(lanes)
+    ctxs = [vpin_amd.Context(local_rank, priority=prios[li]) for li in range(len(lanes))]
 
     def barrier():
         torch.cuda.synchronize()

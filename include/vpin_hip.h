@@ -50,6 +50,9 @@ int vpin_abi_version(void);
 
 /* ---- context ------------------------------------------------------------------- */
 int vpin_ctx_create(int device, vpin_ctx** out);
+/* Same with a stream priority: < 0 high (its kernels are dispatched ahead of other streams' queued
+ * workgroups), 0 normal, > 0 low.  For running latency-bound small proofs beside a large one. */
+int vpin_ctx_create_prio(int device, int priority, vpin_ctx** out);
 void vpin_ctx_destroy(vpin_ctx* ctx);
 /* hipStream_t the ctx launches on (as void*), for callers that time with HIP events */
 void* vpin_ctx_stream(vpin_ctx* ctx);

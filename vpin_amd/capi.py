@@ -74,6 +74,7 @@ def lib():
     L.vpin_last_error.restype = C.c_char_p
     L.vpin_abi_version.restype = C.c_int
     L.vpin_ctx_create.argtypes = [C.c_int, C.POINTER(vp)]
+    L.vpin_ctx_create_prio.argtypes = [C.c_int, C.c_int, C.POINTER(vp)]
     L.vpin_ctx_destroy.argtypes = [vp]
     L.vpin_ctx_destroy.restype = None
     L.vpin_ctx_stream.argtypes = [vp]
@@ -247,9 +248,10 @@ class Gens:
 
 
 class Context:
-    def __init__(self, device=0):
+    def __init__(self, device=0, priority=0):
+        """priority < 0: high-priority stream (latency-bound small proofs beside a large one); > 0: low."""
         self.h = C.c_void_p()
-        _chk(lib().vpin_ctx_create(device, C.byref(self.h)), "vpin_ctx_create")
+        _chk(lib().vpin_ctx_create_prio(device, priority, C.byref(self.h)), "vpin_ctx_create_prio")
 
     def close(self):
         if self.h:

@@ -100,7 +100,12 @@ const char* vpin_last_error(void) { return g_last_error.c_str(); }
 
 int vpin_abi_version(void) { return 1; }
 
-int vpin_ctx_create(int device, vpin_ctx** out) {
+static int ctx_create(int device, int priority, vpin_ctx** out);
+
+int vpin_ctx_create(int device, vpin_ctx** out) { return ctx_create(device, 0, out); }
+int vpin_ctx_create_prio(int device, int priority, vpin_ctx** out) { return ctx_create(device, priority, out); }
+
+static int ctx_create(int device, int priority, vpin_ctx** out) {
   if (!out) return VPIN_EINVAL;
   // host OpenMP teams must wait passively (see prover.cpp host_threads); set before the runtime starts
   setenv("KMP_BLOCKTIME", "0", 0);
@@ -115,7 +120,12 @@ int vpin_ctx_create(int device, vpin_ctx** out) {
   c->device = device;
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->num_cus = prop.multiProcessorCount;
-  hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+  // priority: < 0 = scheduled ahead of normal streams (for latency-bound proofs of small instances that
+  // share the device with a large one), > 0 = behind them; clamped to the device's range
+  int lo = 0, hi = 0;  // numerically: hi <= 0 <= lo
+  (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+  int prio = priority < 0 ? hi : priority > 0 ? lo : 0;
+  hipError_t e = hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio);
   if (e != hipSuccess) { set_last_error("hipStreamCreate", e); delete c; return VPIN_EHIP; }
   c->partials_cap = 8192 * 4;
   if (hipMalloc(&c->d_partials, c->partials_cap * sizeof(fq)) != hipSuccess ||

@@ -67,6 +67,7 @@ def parse():
     ap.add_argument("--snark", action="store_true", help="(default) whole SNARK: sat proof + inst_evals + SPARK R1CSEvalProof, "
                     "my_lib_prove in full; SNARK::encode runs once per instance before the timed region and is reported beside it")
     ap.add_argument("--only", choices=["mult", "add"], default=None, help="keep only the point-mult / point-add instances of the trace")
+    ap.add_argument("--no-verify", action="store_true", help="skip the post-run verification of the last step's SNARKs")
     ap.add_argument("--no-prof", action="store_true", help="no HIP-event bracketing of kernels (no roofline object)")
     ap.add_argument("--pmc-traffic", type=float, default=None,
                     help="HBM bytes per launch of the roofline kernel from a separate rocprofv3 --pmc pass")
@@ -126,7 +127,7 @@ def main():
 
     # instance + the three assignments resident in HBM before the timed region (the PCIe-inclusive
     # variant is vpin_sat_prove / --host-buffers; its rate is noted in DESIGN.md)
-    resident, dicts, decomms, encode_ms, comm_bytes = {}, {}, {}, {}, {}
+    resident, dicts, decomms, encode_ms, comm_bytes, verify_meta, last_proof = {}, {}, {}, {}, {}, {}, {}
     t0 = time.perf_counter()
     for li, lane in enumerate(lanes):
         for name, _, inst in lane:
@@ -148,6 +149,7 @@ def main():
                 decomms[name], comm = cx.spark_encode(d)
                 encode_ms[name] = round((time.perf_counter() - te) * 1e3, 3)
                 comm_bytes[name] = len(comm)
+                verify_meta[name] = (comm, {"inputs": d["inputs"], "num_inputs": d["num_inputs"]})
             inst.free()
     upload_s = time.perf_counter() - t0
     lane_names = [[w[0] for w in lane] for lane in lanes]
@@ -165,6 +167,7 @@ def main():
             r = cx.snark_prove_resident(di, decomms[name], tp, ti, tv, inp, SEED_C, SEED_P)
             last_spans[name] = dict(cx.sat_timings(), **{"spark_" + k: v for k, v in cx.spark_timings().items() if k != "_"})
             proof_bytes[name] = len(r["proof"])
+            last_proof[name] = r
             return len(r["proof"])
         if args.host_buffers:
             r = cx.sat_prove(dicts[name], SEED_C, SEED_P)
@@ -308,6 +311,18 @@ def main():
     if args.snark:
         line["encode_ms"] = encode_ms
         line["comm_bytes"] = comm_bytes
+        if not args.no_verify:
+            # after the timed region: every proof of the last step through the product's verifier
+            # (my_lib_verify: vpin_snark_verify), at full size
+            tv = time.perf_counter()
+            verified = {}
+            for li, names in enumerate(lane_names):
+                for name in names:
+                    comm, meta = verify_meta[name]
+                    verified[name] = bool(ctxs[li].snark_verify(meta, dict(last_proof[name], comm=comm)))
+            line["verified"] = verified
+            line["verify_s"] = round(time.perf_counter() - tv, 2)
+            assert all(verified.values()), verified
 
     # ---- CPU baseline: the oracle on a bounded sample, rank 0, N=1 only ----
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

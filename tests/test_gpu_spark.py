@@ -104,3 +104,19 @@ def test_product_verifier_mult(ctx):
     got = ctx.snark_prove(inst, SEED_C, SEED_P)
     assert ctx.snark_verify(inst, got)
     assert ctx.snark_verify(inst, O.snark_prove(inst, SEED_C, bytes(64)))
+
+
+def test_mid_size_snark_verifies_with_both_verifiers(ctx):
+    """64 point-mults (221,696 constraints, N = 2^19): the sizes at which the round kernels run multi-block
+    with several pairs per thread, the forests have 19 layers and the SPARK generators use wide windows.
+    The proof must pass the product's verifier AND the oracle's (independent code), and tampering must fail."""
+    from vpin_amd import gadgets as G
+    inst = G.synthetic_mult_instance("A", 64)
+    d = inst.as_dict()
+    inst.free()
+    got = ctx.snark_prove(d, SEED_C, SEED_P)
+    assert ctx.snark_verify(d, got)
+    assert O.snark_verify(d, got) == 1
+    bad = bytearray(got["proof"])
+    bad[len(bad) * 2 // 3] ^= 0x10
+    assert not ctx.snark_verify(d, got, proof=bytes(bad))

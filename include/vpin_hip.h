@@ -304,6 +304,43 @@ int vpin_instance_is_sat(const vpin_instance* g);
  * curve E2 (src/convolution/Client.py:134-143), k from SplitMix64(seed); 32-byte LE x and y */
 int vpin_synthetic_points(uint64_t seed, size_t count, uint8_t* out_x, uint8_t* out_y);
 
+/* ---- gadgets built on the device ---------------------------------------------------------------
+ * The same two gadgets with the instance never existing on the host: per-operation template replicated by
+ * kernels into CSR/CSC, witness synthesis (one thread per operation), Instance::new's padding and column
+ * remap, is_sat, and SNARK::encode's dense representation (addresses, read/audit timestamps) in closed form.
+ * Replaces, inside the reference's timed span (proof_point_mult.rs:24-101): point_mult.rs:61-704,
+ * point_addition.rs:67-327, Spartan/src/lib.rs:138-244, r1csinstance.rs:240-270, sparse_mlpoly.rs:232-265,368-438.
+ * Results are bit-identical to vpin_gadget_point_* + vpin_r1cs_upload + vpin_spark_encode on the same inputs. */
+typedef struct vpin_dev_instance vpin_dev_instance;
+int vpin_gadget_point_add_dev(vpin_ctx* ctx, const uint8_t* px, const uint8_t* py, const uint8_t* rx, const uint8_t* ry,
+                              const uint8_t* rz, size_t N, vpin_dev_instance** out);
+int vpin_gadget_point_mult_dev(vpin_ctx* ctx, const uint8_t* weights_le16, const uint8_t* px, const uint8_t* py, size_t N,
+                               vpin_dev_instance** out);
+void vpin_dev_instance_free(vpin_ctx* ctx, vpin_dev_instance* g);
+const vpin_r1cs_dev* vpin_dev_instance_r1cs(const vpin_dev_instance* g);
+const vpin_table* vpin_dev_instance_vars_para(const vpin_dev_instance* g);
+const vpin_table* vpin_dev_instance_vars_input(const vpin_dev_instance* g);
+const vpin_table* vpin_dev_instance_vars(const vpin_dev_instance* g);
+const uint8_t* vpin_dev_instance_inputs(const vpin_dev_instance* g); /* host bytes, num_inputs x 32 B or NULL */
+size_t vpin_dev_instance_num_cons_unpadded(const vpin_dev_instance* g);
+size_t vpin_dev_instance_num_vars_unpadded(const vpin_dev_instance* g);
+size_t vpin_dev_instance_nnz(const vpin_dev_instance* g, int m);
+/* push-order triplets of matrix m (0 = A, 1 = B, 2 = C) after Instance::new's column remap, copied to the host */
+int vpin_dev_instance_triplets(vpin_ctx* ctx, const vpin_dev_instance* g, int m, uint32_t* row_out, uint32_t* col_out,
+                               uint8_t* val_out /* nnz x 32 B */);
+/* R1CSInstance::is_sat on the device: 1 satisfied, 0 not, < 0 error */
+int vpin_dev_instance_is_sat(vpin_ctx* ctx, const vpin_dev_instance* g);
+/* SNARK::encode for a device-built instance (same outputs as vpin_spark_encode) */
+int vpin_spark_encode_dev(vpin_ctx* ctx, const vpin_dev_instance* g, vpin_spark_decomm** out, uint8_t* comm_out,
+                          size_t comm_cap, size_t* comm_len);
+size_t vpin_dev_instance_comm_bytes(const vpin_dev_instance* g);
+size_t vpin_dev_instance_proof_max_bytes(const vpin_dev_instance* g);
+/* proof_point_mult.rs:38-94 for a device-built instance: SNARK::encode + my_lib_prove in full */
+int vpin_snark_prove_dev(vpin_ctx* ctx, const vpin_dev_instance* g, const uint8_t seed_commit64[64],
+                         const uint8_t seed_proof64[64], uint8_t* proof_out, size_t proof_cap, size_t* proof_len,
+                         uint8_t* comm_out, size_t comm_cap, size_t* comm_len, uint8_t* comm_para_out,
+                         uint8_t* comm_input_out);
+
 /* ---- host-only entry points (no GPU needed) -------------------------------------------- */
 /* MultiCommitGens::new (Spartan/src/commitments.rs:20-38): first nb points of the stream */
 int vpin_host_gens_derive(const char* label, size_t nb, uint8_t* out_xyzt /* nb*128 */);

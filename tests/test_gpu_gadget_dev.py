@@ -1,0 +1,178 @@
+"""GPU parity for the gadgets built on the device (vpin_gadget_point_*_dev): the R1CS triplets, the padded
+assignments, is_sat, the computation commitment and the whole SNARK must be bit-identical to what the
+Python model of the reference's gadgets (tests/gadgets_model.py: VP/point_addition.rs, VP/point_mult.rs,
+Instance::new) and the CPU oracle produce from the same witness inputs."""
+import numpy as np
+import pytest
+
+import gadgets_model as GM
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+SEED_C = bytes(range(64))
+SEED_P = bytes((11 * i + 5) % 256 for i in range(64))
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import vpin_amd
+    c = vpin_amd.Context(0)
+    yield c
+    c.close()
+
+
+def b32(vals):
+    return np.frombuffer(b"".join(int(v).to_bytes(32, "little") for v in vals), dtype=np.uint8).reshape(-1, 32).copy()
+
+
+def dev_add(ctx, ops):
+    return ctx.gadget_point_add_dev(b32(o[0] for o in ops), b32(o[1] for o in ops), b32(o[2] for o in ops),
+                                    b32(o[3] for o in ops), np.array([o[4] for o in ops], dtype=np.uint8))
+
+
+def dev_mult(ctx, ops):
+    return ctx.gadget_point_mult_dev([o[0] for o in ops], b32(o[1] for o in ops), b32(o[2] for o in ops))
+
+
+def assert_same_instance(ctx, g, inst):
+    """g: DevInstance; inst: the model's padded instance dict"""
+    assert (g.num_cons, g.num_vars, g.num_inputs) == (inst["num_cons"], inst["num_vars"], inst["num_inputs"])
+    assert g.num_cons_unpadded == inst["num_cons_unpadded"] and g.num_vars_unpadded == inst["num_vars_unpadded"]
+    for m, name in enumerate("ABC"):
+        row, col, val = g.triplets(m)
+        er, ec, ev = inst[name]
+        assert np.array_equal(row, er), f"{name} rows"
+        assert np.array_equal(col, ec), f"{name} cols"
+        assert np.array_equal(val, np.asarray(ev).reshape(-1, 4)), f"{name} vals"
+    for k in ("vars_para", "vars_input", "vars"):
+        got = getattr(g, k).read()
+        exp = np.asarray(inst[k]).reshape(-1, 4)
+        if not np.array_equal(got, exp):
+            bad = np.nonzero((got != exp).any(axis=1))[0]
+            raise AssertionError(f"{k}: {len(bad)} entries differ, first at {bad[0]}")
+    assert np.array_equal(g.inputs, np.asarray(inst["inputs"]).reshape(-1, 4))
+
+
+def assert_same_products(ctx, g, inst):
+    """CSR / CSC built from the template vs built by vpin_r1cs_upload from the triplets: SpMV and eval table"""
+    d2 = ctx.r1cs_upload(inst)
+    z = ctx.r1cs_build_z(g.r1cs, g.vars, g.inputs)
+    a1, a2 = ctx.r1cs_multiply_vec(g.r1cs, z), ctx.r1cs_multiply_vec(d2, z)
+    for x, y in zip(a1, a2):
+        assert np.array_equal(x.read(), y.read())
+    rng = np.random.default_rng(7)
+    rx = np.zeros(((inst["num_cons"]).bit_length() - 1, 4), dtype=np.uint64)
+    rx[:, :3] = rng.integers(0, 2**63, size=(rx.shape[0], 3), dtype=np.uint64)
+    ex = ctx.eq_table(rx)
+    r_abc = np.zeros((3, 4), dtype=np.uint64)
+    r_abc[:, :2] = rng.integers(0, 2**63, size=(3, 2), dtype=np.uint64)
+    t1, t2 = ctx.r1cs_eval_table(g.r1cs, ex, r_abc), ctx.r1cs_eval_table(d2, ex, r_abc)
+    assert np.array_equal(t1.read(), t2.read())
+    for t in (z, ex, t1, t2, *a1, *a2):
+        t.free()
+    d2.free()
+
+
+def check_snark(ctx, g, inst):
+    got = g.snark_prove(SEED_C, SEED_P)
+    exp = O.snark_prove(inst, SEED_C, SEED_P)
+    assert got["comm"] == exp["comm"], "computation commitment (closed-form memory trace) differs from the oracle's"
+    assert np.array_equal(got["comm_para"], exp["comm_para"]) and np.array_equal(got["comm_input"], exp["comm_input"])
+    assert got["proof"] == exp["proof"]
+    assert O.snark_verify(inst, got) == 1
+    assert ctx.snark_verify(inst, got)
+
+
+def test_point_add_dev_matches_model(ctx):
+    ops = GM.synthetic_add_ops(0x5650494E + 40, 7, rz_one_every=3)
+    inst = GM.instance_new(GM.build_point_add(ops))
+    g = dev_add(ctx, ops)
+    assert_same_instance(ctx, g, inst)
+    assert_same_products(ctx, g, inst)
+    assert g.is_sat() and O.is_sat(inst)
+    check_snark(ctx, g, inst)
+    g.free()
+    # R == P: the inverse of zero stays zero (dalek's invert); same witness, and unsatisfied on both sides
+    ops.append((ops[1][0], ops[1][1], ops[1][0], ops[1][1], 0))
+    inst = GM.instance_new(GM.build_point_add(ops))
+    g = dev_add(ctx, ops)
+    assert_same_instance(ctx, g, inst)
+    assert not g.is_sat() and not O.is_sat(inst)
+    g.free()
+
+
+def test_point_add_dev_single_op(ctx):
+    ops = GM.synthetic_add_ops(0x5650494E + 41, 1)
+    inst = GM.instance_new(GM.build_point_add(ops))
+    g = dev_add(ctx, ops)
+    assert_same_instance(ctx, g, inst)
+    assert g.is_sat()
+    check_snark(ctx, g, inst)
+    g.free()
+
+
+def test_point_mult_dev_matches_model(ctx):
+    ws = [(1 << 127) + 0x1234567, 0, 5]
+    ops = GM.synthetic_mult_ops(0x5650494E + 42, 3, weights=ws)
+    inst = GM.instance_new(GM.build_point_mult(ops))
+    g = dev_mult(ctx, ops)
+    assert_same_instance(ctx, g, inst)
+    assert_same_products(ctx, g, inst)
+    assert g.is_sat()
+    check_snark(ctx, g, inst)
+    g.free()
+
+
+def test_point_mult_dev_degenerate_inputs(ctx):
+    """zero coordinates (2*ay = 0: inverse of zero) and byte strings >= q (from_bytes_mod_order reduces them): same
+    tables as the host builder (vpin_gadget_point_mult, itself checked against the model in test_gadgets.py)"""
+    from vpin_amd import gadgets as G
+    q = GM.Q
+    ws = [(1 << 128) - 1, 3]
+    x, y = b32([0, q + 5]), b32([0, (1 << 256) - 1])
+    host = G.point_mult(ws, x, y)
+    g = ctx.gadget_point_mult_dev(ws, x, y)
+    assert_same_instance(ctx, g, host.as_dict())
+    host.free()
+    g.free()
+
+
+def test_is_sat_detects_a_bad_witness(ctx):
+    ops = GM.synthetic_add_ops(0x5650494E + 43, 4)
+    g = dev_add(ctx, ops)
+    assert g.is_sat()
+    # overwrite one witness entry on the device (x3 of the first addition)
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    bad = np.ones(8, dtype=np.uint32)
+    rc = hip.hipMemcpy(C.c_void_p(g.vars.device_ptr + 32 * 13), bad.ctypes.data_as(C.c_void_p), C.c_size_t(32), C.c_int(1))
+    assert rc == 0
+    assert not g.is_sat()
+    g.free()
+
+
+def test_dev_instance_equals_host_path_at_config_size(ctx):
+    """BASELINE configs[0] (conv 3x3, 32x32: 18 point-mults, 16 point-adds): the device-built instances give the
+    same SNARK bytes as the host-built ones proven through vpin_snark_prove"""
+    from vpin_amd import gadgets as G
+    w, x, y = G.synthetic_mult_inputs("3_32")
+    host = G.point_mult(w, x, y)
+    d = host.as_dict()
+    exp = ctx.snark_prove(d, SEED_C, SEED_P)
+    g = ctx.gadget_point_mult_dev(w, x, y)
+    assert g.is_sat()
+    got = g.snark_prove(SEED_C, SEED_P)
+    assert got["comm"] == exp["comm"] and got["proof"] == exp["proof"]
+    assert np.array_equal(g.vars.read(), d["vars"])
+    host.free()
+    g.free()
+    px, py, rx, ry, rz = G.synthetic_add_inputs("3_32")
+    host = G.point_add(px, py, rx, ry, rz)
+    d = host.as_dict()
+    exp = ctx.snark_prove(d, SEED_C, SEED_P)
+    g = ctx.gadget_point_add_dev(px, py, rx, ry, rz)
+    got = g.snark_prove(SEED_C, SEED_P)
+    assert got["comm"] == exp["comm"] and got["proof"] == exp["proof"]
+    host.free()
+    g.free()

@@ -144,6 +144,22 @@ def lib():
     L.vpin_host_gens_derive.argtypes = [C.c_char_p, C.c_size_t, vp]
     L.vpin_host_merlin_kat.argtypes = [C.c_char_p, C.c_char_p, vp, C.c_size_t, C.c_char_p, vp, C.c_size_t]
     L.vpin_host_commit.argtypes = [C.c_char_p, vp, C.c_size_t, vp, vp]
+    L.vpin_gadget_point_add_dev.argtypes = [vp, vp, vp, vp, vp, vp, C.c_size_t, C.POINTER(vp)]
+    L.vpin_gadget_point_mult_dev.argtypes = [vp, vp, vp, vp, C.c_size_t, C.POINTER(vp)]
+    L.vpin_dev_instance_free.argtypes = [vp, vp]
+    L.vpin_dev_instance_free.restype = None
+    for name in ("r1cs", "vars_para", "vars_input", "vars", "inputs"):
+        f = getattr(L, "vpin_dev_instance_" + name)
+        f.argtypes, f.restype = [vp], vp
+    for name in ("num_cons_unpadded", "num_vars_unpadded", "comm_bytes", "proof_max_bytes"):
+        f = getattr(L, "vpin_dev_instance_" + name)
+        f.argtypes, f.restype = [vp], C.c_size_t
+    L.vpin_dev_instance_nnz.argtypes = [vp, C.c_int]
+    L.vpin_dev_instance_nnz.restype = C.c_size_t
+    L.vpin_dev_instance_triplets.argtypes = [vp, vp, C.c_int, vp, vp, vp]
+    L.vpin_dev_instance_is_sat.argtypes = [vp, vp]
+    L.vpin_spark_encode_dev.argtypes = [vp, vp, C.POINTER(vp), vp, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.vpin_snark_prove_dev.argtypes = [vp, vp, vp, vp, vp, C.c_size_t, C.POINTER(C.c_size_t), vp, C.c_size_t, C.POINTER(C.c_size_t), vp, vp]
     L.vpin_prof_enable.argtypes = [vp, C.c_int]
     L.vpin_prof_reset.argtypes = [vp]
     L.vpin_prof_read.argtypes = [vp, C.POINTER(KStat)]
@@ -228,6 +244,70 @@ class R1csDev:
     def free(self):
         if self.h:
             lib().vpin_r1cs_free(self.ctx.h, self.h)
+            self.h = None
+
+
+class DevInstance:
+    """A gadget instance built on the device (vpin_gadget_point_*_dev): R1CS (CSR + CSC), the three assignments and
+    the per-operation template, all resident in HBM."""
+
+    def __init__(self, ctx, handle):
+        self.ctx, self.h = ctx, handle
+        L = lib()
+        nc, nv, ni = C.c_size_t(), C.c_size_t(), C.c_size_t()
+        L.vpin_r1cs_dims(L.vpin_dev_instance_r1cs(handle), C.byref(nc), C.byref(nv), C.byref(ni))
+        self.num_cons, self.num_vars, self.num_inputs = nc.value, nv.value, ni.value
+        self.num_cons_unpadded = L.vpin_dev_instance_num_cons_unpadded(handle)
+        self.num_vars_unpadded = L.vpin_dev_instance_num_vars_unpadded(handle)
+        # borrowed views: freed with the instance
+        self.r1cs = R1csDev(ctx, C.c_void_p(L.vpin_dev_instance_r1cs(handle)), self.num_cons, self.num_vars, self.num_inputs)
+        self.vars_para = Table(ctx, C.c_void_p(L.vpin_dev_instance_vars_para(handle)))
+        self.vars_input = Table(ctx, C.c_void_p(L.vpin_dev_instance_vars_input(handle)))
+        self.vars = Table(ctx, C.c_void_p(L.vpin_dev_instance_vars(handle)))
+        ip = L.vpin_dev_instance_inputs(handle)
+        self.inputs = (np.ctypeslib.as_array(C.cast(ip, C.POINTER(C.c_uint64)), shape=(self.num_inputs, 4)).copy()
+                       if ip else np.zeros((0, 4), dtype=np.uint64))
+
+    def triplets(self, m):
+        n = lib().vpin_dev_instance_nnz(self.h, m)
+        row, col, val = np.zeros(n, np.uint32), np.zeros(n, np.uint32), np.zeros((n, 4), np.uint64)
+        p = lambda a: a.ctypes.data_as(C.c_void_p)
+        _chk(lib().vpin_dev_instance_triplets(self.ctx.h, self.h, m, p(row), p(col), p(val)), "vpin_dev_instance_triplets")
+        return row, col, val
+
+    def is_sat(self):
+        rc = lib().vpin_dev_instance_is_sat(self.ctx.h, self.h)
+        if rc < 0:
+            _chk(rc, "vpin_dev_instance_is_sat")
+        return rc == 1
+
+    def spark_encode(self):
+        cap = lib().vpin_dev_instance_comm_bytes(self.h)
+        comm = np.zeros(cap, dtype=np.uint8)
+        n = C.c_size_t(0)
+        h = C.c_void_p()
+        _chk(lib().vpin_spark_encode_dev(self.ctx.h, self.h, C.byref(h), comm.ctypes.data_as(C.c_void_p), cap, C.byref(n)),
+             "vpin_spark_encode_dev")
+        return SparkDecomm(self.ctx, h, lib().vpin_dev_instance_proof_max_bytes(self.h)), bytes(comm[:n.value])
+
+    def snark_prove(self, seed_commit, seed_proof):
+        """SNARK::encode + my_lib_prove: dict(proof, comm, comm_para, comm_input)"""
+        L = lib()
+        cap, ccap = L.vpin_dev_instance_proof_max_bytes(self.h), L.vpin_dev_instance_comm_bytes(self.h)
+        Ls = 1 << ((self.num_vars.bit_length() - 1) // 2)
+        proof, comm = np.zeros(cap, np.uint8), np.zeros(ccap, np.uint8)
+        cp, ci = np.zeros((Ls, 32), np.uint8), np.zeros((Ls, 32), np.uint8)
+        sc = np.frombuffer(bytes(seed_commit), dtype=np.uint8).copy()
+        sp = np.frombuffer(bytes(seed_proof), dtype=np.uint8).copy()
+        n, cn = C.c_size_t(0), C.c_size_t(0)
+        p = lambda a: a.ctypes.data_as(C.c_void_p)
+        _chk(L.vpin_snark_prove_dev(self.ctx.h, self.h, p(sc), p(sp), p(proof), cap, C.byref(n), p(comm), ccap, C.byref(cn), p(cp), p(ci)),
+             "vpin_snark_prove_dev")
+        return dict(proof=bytes(proof[:n.value]), comm=bytes(comm[:cn.value]), comm_para=cp, comm_input=ci)
+
+    def free(self):
+        if self.h:
+            lib().vpin_dev_instance_free(self.ctx.h, self.h)
             self.h = None
 
 
@@ -534,6 +614,23 @@ class Context:
         lib().vpin_sat_last_timings(out)
         names = ("polycommit", "sc_phase_one", "sc_phase_two", "polyeval", "total", "gens", "host_spmv", "inst_evaluate")
         return dict(zip(names, out))
+
+    # ---- gadgets on the device ----
+    def gadget_point_add_dev(self, px, py, rx, ry, rz):
+        arrs = [np.ascontiguousarray(a, dtype=np.uint8) for a in (px, py, rx, ry, rz)]
+        h = C.c_void_p()
+        _chk(lib().vpin_gadget_point_add_dev(self.h, *[a.ctypes.data_as(C.c_void_p) for a in arrs], len(arrs[4]), C.byref(h)),
+             "vpin_gadget_point_add_dev")
+        return DevInstance(self, h)
+
+    def gadget_point_mult_dev(self, weights, px, py):
+        """weights: Python ints < 2^128"""
+        w = np.frombuffer(b"".join(int(v).to_bytes(16, "little") for v in weights), dtype=np.uint8).copy()
+        x, y = np.ascontiguousarray(px, dtype=np.uint8), np.ascontiguousarray(py, dtype=np.uint8)
+        h = C.c_void_p()
+        p = lambda a: a.ctypes.data_as(C.c_void_p)
+        _chk(lib().vpin_gadget_point_mult_dev(self.h, p(w), p(x), p(y), len(weights), C.byref(h)), "vpin_gadget_point_mult_dev")
+        return DevInstance(self, h)
 
     # ---- profiling ----
     def prof_enable(self, on=True):

@@ -141,6 +141,18 @@ long long ms_since(Clock::time_point t0) {
 
 struct Result { size_t size = 0; long long gen_ms = 0, ver_ms = 0; };
 
+// VPIN_CLI_TRACE=1: where the reference's "Proof generation time" span goes, on stderr
+struct Lap {
+  Clock::time_point t = Clock::now();
+  const bool on = getenv("VPIN_CLI_TRACE") != nullptr;
+  void operator()(const char* what) {
+    if (!on) return;
+    auto n = Clock::now();
+    fprintf(stderr, "[vpin_prove] %-24s %9.1f ms\n", what, std::chrono::duration<double, std::milli>(n - t).count());
+    t = n;
+  }
+};
+
 void check(int rc, const char* what) {
   if (rc != 0) die(std::string(what) + ": " + vpin_strerror(rc) + " [" + vpin_last_error() + "]");
 }
@@ -148,7 +160,9 @@ void check(int rc, const char* what) {
 bool g_sat_only = false;
 
 Result prove(vpin_ctx* ctx, vpin_instance* inst, const uint8_t seeds[128], const std::string& dump_prefix, Clock::time_point t0) {
+  Lap lap;
   if (vpin_instance_is_sat(inst) != 1) die("assertion failed: instance is not satisfied");  // point_mult.rs:650-651
+  lap("is_sat");
   const vpin_r1cs* r = vpin_instance_r1cs(inst);
   size_t cap = g_sat_only ? vpin_sat_proof_max_bytes(r->num_cons, r->num_vars) : vpin_snark_proof_max_bytes(r), len = 0;
   size_t ell = 0;
@@ -166,6 +180,7 @@ Result prove(vpin_ctx* ctx, vpin_instance* inst, const uint8_t seeds[128], const
                            vpin_instance_inputs(inst), seeds, seeds + 64, proof.data(), cap, &len, comm.data(), comm.size(),
                            &comm_len, cp.data(), ci.data()),
           "vpin_snark_prove");
+  lap("prove call");
   Result res;
   res.size = len;
   printf("Proof size: %zu bytes\n", len);
@@ -193,6 +208,57 @@ Result prove(vpin_ctx* ctx, vpin_instance* inst, const uint8_t seeds[128], const
   return res;
 }
 
+
+// the same span with the instance built on the device (vpin_gadget_point_*_dev): default path
+Result prove_dev(vpin_ctx* ctx, vpin_dev_instance* inst, const uint8_t seeds[128], const std::string& dump_prefix, Clock::time_point t0) {
+  Lap lap;
+  if (vpin_dev_instance_is_sat(ctx, inst) != 1) die("assertion failed: instance is not satisfied");  // point_mult.rs:650-651
+  lap("is_sat (device)");
+  const vpin_r1cs_dev* r = vpin_dev_instance_r1cs(inst);
+  size_t num_cons = 0, num_vars = 0, num_inputs = 0;
+  vpin_r1cs_dims(r, &num_cons, &num_vars, &num_inputs);
+  size_t cap = g_sat_only ? vpin_sat_proof_max_bytes(num_cons, num_vars) : vpin_dev_instance_proof_max_bytes(inst), len = 0;
+  size_t ell = 0;
+  while (((size_t)1 << ell) < num_vars) ell++;
+  size_t L = (size_t)1 << (ell / 2);
+  std::vector<uint8_t> proof(cap), cp(32 * L), ci(32 * L), ev(96), comm(g_sat_only ? 0 : vpin_dev_instance_comm_bytes(inst));
+  size_t comm_len = 0;
+  if (g_sat_only)
+    check(vpin_sat_prove_resident(ctx, r, vpin_dev_instance_vars_para(inst), vpin_dev_instance_vars_input(inst),
+                                  vpin_dev_instance_vars(inst), vpin_dev_instance_inputs(inst), seeds, seeds + 64, proof.data(), cap,
+                                  &len, cp.data(), ci.data(), ev.data(), nullptr, nullptr),
+          "vpin_sat_prove_resident");
+  else
+    check(vpin_snark_prove_dev(ctx, inst, seeds, seeds + 64, proof.data(), cap, &len, comm.data(), comm.size(), &comm_len, cp.data(),
+                               ci.data()),
+          "vpin_snark_prove_dev");
+  lap("prove call");
+  Result res;
+  res.size = len;
+  printf("Proof size: %zu bytes\n", len);
+  res.gen_ms = ms_since(t0);
+  printf("Proof generation time: %lld ms\n", res.gen_ms);
+  {
+    auto t1 = Clock::now();
+    int vrc = g_sat_only ? vpin_sat_verify(ctx, proof.data(), len, num_cons, num_vars, vpin_dev_instance_inputs(inst), num_inputs,
+                                           ev.data(), cp.data(), ci.data())
+                         : vpin_snark_verify(ctx, proof.data(), len, comm.data(), comm_len, vpin_dev_instance_inputs(inst), num_inputs,
+                                             cp.data(), ci.data());
+    if (vrc != 0) die(std::string("assertion failed: proof verification: ") + vpin_strerror(vrc));
+    printf("Proof verification successful!\n");
+    res.ver_ms = ms_since(t1);
+    printf("Proof verification time: %lld ms\n", res.ver_ms);
+  }
+  if (!dump_prefix.empty()) {
+    std::ofstream(dump_prefix + ".proof", std::ios::binary).write((const char*)proof.data(), (std::streamsize)len);
+    std::ofstream(dump_prefix + ".comm_para", std::ios::binary).write((const char*)cp.data(), (std::streamsize)cp.size());
+    std::ofstream(dump_prefix + ".comm_input", std::ios::binary).write((const char*)ci.data(), (std::streamsize)ci.size());
+    if (g_sat_only) std::ofstream(dump_prefix + ".inst_evals", std::ios::binary).write((const char*)ev.data(), 96);
+    else std::ofstream(dump_prefix + ".comm", std::ios::binary).write((const char*)comm.data(), (std::streamsize)comm_len);
+  }
+  return res;
+}
+
 }  // namespace
 
 int main(int argc, char** argv) {
@@ -200,12 +266,13 @@ int main(int argc, char** argv) {
   std::string dump_dir;
   int device = 0;
   uint8_t seeds[128];
-  bool have_seed = false;
+  bool have_seed = false, host_gadgets = false;
   for (int i = 2; i < argc; i++) {
     std::string a = argv[i];
     if (a == "--device" && i + 1 < argc) device = atoi(argv[++i]);
     else if (a == "--write-proof" && i + 1 < argc) dump_dir = argv[++i];
     else if (a == "--sat-only") g_sat_only = true;
+    else if (a == "--host-gadgets") host_gadgets = true;  // build instance + witness on the host cores, upload, then prove
     else if (a == "--seed" && i + 1 < argc) {
       std::string h = argv[++i];  // hex, repeated cyclically to 128 bytes: commit seed | proof seed
       size_t usable = h.size() & ~(size_t)1;
@@ -236,11 +303,24 @@ int main(int argc, char** argv) {
   if (n2 != n1 || n3 != n1 || n4 != n1 || arz.size() != n1) die("point addition witness files disagree on the number of operations");
   printf("Point Addition Gadget...\n");
   printf("Number of Point Additions: %zu\n", n1);
+  Lap lap;
   check(vpin_ctx_create(device, &ctx), "vpin_ctx_create");
-  vpin_instance* add = nullptr;
-  check(vpin_gadget_point_add(apx.data(), apy.data(), arx.data(), ary.data(), arz.data(), n1, &add), "vpin_gadget_point_add");
-  Result ra = prove(ctx, add, seeds, dump_dir.empty() ? "" : dump_dir + "/" + network + "_add", t0);
-  vpin_instance_free(add);
+  lap("ctx_create");
+  Result ra;
+  const std::string add_prefix = dump_dir.empty() ? "" : dump_dir + "/" + network + "_add";
+  if (host_gadgets || n1 == 0) {
+    vpin_instance* add = nullptr;
+    check(vpin_gadget_point_add(apx.data(), apy.data(), arx.data(), ary.data(), arz.data(), n1, &add), "vpin_gadget_point_add");
+    lap("gadget_point_add");
+    ra = prove(ctx, add, seeds, add_prefix, t0);
+    vpin_instance_free(add);
+  } else {
+    vpin_dev_instance* add = nullptr;
+    check(vpin_gadget_point_add_dev(ctx, apx.data(), apy.data(), arx.data(), ary.data(), arz.data(), n1, &add), "vpin_gadget_point_add_dev");
+    lap("gadget_point_add (device)");
+    ra = prove_dev(ctx, add, seeds, add_prefix, t0);
+    vpin_dev_instance_free(ctx, add);
+  }
   printf("\n");
 
   // ---- point multiplication (proof_point_mult.rs); L2/L4 have none (main.rs:24-31) ----
@@ -252,6 +332,7 @@ int main(int argc, char** argv) {
     printf("Proof verification time: 0 ms\n");
   } else {
     t0 = Clock::now();
+    lap("(between gadgets)");
     size_t nw = 0, m1 = 0, m2 = 0;
     std::vector<uint8_t> w = load_weights(base + "pointMult/weight.json", &nw);
     std::vector<uint8_t> mpx = load_bytes32(base + "pointMult/point_mult_px_byte.json", &m1);
@@ -260,11 +341,23 @@ int main(int argc, char** argv) {
     printf("Point Multiplication Gadget...\n");
     printf("Number of Point Multiplications: %zu\n", nw);
     printf("Generating Proof...\n");
-    vpin_instance* mult = nullptr;
-    check(vpin_gadget_point_mult(w.data(), mpx.data(), mpy.data(), nw, &mult), "vpin_gadget_point_mult");
-    printf("Still working on...\n");
-    rm = prove(ctx, mult, seeds, dump_dir.empty() ? "" : dump_dir + "/" + network + "_mult", t0);
-    vpin_instance_free(mult);
+    lap("load mult json");
+    const std::string mult_prefix = dump_dir.empty() ? "" : dump_dir + "/" + network + "_mult";
+    if (host_gadgets || nw == 0) {
+      vpin_instance* mult = nullptr;
+      check(vpin_gadget_point_mult(w.data(), mpx.data(), mpy.data(), nw, &mult), "vpin_gadget_point_mult");
+      lap("gadget_point_mult");
+      printf("Still working on...\n");
+      rm = prove(ctx, mult, seeds, mult_prefix, t0);
+      vpin_instance_free(mult);
+    } else {
+      vpin_dev_instance* mult = nullptr;
+      check(vpin_gadget_point_mult_dev(ctx, w.data(), mpx.data(), mpy.data(), nw, &mult), "vpin_gadget_point_mult_dev");
+      lap("gadget_point_mult (device)");
+      printf("Still working on...\n");
+      rm = prove_dev(ctx, mult, seeds, mult_prefix, t0);
+      vpin_dev_instance_free(ctx, mult);
+    }
   }
   printf("\n====================================\n");
   printf("Total proof size: %zu bytes\n", ra.size + rm.size);

@@ -2,6 +2,9 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <map>
 #include <string>
 #include <unordered_map>
@@ -110,5 +113,21 @@ int sc_round_wait(vpin_ctx* c, int K, uint8_t* out);
 int sc_cubic3_launch(vpin_ctx* c, vpin_table* const* t, const vpin_table* pyramid, int ell, int level, const uint8_t* r);
 
 inline bool is_pow2(size_t x) { return x && !(x & (x - 1)); }
+
+// VPIN_CLI_TRACE=1: wall-clock laps of the cold (one-shot CLI) path on stderr; each lap drains the stream
+struct TraceLap {
+  vpin_ctx* c;
+  const char* who;
+  bool on;
+  std::chrono::steady_clock::time_point t;
+  TraceLap(vpin_ctx* ctx, const char* w) : c(ctx), who(w), on(getenv("VPIN_CLI_TRACE") != nullptr), t(std::chrono::steady_clock::now()) {}
+  void operator()(const char* what) {
+    if (!on) return;
+    if (c) (void)hipStreamSynchronize(c->stream);
+    auto n = std::chrono::steady_clock::now();
+    fprintf(stderr, "[%s] %-22s %9.1f ms\n", who, what, std::chrono::duration<double, std::milli>(n - t).count());
+    t = n;
+  }
+};
 
 }  // namespace vpin

@@ -15,6 +15,7 @@
 
 #include "../../include/vpin_hip.h"
 #include "host/field.h"
+#include "host/gadget_ops.h"
 
 namespace {
 
@@ -24,6 +25,13 @@ struct Trip {
   std::vector<uint32_t> row, col;
   std::vector<Fq> val;
   void push(size_t r, size_t c, const Fq& v) { row.push_back((uint32_t)r); col.push_back((uint32_t)c); val.push_back(v); }
+};
+
+struct TripSink {
+  Trip* M;
+  void A(size_t r, size_t c, const Fq& v) { M[0].push(r, c, v); }
+  void B(size_t r, size_t c, const Fq& v) { M[1].push(r, c, v); }
+  void C(size_t r, size_t c, const Fq& v) { M[2].push(r, c, v); }
 };
 
 static size_t next_pow2(size_t x) { size_t p = 1; while (p < x) p <<= 1; return p; }
@@ -118,22 +126,10 @@ int vpin_gadget_point_add(const uint8_t* px_b, const uint8_t* py_b, const uint8_
   vpin_instance* g = new (std::nothrow) vpin_instance();
   if (!g) return VPIN_ENOMEM;
   const size_t num_cons = 10 * N, num_vars = 15 * N + 1, nv = num_vars;
-  const Fq one = Fq::one(), m1 = one.neg();
-  Trip &A = g->M[0], &Bm = g->M[1], &C = g->M[2];
-  for (size_t i = 0; i < N; i++) {
-    const size_t r = 10 * i, v = 15 * i;
-    A.push(r + 0, v + 0, one); Bm.push(r + 0, v + 1, one); Bm.push(r + 0, v + 2, m1); C.push(r + 0, nv, one);
-    A.push(r + 1, v + 3, one); A.push(r + 1, v + 4, m1); Bm.push(r + 1, v + 0, one); C.push(r + 1, v + 6, one);
-    A.push(r + 2, v + 6, one); Bm.push(r + 2, v + 6, one); C.push(r + 2, v + 7, one);
-    A.push(r + 3, v + 7, one); A.push(r + 3, v + 2, m1); A.push(r + 3, v + 1, m1);
-    Bm.push(r + 3, nv, one); Bm.push(r + 3, v + 5, m1); C.push(r + 3, v + 9, one);
-    A.push(r + 4, v + 2, one); Bm.push(r + 4, v + 5, one); C.push(r + 4, v + 10, one);
-    A.push(r + 5, v + 9, one); A.push(r + 5, v + 10, one); Bm.push(r + 5, nv, one); C.push(r + 5, v + 13, one);
-    A.push(r + 6, v + 6, one); Bm.push(r + 6, v + 2, one); Bm.push(r + 6, v + 13, m1); C.push(r + 6, v + 8, one);
-    A.push(r + 7, v + 8, one); A.push(r + 7, v + 4, m1); Bm.push(r + 7, nv, one); Bm.push(r + 7, v + 5, m1); C.push(r + 7, v + 11, one);
-    A.push(r + 8, v + 4, one); Bm.push(r + 8, v + 5, one); C.push(r + 8, v + 12, one);
-    A.push(r + 9, v + 11, one); A.push(r + 9, v + 12, one); Bm.push(r + 9, nv, one); C.push(r + 9, v + 14, one);
-  }
+  const vpin_gadgets::Consts K;
+  const Fq one = K.one;
+  TripSink sink{g->M};
+  for (size_t i = 0; i < N; i++) vpin_gadgets::emit_add_op(sink, 10 * i, 15 * i, nv, K);
   g->vars_input.assign(num_vars, Fq::zero());
   std::vector<Fq> cinv(N);
   std::vector<Fq> px(N), py(N), rx(N), ry(N), rz(N);
@@ -168,66 +164,17 @@ int vpin_gadget_point_mult(const uint8_t* weights_le16, const uint8_t* px_b, con
   if (!g) return VPIN_ENOMEM;
   const size_t n = 128, oc = 27 * n + 8, ov = n + 10 + n * 26;
   const size_t num_cons = oc * N, num_vars = ov * N + 1, nv = num_vars;
-  const Fq one = Fq::one(), zero = Fq::zero(), two = one + one, three = two + one, m1 = one.neg(), m2 = two.neg();
-  Trip &A = g->M[0], &Bm = g->M[1], &C = g->M[2];
+  const vpin_gadgets::Consts K;
+  const Fq one = K.one, zero = Fq::zero(), two = K.two, three = K.three;
+  const std::vector<Fq>& pow2 = K.pow2;
   for (int m = 0; m < 3; m++) {
     size_t per = m == 0 ? 5260 : m == 1 ? 4488 : 3201;
     g->M[m].row.reserve(per * N); g->M[m].col.reserve(per * N); g->M[m].val.reserve(per * N);
   }
-  std::vector<Fq> pow2(n);
-  pow2[0] = one;
-  for (size_t i = 1; i < n; i++) pow2[i] = pow2[i - 1] + pow2[i - 1];
-  for (size_t j = 0; j < N; j++) {
-    const size_t r0 = oc * j, v0 = ov * j;
-    for (size_t i = 0; i < n; i++) A.push(r0, v0 + i, pow2[i]);
-    Bm.push(r0, nv, one); C.push(r0, v0 + n, one);
-    for (size_t i = 1; i <= n; i++) { A.push(r0 + i, v0 + i - 1, one); Bm.push(r0 + i, v0 + i - 1, one); C.push(r0 + i, v0 + i - 1, one); }
-    A.push(r0 + n + 1, v0 + n + 1, one); A.push(r0 + n + 1, v0 + 10 * n + 8, m1); Bm.push(r0 + n + 1, nv, one);
-    A.push(r0 + n + 2, v0 + 2 * n + 2, one); A.push(r0 + n + 2, v0 + 10 * n + 9, m1); Bm.push(r0 + n + 2, nv, one);
-    A.push(r0 + n + 3, v0 + 3 * n + 3, one); Bm.push(r0 + n + 3, nv, one);
-    A.push(r0 + n + 4, v0 + 4 * n + 4, one); Bm.push(r0 + n + 4, nv, one);
-    A.push(r0 + n + 5, v0 + 5 * n + 5, one); A.push(r0 + n + 5, nv, m1); Bm.push(r0 + n + 5, nv, one);
-    for (size_t i = 0; i < n; i++) {
-      const size_t r = r0 + i * 26 + n, v = v0 + i;
-      // PA (point_mult.rs:127-189)
-      A.push(r + 6, v + 10 * n + 10, one); Bm.push(r + 6, v + 3 * n + 3, one); Bm.push(r + 6, v + n + 1, m1); C.push(r + 6, nv, one);
-      A.push(r + 7, v + 4 * n + 4, one); A.push(r + 7, v + 2 * n + 2, m1); Bm.push(r + 7, v + 10 * n + 10, one); C.push(r + 7, v + 11 * n + 10, one);
-      A.push(r + 8, v + 11 * n + 10, one); Bm.push(r + 8, v + 11 * n + 10, one); C.push(r + 8, v + 12 * n + 10, one);
-      A.push(r + 9, v + 12 * n + 10, one); A.push(r + 9, v + n + 1, m1); A.push(r + 9, v + 3 * n + 3, m1);
-      Bm.push(r + 9, nv, one); Bm.push(r + 9, v + 5 * n + 5, m1); C.push(r + 9, v + 14 * n + 10, one);
-      A.push(r + 10, v + n + 1, one); Bm.push(r + 10, v + 5 * n + 5, one); C.push(r + 10, v + 15 * n + 10, one);
-      A.push(r + 11, v + 14 * n + 10, one); A.push(r + 11, v + 15 * n + 10, one); Bm.push(r + 11, nv, one); C.push(r + 11, v + 6 * n + 6, one);
-      A.push(r + 12, v + 11 * n + 10, one); Bm.push(r + 12, v + n + 1, one); Bm.push(r + 12, v + 6 * n + 6, m1); C.push(r + 12, v + 13 * n + 10, one);
-      A.push(r + 13, v + 13 * n + 10, one); A.push(r + 13, v + 2 * n + 2, m1); Bm.push(r + 13, nv, one); Bm.push(r + 13, v + 5 * n + 5, m1); C.push(r + 13, v + 16 * n + 10, one);
-      A.push(r + 14, v + 2 * n + 2, one); Bm.push(r + 14, v + 5 * n + 5, one); C.push(r + 14, v + 17 * n + 10, one);
-      A.push(r + 15, v + 16 * n + 10, one); A.push(r + 15, v + 17 * n + 10, one); Bm.push(r + 15, nv, one); C.push(r + 15, v + 7 * n + 6, one);
-      // PD (point_mult.rs:197-241)
-      A.push(r + 16, v + 18 * n + 10, one); Bm.push(r + 16, v + 2 * n + 2, two); C.push(r + 16, nv, one);
-      A.push(r + 17, v + n + 1, one); Bm.push(r + 17, v + n + 1, one); C.push(r + 17, v + 19 * n + 10, one);
-      A.push(r + 18, v + 19 * n + 10, three); A.push(r + 18, nv + 1, one); Bm.push(r + 18, v + 18 * n + 10, one); C.push(r + 18, v + 20 * n + 10, one);
-      A.push(r + 19, v + 20 * n + 10, one); Bm.push(r + 19, v + 20 * n + 10, one); C.push(r + 19, v + 21 * n + 10, one);
-      A.push(r + 20, v + 21 * n + 10, one); A.push(r + 20, v + n + 1, m2); Bm.push(r + 20, nv, one); C.push(r + 20, v + 8 * n + 6, one);
-      A.push(r + 21, v + 20 * n + 10, one); Bm.push(r + 21, v + n + 1, one); Bm.push(r + 21, v + 8 * n + 6, m1); C.push(r + 21, v + 22 * n + 10, one);
-      A.push(r + 22, v + 22 * n + 10, one); A.push(r + 22, v + 2 * n + 2, m1); Bm.push(r + 22, nv, one); C.push(r + 22, v + 9 * n + 6, one);
-      // bit select (point_mult.rs:247-302)
-      A.push(r + 23, v + 6 * n + 6, one); Bm.push(r + 23, v, one); C.push(r + 23, v + 23 * n + 10, one);
-      A.push(r + 24, v + 3 * n + 3, one); Bm.push(r + 24, nv, one); Bm.push(r + 24, v, m1); C.push(r + 24, v + 24 * n + 10, one);
-      A.push(r + 25, v + 23 * n + 10, one); A.push(r + 25, v + 24 * n + 10, one); Bm.push(r + 25, nv, one); C.push(r + 25, v + 3 * n + 4, one);
-      A.push(r + 26, v + 7 * n + 6, one); Bm.push(r + 26, v, one); C.push(r + 26, v + 25 * n + 10, one);
-      A.push(r + 27, v + 4 * n + 4, one); Bm.push(r + 27, nv, one); Bm.push(r + 27, v, m1); C.push(r + 27, v + 26 * n + 10, one);
-      A.push(r + 28, v + 25 * n + 10, one); A.push(r + 28, v + 26 * n + 10, one); Bm.push(r + 28, nv, one); C.push(r + 28, v + 4 * n + 5, one);
-      A.push(r + 29, v + 5 * n + 5, one); Bm.push(r + 29, nv, one); Bm.push(r + 29, v, m1); C.push(r + 29, v + 5 * n + 6, one);
-      A.push(r + 30, v + n + 2, one); A.push(r + 30, v + 8 * n + 6, m1); Bm.push(r + 30, nv, one);
-      A.push(r + 31, v + 2 * n + 3, one); A.push(r + 31, v + 9 * n + 6, m1); Bm.push(r + 31, nv, one);
-    }
-    A.push(r0 + oc - 2, v0 + 10 * n + 6, one); A.push(r0 + oc - 2, v0 + 3 * n + 3 + n, m1); Bm.push(r0 + oc - 2, nv, one);
-    A.push(r0 + oc - 1, v0 + 10 * n + 7, one); A.push(r0 + oc - 1, v0 + 4 * n + 4 + n, m1); Bm.push(r0 + oc - 1, nv, one);
-  }
+  TripSink sink{g->M};
+  for (size_t j = 0; j < N; j++) vpin_gadgets::emit_mult_op(sink, oc * j, ov * j, nv, K);
 
-  // a_pd (point_mult.rs:341-342): the curve coefficient a of E2
-  static const uint8_t a_pd_byte[32] = {157, 27, 50, 101, 63, 42, 38, 142, 68, 159, 245, 15, 16, 47, 75, 58,
-                                        203, 87, 15, 3, 219, 183, 77, 94, 64, 118, 147, 233, 124, 16, 184, 7};
-  const Fq a_pd = fq_from_le32(a_pd_byte);
+  const Fq a_pd = fq_from_le32(vpin_gadgets::kAPdBytes);
 
   // witness synthesis (point_mult.rs:414-500, pa :667-686, pd :688-704).  The doubling chain
   // A_i does not depend on the bits, so all N*n doublings are done first with one batched

@@ -391,6 +391,7 @@ static int gens_build(vpin_ctx* c, const uint8_t* gens_xyzt, size_t nb, size_t b
     if (nb * (size_t)g->W * (size_t)g->E * sizeof(niels_slot) <= budget) break;
   }
   const size_t entries = nb * (size_t)g->W * g->E;
+  TraceLap lap(c, "gens_build");
   DevBuf raw(c);
   ge_ext* shifts = nullptr;
   fp* prefix = nullptr;
@@ -403,6 +404,7 @@ static int gens_build(vpin_ctx* c, const uint8_t* gens_xyzt, size_t nb, size_t b
     delete g;
     return VPIN_ENOMEM;
   }
+  lap("hipMalloc");
   hipError_t e = hipMemcpyAsync(raw.p, gens_xyzt, nb * 128, hipMemcpyHostToDevice, c->stream);
   if (e == hipSuccess) {
     hipLaunchKernelGGL(gens_shift_kernel, dim3((unsigned)((nb + 63) / 64)), dim3(64), 0, c->stream, (const fp*)raw.p, nb, g->W,
@@ -412,8 +414,10 @@ static int gens_build(vpin_ctx* c, const uint8_t* gens_xyzt, size_t nb, size_t b
     e = hipGetLastError();
   }
   if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  lap("table kernels");
   (void)hipFree(shifts);
   (void)hipFree(prefix);
+  lap("hipFree temporaries");
   if (e != hipSuccess) {
     set_last_error("vpin_gens_create", e);
     (void)hipFree(g->table);

@@ -53,7 +53,9 @@ static int get_gens(vpin_ctx* c, size_t num_vars, SatGens** out) {
   sg->L = (size_t)1 << left;
   sg->R = (size_t)1 << (sg->ell - left);
   sg->nb = sg->R + 2 < 5 ? 5 : sg->R + 2;
+  vpin::TraceLap lap(nullptr, "sat gens");
   derive_gens(sg->g, sg->nb, "gens_r1cs_sat");
+  lap("derive_gens (host)");
 #pragma omp parallel for schedule(dynamic, 1) num_threads(host_threads())
   for (int i = 0; i < 7; i++) {
     if (i < 5) sg->fb[i] = FixedBase(sg->g[i]);
@@ -72,6 +74,7 @@ static int get_gens(vpin_ctx* c, size_t num_vars, SatGens** out) {
     rc = vpin_gens_shared(c, "gens_r1cs_sat", xyzt.data(), sg->nb, 0, &sg->dev);
   }
   if (rc) return rc;
+  lap("fixed bases + table");
   sg->pc.dev = sg->dev;
   *out = sg.get();
   pc->by_nv[num_vars] = std::move(sg);

@@ -17,6 +17,7 @@
 #include <cstdio>
 
 #include "host/prover_common.h"
+#include "gadget_dev.h"
 #include "spark_dev.h"
 
 namespace {
@@ -69,7 +70,9 @@ static int get_view(vpin_ctx* c, size_t ell, const PcGens** out) {
   if (it == sg->views.end()) {
     const size_t left = ell / 2, R = (size_t)1 << (ell - left), nb = R + 2;
     // every MultiCommitGens::new(n, label) is a prefix of the same SHAKE stream
+    vpin::TraceLap lap(nullptr, "spark get_view");
     if (sg->g.size() < nb) derive_gens(sg->g, nb, "gens_r1cs_eval");
+    lap("derive_gens (host)");
     std::unique_ptr<PcGens> v(new PcGens());
     v->ell = ell; v->L = (size_t)1 << left; v->R = R;
     int rc = vpin_gens_shared(c, "gens_r1cs_eval", nullptr, nb, 0, &v->dev);
@@ -565,6 +568,34 @@ void vpin_spark_decomm_free(vpin_ctx* c, vpin_spark_decomm* d) {
   delete d;
 }
 
+// second half of SNARK::encode: commit comb_ops / comb_mem (dense_mlpoly.rs:193-218 under b"gens_r1cs_eval") and
+// serialise bincode(R1CSCommitment) (r1csinstance.rs:53-58, sparse_mlpoly.rs:332-338)
+static int encode_commit(vpin_ctx* c, const Shape& s, std::unique_ptr<vpin_spark_decomm>& d, vpin::TraceLap& lap, size_t num_cons,
+                         size_t num_vars, size_t num_inputs, vpin_spark_decomm** out, uint8_t* comm_out, size_t comm_cap,
+                         size_t* comm_len, Clock::time_point t0) {
+  auto fail = [&](int rc) { vpin_spark_decomm_free(c, d.release()); return rc; };
+  int rc;
+  const PcGens *g_ops = nullptr, *g_mem = nullptr;
+  if ((rc = get_view(c, std::max(s.v_ops, s.v_mem), &g_ops)) || (rc = get_view(c, s.v_ops, &g_ops)) ||
+      (rc = get_view(c, s.v_mem, &g_mem)))
+    return fail(rc);
+  lap("generators (views)");
+  std::vector<CG> c_ops, c_mem;
+  if ((rc = commit_noblind(c, g_ops, d->comb_ops, c_ops)) || (rc = commit_noblind(c, g_mem, d->comb_mem, c_mem))) return fail(rc);
+  lap("commit ops + mem");
+  Writer w;
+  w.u64(num_cons); w.u64(num_vars); w.u64(num_inputs);
+  w.u64(3); w.u64(s.N); w.u64(s.M);
+  w.u64(c_ops.size()); for (auto& p : c_ops) w.point(p);
+  w.u64(c_mem.size()); for (auto& p : c_mem) w.point(p);
+  if (w.buf.size() > comm_cap) return fail(VPIN_ESHAPE);
+  memcpy(comm_out, w.buf.data(), w.buf.size());
+  *comm_len = w.buf.size();
+  *out = d.release();
+  g_spark_timings[0] = secs(t0, Clock::now());
+  return VPIN_OK;
+}
+
 // SNARK::encode (lib.rs:347-359) = R1CSInstance::commit (r1csinstance.rs:309-322) =
 // SparseMatPolynomial::multi_commit (sparse_mlpoly.rs:500-520)
 int vpin_spark_encode(vpin_ctx* c, const vpin_r1cs* inst, vpin_spark_decomm** out, uint8_t* comm_out, size_t comm_cap,
@@ -586,6 +617,7 @@ int vpin_spark_encode(vpin_ctx* c, const vpin_r1cs* inst, vpin_spark_decomm** ou
 
   // sparse_to_dense_vecs (:368-380) + AddrTimestamps::new (:232-265) on the host: the timestamps are a
   // sequential memory trace (audit_ts runs on across A, B, C), O(N) integer work done once per circuit
+  vpin::TraceLap lap(c, "spark_encode");
   std::vector<uint32_t> idx(12 * N + 2 * M, 0);
   for (int m = 0; m < 3; m++) {
     for (size_t k = 0; k < inst->nnz[m]; k++) {
@@ -603,6 +635,7 @@ int vpin_spark_encode(vpin_ctx* c, const vpin_r1cs* inst, vpin_spark_decomm** ou
       for (size_t i = 0; i < N; i++) ts[i] = audit[addr[i]]++;
     }
   }
+  lap("host idx + timestamps");
   int rc;
   if ((rc = vpin::dev_alloc(c, idx.size() * 4, (void**)&d->idx))) return fail(rc);
   if (hipMemcpyAsync(d->idx, idx.data(), idx.size() * 4, hipMemcpyHostToDevice, c->stream) != hipSuccess) return fail(VPIN_EHIP);
@@ -618,25 +651,54 @@ int vpin_spark_encode(vpin_ctx* c, const vpin_r1cs* inst, vpin_spark_decomm** ou
                                        c->stream) != hipSuccess)
       return fail(VPIN_EHIP);
   if (hipStreamSynchronize(c->stream) != hipSuccess) return fail(VPIN_EHIP);
+  lap("upload + comb tables");
 
-  const PcGens *g_ops = nullptr, *g_mem = nullptr;
-  if ((rc = get_view(c, std::max(s.v_ops, s.v_mem), &g_ops)) || (rc = get_view(c, s.v_ops, &g_ops)) ||
-      (rc = get_view(c, s.v_mem, &g_mem)))
-    return fail(rc);
-  std::vector<CG> c_ops, c_mem;
-  if ((rc = commit_noblind(c, g_ops, d->comb_ops, c_ops)) || (rc = commit_noblind(c, g_mem, d->comb_mem, c_mem))) return fail(rc);
-  // bincode(R1CSCommitment) (r1csinstance.rs:53-58, sparse_mlpoly.rs:332-338)
-  Writer w;
-  w.u64(inst->num_cons); w.u64(inst->num_vars); w.u64(inst->num_inputs);
-  w.u64(3); w.u64(N); w.u64(M);
-  w.u64(c_ops.size()); for (auto& p : c_ops) w.point(p);
-  w.u64(c_mem.size()); for (auto& p : c_mem) w.point(p);
-  if (w.buf.size() > comm_cap) return fail(VPIN_ESHAPE);
-  memcpy(comm_out, w.buf.data(), w.buf.size());
-  *comm_len = w.buf.size();
-  *out = d.release();
-  g_spark_timings[0] = secs(t0, Clock::now());
-  return VPIN_OK;
+  return encode_commit(c, s, d, lap, inst->num_cons, inst->num_vars, inst->num_inputs, out, comm_out, comm_cap, comm_len, t0);
+}
+
+// SNARK::encode for a device-built gadget instance: the dense representation comes from gadget_dev.hip's
+// closed forms instead of the host's sequential memory trace
+int vpin_spark_encode_dev(vpin_ctx* c, const vpin_dev_instance* g, vpin_spark_decomm** out, uint8_t* comm_out, size_t comm_cap,
+                          size_t* comm_len) {
+  if (!c || !g || !g->r1cs || !out || !comm_out || !comm_len) return VPIN_EINVAL;
+  auto t0 = Clock::now();
+  (void)hipSetDevice(c->device);
+  const size_t num_cons = g->r1cs->num_cons, num_vars = g->r1cs->num_vars;
+  const Shape s = shape_of(num_cons, num_vars, g->nnz);
+  const size_t N = s.N, M = s.M;
+  if (N < 4 || M < 4 || M > ((size_t)1 << 32) || N > ((size_t)1 << 31)) return VPIN_ESHAPE;
+  if (comm_cap < vpin_dev_instance_comm_bytes(g)) return VPIN_ESHAPE;
+  std::unique_ptr<vpin_spark_decomm> d(new vpin_spark_decomm());
+  d->num_cons = num_cons; d->num_vars = num_vars; d->num_inputs = g->num_inputs;
+  d->nx = s.nx; d->ny = s.ny; d->N = N; d->M = M;
+  auto fail = [&](int rc) { vpin_spark_decomm_free(c, d.release()); return rc; };
+  vpin::TraceLap lap(c, "spark_encode_dev");
+  int rc;
+  if ((rc = vpin::dev_alloc(c, (12 * N + 2 * M) * 4, (void**)&d->idx))) return fail(rc);
+  if ((rc = vpin::table_alloc_uninit(c, 16 * N, &d->comb_ops))) return fail(rc);
+  if ((rc = vpin::table_alloc_uninit(c, 2 * M, &d->comb_mem))) return fail(rc);
+  if ((rc = vpin::gadget_fill_decomm(c, g, d.get()))) return fail(rc);
+  if ((rc = vpin::spark_u32_to_fq(c, d->idx, d->comb_ops->d, 12 * N))) return fail(rc);
+  if ((rc = vpin::spark_u32_to_fq(c, d->idx + 12 * N, d->comb_mem->d, 2 * M))) return fail(rc);
+  if (hipMemsetAsync(d->comb_ops->d + 15 * N, 0, N * 32, c->stream) != hipSuccess) return fail(VPIN_EHIP);
+  lap("trace + comb tables");
+  return encode_commit(c, s, d, lap, num_cons, num_vars, g->num_inputs, out, comm_out, comm_cap, comm_len, t0);
+}
+
+size_t vpin_dev_instance_comm_bytes(const vpin_dev_instance* g) {
+  if (!g || !g->r1cs) return 0;
+  vpin_r1cs r{};
+  r.num_cons = g->r1cs->num_cons; r.num_vars = g->r1cs->num_vars; r.num_inputs = g->num_inputs;
+  for (int m = 0; m < 3; m++) r.nnz[m] = g->nnz[m];
+  return vpin_spark_comm_bytes(&r);
+}
+
+size_t vpin_dev_instance_proof_max_bytes(const vpin_dev_instance* g) {
+  if (!g || !g->r1cs) return 0;
+  vpin_r1cs r{};
+  r.num_cons = g->r1cs->num_cons; r.num_vars = g->r1cs->num_vars; r.num_inputs = g->num_inputs;
+  for (int m = 0; m < 3; m++) r.nnz[m] = g->nnz[m];
+  return vpin_snark_proof_max_bytes(&r);
 }
 
 // my_lib_prove (commit_test.rs:59-133) in full: R1CSProof, inst_evals, R1CSEvalProof -> bincode(SNARK)
@@ -684,21 +746,51 @@ int vpin_snark_prove(vpin_ctx* c, const vpin_r1cs* inst, const uint8_t* vars_par
   if (!vpin::is_pow2(nv) || !vpin::is_pow2(inst->num_cons) || inst->num_inputs >= nv) return VPIN_ESHAPE;
   vpin_r1cs_dev* dinst = nullptr;
   vpin_spark_decomm* decomm = nullptr;
+  const bool trace = getenv("VPIN_CLI_TRACE") != nullptr;
+  auto t0 = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) {
+    if (!trace) return;
+    (void)hipStreamSynchronize(c->stream);
+    auto t1 = std::chrono::steady_clock::now();
+    fprintf(stderr, "[vpin_snark_prove] %-18s %9.1f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+    t0 = t1;
+  };
   int rc = vpin_r1cs_upload(c, inst, &dinst);
   if (rc) return rc;
+  lap("r1cs_upload");
   TableGuard tg(c);
   vpin_table *d_para = nullptr, *d_input = nullptr, *d_vars = nullptr;
   rc = vpin_spark_encode(c, inst, &decomm, comm_out, comm_cap, comm_len);
+  lap("spark_encode");
   if (!rc) rc = vpin_table_upload(c, vars_para, nv, &d_para);
   if (!rc) { tg.add(d_para); rc = vpin_table_upload(c, vars_input, nv, &d_input); }
   if (!rc) { tg.add(d_input); rc = vpin_table_upload(c, vars, nv, &d_vars); }
+  lap("witness_upload");
   if (!rc) {
     tg.add(d_vars);
     rc = vpin_snark_prove_resident(c, dinst, decomm, d_para, d_input, d_vars, inputs, seed_commit64, seed_proof64, proof_out,
                                    proof_cap, proof_len, comm_para_out, comm_input_out);
   }
+  lap("prove_resident");
   vpin_spark_decomm_free(c, decomm);
   vpin_r1cs_free(c, dinst);
+  return rc;
+}
+
+// the same span for a device-built instance (vpin_gadget_point_*_dev): nothing crosses PCIe but the proof
+int vpin_snark_prove_dev(vpin_ctx* c, const vpin_dev_instance* g, const uint8_t seed_commit64[64], const uint8_t seed_proof64[64],
+                         uint8_t* proof_out, size_t proof_cap, size_t* proof_len, uint8_t* comm_out, size_t comm_cap,
+                         size_t* comm_len, uint8_t* comm_para_out, uint8_t* comm_input_out) {
+  if (!c || !g || !g->r1cs) return VPIN_EINVAL;
+  vpin_spark_decomm* decomm = nullptr;
+  vpin::TraceLap lap(c, "vpin_snark_prove_dev");
+  int rc = vpin_spark_encode_dev(c, g, &decomm, comm_out, comm_cap, comm_len);
+  lap("spark_encode_dev");
+  if (!rc)
+    rc = vpin_snark_prove_resident(c, g->r1cs, decomm, g->vars_para, g->vars_input, g->vars, g->num_inputs ? g->inputs : nullptr,
+                                   seed_commit64, seed_proof64, proof_out, proof_cap, proof_len, comm_para_out, comm_input_out);
+  lap("prove_resident");
+  vpin_spark_decomm_free(c, decomm);
   return rc;
 }
 

@@ -139,7 +139,8 @@ CONFIGS = {
 LENET = ("L1", "L2", "L3", "L4", "L5", "L6", "L7")
 
 
-def synthetic_mult_instance(label, n_override=None):
+def synthetic_mult_inputs(label, n_override=None):
+    """(weights as Python ints, px, py) of a configuration's point multiplications, or None"""
     cfg = CONFIGS[label]
     n = n_override or cfg["n_mult"]
     if n == 0:
@@ -159,10 +160,15 @@ def synthetic_mult_instance(label, n_override=None):
             st, a = splitmix64(st)
             st, b = splitmix64(st)
             w.append(((a << 64) | b) >> 1)
-    return point_mult(w, x, y)
+    return w, x, y
 
 
-def synthetic_add_instance(label, n_override=None):
+def synthetic_mult_instance(label, n_override=None):
+    inp = synthetic_mult_inputs(label, n_override)
+    return None if inp is None else point_mult(*inp)
+
+
+def synthetic_add_inputs(label, n_override=None):
     cfg = CONFIGS[label]
     n = n_override or cfg["n_add"]
     x, y = synthetic_points(SEED + 100 + cfg["index"], 2 * n)
@@ -174,4 +180,35 @@ def synthetic_add_instance(label, n_override=None):
         rz[idx] = 1
         rx[idx] = 0
         ry[idx] = 0
-    return point_add(px, py, rx, ry, rz)
+    return px, py, rx, ry, rz
+
+
+def synthetic_add_instance(label, n_override=None):
+    return point_add(*synthetic_add_inputs(label, n_override))
+
+
+def write_witness_files(root, label, n_mult=None, n_add=None):
+    """The 8 JSON files of one network label under root/rust_files/<label>/, in the format the reference's
+    Python service writes (src/convolution/Server.py:324-417) and VP/load_data*.rs read: N x 32 arrays of
+    byte values, rz flags as ints, weights as decimal strings.  L2/L4 get no pointMult directory content."""
+    import json
+    import os
+    pa = os.path.join(root, "rust_files", label, "pointAdd")
+    pm = os.path.join(root, "rust_files", label, "pointMult")
+    os.makedirs(pa, exist_ok=True)
+    os.makedirs(pm, exist_ok=True)
+    px, py, rx, ry, rz = synthetic_add_inputs(label, n_add)
+    for name, a in (("px", px), ("py", py), ("rx", rx), ("ry", ry)):
+        with open(os.path.join(pa, f"point_add_{name}_byte.json"), "w") as f:
+            json.dump(a.tolist(), f)
+    with open(os.path.join(pa, "point_add_rz_byte.json"), "w") as f:
+        json.dump([int(v) for v in rz], f)
+    m = synthetic_mult_inputs(label, n_mult)
+    if m is not None:
+        w, x, y = m
+        with open(os.path.join(pm, "weight.json"), "w") as f:
+            json.dump([str(v) for v in w], f)
+        with open(os.path.join(pm, "point_mult_px_byte.json"), "w") as f:
+            json.dump(x.tolist(), f)
+        with open(os.path.join(pm, "point_mult_py_byte.json"), "w") as f:
+            json.dump(y.tolist(), f)

@@ -91,23 +91,25 @@ def main():
     trace = args.label or args.trace
     labels = list(G.LENET) if trace == "lenet" else [trace]
 
-    # ---- synthetic workload (host side, outside the timed region) ----
+    # ---- synthetic workload: witness inputs on the host, instances built on the device (outside the timed region) ----
     t0 = time.perf_counter()
-    work = []  # (name, kind, Instance)
+    work = []  # (name, kind, inputs, unpadded constraints)
     for lab in labels:
-        m = G.synthetic_mult_instance(lab)
+        m = G.synthetic_mult_inputs(lab)
         if m is not None:
-            work.append((f"{lab}-mult", "mult", m))
-        work.append((f"{lab}-add", "add", G.synthetic_add_instance(lab)))
+            work.append((f"{lab}-mult", "mult", m, 3464 * len(m[0])))
+        a = G.synthetic_add_inputs(lab)
+        work.append((f"{lab}-add", "add", a, 10 * len(a[4])))
     if args.only:
         work = [w for w in work if w[1] == args.only]
     setup_s = time.perf_counter() - t0
-    cons = {w[0]: w[2].num_cons_unpadded for w in work}
+    cons = {w[0]: w[3] for w in work}
     total_cons_step = sum(cons.values())
+    inputs_of = {w[0]: (w[1], w[2]) for w in work}
 
     # lanes: mult instances largest first on lane 0; add instances on lane 1 (started after the
     # largest mult instance unless --serial)
-    mults = sorted([w for w in work if w[1] == "mult"], key=lambda w: -w[2].num_cons_unpadded)
+    mults = sorted([w for w in work if w[1] == "mult"], key=lambda w: -w[3])
     adds = [w for w in work if w[1] == "add"]
     lanes = [mults + adds] if (args.serial or not mults) else [mults, adds]
     if args.snark and not args.serial and len(mults) > 2:
@@ -125,32 +127,41 @@ def main():
         grp.barrier()
         torch.cuda.synchronize()
 
+    def build_instance(cx, kind, inp):
+        """gadget + witness + Instance::new on the device (vpin_gadget_point_*_dev)"""
+        return cx.gadget_point_mult_dev(*inp) if kind == "mult" else cx.gadget_point_add_dev(*inp)
+
     # instance + the three assignments resident in HBM before the timed region (the PCIe-inclusive
     # variant is vpin_sat_prove / --host-buffers; its rate is noted in DESIGN.md)
-    resident, dicts, decomms, encode_ms, comm_bytes, verify_meta, last_proof = {}, {}, {}, {}, {}, {}, {}
+    resident, dicts, decomms, encode_ms, comm_bytes, verify_meta, last_proof, dev_insts = {}, {}, {}, {}, {}, {}, {}, {}
     t0 = time.perf_counter()
     for li, lane in enumerate(lanes):
-        for name, _, inst in lane:
-            d = inst.as_dict()
+        for name, kind, inp, _ in lane:
             cx = ctxs[li]
             if args.host_buffers:
+                inst = G.point_mult(*inp) if kind == "mult" else G.point_add(*inp)
+                d = inst.as_dict()
                 dicts[name] = d
+                num_vars = d["num_vars"]
+                inst.free()
             else:
-                resident[name] = (cx.r1cs_upload(d), cx.upload(d["vars_para"]), cx.upload(d["vars_input"]),
-                                  cx.upload(d["vars"]), d["inputs"])
+                g = build_instance(cx, kind, inp)
+                assert g.num_cons_unpadded == cons[name]
+                dev_insts[name] = g
+                resident[name] = (g.r1cs, g.vars_para, g.vars_input, g.vars, g.inputs)
+                num_vars = g.num_vars
             # generator sets before the timed region, largest polynomial first (lane 0 comes first), so every
             # lane shares the one window table per label
-            cx.sat_prepare(d["num_vars"])
+            cx.sat_prepare(num_vars)
             if args.snark:
                 # SNARK::encode: once per circuit, outside the timed region (the computation commitment
                 # does not depend on the witness); first call also builds the generator table
-                cx.spark_encode(d)[0].free()
+                g.spark_encode()[0].free()
                 te = time.perf_counter()
-                decomms[name], comm = cx.spark_encode(d)
+                decomms[name], comm = g.spark_encode()
                 encode_ms[name] = round((time.perf_counter() - te) * 1e3, 3)
                 comm_bytes[name] = len(comm)
-                verify_meta[name] = (comm, {"inputs": d["inputs"], "num_inputs": d["num_inputs"]})
-            inst.free()
+                verify_meta[name] = (comm, {"inputs": g.inputs, "num_inputs": g.num_inputs})
     upload_s = time.perf_counter() - t0
     lane_names = [[w[0] for w in lane] for lane in lanes]
 
@@ -305,7 +316,8 @@ def main():
                               "GBps_alg": (v["alg_bytes"] / (v["ms"] * 1e-3) / 1e9) if v["ms"] else None}
                        for name, v in stats.items()}
     line["spans_ms_last_step"] = {n: {kk: round(vv * 1e3, 3) for kk, vv in sp.items()} for n, sp in last_spans.items()}
-    line["setup_s"] = {"gadgets_and_witness": round(setup_s, 3), "upload_and_csr": round(upload_s, 3)}
+    line["setup_s"] = {"synthetic_witness_inputs": round(setup_s, 3),
+                       "device_gadgets_generator_tables_encode": round(upload_s, 3)}
     line["proof_bytes"] = proof_bytes
     line["hbm_in_use_gib_after_timed_region"] = hbm_used_gb  # instances, decommitments, generator tables, pooled temporaries
     if args.snark:
@@ -323,6 +335,30 @@ def main():
             line["verified"] = verified
             line["verify_s"] = round(time.perf_counter() - tv, 2)
             assert all(verified.values()), verified
+        # ---- the reference's own span (proof_point_mult.rs:24-101: witness inputs -> gadget + witness ->
+        # is_sat -> SNARK::encode -> my_lib_prove), one instance after the other, generator tables warm; the
+        # resident copies are released first.  Same seeds, so the bytes must equal the timed region's proofs.
+        for name in list(dev_insts):
+            decomms.pop(name).free()
+            dev_insts.pop(name).free()
+        span = {}
+        ts = time.perf_counter()
+        for li, names in enumerate(lane_names):
+            for name in names:
+                t1 = time.perf_counter()
+                kind, inp = inputs_of[name]
+                g = build_instance(ctxs[li], kind, inp)
+                assert g.is_sat()
+                r = g.snark_prove(SEED_C, SEED_P)
+                span[name] = round((time.perf_counter() - t1) * 1e3, 2)
+                assert r["proof"] == last_proof[name]["proof"], f"{name}: reference-span proof differs from the timed region's"
+                g.free()
+        span_s = time.perf_counter() - ts
+        line["reference_span"] = {
+            "ms_per_trace": round(span_s * 1e3, 1), "constraints_per_s": total_cons_step / span_s, "ms": span,
+            "scope": "per instance, serially: witness inputs in host memory -> gadget + witness synthesis + Instance::new "
+                     "(device) -> is_sat -> SNARK::encode -> my_lib_prove -> proof bytes on the host; generator tables warm",
+        }
 
     # ---- CPU baseline: the oracle on a bounded sample, rank 0, N=1 only ----
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -11,12 +11,40 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
+SCRUB = r"""
+import ctypes as C, time
+hip = C.CDLL("libamdhip64.so")
+hip.hipSetDevice(0)
+blocks = []
+while True:
+    p = C.c_void_p()
+    if hip.hipMalloc(C.byref(p), C.c_size_t(8 << 30)) != 0:
+        break
+    blocks.append(p)
+for p in blocks:
+    hip.hipFree(p)
+print(f"scrub: took and explicitly freed {8 * len(blocks)} GB", flush=True)
+"""
+
+
+def scrub():
+    """Bring VRAM to the state of an idle GPU: memory a previous process left behind at exit is only wiped when it
+    is allocated again; allocate everything once, free it explicitly and give the background wipe time to finish."""
+    subprocess.run([sys.executable, "-c", SCRUB], check=False)
+    time.sleep(12)
+
+
 def main():
-    labels = sys.argv[1:] or ["A"]
+    labels = [a for a in sys.argv[1:] if not a.startswith("--")] or ["A"]
     from vpin_amd import gadgets as G
     binp = os.path.join(ROOT, "vpin_amd", "bin", "vpin_prove")
     with tempfile.TemporaryDirectory() as d:
         for lab in labels:
+            # VRAM freed by an earlier process is wiped by the driver before it can be allocated again (~30 GB/s);
+            # let that finish so the run starts from the state an idle GPU is in
+            time.sleep(float(os.environ.get("TIME_CLI_IDLE_S", "0")))
+            if "--scrub" in sys.argv:
+                scrub()
             t0 = time.perf_counter()
             G.write_witness_files(d, lab)
             print(f"== {lab}: witness files written in {time.perf_counter() - t0:.2f} s", flush=True)

@@ -364,6 +364,9 @@ int main(int argc, char** argv) {
   printf("Total proof generation time: %lld ms\n", ra.gen_ms + rm.gen_ms);
   printf("Total proof verification time: %lld ms\n", ra.ver_ms + rm.ver_ms);
   printf("====================================\n");
+  // hand every block back explicitly: VRAM released by hipFree is wiped by the driver in the background, VRAM
+  // reclaimed at process teardown is wiped when the next process allocates it (tools/ubench_malloc*.hip)
   vpin_ctx_destroy(ctx);
+  vpin_gens_shared_clear();
   return 0;
 }

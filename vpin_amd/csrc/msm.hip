@@ -392,18 +392,17 @@ static int gens_build(vpin_ctx* c, const uint8_t* gens_xyzt, size_t nb, size_t b
   }
   const size_t entries = nb * (size_t)g->W * g->E;
   TraceLap lap(c, "gens_build");
-  DevBuf raw(c);
-  ge_ext* shifts = nullptr;
-  fp* prefix = nullptr;
-  if (raw.alloc(nb * 128) != VPIN_OK || hipMalloc((void**)&shifts, nb * g->W * sizeof(ge_ext)) != hipSuccess ||
-      hipMalloc((void**)&prefix, entries * sizeof(fp)) != hipSuccess ||
-      hipMalloc((void**)&g->table, entries * sizeof(niels_slot)) != hipSuccess) {
-    if (shifts) (void)hipFree(shifts);
-    if (prefix) (void)hipFree(prefix);
+  // temporaries come from the context pool, so the blocks go on to serve proof temporaries instead of being
+  // returned to the driver (freed VRAM is wiped before it can be handed out again: tools/ubench_malloc2.hip)
+  DevBuf raw(c), b_shifts(c), b_prefix(c);
+  if (raw.alloc(nb * 128) != VPIN_OK || b_shifts.alloc(nb * g->W * sizeof(ge_ext)) != VPIN_OK ||
+      b_prefix.alloc(entries * sizeof(fp)) != VPIN_OK || hipMalloc((void**)&g->table, entries * sizeof(niels_slot)) != hipSuccess) {
     if (g->table) (void)hipFree(g->table);
     delete g;
     return VPIN_ENOMEM;
   }
+  ge_ext* shifts = (ge_ext*)b_shifts.p;
+  fp* prefix = (fp*)b_prefix.p;
   lap("hipMalloc");
   hipError_t e = hipMemcpyAsync(raw.p, gens_xyzt, nb * 128, hipMemcpyHostToDevice, c->stream);
   if (e == hipSuccess) {
@@ -415,9 +414,6 @@ static int gens_build(vpin_ctx* c, const uint8_t* gens_xyzt, size_t nb, size_t b
   }
   if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
   lap("table kernels");
-  (void)hipFree(shifts);
-  (void)hipFree(prefix);
-  lap("hipFree temporaries");
   if (e != hipSuccess) {
     set_last_error("vpin_gens_create", e);
     (void)hipFree(g->table);

@@ -66,6 +66,8 @@ def parse():
                     help="time only the R1CS satisfiability proof (SURVEY.md 8(a) rows H1-H10) instead of the whole SNARK")
     ap.add_argument("--snark", action="store_true", help="(default) whole SNARK: sat proof + inst_evals + SPARK R1CSEvalProof, "
                     "my_lib_prove in full; SNARK::encode runs once per instance before the timed region and is reported beside it")
+    ap.add_argument("--mult-lanes", type=int, default=int(os.environ.get("VPIN_BENCH_MULT_LANES", "1")),
+                    help="streams / host threads for the point-mult instances other than the largest")
     ap.add_argument("--only", choices=["mult", "add"], default=None, help="keep only the point-mult / point-add instances of the trace")
     ap.add_argument("--no-verify", action="store_true", help="skip the post-run verification of the last step's SNARKs")
     ap.add_argument("--no-prof", action="store_true", help="no HIP-event bracketing of kernels (no roofline object)")
@@ -116,7 +118,10 @@ def main():
         # whole SNARKs are long enough to be worth three host threads / streams: the largest instance
         # alone, the other point-mult instances, the point-add instances; lanes 1 and 2 start when the
         # largest instance's sat part is done, so its sum-check kernels are timed undisturbed
-        lanes = [mults[:1], mults[1:], adds]
+        rest = [[] for _ in range(max(1, min(args.mult_lanes, len(mults) - 1)))]
+        for w in mults[1:]:  # largest first onto the least loaded lane
+            min(rest, key=lambda l: sum(x[3] for x in l)).append(w)
+        lanes = [mults[:1]] + rest + [adds]
     # the lanes of small, latency-bound instances get high-priority streams: their one-workgroup round
     # kernels are then dispatched ahead of the large instance's queued workgroups instead of behind them
     prios = [0] + [-1] * (len(lanes) - 1) if not os.environ.get("VPIN_BENCH_NO_PRIO") else [0] * len(lanes)
@@ -168,7 +173,7 @@ def main():
     last_spans, proof_bytes = {}, {}
     import numpy as np
     progress = np.zeros(4, dtype=np.int32)
-    if args.snark and len(lanes) == 3:
+    if args.snark and len(lanes) >= 3:
         ctxs[0].set_progress_flag(progress)
 
     def prove(li, name):
@@ -199,7 +204,7 @@ def main():
         if len(lanes) == 1:
             run_lane(0, None)
             return
-        if len(lanes) == 3:
+        if len(lanes) >= 3:
             progress[0] = 0
             gate = threading.Event()
 
@@ -207,7 +212,7 @@ def main():
                 while progress[0] == 0 and not gate.is_set():
                     time.sleep(0.0005)
                 gate.set()
-            ts = [threading.Thread(target=run_lane, args=(li, gate)) for li in (1, 2)] + [threading.Thread(target=watch)]
+            ts = [threading.Thread(target=run_lane, args=(li, gate)) for li in range(1, len(lanes))] + [threading.Thread(target=watch)]
             for t in ts:
                 t.start()
             run_lane(0, None)
@@ -281,8 +286,9 @@ def main():
                       "R1CSProof (commitments + both ZK sum-checks + evaluation proof); SPARK encode/eval proof not included"),
             "parallelism": f"one trace per rank x {world} rank(s), no collective; per rank "
                            + ("instances proven serially" if len(lanes) == 1 else
-                              "3 streams: largest instance | other mult instances | add instances (2nd, 3rd start after the largest's sat part)"
-                              if len(lanes) == 3 else
+                              f"{len(lanes)} streams: largest instance | other mult instances on {len(lanes) - 2} | add instances (all but the first "
+                              "start after the largest's sat part)"
+                              if len(lanes) >= 3 else
                               "mult instances serially, add instances on a second stream after the largest"),
             "inputs": "host buffers (PCIe-inclusive, CSR/CSC built per proof)" if args.host_buffers else "resident in HBM",
         },

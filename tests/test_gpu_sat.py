@@ -109,3 +109,30 @@ def test_resident_path_same_proof(ctx):
     for t, k in zip(tabs, ("vars_para", "vars_input", "vars")):
         assert np.array_equal(t.read(), inst[k])
     di.free()
+
+
+def test_unsatisfied_witness_gives_the_reference_bytes(ctx):
+    """A witness that does not satisfy the instance: phase 1's claim (0) is then not the true sum, so the prover must
+    leave the leading-coefficient rounds (which derive t(1) from the claim) for the three-sum kernels; the proof is
+    still byte-identical to the oracle's (and the verifier rejects it)."""
+    inst = GM.instance_new(GM.build_point_add(GM.synthetic_add_ops(0x5650494E + 9, 5)))
+    assert O.is_sat(inst)
+    bad = dict(inst)
+    for k in ("vars_input", "vars"):
+        t = np.array(inst[k], copy=True)
+        t[13] = t[14]  # x3 of the first addition := y3
+        bad[k] = t
+    assert not O.is_sat(bad)
+    got = ctx.sat_prove(bad, SEED_C, SEED_P)
+    exp = O.sat_prove(bad, SEED_C, SEED_P)
+    assert got["proof"] == exp["proof"]
+    assert O.sat_verify(bad, got) != 1
+    # and a mult instance large enough for the multi-workgroup kernels
+    inst = GM.instance_new(GM.build_point_mult(GM.synthetic_mult_ops(0x5650494E + 10, 1)))
+    bad = dict(inst)
+    for k in ("vars_input", "vars"):
+        t = np.array(inst[k], copy=True)
+        t[130] = t[131]  # dx of the first doubling := dx of the second
+        bad[k] = t
+    assert not O.is_sat(bad)
+    assert ctx.sat_prove(bad, SEED_C, SEED_P)["proof"] == O.sat_prove(bad, SEED_C, SEED_P)["proof"]

@@ -110,7 +110,8 @@ int commit_pair_finish(vpin_ctx* c, const vpin_gens* g, CommitPairState* st, con
 // asynchronous round launch / collect (sumcheck.hip), for the host prover's overlap
 int sc_round_launch(vpin_ctx* c, int K, vpin_table* const* tabs, const uint8_t* r);
 int sc_round_wait(vpin_ctx* c, int K, uint8_t* out);
-int sc_cubic3_launch(vpin_ctx* c, vpin_table* const* t, const vpin_table* pyramid, int ell, int level, const uint8_t* r);
+int sc_cubic3_launch(vpin_ctx* c, vpin_table* const* t, const vpin_table* pyramid, int ell, int level, const uint8_t* r,
+                     bool lead = false);
 
 inline bool is_pow2(size_t x) { return x && !(x & (x - 1)); }
 

@@ -142,14 +142,47 @@ static int zk_sumcheck(vpin_ctx* c, int K, vpin_table** tabs, const Fq& claim, c
   Fq claim_pr = claim;
   CG comm_claim = compress(commit1(claim_pr, blind_claim, g1));
   r_out.clear();
-  int rc = factored ? vpin::sc_cubic3_launch(c, tabs, pyramid, rounds, 1, nullptr) : vpin::sc_round_launch(c, K, tabs, nullptr);
+  // Leading-coefficient rounds (sc_dev.h lead_bcd): the kernel returns t(0) and the x^2 coefficient of the
+  // quadratic t(x) = sum_i E[i] (Az_x Bz_x - Cz_x)[i]; t(1) follows from the round's claim.  Round 0 returns
+  // t(0), t(1) and the coefficient directly; when its claim does not check (a witness that does not satisfy the
+  // instance: claim 0 is then not the true sum) or a tau_j is zero, every later round uses the three-sum kernel,
+  // so the bytes are those of the reference in that case too.
+  bool lead = factored;
+  std::vector<Fq> tau_inv;
+  if (factored) {
+    tau_inv.assign(tau->begin(), tau->begin() + rounds);
+    for (auto& x : tau_inv) lead = lead && !x.is_zero();
+    if (lead) {
+      std::vector<Fq> pre(rounds);
+      Fq acc = f_one;
+      for (int j = 0; j < rounds; j++) { pre[j] = acc; acc = acc * tau_inv[j]; }
+      acc = acc.invert();
+      for (int j = rounds - 1; j >= 0; j--) { Fq t = acc * tau_inv[j]; tau_inv[j] = acc * pre[j]; acc = t; }
+    }
+  }
+  Fq cn = claim;  // claim_pr / s_eq: the claim on the quadratic t
+  int rc = factored ? vpin::sc_cubic3_launch(c, tabs, pyramid, rounds, 1, nullptr, lead) : vpin::sc_round_launch(c, K, tabs, nullptr);
   if (rc) return rc;
   Fq r_j = Fq::zero();
   for (int j = 0; j < rounds; j++) {
     Fq e[3];
     if ((rc = vpin::sc_round_wait(c, K, B(e)))) return rc;
+    bool lead_next = lead;
+    Fq t0, t1, tinf;
     if (factored) {
       const Fq& t = (*tau)[j];
+      if (lead) {
+        t0 = e[0]; tinf = e[1];
+        if (j == 0) {
+          t1 = e[2];
+          lead_next = (cn == (f_one - t) * t0 + t * t1);  // s_eq = 1
+        } else {
+          t1 = (cn - (f_one - t) * t0) * tau_inv[j];
+        }
+        const Fq d10 = t1 - t0, two_inf = tinf + tinf;
+        e[1] = t1 + d10 + two_inf;                    // t(2) = 2 t(1) - t(0) + 2 tinf
+        e[2] = e[1] + d10 + two_inf + two_inf;        // t(3) = 3 t(1) - 2 t(0) + 6 tinf
+      }
       e[0] = e[0] * (s_eq * (f_one - t));
       e[1] = e[1] * (s_eq * (f_three * t - f_one));
       e[2] = e[2] * (s_eq * (f_five * t - f_two));
@@ -166,9 +199,11 @@ static int zk_sumcheck(vpin_ctx* c, int K, vpin_table** tabs, const Fq& claim, c
     r_j = tr.challenge_scalar("challenge_nextround");
     // fold with r_j and evaluate the next round while the host finishes this one
     if (j + 1 < rounds) {
-      rc = factored ? vpin::sc_cubic3_launch(c, tabs, pyramid, rounds, j + 2, B(&r_j)) : vpin::sc_round_launch(c, K, tabs, B(&r_j));
+      rc = factored ? vpin::sc_cubic3_launch(c, tabs, pyramid, rounds, j + 2, B(&r_j), lead_next) : vpin::sc_round_launch(c, K, tabs, B(&r_j));
       if (rc) return rc;
     }
+    if (lead) cn = t0 + r_j * ((t1 - t0 - tinf) + r_j * tinf);  // t(r_j)
+    lead = lead_next;
     if (factored) {  // s_{j+1} = s_j * eq1(tau_j, r_j)
       const Fq& t = (*tau)[j];
       s_eq = s_eq * (t * r_j + (f_one - t) * (f_one - r_j));

@@ -65,6 +65,22 @@ struct Acc<4> {
     e[1] = fq_add(e[1], fq_mul(E, u[1]));
     e[2] = fq_add(e[2], fq_mul(E, u[2]));
   }
+  // Leading-coefficient form.  With the eq factor split off, the round polynomial is l(x) * t(x) with l linear and
+  // t(x) = sum_i E[i] u_x[i] quadratic, so t(0), the x^2 coefficient of t and the round's claim (which fixes t(1))
+  // determine it: e[0] += E * u(0), e[1] += E * dB*dC -- two products and no p+2d / p+3d chains per pair instead
+  // of three.  `first` rounds (claim not yet known to be consistent) also return e[2] += E * u(1).
+  __device__ __forceinline__ void lead_bc(const fq& pb, const fq& db, const fq& pc, const fq& dc, const fq& E) {
+    e[0] = fq_add(e[0], fq_mul(E, fq_mul(pb, pc)));
+    e[1] = fq_add(e[1], fq_mul(E, fq_mul(db, dc)));
+  }
+  __device__ __forceinline__ void lead_bcd(const fq& pb, const fq& db, const fq& pc, const fq& dc, const fq& pd, const fq& E) {
+    e[0] = fq_add(e[0], fq_mul(E, fq_sub(fq_mul(pb, pc), pd)));
+    e[1] = fq_add(e[1], fq_mul(E, fq_mul(db, dc)));
+  }
+  __device__ __forceinline__ void lead_one(const fq& pb, const fq& db, const fq& pc, const fq& dc, const fq& pd, const fq& dd,
+                                           const fq& E) {
+    e[2] = fq_add(e[2], fq_mul(E, fq_sub(fq_mul(fq_add(pb, db), fq_add(pc, dc)), fq_add(pd, dd))));
+  }
   __device__ __forceinline__ void stage_a(const fq* u, fq pa, const fq& da) {
     e[0] = fq_add(e[0], fq_mul(pa, u[0]));
     pa = fq_add(fq_add(pa, da), da);

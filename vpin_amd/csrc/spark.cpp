@@ -277,17 +277,43 @@ static int batched_prove(vpin_ctx* c, vpin::SparkForest& f, DotpCtx* dotp, Trans
       if ((rc = vpin_eq_suffix_tables(c, B(rand.data()), k, &pyr))) return rc;
       tg.add(pyr);
       Fq s = one;
+      // Leading-coefficient rounds: per circuit the kernel returns t(0) and the x^2 coefficient of
+      // t(x) = sum_i E[i] (A_x B_x)[i]; t(1) follows from the circuit's claim, which the prover knows exactly
+      // (claims[] are evaluations of the trees it built): with cn = (sum_t coeff_t claim_t) / s the combined
+      // quadratic T satisfies cn = (1-rho) T(0) + rho T(1), and cn becomes T(r_j) after the round.  Exact field
+      // identities: same c0, c2, c3 as summing at x = 0, 2, 3.  A zero rho_j (never, for a transcript
+      // challenge) takes the three-sum kernel for that round.
+      std::vector<Fq> rho_inv(rand.begin(), rand.begin() + k);
+      bool lead_ok = true;
+      for (auto& x : rho_inv) lead_ok = lead_ok && !x.is_zero();
+      if (lead_ok) {  // Montgomery's trick: one inversion per layer
+        std::vector<Fq> pre(k);
+        Fq acc = one;
+        for (int j = 0; j < k; j++) { pre[j] = acc; acc = acc * rho_inv[j]; }
+        acc = acc.invert();
+        for (int j = k - 1; j >= 0; j--) { Fq t = acc * rho_inv[j]; rho_inv[j] = acc * pre[j]; acc = t; }
+      }
+      Fq cn = Fq::zero();
+      for (int t = 0; t < npc; t++) cn = cn + claims[t] * coeffs[t];
       for (int j = 0; j < k; j++) {
         const size_t len = j == 0 ? h : (h >> (j - 1));  // live length before this round's launch
         const vpin::fq* E = pyr->d + pyramid_offset(k, j + 1);
         const uint8_t* rprev = j ? B(&r[j - 1]) : nullptr;
-        if ((rc = vpin::spark_prod_round(c, &f, layer_id, len, E, rprev, with_dotp))) return rc;
+        if ((rc = vpin::spark_prod_round(c, &f, layer_id, len, E, rprev, with_dotp, lead_ok))) return rc;
         if (with_dotp && (rc = vpin::spark_dotp_round(c, dotp->d, dotp->comb_derefs, dotp->scratch, len, j == 1, rprev))) return rc;
         if ((rc = vpin::spark_wait_flag(c))) return rc;
         const Fq* res = reinterpret_cast<const Fq*>(c->h_spark);
-        Fq S0 = Fq::zero(), S2 = Fq::zero(), S3 = Fq::zero();
-        for (int t = 0; t < npc; t++) { S0 = S0 + res[3 * t] * coeffs[t]; S2 = S2 + res[3 * t + 1] * coeffs[t]; S3 = S3 + res[3 * t + 2] * coeffs[t]; }
         const Fq rho = rand[j], omr = one - rho;
+        Fq S0 = Fq::zero(), S2 = Fq::zero(), S3 = Fq::zero(), T1 = Fq::zero(), Sinf = Fq::zero();
+        if (lead_ok) {
+          for (int t = 0; t < npc; t++) { S0 = S0 + res[3 * t] * coeffs[t]; Sinf = Sinf + res[3 * t + 1] * coeffs[t]; }
+          T1 = (cn - omr * S0) * rho_inv[j];
+          const Fq two_inf = Sinf + Sinf, d10 = T1 - S0;
+          S2 = T1 + d10 + two_inf;                               // T(2) = 2 T(1) - T(0) + 2 Tinf
+          S3 = S2 + d10 + two_inf + two_inf;                     // T(3) = 3 T(1) - 2 T(0) + 6 Tinf
+        } else {
+          for (int t = 0; t < npc; t++) { S0 = S0 + res[3 * t] * coeffs[t]; S2 = S2 + res[3 * t + 1] * coeffs[t]; S3 = S3 + res[3 * t + 2] * coeffs[t]; }
+        }
         const Fq two_rho = rho + rho;
         Fq c0 = s * omr * S0;
         Fq c2 = s * (two_rho + rho - one) * S2;                       // (1-rho) + 2(2rho-1) = 3rho - 1
@@ -303,6 +329,7 @@ static int batched_prove(vpin_ctx* c, vpin::SparkForest& f, DotpCtx* dotp, Trans
         Fq rj = tr.challenge_scalar("challenge_nextround");
         r[j] = rj;
         e = unipoly_eval(cf, 4, rj);
+        if (lead_ok) cn = S0 + rj * ((T1 - S0 - Sinf) + rj * Sinf);   // T(r_j)
         s = s * (rho * rj + omr * (one - rj));
         polys[3 * j] = cf[0]; polys[3 * j + 1] = cf[2]; polys[3 * j + 2] = cf[3];
       }

@@ -218,7 +218,8 @@ __device__ __forceinline__ void fold_pd2(const fq* src, fq* dst, size_t i, size_
   d = fq_sub(hi, p);
 }
 
-template <bool BIND>
+// LEAD: return sum E*A_0*B_0 and sum E*dA*dB (sc_dev.h lead_bc) instead of the sums at x = 0, 2, 3
+template <bool BIND, bool LEAD>
 __global__ __launch_bounds__(kBlock, kMinWaves) void prod_round_kernel(fq* __restrict__ forest, size_t stride, size_t off, size_t h,
                                                                        const fq* __restrict__ E, size_t pairs, fq r, Finisher fin) {
   fq* A = forest + (size_t)blockIdx.y * stride + off;
@@ -229,8 +230,12 @@ __global__ __launch_bounds__(kBlock, kMinWaves) void prod_round_kernel(fq* __res
     fq u[3], p1, d1, p2, d2;
     if (BIND) { fold_pd(A, i, pairs, r, p1, d1); fold_pd(B, i, pairs, r, p2, d2); }
     else { load_pd(A, i, pairs, p1, d1); load_pd(B, i, pairs, p2, d2); }
-    acc.stage_bc(u, p1, d1, p2, d2);
-    acc.stage_e(u, fq_load(E + i));
+    if (LEAD) {
+      acc.lead_bc(p1, d1, p2, d2, fq_load(E + i));
+    } else {
+      acc.stage_bc(u, p1, d1, p2, d2);
+      acc.stage_e(u, fq_load(E + i));
+    }
   }
   finish_block(acc.e, fin);
 }
@@ -492,7 +497,8 @@ static Finisher make_finisher(vpin_ctx* c, fq* partials, int inst0, int total_in
   return f;
 }
 
-int spark_prod_round(vpin_ctx* c, const SparkForest* f, int level, size_t len, const fq* E, const uint8_t* r, bool with_dotp) {
+int spark_prod_round(vpin_ctx* c, const SparkForest* f, int level, size_t len, const fq* E, const uint8_t* r, bool with_dotp,
+                     bool lead) {
   if (!c || !f || !f->base || !E) return VPIN_EINVAL;
   const size_t h = f->n >> (level + 1);
   if (h == 0 || len > h || !is_pow2(len) || len < (r ? 4u : 2u) || f->ncirc > 12) return VPIN_ESHAPE;
@@ -511,12 +517,12 @@ int spark_prod_round(vpin_ctx* c, const SparkForest* f, int level, size_t len, c
     // folded halves written
     const double bytes = (double)f->ncirc * 2 * 32.0 * (r ? (double)len * 1.5 : (double)len) + 32.0 * (r ? (double)len * 1.5 : (double)len);
     ProfScope ps(c, VPIN_K_SPARK_ROUND, bytes);
-    if (r)
-      hipLaunchKernelGGL((prod_round_kernel<true>), dim3(grid, f->ncirc), dim3(kBlock), 0, c->stream, f->base, f->stride(),
-                         f->level_off(level), h, E, pairs, rr, fin);
-    else
-      hipLaunchKernelGGL((prod_round_kernel<false>), dim3(grid, f->ncirc), dim3(kBlock), 0, c->stream, f->base, f->stride(),
-                         f->level_off(level), h, E, pairs, rr, fin);
+#define VPIN_PROD_LAUNCH(B_, L_)                                                                                             \
+  hipLaunchKernelGGL((prod_round_kernel<B_, L_>), dim3(grid, f->ncirc), dim3(kBlock), 0, c->stream, f->base, f->stride(), \
+                     f->level_off(level), h, E, pairs, rr, fin)
+    if (r) { if (lead) VPIN_PROD_LAUNCH(true, true); else VPIN_PROD_LAUNCH(true, false); }
+    else { if (lead) VPIN_PROD_LAUNCH(false, true); else VPIN_PROD_LAUNCH(false, false); }
+#undef VPIN_PROD_LAUNCH
   }
   VPIN_HIP_TRY(hipGetLastError());
   return VPIN_OK;

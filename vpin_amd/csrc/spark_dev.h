@@ -60,7 +60,10 @@ int spark_fetch_tops(vpin_ctx* c, const SparkForest* f, size_t cnt);
 // when r != nullptr and the tables are first folded with r, len/4 entries).  Results land in
 // ctx->h_spark[3*t + k] once spark_wait_flag returns.  `len` is the live length BEFORE this call.
 // Starts a new launch group; with_dotp announces that spark_dotp_round follows in the same group.
-int spark_prod_round(vpin_ctx* c, const SparkForest* f, int level, size_t len, const fq* E, const uint8_t* r, bool with_dotp);
+// lead = true: h_spark[3*t] = sum_i E[i]*(A_0 B_0)[i] and h_spark[3*t + 1] = sum_i E[i]*(dA dB)[i] (value at 0 and x^2
+// coefficient of the quadratic; the host derives the values at 2 and 3 from the circuit's claim), third slot zero.
+int spark_prod_round(vpin_ctx* c, const SparkForest* f, int level, size_t len, const fq* E, const uint8_t* r, bool with_dotp,
+                     bool lead = false);
 
 // Same for the 6 DotProductCircuit halves of layer 0 (comb = A*B*C, three foldable tables each,
 // sumcheck.rs:304-330).  src tables: left = comb_derefs row slices, right = col slices, weight =

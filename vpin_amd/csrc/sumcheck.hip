@@ -76,7 +76,9 @@ __global__ __launch_bounds__(kBlock, kMinWaves) void sc_bind_eval_kernel(Tabs<K>
 // Phase-1 kernel without the eq(tau,.) table: three foldable tables (Az,Bz,Cz) and the suffix table
 // E = eq(tau_{j+1..}, .) of this round (read-only, one element per pair).  12 Montgomery products
 // and 13 loads / 6 stores per pair instead of 14 / 16 / 8; the three sums are scaled by the host.
-template <bool BIND>
+// LEAD (sc_dev.h lead_bcd): return t(0) = sum E*(B_0 C_0 - D_0) and the x^2 coefficient sum E*dB*dC of the round's
+// quadratic (10 products per pair); without BIND (the first round) also t(1), so the host can check the claim.
+template <bool BIND, bool LEAD>
 __global__ __launch_bounds__(kBlock, kMinWaves) void sc_cubic3_kernel(Tabs<3> tabs, const fq* __restrict__ E, size_t pairs,
                                                                       fq r, fq* __restrict__ partials) {
   Acc<4> acc;
@@ -85,11 +87,20 @@ __global__ __launch_bounds__(kBlock, kMinWaves) void sc_cubic3_kernel(Tabs<3> ta
     fq u[3], p1, d1, p2, d2;
     if (BIND) { fold_pd(tabs.t[0], i, pairs, r, p1, d1); fold_pd(tabs.t[1], i, pairs, r, p2, d2); }
     else { load_pd(tabs.t[0], i, pairs, p1, d1); load_pd(tabs.t[1], i, pairs, p2, d2); }
-    acc.stage_bc(u, p1, d1, p2, d2);
-    if (BIND) fold_pd(tabs.t[2], i, pairs, r, p1, d1);
-    else load_pd(tabs.t[2], i, pairs, p1, d1);
-    acc.stage_d(u, p1, d1);
-    acc.stage_e(u, fq_load(E + i));
+    if (LEAD) {
+      fq p3, d3;
+      if (BIND) fold_pd(tabs.t[2], i, pairs, r, p3, d3);
+      else load_pd(tabs.t[2], i, pairs, p3, d3);
+      const fq e = fq_load(E + i);
+      acc.lead_bcd(p1, d1, p2, d2, p3, e);
+      if (!BIND) acc.lead_one(p1, d1, p2, d2, p3, d3, e);
+    } else {
+      acc.stage_bc(u, p1, d1, p2, d2);
+      if (BIND) fold_pd(tabs.t[2], i, pairs, r, p1, d1);
+      else load_pd(tabs.t[2], i, pairs, p1, d1);
+      acc.stage_d(u, p1, d1);
+      acc.stage_e(u, fq_load(E + i));
+    }
   }
   block_reduce_store<3>(acc.e, partials);
 }
@@ -145,7 +156,7 @@ __global__ __launch_bounds__(kSmallBlock) void sc_tail_kernel(Tabs<K> tabs, size
   }
 }
 
-template <bool BIND>
+template <bool BIND, bool LEAD>
 __global__ __launch_bounds__(kSmallBlock) void sc_tail3_kernel(Tabs<3> tabs, const fq* __restrict__ E, size_t pairs, fq r,
                                                                fq* __restrict__ out) {
   Acc<4> acc;
@@ -155,11 +166,20 @@ __global__ __launch_bounds__(kSmallBlock) void sc_tail3_kernel(Tabs<3> tabs, con
     fq u[3], p1, d1, p2, d2;
     if (BIND) { fold_pd(tabs.t[0], i, pairs, r, p1, d1); fold_pd(tabs.t[1], i, pairs, r, p2, d2); }
     else { load_pd(tabs.t[0], i, pairs, p1, d1); load_pd(tabs.t[1], i, pairs, p2, d2); }
-    acc.stage_bc(u, p1, d1, p2, d2);
-    if (BIND) fold_pd(tabs.t[2], i, pairs, r, p1, d1);
-    else load_pd(tabs.t[2], i, pairs, p1, d1);
-    acc.stage_d(u, p1, d1);
-    acc.stage_e(u, fq_load(E + i));
+    if (LEAD) {
+      fq p3, d3;
+      if (BIND) fold_pd(tabs.t[2], i, pairs, r, p3, d3);
+      else load_pd(tabs.t[2], i, pairs, p3, d3);
+      const fq e = fq_load(E + i);
+      acc.lead_bcd(p1, d1, p2, d2, p3, e);
+      if (!BIND) acc.lead_one(p1, d1, p2, d2, p3, d3, e);
+    } else {
+      acc.stage_bc(u, p1, d1, p2, d2);
+      if (BIND) fold_pd(tabs.t[2], i, pairs, r, p1, d1);
+      else load_pd(tabs.t[2], i, pairs, p1, d1);
+      acc.stage_d(u, p1, d1);
+      acc.stage_e(u, fq_load(E + i));
+    }
   }
   __shared__ fq sh[kSmallBlock / 64][3];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -343,8 +363,9 @@ static inline size_t pyramid_offset(int ell, int k) { return ((size_t)1 << ell) 
 
 // Phase-1 round on (Az,Bz,Cz) + the suffix table of level `level` (= round index + 1); r == nullptr
 // evaluates the tables as they are, otherwise binds them with r first.  Results: the three UNSCALED
-// sums  sum_i E[i]*(B_x C_x - D_x)[i]  for x = 0, 2, 3.
-int sc_cubic3_launch(vpin_ctx* c, vpin_table* const* t, const vpin_table* pyramid, int ell, int level, const uint8_t* r) {
+// sums  sum_i E[i]*(B_x C_x - D_x)[i]  for x = 0, 2, 3; with `lead`: the sum at x = 0, the x^2 coefficient
+// sum_i E[i]*(dB dC)[i] and (first round only) the sum at x = 1.
+int sc_cubic3_launch(vpin_ctx* c, vpin_table* const* t, const vpin_table* pyramid, int ell, int level, const uint8_t* r, bool lead) {
   int rc = check_tabs<3>(c, t, r ? 4 : 2);
   if (rc) return rc;
   if (!pyramid || level < 1 || level > ell || pyramid->len != ((size_t)1 << ell)) return VPIN_ESHAPE;
@@ -360,16 +381,20 @@ int sc_cubic3_launch(vpin_ctx* c, vpin_table* const* t, const vpin_table* pyrami
   if (pairs <= kSmallPairs) {
     {
       ProfScope ps(c, VPIN_K_SC_TAIL, bytes);
-      if (r) hipLaunchKernelGGL((sc_tail3_kernel<true>), dim3(1), dim3(kSmallBlock), 0, c->stream, tabs, E, pairs, rr, c->h_out);
-      else hipLaunchKernelGGL((sc_tail3_kernel<false>), dim3(1), dim3(kSmallBlock), 0, c->stream, tabs, E, pairs, rr, c->h_out);
+#define VPIN_T3(B_, L_) hipLaunchKernelGGL((sc_tail3_kernel<B_, L_>), dim3(1), dim3(kSmallBlock), 0, c->stream, tabs, E, pairs, rr, c->h_out)
+      if (r) { if (lead) VPIN_T3(true, true); else VPIN_T3(true, false); }
+      else { if (lead) VPIN_T3(false, true); else VPIN_T3(false, false); }
+#undef VPIN_T3
     }
     VPIN_HIP_TRY(hipGetLastError());
   } else {
     int grid = grid_for(pairs);
     {
       ProfScope ps(c, r ? VPIN_K_SC_CUBIC_FUSED : VPIN_K_SC_CUBIC, bytes);
-      if (r) hipLaunchKernelGGL((sc_cubic3_kernel<true>), dim3(grid), dim3(kBlock), 0, c->stream, tabs, E, pairs, rr, c->d_partials);
-      else hipLaunchKernelGGL((sc_cubic3_kernel<false>), dim3(grid), dim3(kBlock), 0, c->stream, tabs, E, pairs, rr, c->d_partials);
+#define VPIN_C3(B_, L_) hipLaunchKernelGGL((sc_cubic3_kernel<B_, L_>), dim3(grid), dim3(kBlock), 0, c->stream, tabs, E, pairs, rr, c->d_partials)
+      if (r) { if (lead) VPIN_C3(true, true); else VPIN_C3(true, false); }
+      else { if (lead) VPIN_C3(false, true); else VPIN_C3(false, false); }
+#undef VPIN_C3
     }
     VPIN_HIP_TRY(hipGetLastError());
     rc = finish_launch<3>(c, grid);
@@ -490,14 +515,14 @@ int vpin_sc_cubic3_round(vpin_ctx* c, const vpin_table* pyramid, int ell, int le
                          vpin_table* Cz, uint8_t out[96]) {
   if (!out) return VPIN_EINVAL;
   vpin_table* t[3] = {Az, Bz, Cz};
-  int rc = sc_cubic3_launch(c, t, pyramid, ell, level, nullptr);
+  int rc = sc_cubic3_launch(c, t, pyramid, ell, level, nullptr, false);
   return rc ? rc : sc_round_wait(c, 4, out);
 }
 int vpin_sc_cubic3_bind_round(vpin_ctx* c, const vpin_table* pyramid, int ell, int level, vpin_table* Az, vpin_table* Bz,
                               vpin_table* Cz, const uint8_t r[32], uint8_t out[96]) {
   if (!out || !r) return VPIN_EINVAL;
   vpin_table* t[3] = {Az, Bz, Cz};
-  int rc = sc_cubic3_launch(c, t, pyramid, ell, level, r);
+  int rc = sc_cubic3_launch(c, t, pyramid, ell, level, r, false);
   return rc ? rc : sc_round_wait(c, 4, out);
 }
 

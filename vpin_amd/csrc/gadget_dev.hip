@@ -328,8 +328,9 @@ struct Blob {
   size_t vec(const std::vector<T>& v) { return add(v.data(), v.size() * sizeof(T)); }
 };
 
+// pooled: a service proving trace after trace recycles the blocks without a round trip through the driver
 template <class T>
-static int dmalloc(T** p, size_t n) { return hipMalloc((void**)p, (n ? n : 1) * sizeof(T)) == hipSuccess ? VPIN_OK : VPIN_ENOMEM; }
+static int dmalloc(vpin_ctx* c, T** p, size_t n) { return dev_alloc(c, (n ? n : 1) * sizeof(T), (void**)p); }
 
 static unsigned blocks(size_t n) { return (unsigned)((n + kGB - 1) / kGB); }
 
@@ -408,7 +409,7 @@ static int build_instance(vpin_ctx* c, const TmplSink& ts, int kind, size_t n_op
   const size_t off_tot_row = blob.vec(tot_row), off_tot_col = blob.vec(tot_col);
 
   (void)hipSetDevice(c->device);
-  if (hipMalloc(&g->blob, blob.bytes.size()) != hipSuccess) return VPIN_ENOMEM;
+  if (dev_alloc(c, blob.bytes.size(), &g->blob)) return VPIN_ENOMEM;
   auto fail = [&](int rc) { vpin_dev_instance_free(c, g.release()); return rc; };
   if (hipMemcpyAsync(g->blob, blob.bytes.data(), blob.bytes.size(), hipMemcpyHostToDevice, c->stream) != hipSuccess) return fail(VPIN_EHIP);
   const uint8_t* base = (const uint8_t*)g->blob;
@@ -430,14 +431,15 @@ static int build_instance(vpin_ctx* c, const TmplSink& ts, int kind, size_t n_op
   vpin_r1cs_dev* d = new (std::nothrow) vpin_r1cs_dev();
   if (!d) return fail(VPIN_ENOMEM);
   g->r1cs = d;
+  d->pooled = true;
   d->num_cons = nc_pad; d->num_vars = nv_pad; d->num_inputs = num_inputs;
   const size_t ncols = 2 * nv_pad;
   for (int m = 0; m < 3; m++) {
     const GadgetTmplDev& t = g->tmpl[m];
     const size_t nnz = g->nnz[m];
     d->nnz[m] = nnz;
-    if (dmalloc(&d->rowptr[m], nc_pad + 1) || dmalloc(&d->csr_col[m], nnz) || dmalloc(&d->csr_val[m], nnz) ||
-        dmalloc(&d->colptr[m], ncols + 1) || dmalloc(&d->csc_row[m], nnz) || dmalloc(&d->csc_val[m], nnz))
+    if (dmalloc(c, &d->rowptr[m], nc_pad + 1) || dmalloc(c, &d->csr_col[m], nnz) || dmalloc(c, &d->csr_val[m], nnz) ||
+        dmalloc(c, &d->colptr[m], ncols + 1) || dmalloc(c, &d->csc_row[m], nnz) || dmalloc(c, &d->csc_val[m], nnz))
       return fail(VPIN_ENOMEM);
     hipLaunchKernelGGL(gd_rowptr_kernel, dim3(blocks(nc_pad + 1)), dim3(kGB), 0, c->stream, t, oc, n_ops, nc_pad, d->rowptr[m]);
     hipLaunchKernelGGL(gd_colptr_kernel, dim3(blocks(ncols + 1)), dim3(kGB), 0, c->stream, t, ov, n_ops, nv_pad, d->colptr[m]);
@@ -464,7 +466,7 @@ static int build_instance(vpin_ctx* c, const TmplSink& ts, int kind, size_t n_op
     d->n_long[m] = longs.size();
     d->n_chunks[m] = ck0.size();
     auto upv = [&](uint32_t** dst, const std::vector<uint32_t>& v) {
-      if (dmalloc(dst, v.size())) return (int)VPIN_ENOMEM;
+      if (dmalloc(c, dst, v.size())) return (int)VPIN_ENOMEM;
       if (!v.empty() && hipMemcpyAsync(*dst, v.data(), v.size() * 4, hipMemcpyHostToDevice, c->stream) != hipSuccess) return (int)VPIN_EHIP;
       return (int)VPIN_OK;
     };
@@ -476,7 +478,7 @@ static int build_instance(vpin_ctx* c, const TmplSink& ts, int kind, size_t n_op
   }
   {
     size_t mx = std::max(d->n_chunks[0], std::max(d->n_chunks[1], d->n_chunks[2]));
-    if (dmalloc(&d->chunk_partials, mx ? mx : 1)) return fail(VPIN_ENOMEM);
+    if (dmalloc(c, &d->chunk_partials, mx ? mx : 1)) return fail(VPIN_ENOMEM);
   }
   if (hipGetLastError() != hipSuccess) return fail(VPIN_EHIP);
 
@@ -546,7 +548,7 @@ void vpin_dev_instance_free(vpin_ctx* c, vpin_dev_instance* g) {
   vpin_table_free(c, g->vars_para);
   vpin_table_free(c, g->vars_input);
   vpin_table_free(c, g->vars);
-  if (g->blob) (void)hipFree(g->blob);
+  if (g->blob) { if (c) dev_free(c, g->blob); else (void)hipFree(g->blob); }
   delete g;
 }
 

@@ -34,8 +34,9 @@ static_assert(sizeof(niels_slot) == VPIN_NIELS_SLOT, "table entry size");
 }  // namespace vpin
 
 struct vpin_gens {
-  vpin::niels_slot* table = nullptr;  // [W][nb][E]
+  vpin::niels_slot* table = nullptr;  // [W][nbt][E]
   size_t nb = 0;                    // number of bases in the stream
+  size_t nbt = 0;                   // bases in the table: the stream, then the prefix sums S_k = g_0 + ... + g_{2^k - 1}
   int c = 12, W = 22, E = 2048;     // window bits, windows, entries per window (= 2^(c-1))
 };
 
@@ -43,11 +44,54 @@ namespace vpin {
 
 struct TableView {
   const niels_slot* t;
-  size_t nb;
+  size_t nb;    // bases per window in the table (stream + prefix sums)
   int c, W, E;
+  size_t sum0;  // table index of S_0; S_k = g_0 + ... + g_{2^k - 1} sits at sum0 + k
 };
 
 // ---- table construction ---------------------------------------------------------------
+
+// Prefix sums of the stream over power-of-two lengths, kept in the table as extra bases: a commitment row whose
+// scalars are all one value s (the padding tails of the SPARK polynomials are runs of a single eq value, a
+// quarter of the derefs polynomial for vPIN's instances) is s * S_k, one scalar multiplication instead of 2^k.
+// Block k sums g_j over [2^(k-1), 2^k) (block 0: g_0) into xyzt[nb + k]; gens_sum_scan_kernel then accumulates.
+__global__ __launch_bounds__(256) void gens_sum_kernel(fp* __restrict__ xyzt, size_t nb) {
+  const int k = blockIdx.x;
+  const size_t lo = k ? ((size_t)1 << (k - 1)) : 0, hi = (size_t)1 << k;
+  ge_ext acc = ge_identity();
+  for (size_t j = lo + threadIdx.x; j < hi && j < nb; j += 256) {
+    ge_ext p;
+    p.X = fp_load(xyzt + 4 * j); p.Y = fp_load(xyzt + 4 * j + 1); p.Z = fp_load(xyzt + 4 * j + 2); p.T = fp_load(xyzt + 4 * j + 3);
+    acc = ge_add(acc, p);
+  }
+  __shared__ ge_ext sh[256];
+  sh[threadIdx.x] = acc;
+  __syncthreads();
+  for (int st = 128; st >= 1; st >>= 1) {
+    if ((int)threadIdx.x < st) {
+      acc = ge_add(acc, sh[threadIdx.x + st]);
+      sh[threadIdx.x] = acc;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    fp* o = xyzt + 4 * (nb + k);
+    fp_store(o, acc.X); fp_store(o + 1, acc.Y); fp_store(o + 2, acc.Z); fp_store(o + 3, acc.T);
+  }
+}
+__global__ void gens_sum_scan_kernel(fp* __restrict__ xyzt, size_t nb, int nsum) {
+  if (threadIdx.x || blockIdx.x) return;
+  ge_ext acc;
+  fp* o = xyzt + 4 * nb;
+  acc.X = fp_load(o); acc.Y = fp_load(o + 1); acc.Z = fp_load(o + 2); acc.T = fp_load(o + 3);
+  for (int k = 1; k < nsum; k++) {
+    fp* q = xyzt + 4 * (nb + k);
+    ge_ext d;
+    d.X = fp_load(q); d.Y = fp_load(q + 1); d.Z = fp_load(q + 2); d.T = fp_load(q + 3);
+    acc = ge_add(acc, d);
+    fp_store(q, acc.X); fp_store(q + 1, acc.Y); fp_store(q + 2, acc.Z); fp_store(q + 3, acc.T);
+  }
+}
 
 // one thread per base: shifts[j][w] = 2^(c*w) * g_j
 __global__ __launch_bounds__(64) void gens_shift_kernel(const fp* __restrict__ xyzt, size_t nb, int W, int c,
@@ -122,6 +166,13 @@ __device__ __forceinline__ fq fq_from_mont(const fq& a) {
 #pragma unroll
   for (int i = 0; i < 8; i++) r.v[i] = t[i];
   return fq_cond_sub_q(r);
+}
+
+__device__ __forceinline__ bool fq_same(const fq& a, const fq& b) {
+  uint32_t o = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) o |= a.v[i] ^ b.v[i];
+  return o == 0;
 }
 
 // accumulate s * g_j into acc through the window table; s canonical, non-zero
@@ -203,6 +254,28 @@ __global__ __launch_bounds__(kMsmBlock, 3) void msm_rows_kernel(const fq* __rest
   const size_t row = blockIdx.x;
   ge_ext acc = ge_identity();
   const size_t total = ncols + (size_t)n_extra;
+  // A row of one repeated scalar s: s * (g_0 + ... + g_{ncols-1}) from the prefix-sum base (see gens_sum_kernel).
+  // Three probes keep ordinary rows from paying for the full comparison pass.
+  if (gridDim.y == 1 && ncols >= 256 && (ncols & (ncols - 1)) == 0 && ((size_t)1 << (tv.nb - tv.sum0 - 1)) >= ncols) {
+    const fq* zr = Z + row * stride;
+    const fq first = fq_load(zr);
+    if (fq_same(first, fq_load(zr + 1)) && fq_same(first, fq_load(zr + ncols / 2)) && fq_same(first, fq_load(zr + ncols - 1))) {
+      int same = 1;
+      for (size_t j = threadIdx.x; j < ncols; j += kMsmBlock) same &= fq_same(first, fq_load(zr + j)) ? 1 : 0;
+      if (__syncthreads_and(same)) {
+        if (threadIdx.x == 0) {
+          if (!fq_is_zero(first)) table_mul_acc(acc, fq_from_mont(first), tv, tv.sum0 + (size_t)(63 - __builtin_clzll((unsigned long long)ncols)));
+          for (int e = 0; e < n_extra; e++) {
+            const fq x = fq_load(extra + row * (size_t)n_extra + e);
+            if (!fq_is_zero(x)) table_mul_acc(acc, fq_from_mont(x), tv, extra_base0 + e);
+          }
+          ge_ext* o = out + row;
+          fp_store(&o->X, acc.X); fp_store(&o->Y, acc.Y); fp_store(&o->Z, acc.Z); fp_store(&o->T, acc.T);
+        }
+        return;
+      }
+    }
+  }
   // gridDim.y column chunks per row (few-row MSMs need more than `rows` workgroups)
   const size_t per = (total + gridDim.y - 1) / gridDim.y;
   const size_t j0 = (size_t)blockIdx.y * per, j1 = (j0 + per < total) ? j0 + per : total;
@@ -383,6 +456,10 @@ static int gens_build(vpin_ctx* c, const uint8_t* gens_xyzt, size_t nb, size_t b
   vpin_gens* g = new (std::nothrow) vpin_gens();
   if (!g) return VPIN_ENOMEM;
   g->nb = nb;
+  int nsum = 1;
+  while (((size_t)2 << (nsum - 1)) <= nb) nsum++;  // S_0 .. S_floor(log2 nb)
+  const size_t nbt = nb + (size_t)nsum;
+  g->nbt = nbt;
   // window width by table budget (<= ~24 GB): 12 bits up to ~5k generators, 11 up to ~10k, ... 8 for
   // the 32k-generator sets of the largest SPARK commitments
   for (g->c = 12; g->c > 6; g->c--) {
@@ -390,12 +467,12 @@ static int gens_build(vpin_ctx* c, const uint8_t* gens_xyzt, size_t nb, size_t b
     g->E = 1 << (g->c - 1);
     if (nb * (size_t)g->W * (size_t)g->E * sizeof(niels_slot) <= budget) break;
   }
-  const size_t entries = nb * (size_t)g->W * g->E;
+  const size_t entries = nbt * (size_t)g->W * g->E;
   TraceLap lap(c, "gens_build");
   // temporaries come from the context pool, so the blocks go on to serve proof temporaries instead of being
   // returned to the driver (freed VRAM is wiped before it can be handed out again: tools/ubench_malloc2.hip)
   DevBuf raw(c), b_shifts(c), b_prefix(c);
-  if (raw.alloc(nb * 128) != VPIN_OK || b_shifts.alloc(nb * g->W * sizeof(ge_ext)) != VPIN_OK ||
+  if (raw.alloc(nbt * 128) != VPIN_OK || b_shifts.alloc(nbt * g->W * sizeof(ge_ext)) != VPIN_OK ||
       b_prefix.alloc(entries * sizeof(fp)) != VPIN_OK || hipMalloc((void**)&g->table, entries * sizeof(niels_slot)) != hipSuccess) {
     if (g->table) (void)hipFree(g->table);
     delete g;
@@ -406,9 +483,11 @@ static int gens_build(vpin_ctx* c, const uint8_t* gens_xyzt, size_t nb, size_t b
   lap("hipMalloc");
   hipError_t e = hipMemcpyAsync(raw.p, gens_xyzt, nb * 128, hipMemcpyHostToDevice, c->stream);
   if (e == hipSuccess) {
-    hipLaunchKernelGGL(gens_shift_kernel, dim3((unsigned)((nb + 63) / 64)), dim3(64), 0, c->stream, (const fp*)raw.p, nb, g->W,
+    hipLaunchKernelGGL(gens_sum_kernel, dim3((unsigned)nsum), dim3(256), 0, c->stream, (fp*)raw.p, nb);
+    hipLaunchKernelGGL(gens_sum_scan_kernel, dim3(1), dim3(64), 0, c->stream, (fp*)raw.p, nb, nsum);
+    hipLaunchKernelGGL(gens_shift_kernel, dim3((unsigned)((nbt + 63) / 64)), dim3(64), 0, c->stream, (const fp*)raw.p, nbt, g->W,
                        g->c, shifts);
-    hipLaunchKernelGGL(gens_table_kernel, dim3((unsigned)((nb * g->W + 63) / 64)), dim3(64), 0, c->stream, shifts, nb, g->W,
+    hipLaunchKernelGGL(gens_table_kernel, dim3((unsigned)((nbt * g->W + 63) / 64)), dim3(64), 0, c->stream, shifts, nbt, g->W,
                        g->E, g->table, prefix);
     e = hipGetLastError();
   }
@@ -486,7 +565,7 @@ size_t vpin_gens_count(const vpin_gens* g) { return g ? g->nb : 0; }
 size_t vpin_gens_entry_bytes(void) { return sizeof(niels_slot); }
 
 // shared implementation: rows of scalars -> points (kept on device), then optional outputs
-static inline TableView view(const vpin_gens* g) { return TableView{g->table, g->nb, g->c, g->W, g->E}; }
+static inline TableView view(const vpin_gens* g) { return TableView{g->table, g->nbt, g->c, g->W, g->E, g->nb}; }
 
 static int msm_rows(vpin_ctx* c, const vpin_gens* g, const fq* dZ, size_t rows, size_t stride, size_t ncols,
                     const fq* d_extra, int n_extra, size_t extra_base0, ge_ext* d_points) {

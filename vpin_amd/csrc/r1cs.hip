@@ -175,9 +175,9 @@ void vpin_r1cs_free(vpin_ctx* c, vpin_r1cs_dev* d) {
     void* ps[] = {d->rowptr[m], d->csr_col[m], d->csr_val[m], d->colptr[m], d->csc_row[m], d->csc_val[m], d->long_cols[m],
                   d->long_first[m], d->chunk_k0[m], d->chunk_k1[m]};
     for (void* p : ps)
-      if (p) (void)hipFree(p);
+      if (p) { if (d->pooled && c) dev_free(c, p); else (void)hipFree(p); }
   }
-  if (d->chunk_partials) (void)hipFree(d->chunk_partials);
+  if (d->chunk_partials) { if (d->pooled && c) dev_free(c, d->chunk_partials); else (void)hipFree(d->chunk_partials); }
   delete d;
 }
 

@@ -19,6 +19,7 @@ struct vpin_r1cs_dev {
   uint32_t* chunk_k1[3] = {};    // [n_chunks] end entry
   size_t n_long[3] = {0, 0, 0}, n_chunks[3] = {0, 0, 0};
   vpin::fq* chunk_partials = nullptr;  // [max n_chunks]
+  bool pooled = false;  // arrays come from the context pool (dev_alloc) instead of hipMalloc
 };
 
 namespace vpin {

@@ -306,10 +306,11 @@ def main():
         pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
         if traffic is None and os.path.exists(pmc):
             with open(pmc) as f:
-                ent = json.load(f).get("bench_default", {}).get("sc_cubic3_kernel<true>", {})
+                ent = json.load(f).get("bench_default", {}).get("sc_cubic3_kernel<true, true>", {})
             traffic = ent.get("hbm_bytes_per_launch")
         line["roofline"] = {
-            "kernel": "sc_cubic3_kernel<true> (fused fold + cubic round evaluation of phase 1, eq-factored; rounds with > 512 pairs)",
+            "kernel": "sc_cubic3_kernel<true, true> (fused fold + cubic round evaluation of phase 1, eq-factored, leading-coefficient form; "
+                      "rounds with > 512 pairs)",
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
             "launches": k["launches"], "avg_launch_us": k["ms"] * 1e3 / k["launches"],

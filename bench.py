@@ -68,6 +68,10 @@ def parse():
                     "my_lib_prove in full; SNARK::encode runs once per instance before the timed region and is reported beside it")
     ap.add_argument("--mult-lanes", type=int, default=int(os.environ.get("VPIN_BENCH_MULT_LANES", "1")),
                     help="streams / host threads for the point-mult instances other than the largest")
+    ap.add_argument("--lanes-spec", default=os.environ.get("VPIN_BENCH_LANES"),
+                    help="explicit schedule: lanes separated by ';', instance names by ',' (first lane starts at once, the "
+                         "others when its first instance's sat part is done); 'adds' = every point-add instance")
+    ap.add_argument("--no-span", action="store_true", help="skip the reference-span pass after the timed region")
     ap.add_argument("--only", choices=["mult", "add"], default=None, help="keep only the point-mult / point-add instances of the trace")
     ap.add_argument("--no-verify", action="store_true", help="skip the post-run verification of the last step's SNARKs")
     ap.add_argument("--no-prof", action="store_true", help="no HIP-event bracketing of kernels (no roofline object)")
@@ -122,6 +126,16 @@ def main():
         for w in mults[1:]:  # largest first onto the least loaded lane
             min(rest, key=lambda l: sum(x[3] for x in l)).append(w)
         lanes = [mults[:1]] + rest + [adds]
+    if args.lanes_spec:
+        by_name = {w[0]: w for w in work}
+        lanes = []
+        for part in args.lanes_spec.split(";"):
+            lane = []
+            for nm in part.split(","):
+                nm = nm.strip()
+                lane += adds if nm == "adds" else [by_name[nm]]
+            lanes.append(lane)
+        assert sorted(w[0] for l in lanes for w in l) == sorted(w[0] for w in work), "--lanes-spec must name every instance once"
     # the lanes of small, latency-bound instances get high-priority streams: their one-workgroup round
     # kernels are then dispatched ahead of the large instance's queued workgroups instead of behind them
     prios = [0] + [-1] * (len(lanes) - 1) if not os.environ.get("VPIN_BENCH_NO_PRIO") else [0] * len(lanes)
@@ -348,24 +362,25 @@ def main():
         for name in list(dev_insts):
             decomms.pop(name).free()
             dev_insts.pop(name).free()
-        span = {}
-        ts = time.perf_counter()
-        for li, names in enumerate(lane_names):
-            for name in names:
-                t1 = time.perf_counter()
-                kind, inp = inputs_of[name]
-                g = build_instance(ctxs[li], kind, inp)
-                assert g.is_sat()
-                r = g.snark_prove(SEED_C, SEED_P)
-                span[name] = round((time.perf_counter() - t1) * 1e3, 2)
-                assert r["proof"] == last_proof[name]["proof"], f"{name}: reference-span proof differs from the timed region's"
-                g.free()
-        span_s = time.perf_counter() - ts
-        line["reference_span"] = {
-            "ms_per_trace": round(span_s * 1e3, 1), "constraints_per_s": total_cons_step / span_s, "ms": span,
-            "scope": "per instance, serially: witness inputs in host memory -> gadget + witness synthesis + Instance::new "
-                     "(device) -> is_sat -> SNARK::encode -> my_lib_prove -> proof bytes on the host; generator tables warm",
-        }
+        if not args.no_span:
+            span = {}
+            ts = time.perf_counter()
+            for li, names in enumerate(lane_names):
+                for name in names:
+                    t1 = time.perf_counter()
+                    kind, inp = inputs_of[name]
+                    g = build_instance(ctxs[li], kind, inp)
+                    assert g.is_sat()
+                    r = g.snark_prove(SEED_C, SEED_P)
+                    span[name] = round((time.perf_counter() - t1) * 1e3, 2)
+                    assert r["proof"] == last_proof[name]["proof"], f"{name}: reference-span proof differs from the timed region's"
+                    g.free()
+            span_s = time.perf_counter() - ts
+            line["reference_span"] = {
+                "ms_per_trace": round(span_s * 1e3, 1), "constraints_per_s": total_cons_step / span_s, "ms": span,
+                "scope": "per instance, serially: witness inputs in host memory -> gadget + witness synthesis + Instance::new "
+                         "(device) -> is_sat -> SNARK::encode -> my_lib_prove -> proof bytes on the host; generator tables warm",
+            }
 
     # ---- CPU baseline: the oracle on a bounded sample, rank 0, N=1 only ----
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -1,0 +1,162 @@
+// bullet.hip -- device side of the inner-product (bullet) reduction inside DotProductProofLog::prove
+//   Spartan/src/nizk/bullet.rs:32-132   BulletReductionProof::prove
+// The reference folds the generator vector G each round; here G is never folded: the folded generator is
+// G_k[i] = sum_{j = i mod n} s_j g_j for known coefficients s_j, so every L / R is a fixed-base MSM over the
+// original stream with scalars a_i * s_j (host/prover_common.h: dplog_prove).  Those O(R) scalar vectors, the two
+// cross inner products <a_L, b_R>, <a_R, b_L> and the folds of a, b, s with the round challenge all live on the
+// device (R <= 32768 elements: launch-latency bound); a round moves only the partial points of L and R, the two
+// inner products and the challenge across PCIe.
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "ctx.h"
+
+namespace vpin {
+
+constexpr int kBB = 256;
+
+struct BulletState {
+  fq *av = nullptr, *bv = nullptr, *sj = nullptr;  // [R] each
+  fq* rows = nullptr;                              // [2][R]: scalars of L and R over g_0..g_{R-1}
+  fq* partials = nullptr;                          // [nblk][2] block partials of the two inner products
+  size_t R = 0;
+  int nblk = 0;
+};
+
+__global__ __launch_bounds__(kBB) void bullet_init_kernel(fq* __restrict__ sj, size_t R) {
+  size_t j = (size_t)blockIdx.x * kBB + threadIdx.x;
+  if (j < R) fq_store(sj + j, fq_one());
+}
+
+// n = half of the live length.  rows[0][j] = a_L . G_R scalars, rows[1][j] = a_R . G_L scalars (bullet.rs:63-83);
+// partials[blk] = block sums of a_L[i]*b_R[i] and a_R[i]*b_L[i].
+__global__ __launch_bounds__(kBB) void bullet_rows_kernel(const fq* __restrict__ av, const fq* __restrict__ bv,
+                                                          const fq* __restrict__ sj, size_t n, size_t R, fq* __restrict__ rows,
+                                                          fq* __restrict__ partials) {
+  const size_t j = (size_t)blockIdx.x * kBB + threadIdx.x;
+  fq pl = fq_zero(), pr = fq_zero();
+  if (j < R) {
+    const size_t pos = j & (2 * n - 1);
+    const fq s = fq_load(sj + j);
+    if (pos >= n) {
+      fq_store(rows + j, fq_mul(fq_load(av + (pos - n)), s));
+      fq_store(rows + R + j, fq_zero());
+    } else {
+      fq_store(rows + j, fq_zero());
+      fq_store(rows + R + j, fq_mul(fq_load(av + (n + pos)), s));
+    }
+    if (j < n) {
+      pl = fq_mul(fq_load(av + j), fq_load(bv + n + j));
+      pr = fq_mul(fq_load(av + n + j), fq_load(bv + j));
+    }
+  }
+  __shared__ fq sh[kBB / 64][2];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  pl = fq_wave_sum(pl);
+  pr = fq_wave_sum(pr);
+  if (lane == 0) { sh[wave][0] = pl; sh[wave][1] = pr; }
+  __syncthreads();
+  if (threadIdx.x < 2) {
+    fq s = sh[0][threadIdx.x];
+#pragma unroll
+    for (int w = 1; w < kBB / 64; w++) s = fq_add(s, sh[w][threadIdx.x]);
+    fq_store(partials + 2 * (size_t)blockIdx.x + threadIdx.x, s);
+  }
+}
+
+// a'[i] = a_L[i]*u + u^-1*a_R[i]; b'[i] = b_L[i]*u^-1 + u*b_R[i]; s_j *= u^-1 (j in a left half) or u (bullet.rs:99-109)
+__global__ __launch_bounds__(kBB) void bullet_fold_kernel(fq* __restrict__ av, fq* __restrict__ bv, fq* __restrict__ sj, size_t n,
+                                                          size_t R, fq u, fq u_inv) {
+  const size_t j = (size_t)blockIdx.x * kBB + threadIdx.x;
+  if (j >= R) return;
+  fq_store(sj + j, fq_mul(fq_load(sj + j), ((j & (2 * n - 1)) < n) ? u_inv : u));
+  if (j < n) {
+    const fq al = fq_load(av + j), ar = fq_load(av + n + j), bl = fq_load(bv + j), br = fq_load(bv + n + j);
+    fq_store(av + j, fq_add(fq_mul(al, u), fq_mul(u_inv, ar)));
+    fq_store(bv + j, fq_add(fq_mul(bl, u_inv), fq_mul(u, br)));
+  }
+}
+
+void bullet_free(vpin_ctx* c, BulletState* st) {
+  if (!st) return;
+  for (void* p : {(void*)st->av, (void*)st->bv, (void*)st->sj, (void*)st->rows, (void*)st->partials})
+    if (p) dev_free(c, p);
+  delete st;
+}
+
+// x, a: R Montgomery scalars each (the vectors DotProductProofLog::prove reduces); s_j = 1
+int bullet_begin(vpin_ctx* c, const uint8_t* x_mont, const uint8_t* a_mont, size_t R, BulletState** out) {
+  if (!c || !x_mont || !a_mont || !out || !is_pow2(R)) return VPIN_EINVAL;
+  (void)hipSetDevice(c->device);
+  BulletState* st = new (std::nothrow) BulletState();
+  if (!st) return VPIN_ENOMEM;
+  st->R = R;
+  st->nblk = (int)((R + kBB - 1) / kBB);
+  if (dev_alloc(c, R * 32, (void**)&st->av) || dev_alloc(c, R * 32, (void**)&st->bv) || dev_alloc(c, R * 32, (void**)&st->sj) ||
+      dev_alloc(c, 2 * R * 32, (void**)&st->rows) || dev_alloc(c, (size_t)st->nblk * 64, (void**)&st->partials)) {
+    bullet_free(c, st);
+    return VPIN_ENOMEM;
+  }
+  hipError_t e = hipMemcpyAsync(st->av, x_mont, R * 32, hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(st->bv, a_mont, R * 32, hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(bullet_init_kernel, dim3(st->nblk), dim3(kBB), 0, c->stream, st->sj, R);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);  // caller buffers
+  if (e != hipSuccess) { set_last_error("bullet_begin", e); bullet_free(c, st); return VPIN_EHIP; }
+  *out = st;
+  return VPIN_OK;
+}
+
+// One round at half length n: partial points of L and R (2 x vpin_gens_msm_parts_count(R) x 128 B, over the R
+// stream generators only; the c*Q and blind*H terms are the caller's) and the inner products c_L, c_R.
+int bullet_round(vpin_ctx* c, const vpin_gens* g, BulletState* st, size_t n, uint8_t* parts_xyzt, uint8_t cLR[64]) {
+  if (!c || !g || !st || !parts_xyzt || !cLR || n == 0 || 2 * n > st->R) return VPIN_EINVAL;
+  (void)hipSetDevice(c->device);
+  hipLaunchKernelGGL(bullet_rows_kernel, dim3(st->nblk), dim3(kBB), 0, c->stream, (const fq*)st->av, (const fq*)st->bv,
+                     (const fq*)st->sj, n, st->R, st->rows, st->partials);
+  VPIN_HIP_TRY(hipGetLastError());
+  // only the blocks covering i < n carry non-zero partials
+  const int used = (int)((n + kBB - 1) / kBB);
+  std::vector<fq> part((size_t)used * 2);
+  VPIN_HIP_TRY(hipMemcpyAsync(part.data(), st->partials, part.size() * 32, hipMemcpyDeviceToHost, c->stream));
+  int rc = gens_msm_parts_dev(c, g, st->rows, 2, st->R, parts_xyzt);  // synchronises the stream
+  if (rc) return rc;
+  // block partials summed on the host (<= 64 pairs): plain modular additions of Montgomery values
+  auto add = [](fq& a, const fq& b) {
+    uint64_t cy = 0;
+    uint32_t t[8];
+    for (int i = 0; i < 8; i++) { cy += (uint64_t)a.v[i] + b.v[i]; t[i] = (uint32_t)cy; cy >>= 32; }
+    uint32_t d[8];
+    int64_t bw = 0;
+    for (int i = 0; i < 8; i++) { bw += (int64_t)t[i] - (int64_t)fq_modulus_limb(i); d[i] = (uint32_t)bw; bw >>= 32; }
+    for (int i = 0; i < 8; i++) a.v[i] = bw ? t[i] : d[i];
+  };
+  fq sums[2] = {part[0], part[1]};
+  for (int b = 1; b < used; b++) { add(sums[0], part[2 * (size_t)b]); add(sums[1], part[2 * (size_t)b + 1]); }
+  memcpy(cLR, sums, 64);
+  return VPIN_OK;
+}
+
+// asynchronous: the next bullet_round / bullet_finish is ordered behind it on the stream
+int bullet_fold(vpin_ctx* c, BulletState* st, size_t n, const uint8_t u[32], const uint8_t u_inv[32]) {
+  if (!c || !st || !u || !u_inv || n == 0 || 2 * n > st->R) return VPIN_EINVAL;
+  fq fu, fi;
+  memcpy(fu.v, u, 32);
+  memcpy(fi.v, u_inv, 32);
+  hipLaunchKernelGGL(bullet_fold_kernel, dim3(st->nblk), dim3(kBB), 0, c->stream, st->av, st->bv, st->sj, n, st->R, fu, fi);
+  VPIN_HIP_TRY(hipGetLastError());
+  return VPIN_OK;
+}
+
+// after the last fold: x_hat = a[0], a_hat = b[0] and the partial points of g_hat = sum_j s_j g_j
+int bullet_finish(vpin_ctx* c, const vpin_gens* g, BulletState* st, uint8_t xhat_ahat[64], uint8_t* parts_xyzt) {
+  if (!c || !g || !st || !xhat_ahat || !parts_xyzt) return VPIN_EINVAL;
+  VPIN_HIP_TRY(hipMemcpyAsync(xhat_ahat, st->av, 32, hipMemcpyDeviceToHost, c->stream));
+  VPIN_HIP_TRY(hipMemcpyAsync(xhat_ahat + 32, st->bv, 32, hipMemcpyDeviceToHost, c->stream));
+  return gens_msm_parts_dev(c, g, st->sj, 1, st->R, parts_xyzt);
+}
+
+}  // namespace vpin

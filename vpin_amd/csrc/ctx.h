@@ -115,6 +115,18 @@ int sc_cubic3_launch(vpin_ctx* c, vpin_table* const* t, const vpin_table* pyrami
 
 inline bool is_pow2(size_t x) { return x && !(x & (x - 1)); }
 
+// few-row fixed-base MSM over device-resident scalars (msm.hip): rows x ncols Montgomery scalars ->
+// rows x vpin_gens_msm_parts_count(ncols) partial points (canonical X|Y|Z|T) in host memory; synchronises
+int gens_msm_parts_dev(vpin_ctx* c, const vpin_gens* g, const fq* d_scalars, size_t rows, size_t ncols, uint8_t* parts_xyzt);
+
+// device side of the bullet reduction (bullet.hip)
+struct BulletState;
+int bullet_begin(vpin_ctx* c, const uint8_t* x_mont, const uint8_t* a_mont, size_t R, BulletState** out);
+int bullet_round(vpin_ctx* c, const vpin_gens* g, BulletState* st, size_t n, uint8_t* parts_xyzt, uint8_t cLR[64]);
+int bullet_fold(vpin_ctx* c, BulletState* st, size_t n, const uint8_t u[32], const uint8_t u_inv[32]);
+int bullet_finish(vpin_ctx* c, const vpin_gens* g, BulletState* st, uint8_t xhat_ahat[64], uint8_t* parts_xyzt);
+void bullet_free(vpin_ctx* c, BulletState* st);
+
 // VPIN_CLI_TRACE=1: wall-clock laps of the cold (one-shot CLI) path on stderr; each lap drains the stream
 struct TraceLap {
   vpin_ctx* c;

@@ -288,53 +288,42 @@ static int dplog_prove(vpin_ctx* c, const PcGens& pc, Transcript& tr, Transcript
   Fq r_ = tr.challenge_scalar("r");
   // gens_1_scaled.G[0] = r * g[R]; every use below multiplies g[R] by r times something
   Fq blind_Gamma = LZ_blind + r_ * blind_y;
-  std::vector<Fq> av(LZ), bvv(Rv), sj(R, Fq::one());
   out.Lvec.resize(lgR); out.Rvec.resize(lgR);
   Fq blind_fin = blind_Gamma;
+  // The vectors a, b and the generator coefficients s_j stay on the device (bullet.hip); per round the GPU
+  // returns the partial points of  a_L . G_R  and  a_R . G_L  over the stream generators and the two cross
+  // inner products; the c*Q + blind*H terms (Q = r * g[R]) are two fixed-base multiplications each here.
+  vpin::BulletState* bs = nullptr;
+  if ((rc = vpin::bullet_begin(c, B(LZ.data()), B(Rv.data()), R, &bs))) return rc;
+  struct BsGuard { vpin_ctx* c; vpin::BulletState* s; ~BsGuard() { vpin::bullet_free(c, s); } } bs_guard{c, bs};
+  const size_t np = vpin_gens_msm_parts_count(R);
+  std::vector<uint8_t> parts(2 * np * 128);
+  auto sum_parts = [&](const uint8_t* p) {
+    Point acc = Point::from_xyzt(p);
+    for (size_t k = 1; k < np; k++) acc = acc + Point::from_xyzt(p + k * 128);
+    return acc;
+  };
   size_t n = R;
   for (size_t round = 0; round < lgR; round++) {
     n /= 2;
-    Fq cL = Fq::zero(), cR = Fq::zero();
-    for (size_t i = 0; i < n; i++) { cL = cL + av[i] * bvv[n + i]; cR = cR + av[n + i] * bvv[i]; }
-    Fq* sL = srow.data();
-    Fq* sR = srow.data() + ncols;
-    const size_t mask = 2 * n - 1;
-    const int nthr = R >= 2048 ? host_threads() : 1;  // O(R) host work per round: worth a team only for large R
-#pragma omp parallel for schedule(static) num_threads(nthr)
-    for (long jj = 0; jj < (long)R; jj++) {
-      const size_t j = (size_t)jj;
-      size_t pos = j & mask;
-      if (pos >= n) { sL[j] = av[pos - n] * sj[j]; sR[j] = Fq::zero(); }  // a_L . G_R
-      else { sL[j] = Fq::zero(); sR[j] = av[n + pos] * sj[j]; }           // a_R . G_L
-    }
-    sL[R] = cL * r_; sL[R + 1] = bv1[round];  // c_L * Q + blind_L * H,  Q = r * g[R]
-    sR[R] = cR * r_; sR[R + 1] = bv2[round];
-    Point lr[2];
-    if ((rc = msm_rows_host_sum(c, pc.dev, srow.data(), 2, ncols, lr))) return rc;
+    Fq cLR[2];
+    if ((rc = vpin::bullet_round(c, pc.dev, bs, n, parts.data(), B(cLR)))) return rc;
+    Point lr[2] = {sum_parts(parts.data()), sum_parts(parts.data() + np * 128)};
+    pc.fb_gR.mul_acc(lr[0], cLR[0] * r_); pc.fb_h.mul_acc(lr[0], bv1[round]);  // c_L * Q + blind_L * H
+    pc.fb_gR.mul_acc(lr[1], cLR[1] * r_); pc.fb_h.mul_acc(lr[1], bv2[round]);
     out.Lvec[round] = compress(lr[0]);
     out.Rvec[round] = compress(lr[1]);
     tr.append_point("L", out.Lvec[round].b);
     tr.append_point("R", out.Rvec[round].b);
     Fq u = tr.challenge_scalar("u"), u_inv = u.invert();
-    for (size_t i = 0; i < n; i++) {
-      av[i] = av[i] * u + u_inv * av[n + i];
-      bvv[i] = bvv[i] * u_inv + u * bvv[n + i];
-    }
-#pragma omp parallel for schedule(static) num_threads(nthr)
-    for (long jj = 0; jj < (long)R; jj++) {
-      const size_t j = (size_t)jj;
-      sj[j] = sj[j] * (((j & mask) < n) ? u_inv : u);
-    }
+    if ((rc = vpin::bullet_fold(c, bs, n, B(&u), B(&u_inv)))) return rc;
     blind_fin = blind_fin + bv1[round] * u * u + bv2[round] * u_inv * u_inv;
   }
-  Fq x_hat = av[0], a_hat = bvv[0], y_hat = x_hat * a_hat;
+  Fq xa[2];
   // g_hat = sum_j s_j g_j
-  Point g_hat;
-  {
-    std::vector<Fq> s1(ncols, Fq::zero());
-    memcpy(s1.data(), sj.data(), R * 32);
-    if ((rc = msm_rows_host_sum(c, pc.dev, s1.data(), 1, ncols, &g_hat))) return rc;
-  }
+  if ((rc = vpin::bullet_finish(c, pc.dev, bs, B(xa), parts.data()))) return rc;
+  const Fq x_hat = xa[0], a_hat = xa[1], y_hat = x_hat * a_hat;
+  Point g_hat = sum_parts(parts.data());
   {
     Point p = g_hat.mul(d_);  // d.commit(&r_delta, {G:[g_hat], h})
     pc.fb_h.mul_acc(p, r_delta);

@@ -654,25 +654,10 @@ int vpin_gens_msm_parts(vpin_ctx* c, const vpin_gens* g, const uint8_t* scalars_
   if (!c || !g || !scalars_mont || !parts_xyzt || rows == 0 || ncols == 0) return VPIN_EINVAL;
   if (ncols > g->nb) return VPIN_ESHAPE;
   (void)hipSetDevice(c->device);
-  const size_t nraw = raw_parts(ncols), nparts = vpin_gens_msm_parts_count(ncols);
-  DevBuf ds(c), dp(c), dr(c);
-  if (ds.alloc(rows * ncols * 32) || dp.alloc(rows * nraw * 128) || (nraw > nparts && dr.alloc(rows * nparts * 128))) return VPIN_ENOMEM;
+  DevBuf ds(c);
+  if (ds.alloc(rows * ncols * 32)) return VPIN_ENOMEM;
   VPIN_HIP_TRY(hipMemcpyAsync(ds.p, scalars_mont, rows * ncols * 32, hipMemcpyHostToDevice, c->stream));
-  {
-    ProfScope ps(c, VPIN_K_MSM, 32.0 * (double)rows * (double)ncols);
-    hipLaunchKernelGGL(msm_wide_kernel, dim3((unsigned)nraw, (unsigned)rows), dim3(kMsmBlock), 0, c->stream, (const fq*)ds.p,
-                       ncols, view(g), (fp*)dp.p);
-  }
-  const void* src = dp.p;
-  if (nraw > nparts) {
-    hipLaunchKernelGGL(parts_reduce_kernel, dim3((unsigned)((rows * nparts + 63) / 64)), dim3(64), 0, c->stream, (const fp*)dp.p, rows,
-                       nraw, (int)nparts, (fp*)dr.p);
-    src = dr.p;
-  }
-  VPIN_HIP_TRY(hipGetLastError());
-  VPIN_HIP_TRY(hipMemcpyAsync(parts_xyzt, src, rows * nparts * 128, hipMemcpyDeviceToHost, c->stream));
-  VPIN_HIP_TRY(hipStreamSynchronize(c->stream));
-  return VPIN_OK;
+  return vpin::gens_msm_parts_dev(c, g, (const fq*)ds.p, rows, ncols, parts_xyzt);
 }
 
 }  // extern "C"
@@ -759,3 +744,31 @@ int vpin_gens_msm(vpin_ctx* c, const vpin_gens* g, const uint8_t* scalars_mont, 
 }
 
 }  // extern "C"
+
+namespace vpin {
+
+int gens_msm_parts_dev(vpin_ctx* c, const vpin_gens* g, const fq* d_scalars, size_t rows, size_t ncols, uint8_t* parts_xyzt) {
+  if (!c || !g || !d_scalars || !parts_xyzt || rows == 0 || ncols == 0) return VPIN_EINVAL;
+  if (ncols > g->nb) return VPIN_ESHAPE;
+  (void)hipSetDevice(c->device);
+  const size_t nraw = raw_parts(ncols), nparts = vpin_gens_msm_parts_count(ncols);
+  DevBuf dp(c), dr(c);
+  if (dp.alloc(rows * nraw * 128) || (nraw > nparts && dr.alloc(rows * nparts * 128))) return VPIN_ENOMEM;
+  {
+    ProfScope ps(c, VPIN_K_MSM, 32.0 * (double)rows * (double)ncols);
+    hipLaunchKernelGGL(msm_wide_kernel, dim3((unsigned)nraw, (unsigned)rows), dim3(kMsmBlock), 0, c->stream, d_scalars, ncols,
+                       view(g), (fp*)dp.p);
+  }
+  const void* src = dp.p;
+  if (nraw > nparts) {
+    hipLaunchKernelGGL(parts_reduce_kernel, dim3((unsigned)((rows * nparts + 63) / 64)), dim3(64), 0, c->stream, (const fp*)dp.p, rows,
+                       nraw, (int)nparts, (fp*)dr.p);
+    src = dr.p;
+  }
+  VPIN_HIP_TRY(hipGetLastError());
+  VPIN_HIP_TRY(hipMemcpyAsync(parts_xyzt, src, rows * nparts * 128, hipMemcpyDeviceToHost, c->stream));
+  VPIN_HIP_TRY(hipStreamSynchronize(c->stream));
+  return VPIN_OK;
+}
+
+}  // namespace vpin

@@ -116,6 +116,34 @@ def test_linearity_at_scale(ctx):
     g.free()
 
 
+def test_constant_rows_use_the_prefix_sum_base(ctx):
+    """Rows of one repeated scalar (the padding tails of the SPARK polynomials) take the s * (g_0 + ... + g_{R-1})
+    path; rows that only look constant at the probed positions, all-zero rows and ordinary rows do not.  All must
+    match the oracle's Pippenger, with and without a blind."""
+    Ls, Rs = 8, 256
+    xyzt, og = O.gens_stream_xyzt(Rs + 2)
+    g = ctx.gens_create(xyzt)
+    rng = np.random.default_rng(21)
+    s0 = int(rng.integers(1, 2**62)) ** 4 % Q
+    rows = [
+        [s0] * Rs,                                             # constant, full width
+        [Q - 1] * Rs,                                          # constant, q - 1
+        [1] * Rs,                                              # constant, one
+        [0] * Rs,                                              # all zero
+        [s0] * 7 + [s0 + 1] + [s0] * (Rs - 8),                 # passes the probes (0, 1, R/2, R-1), not constant
+        [s0] * (Rs - 1) + [5],                                 # fails the last probe
+        structured_scalars(rng, Rs),
+        [2] * (Rs // 2) + [3] * (Rs // 2),
+    ]
+    Z = M.ints_to_table([v for r in rows for v in r])
+    dZ = ctx.upload(Z)
+    for blinds in (np.zeros((Ls, 4), dtype=np.uint64), M.ints_to_table([int(rng.integers(0, 2**62)) ** 4 % Q for _ in range(Ls)])):
+        got = ctx.hyrax_commit(g, dZ, blinds, Rs + 1)
+        exp = O.hyrax_commit(Z, Ls, blinds, og, Rs + 1)
+        assert np.array_equal(got, exp)
+    g.free()
+
+
 def test_shape_errors(ctx, gens34):
     import vpin_amd
     g, _ = gens34

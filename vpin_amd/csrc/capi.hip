@@ -127,7 +127,7 @@ static int ctx_create(int device, int priority, vpin_ctx** out) {
   int prio = priority < 0 ? hi : priority > 0 ? lo : 0;
   hipError_t e = hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio);
   if (e != hipSuccess) { set_last_error("hipStreamCreate", e); delete c; return VPIN_EHIP; }
-  c->partials_cap = 8192 * 4;
+  c->partials_cap = (size_t)18 * 4096 * 3;  // kSparkMaxInst x kRoundBlocks x 3 (spark.hip); sumcheck.hip needs kMaxBlocks x 3
   if (hipMalloc(&c->d_partials, c->partials_cap * sizeof(fq)) != hipSuccess ||
       hipMalloc(&c->d_out, 8 * sizeof(fq)) != hipSuccess ||
       hipHostMalloc(&c->h_out, 8 * sizeof(fq), hipHostMallocDefault) != hipSuccess) {

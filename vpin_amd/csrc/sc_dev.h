@@ -12,7 +12,11 @@ namespace vpin {
 #endif
 constexpr int kBlock = 256;
 constexpr int kMinWaves = VPIN_SC_MIN_WAVES;  // waves per SIMD asked of the register allocator
-constexpr int kMaxBlocks = 2048;  // 256 CUs x 8 blocks/CU, grid-stride beyond that
+constexpr int kMaxBlocksCap = 16384;
+inline int max_blocks() {
+  static const int n = [] { const char* e = getenv("VPIN_SC_BLOCKS"); int v = e ? atoi(e) : 2048; return v < 1 ? 1 : v > kMaxBlocksCap ? kMaxBlocksCap : v; }();
+  return n;
+}
 
 // ---- per-pair evaluation -------------------------------------------------------------
 
@@ -174,7 +178,7 @@ __global__ __launch_bounds__(kBlock) void sc_finish_kernel(const fq* __restrict_
 static inline int grid_for(size_t work) {
   size_t b = (work + kBlock - 1) / kBlock;
   if (b < 1) b = 1;
-  if (b > (size_t)kMaxBlocks) b = kMaxBlocks;
+  if (b > (size_t)max_blocks()) b = max_blocks();
   return (int)b;
 }
 

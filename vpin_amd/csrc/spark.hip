@@ -467,11 +467,17 @@ int spark_fetch_tops(vpin_ctx* c, const SparkForest* f, size_t cnt) {
 }
 
 // block partial scratch for up to kSparkMaxInst instances x kRoundBlocks blocks
-constexpr int kRoundBlocks = 512;
+constexpr int kRoundBlocks = 4096;  // layout stride of the partial buffer; the launch cap is round_blocks()
+
+// Workgroups per circuit of a round kernel.  Short-lived workgroups matter more than few partials: when several
+// proofs share the device, a high-priority one-workgroup kernel of a small proof can only start when a
+// workgroup of the large proof's kernel retires, and grid-stride workgroups all retire at the kernel's end.
+static inline int round_blocks() {
+  static const int n = [] { const char* e = getenv("VPIN_ROUND_BLOCKS"); int v = e ? atoi(e) : 512; return v < 1 ? 1 : v > kRoundBlocks ? kRoundBlocks : v; }();
+  return n;
+}
 
 static int round_partials(vpin_ctx* c, fq** out) {
-  // reuse the context's partial buffer when large enough (8192*4 fq = 18 x 512 x 3 fits)
-  static_assert((size_t)kSparkMaxInst * kRoundBlocks * 3 <= 8192 * 4, "partials buffer too small");
   if (c->partials_cap < (size_t)kSparkMaxInst * kRoundBlocks * 3) return VPIN_ENOMEM;
   *out = c->d_partials;
   return VPIN_OK;
@@ -481,7 +487,7 @@ static inline int round_grid(size_t pairs) {
   static const size_t per_thread = [] { const char* e = getenv("VPIN_SPARK_PAIRS_PER_THREAD"); size_t v = e ? (size_t)atoi(e) : 2; return v ? v : 2; }();
   size_t b = (pairs + kBlock * per_thread - 1) / (kBlock * per_thread);
   if (b < 1) b = 1;
-  if (b > (size_t)kRoundBlocks) b = kRoundBlocks;
+  if (b > (size_t)round_blocks()) b = round_blocks();
   return (int)b;
 }
 

@@ -201,13 +201,16 @@ __device__ __forceinline__ void inv_pair(const fq& x, const fq& y, fq& ix, fq& i
   iy = fqm(t, x);
 }
 
-// point_mult.rs:414-500 (pa :667-686, pd :688-704): one thread per multiplication
+// point_mult.rs:414-500 (pa :667-686, pd :688-704) as written: one thread per multiplication, one Fermat
+// exponentiation per step.  The exact path for every input; gd_mult_witness_fast_kernel covers the inputs whose
+// denominators never vanish and leaves the rest (op_list) to this one.
 __global__ __launch_bounds__(64) void gd_mult_witness_kernel(const uint8_t* __restrict__ w16, const uint8_t* __restrict__ px,
                                                              const uint8_t* __restrict__ py, size_t n_ops, fq a_pd,
                                                              fq* __restrict__ vars_para, fq* __restrict__ vars_input,
-                                                             fq* __restrict__ vars) {
-  const size_t j = (size_t)blockIdx.x * 64 + threadIdx.x;
-  if (j >= n_ops) return;
+                                                             fq* __restrict__ vars, const uint32_t* __restrict__ op_list) {
+  const size_t tid = (size_t)blockIdx.x * 64 + threadIdx.x;
+  if (tid >= n_ops) return;
+  const size_t j = op_list ? op_list[tid] : tid;
   constexpr size_t n = vpin_gadgets::kMultBits, ov = vpin_gadgets::kMultVars;
   fq* vi = vars_input + ov * j;
   fq* vv = vars + ov * j;
@@ -261,6 +264,172 @@ __global__ __launch_bounds__(64) void gd_mult_witness_kernel(const uint8_t* __re
   VPIN_W(10 * n + 6, bx);
   VPIN_W(10 * n + 7, by);
 }
+
+
+// ---- the same witness with four batched inversions per multiplication instead of 128 ---------------------------
+// The doubling chain A_i = 2^i P and the sums C_i = B_i + A_i are first computed in Jacobian coordinates (the
+// textbook formulas, which are identities of the affine chord / tangent formulas the gadget encodes: no use of the
+// curve equation, so they agree with the reference for any input whose denominators are non-zero), their Z's are
+// inverted together (Montgomery's trick, sequential inside the thread), and the two inverse witnesses of every step,
+// 1/(bx - ax) and 1/(2 ay), come from one more batch each.  ~8k field multiplications per operation instead of ~42k.
+// A vanishing denominator or Z (y = 0 on the doubling chain, B = +-A, x = 0 while B is the point at infinity: inputs
+// no honest witness produces) makes the results depend on the reference's inverse-of-zero = 0 convention; such an
+// operation is flagged and redone by gd_mult_witness_kernel.  Scratch is slot-major (slot * n_ops + op): coalesced.
+struct JacScratch {
+  fq* s;
+  size_t n_ops, j;
+  __device__ __forceinline__ fq ld(size_t slot) const { return fq_load(s + slot * n_ops + j); }
+  __device__ __forceinline__ void st(size_t slot, const fq& v) const { fq_store(s + slot * n_ops + j, v); }
+};
+
+// v[base .. base+cnt) := their inverses, using prefix slots [pre, pre+cnt); false when one of them is zero
+__device__ __noinline__ bool batch_invert(const JacScratch& sc, size_t base, size_t pre, size_t cnt) {
+  fq run = sc.ld(base);
+  sc.st(pre, run);
+  for (size_t i = 1; i < cnt; i++) {
+    run = fqm(run, sc.ld(base + i));
+    sc.st(pre + i, run);
+  }
+  if (fq_is_zero(run)) return false;
+  fq inv = fq_inv(run);
+  for (size_t i = cnt - 1; i >= 1; i--) {
+    const fq v = sc.ld(base + i);
+    sc.st(base + i, fqm(inv, sc.ld(pre + i - 1)));
+    inv = fqm(inv, v);
+  }
+  sc.st(base, inv);
+  return true;
+}
+
+constexpr size_t kJacSlots = 4 * (vpin_gadgets::kMultBits + 1) + 3 * vpin_gadgets::kMultBits + 2 * vpin_gadgets::kMultBits;
+
+__global__ __launch_bounds__(64) void gd_mult_witness_fast_kernel(const uint8_t* __restrict__ w16, const uint8_t* __restrict__ px,
+                                                                  const uint8_t* __restrict__ py, size_t n_ops, fq a_pd,
+                                                                  fq* __restrict__ vars_para, fq* __restrict__ vars_input,
+                                                                  fq* __restrict__ vars, fq* __restrict__ scratch,
+                                                                  uint32_t* __restrict__ redo_count, uint32_t* __restrict__ redo_list) {
+  const size_t j = (size_t)blockIdx.x * 64 + threadIdx.x;
+  if (j >= n_ops) return;
+  constexpr size_t n = vpin_gadgets::kMultBits, ov = vpin_gadgets::kMultVars;
+  // scratch slots: Jacobian A_i (X, Y, Z: n+1 each), prefix products (2n), Jacobian C_i (X, Y, Z: n each), denominators (2n)
+  constexpr size_t AX = 0, AY = n + 1, AZ = 2 * (n + 1), PRE = 3 * (n + 1), CX = PRE + 2 * n, CY = CX + n, CZ = CY + n, DEN = CZ + n;
+  static_assert(DEN + 2 * n <= kJacSlots + (n + 1), "scratch layout");
+  const JacScratch sc{scratch, n_ops, j};
+  fq* vi = vars_input + ov * j;
+  fq* vv = vars + ov * j;
+  const fq one = fq_one(), zero = fq_zero();
+  uint32_t w[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const uint8_t* b = w16 + 16 * j + 4 * i;
+    w[i] = (uint32_t)b[0] | ((uint32_t)b[1] << 8) | ((uint32_t)b[2] << 16) | ((uint32_t)b[3] << 24);
+  }
+  bool ok = true;
+  // ---- A: doubling chain in Jacobian coordinates, then affine through one inversion
+  {
+    fq X = fq_from_le32(px + 32 * j), Y = fq_from_le32(py + 32 * j), Z = one;
+    sc.st(AX, X); sc.st(AY, Y); sc.st(AZ, Z);
+    for (size_t i = 1; i <= n; i++) {
+      const fq XX = fqm(X, X), YY = fqm(Y, Y), YYYY = fqm(YY, YY), ZZ = fqm(Z, Z);
+      fq S = fqm(X, YY);
+      S = fq_dbl(fq_dbl(S));
+      const fq M = fq_add(fq_add(fq_dbl(XX), XX), fqm(a_pd, fqm(ZZ, ZZ)));
+      const fq X3 = fq_sub(fqm(M, M), fq_dbl(S));
+      const fq Y3 = fq_sub(fqm(M, fq_sub(S, X3)), fq_dbl(fq_dbl(fq_dbl(YYYY))));
+      const fq Z3 = fq_dbl(fqm(Y, Z));
+      X = X3; Y = Y3; Z = Z3;
+      sc.st(AX + i, X); sc.st(AY + i, Y); sc.st(AZ + i, Z);
+    }
+    ok = batch_invert(sc, AZ, PRE, n + 1);
+    if (ok)
+      for (size_t i = 0; i <= n; i++) {
+        const fq zi = sc.ld(AZ + i), z2 = fqm(zi, zi);
+        sc.st(AX + i, fqm(sc.ld(AX + i), z2));
+        sc.st(AY + i, fqm(sc.ld(AY + i), fqm(z2, zi)));
+      }
+  }
+  // ---- C: the sums C_i = B_i + A_i in Jacobian coordinates (C_i = A_i while B is the point at infinity)
+  if (ok) {
+    fq BX = zero, BY = one, BZ = zero;
+    bool inf = true;
+    for (size_t i = 0; i < n; i++) {
+      const fq ax = sc.ld(AX + i), ay = sc.ld(AY + i);
+      fq X3, Y3, Z3;
+      if (inf) { X3 = ax; Y3 = ay; Z3 = one; }
+      else {
+        const fq Z1Z1 = fqm(BZ, BZ), U2 = fqm(ax, Z1Z1), S2 = fqm(ay, fqm(BZ, Z1Z1));
+        const fq H = fq_sub(U2, BX), R = fq_sub(S2, BY), HH = fqm(H, H), HHH = fqm(H, HH), V = fqm(BX, HH);
+        X3 = fq_sub(fq_sub(fqm(R, R), HHH), fq_dbl(V));
+        Y3 = fq_sub(fqm(R, fq_sub(V, X3)), fqm(BY, HHH));
+        Z3 = fqm(BZ, H);
+      }
+      sc.st(CX + i, X3); sc.st(CY + i, Y3); sc.st(CZ + i, Z3);
+      if ((w[i >> 5] >> (i & 31)) & 1u) { BX = X3; BY = Y3; BZ = Z3; inf = false; }
+    }
+    ok = batch_invert(sc, CZ, PRE, n);
+    if (ok)
+      for (size_t i = 0; i < n; i++) {
+        const fq zi = sc.ld(CZ + i), z2 = fqm(zi, zi);
+        sc.st(CX + i, fqm(sc.ld(CX + i), z2));
+        sc.st(CY + i, fqm(sc.ld(CY + i), fqm(z2, zi)));
+      }
+  }
+  // ---- denominators of every step: bx_i - ax_i (slots DEN+i) and 2 ay_i (slots DEN+n+i), one batch
+  if (ok) {
+    fq bx = zero;
+    for (size_t i = 0; i < n; i++) {
+      sc.st(DEN + i, fq_sub(bx, sc.ld(AX + i)));
+      sc.st(DEN + n + i, fq_dbl(sc.ld(AY + i)));
+      if ((w[i >> 5] >> (i & 31)) & 1u) bx = sc.ld(CX + i);
+    }
+    ok = batch_invert(sc, DEN, PRE, 2 * n);
+  }
+  if (!ok) {  // an inverse of zero is involved: the step-by-step kernel redoes this operation
+    redo_list[atomicAdd(redo_count, 1u)] = (uint32_t)j;
+    return;
+  }
+  // ---- the witness, by the gadget's own formulas (point_mult.rs:414-500) with the inverses at hand
+  {
+    fq wt = zero;
+    wt.v[0] = w[0]; wt.v[1] = w[1]; wt.v[2] = w[2]; wt.v[3] = w[3];
+    wt = fqm(wt, fq_r2());  // Scalar::from(u128)
+    fq_store(vars_para + ov * j + n, wt);
+    fq_store(vv + n, wt);
+  }
+#define VPIN_W(k, x) do { fq x_ = (x); fq_store(vi + (k), x_); fq_store(vv + (k), x_); } while (0)
+  fq ax = sc.ld(AX), ay = sc.ld(AY);
+  fq bx = zero, by = zero, bz = one;
+  VPIN_W(n + 1, ax); VPIN_W(2 * n + 2, ay);
+  VPIN_W(3 * n + 3, zero); VPIN_W(4 * n + 4, zero); VPIN_W(5 * n + 5, one);
+  VPIN_W(10 * n + 8, ax); VPIN_W(10 * n + 9, ay);
+  for (size_t i = 0; i < n; i++) {
+    const fq c = sc.ld(DEN + i), cd = sc.ld(DEN + n + i);
+    const fq nbz1 = fq_sub(one, bz);
+    const fq s1 = fqm(fq_sub(by, ay), c), s2 = fqm(s1, s1);
+    const fq t1 = fqm(fq_sub(fq_sub(s2, ax), bx), nbz1), t2 = fqm(ax, bz), cx = fq_add(t1, t2);
+    const fq s3 = fqm(s1, fq_sub(ax, cx)), t3 = fqm(fq_sub(s3, ay), nbz1), t4 = fqm(ay, bz), cy = fq_add(t3, t4);
+    const fq u1 = fqm(ax, ax);
+    const fq v1 = fqm(fq_add(fq_add(fq_dbl(u1), u1), a_pd), cd), v2 = fqm(v1, v1);
+    const fq dx = fq_sub(v2, fq_dbl(ax)), u2 = fqm(v1, fq_sub(ax, dx)), dy = fq_sub(u2, ay);
+    const bool bit = (w[i >> 5] >> (i & 31)) & 1u;
+    const fq z1 = bit ? cx : zero, z2 = bit ? zero : bx, z3 = bit ? cy : zero, z4 = bit ? zero : by;
+    const fq nbx = fq_add(z1, z2), nby = fq_add(z3, z4), nbz = bit ? zero : bz;
+    VPIN_W(i, bit ? one : zero);
+    VPIN_W(n + 2 + i, dx); VPIN_W(2 * n + 3 + i, dy);
+    VPIN_W(3 * n + 4 + i, nbx); VPIN_W(4 * n + 5 + i, nby); VPIN_W(5 * n + 6 + i, nbz);
+    VPIN_W(6 * n + 6 + i, cx); VPIN_W(7 * n + 6 + i, cy); VPIN_W(8 * n + 6 + i, dx); VPIN_W(9 * n + 6 + i, dy);
+    VPIN_W(10 * n + 10 + i, c); VPIN_W(11 * n + 10 + i, s1); VPIN_W(12 * n + 10 + i, s2); VPIN_W(13 * n + 10 + i, s3);
+    VPIN_W(14 * n + 10 + i, t1); VPIN_W(15 * n + 10 + i, t2); VPIN_W(16 * n + 10 + i, t3); VPIN_W(17 * n + 10 + i, t4);
+    VPIN_W(18 * n + 10 + i, cd); VPIN_W(19 * n + 10 + i, u1); VPIN_W(20 * n + 10 + i, v1); VPIN_W(21 * n + 10 + i, v2);
+    VPIN_W(22 * n + 10 + i, u2);
+    VPIN_W(23 * n + 10 + i, z1); VPIN_W(24 * n + 10 + i, z2); VPIN_W(25 * n + 10 + i, z3); VPIN_W(26 * n + 10 + i, z4);
+    ax = dx; ay = dy; bx = nbx; by = nby; bz = nbz;
+  }
+  VPIN_W(10 * n + 6, bx);
+  VPIN_W(10 * n + 7, by);
+#undef VPIN_W
+}
+#define VPIN_W(k, x) do { fq x_ = (x); fq_store(vi + (k), x_); fq_store(vv + (k), x_); } while (0)
 
 // point_addition.rs:207-222: one thread per addition
 __global__ __launch_bounds__(64) void gd_add_witness_kernel(const uint8_t* __restrict__ px_b, const uint8_t* __restrict__ py_b,
@@ -601,9 +770,30 @@ int vpin_gadget_point_mult_dev(vpin_ctx* c, const uint8_t* weights_le16, const u
   hipError_t e = hipMemcpyAsync(p, weights_le16, 16 * N, hipMemcpyHostToDevice, c->stream);
   if (e == hipSuccess) e = hipMemcpyAsync(p + 16 * N, px, 32 * N, hipMemcpyHostToDevice, c->stream);
   if (e == hipSuccess) e = hipMemcpyAsync(p + 48 * N, py, 32 * N, hipMemcpyHostToDevice, c->stream);
-  if (e == hipSuccess) {
+  // fast kernel first (four batched inversions per operation); operations it flags go through the step-by-step kernel
+  DevBuf scr(c), redo(c);
+  const bool literal_only = getenv("VPIN_WITNESS_LITERAL") != nullptr;
+  const size_t scr_slots = kJacSlots + vpin_gadgets::kMultBits + 1;
+  uint32_t n_redo = 0;
+  if (e == hipSuccess && !literal_only) {
+    if (scr.alloc(scr_slots * N * 32) || redo.alloc((N + 1) * 4)) { vpin_dev_instance_free(c, g); return VPIN_ENOMEM; }
+    uint32_t* d_cnt = (uint32_t*)redo.p;
+    e = hipMemsetAsync(d_cnt, 0, 4, c->stream);
+    if (e == hipSuccess) {
+      hipLaunchKernelGGL(gd_mult_witness_fast_kernel, dim3((unsigned)((N + 63) / 64)), dim3(64), 0, c->stream, p, p + 16 * N, p + 48 * N,
+                         N, fq_of_host(a_pd), g->vars_para->d, g->vars_input->d, g->vars->d, (fq*)scr.p, d_cnt, d_cnt + 1);
+      e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(&n_redo, d_cnt, 4, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess && n_redo) {
+      hipLaunchKernelGGL(gd_mult_witness_kernel, dim3((unsigned)((n_redo + 63) / 64)), dim3(64), 0, c->stream, p, p + 16 * N, p + 48 * N,
+                         (size_t)n_redo, fq_of_host(a_pd), g->vars_para->d, g->vars_input->d, g->vars->d, (const uint32_t*)(d_cnt + 1));
+      e = hipGetLastError();
+    }
+  } else if (e == hipSuccess) {
     hipLaunchKernelGGL(gd_mult_witness_kernel, dim3((unsigned)((N + 63) / 64)), dim3(64), 0, c->stream, p, p + 16 * N, p + 48 * N, N,
-                       fq_of_host(a_pd), g->vars_para->d, g->vars_input->d, g->vars->d);
+                       fq_of_host(a_pd), g->vars_para->d, g->vars_input->d, g->vars->d, (const uint32_t*)nullptr);
     e = hipGetLastError();
   }
   if (e == hipSuccess) e = hipStreamSynchronize(c->stream);  // caller buffers

@@ -176,7 +176,20 @@ __device__ __forceinline__ bool fq_same(const fq& a, const fq& b) {
 }
 
 // accumulate s * g_j into acc through the window table; s canonical, non-zero
+// s -> q - s when s is in the upper half (bit 251 or 252 set): s*g = -((q - s)*g).  Nothing for a random scalar,
+// but the R1CS values -1, -2 (a fifth of comb_ops' val slices) become one table add instead of W.
+__device__ __forceinline__ bool fq_fold_sign(fq& s) {
+  if (s.v[7] < 0x08000000u) return false;
+  fq d;
+  unsigned bw = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) d.v[i] = __builtin_subc(fq_modulus_limb(i), s.v[i], bw, &bw);
+  s = d;
+  return true;
+}
+
 __device__ __forceinline__ void table_mul_acc(ge_ext& acc, fq s, const TableView& tv, size_t j) {
+  const bool flip = fq_fold_sign(s);
   uint32_t carry = 0;
   const uint32_t mask = (1u << tv.c) - 1u, half = 1u << (tv.c - 1);
   // software pipeline: the (random, 96-byte) table entry of window w+1 is requested before the
@@ -196,6 +209,7 @@ __device__ __forceinline__ void table_mul_acc(ge_ext& acc, fq s, const TableView
       neg_next = v > half;
       uint32_t mag = neg_next ? (mask + 1u) - v : v;
       carry = neg_next ? 1u : 0u;
+      neg_next ^= flip;
       if (mag != 0) {
         e_next = niels_load(tv.t + ((size_t)w * tv.nb + j) * tv.E + (mag - 1));
         have_next = true;
@@ -227,7 +241,9 @@ __device__ __forceinline__ uint32_t carry_into(const fq& s, int w0, int c) {
 }
 
 // windows [w0, w1) of s * g_j
-__device__ __forceinline__ void table_mul_acc_range(ge_ext& acc, const fq& s, const TableView& tv, size_t j, int w0, int w1) {
+__device__ __forceinline__ void table_mul_acc_range(ge_ext& acc, const fq& s_in, const TableView& tv, size_t j, int w0, int w1) {
+  fq s = s_in;
+  const bool flip = fq_fold_sign(s);
   uint32_t carry = carry_into(s, w0, tv.c);
   const uint32_t full = 1u << tv.c, half = 1u << (tv.c - 1);
 #pragma unroll 1
@@ -236,7 +252,7 @@ __device__ __forceinline__ void table_mul_acc_range(ge_ext& acc, const fq& s, co
     bool neg = v > half;
     uint32_t mag = neg ? full - v : v;
     carry = neg ? 1u : 0u;
-    if (mag != 0) acc = ge_add_niels(acc, niels_load(tv.t + ((size_t)w * tv.nb + j) * tv.E + (mag - 1)), neg);
+    if (mag != 0) acc = ge_add_niels(acc, niels_load(tv.t + ((size_t)w * tv.nb + j) * tv.E + (mag - 1)), neg != flip);
   }
 }
 

@@ -71,6 +71,9 @@ def parse():
     ap.add_argument("--lanes-spec", default=os.environ.get("VPIN_BENCH_LANES"),
                     help="explicit schedule: lanes separated by ';', instance names by ',' (first lane starts at once, the "
                          "others when its first instance's sat part is done); 'adds' = every point-add instance")
+    ap.add_argument("--pipeline", action="store_true",
+                    help="run the K timed steps back to back per lane, the smaller instances of all steps from one shared queue, "
+                         "instead of finishing every step before the next starts (measured: 3 %% faster, +15 GB of pooled memory)")
     ap.add_argument("--no-span", action="store_true", help="skip the reference-span pass after the timed region")
     ap.add_argument("--only", choices=["mult", "add"], default=None, help="keep only the point-mult / point-add instances of the trace")
     ap.add_argument("--no-verify", action="store_true", help="skip the post-run verification of the last step's SNARKs")
@@ -246,16 +249,72 @@ def main():
         gate.set()
         t.join()
 
-    for _ in range(args.warmup):
-        step()
+    # Pipelined schedule (whole SNARKs, >= 3 lanes): lane 0 proves the largest instance of step 0, 1, ... back to
+    # back; the other lanes take the remaining instances of all K steps from one queue (largest first within a
+    # step), so no lane idles at a step boundary while another finishes.  All K x 12 proofs start and end inside the
+    # timed region.  Any context can prove any resident instance (read-only); the warm-up lets every context see
+    # every instance size once, so no generator view is derived inside the timed region.  The other lanes start when
+    # step 0's largest instance has finished its sat part: its sum-check launches are the roofline sample.
+    pipelined = args.snark and len(lanes) >= 3 and args.pipeline and not args.lanes_spec
+    others = sorted([w for lane in lanes[1:] for w in lane], key=lambda w: -w[3]) if pipelined else []
+    other_names = [w[0] for w in others]
+    lane0_snapshot = {}
+
+    def run_pipelined(nsteps, warm):
+        progress[0] = 0
+        gate = threading.Event()
+        jobs = [nm for _ in range(nsteps) for nm in other_names]
+        lock = threading.Lock()
+        pos = [0]
+
+        def watch():
+            while progress[0] == 0 and not gate.is_set():
+                time.sleep(0.0005)
+            gate.set()
+
+        def worker(li):
+            gate.wait()
+            if warm:
+                for nm in other_names:
+                    prove(li, nm)
+                return
+            while True:
+                with lock:
+                    k = pos[0]
+                    pos[0] += 1
+                if k >= len(jobs):
+                    return
+                prove(li, jobs[k])
+
+        ts = [threading.Thread(target=worker, args=(li,)) for li in range(1, len(lanes))] + [threading.Thread(target=watch)]
+        for t in ts:
+            t.start()
+        for k in range(nsteps):
+            for name in lane_names[0]:
+                prove(0, name)
+            if k == 0 and not warm:
+                lane0_snapshot.update(ctxs[0].prof_read())  # step 0: the largest instance's sat part ran alone
+        gate.set()
+        for t in ts:
+            t.join()
+
+    if pipelined:
+        for _ in range(args.warmup):
+            run_pipelined(1, True)
+    else:
+        for _ in range(args.warmup):
+            step()
 
     for cx in ctxs:
         cx.prof_reset()
         cx.prof_enable(not args.no_prof)
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    if pipelined:
+        run_pipelined(args.steps, False)
+    else:
+        for _ in range(args.steps):
+            step()
     for cx in ctxs:
         cx.sync()
     barrier()
@@ -264,7 +323,7 @@ def main():
     for ci, cx in enumerate(ctxs):
         per_ctx = cx.prof_read()
         if ci == 0:
-            stats_lane0 = {n: dict(v) for n, v in per_ctx.items()}
+            stats_lane0 = {n: dict(v) for n, v in (lane0_snapshot or per_ctx).items()}
         for name, v in per_ctx.items():
             a = stats.setdefault(name, {"launches": 0, "ms": 0.0, "alg_bytes": 0.0})
             for kk in a:
@@ -300,8 +359,11 @@ def main():
                       "R1CSProof (commitments + both ZK sum-checks + evaluation proof); SPARK encode/eval proof not included"),
             "parallelism": f"one trace per rank x {world} rank(s), no collective; per rank "
                            + ("instances proven serially" if len(lanes) == 1 else
-                              f"{len(lanes)} streams: largest instance | other mult instances on {len(lanes) - 2} | add instances (all but the first "
-                              "start after the largest's sat part)"
+                              (f"{len(lanes)} streams, the K timed steps pipelined: the largest instance of every step back to back on one, the "
+                               f"other instances of all steps from a shared queue on {len(lanes) - 1} (started after step 0's largest instance's sat part)"
+                               if pipelined else
+                               f"{len(lanes)} streams: largest instance | other mult instances on {len(lanes) - 2} | add instances (all but the first "
+                               "start after the largest's sat part)")
                               if len(lanes) >= 3 else
                               "mult instances serially, add instances on a second stream after the largest"),
             "inputs": "host buffers (PCIe-inclusive, CSR/CSC built per proof)" if args.host_buffers else "resident in HBM",
@@ -329,7 +391,9 @@ def main():
             "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
             "launches": k["launches"], "avg_launch_us": k["ms"] * 1e3 / k["launches"],
             "alg_bytes_per_launch": k["alg_bytes"] / k["launches"],
-            "scope": (f"launches of the largest instance ({lane_names[0][0]}) only: {k['launches']} of {k_all['launches']} launches, "
+            "scope": ((f"launches of the largest instance ({lane_names[0][0]}) in step 0 of the timed region, before the other lanes start: "
+                       if pipelined else f"launches of the largest instance ({lane_names[0][0]}) only: ")
+                      + f"{k['launches']} of {k_all['launches']} launches, "
                       f"{100.0 * k['alg_bytes'] / k_all['alg_bytes']:.1f}% of the kernel's algorithmic bytes in the timed region; the other "
                       "instances run concurrently on other streams" if len(lanes) > 1 else "all launches in the timed region"),
         }

@@ -15,6 +15,7 @@
 // digits are skipped (the witness is ~40% zero padding and full of 0/1 bits), like dalek's
 // vartime MSM.  One 256-thread workgroup per row; per-thread partial sums are combined by
 // an LDS tree.  Integer-ALU bound (~8 field multiplies per table add); no MFMA.
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
@@ -34,20 +35,38 @@ static_assert(sizeof(niels_slot) == VPIN_NIELS_SLOT, "table entry size");
 }  // namespace vpin
 
 struct vpin_gens {
-  vpin::niels_slot* table = nullptr;  // [W][nbt][E]
+  // Two segments: bases [0, split) in `table` with wide windows (the generators every large commitment of a proof
+  // walks), bases [split, nbt) in `table_hi` with narrow ones (the upper half of the 32k-generator stream, touched by
+  // SNARK::encode and one evaluation proof, and the prefix sums).  split == nbt: a single segment.
+  vpin::niels_slot* table = nullptr;     // [W][split][E]
+  vpin::niels_slot* table_hi = nullptr;  // [W_hi][nbt - split][E_hi]
   size_t nb = 0;                    // number of bases in the stream
   size_t nbt = 0;                   // bases in the table: the stream, then the prefix sums S_k = g_0 + ... + g_{2^k - 1}
-  int c = 12, W = 22, E = 2048;     // window bits, windows, entries per window (= 2^(c-1))
+  size_t split = 0;
+  int c = 12, W = 22, E = 2048;     // window bits, windows, entries per window (= 2^(c-1)) of the first segment
+  int c_hi = 8, W_hi = 32, E_hi = 128;
 };
 
 namespace vpin {
 
 struct TableView {
-  const niels_slot* t;
-  size_t nb;    // bases per window in the table (stream + prefix sums)
-  int c, W, E;
+  const niels_slot* t;     // first segment
+  const niels_slot* t_hi;  // second segment
+  size_t split, nbt;       // bases [0, split) | [split, nbt)
+  int c, W, E, c_hi, W_hi, E_hi;
   size_t sum0;  // table index of S_0; S_k = g_0 + ... + g_{2^k - 1} sits at sum0 + k
 };
+
+// the segment of base j: table, index inside it, bases per window, window parameters
+struct TableSeg {
+  const niels_slot* t;
+  size_t j, nb;
+  int c, W, E;
+};
+__device__ __forceinline__ TableSeg table_seg(const TableView& tv, size_t j) {
+  if (j < tv.split) return TableSeg{tv.t, j, tv.split, tv.c, tv.W, tv.E};
+  return TableSeg{tv.t_hi, j - tv.split, tv.nbt - tv.split, tv.c_hi, tv.W_hi, tv.E_hi};
+}
 
 // ---- table construction ---------------------------------------------------------------
 
@@ -190,28 +209,29 @@ __device__ __forceinline__ bool fq_fold_sign(fq& s) {
 
 __device__ __forceinline__ void table_mul_acc(ge_ext& acc, fq s, const TableView& tv, size_t j) {
   const bool flip = fq_fold_sign(s);
+  const TableSeg sg = table_seg(tv, j);
   uint32_t carry = 0;
-  const uint32_t mask = (1u << tv.c) - 1u, half = 1u << (tv.c - 1);
+  const uint32_t mask = (1u << sg.c) - 1u, half = 1u << (sg.c - 1);
   // software pipeline: the (random, 96-byte) table entry of window w+1 is requested before the
   // 7-multiply add of window w, so the gather latency hides behind arithmetic
   ge_niels e_cur;
   bool have_cur = false, neg_cur = false;
 #pragma unroll 1
-  for (int w = 0; w <= tv.W; w++) {
+  for (int w = 0; w <= sg.W; w++) {
     ge_niels e_next;
     bool have_next = false, neg_next = false;
-    if (w < tv.W) {
+    if (w < sg.W) {
       uint32_t v = (s.v[0] & mask) + carry;
       // shift the 256-bit scalar right by c bits (static register indices only)
 #pragma unroll
-      for (int i = 0; i < 7; i++) s.v[i] = __builtin_amdgcn_alignbit(s.v[i + 1], s.v[i], tv.c);
-      s.v[7] >>= tv.c;
+      for (int i = 0; i < 7; i++) s.v[i] = __builtin_amdgcn_alignbit(s.v[i + 1], s.v[i], sg.c);
+      s.v[7] >>= sg.c;
       neg_next = v > half;
       uint32_t mag = neg_next ? (mask + 1u) - v : v;
       carry = neg_next ? 1u : 0u;
       neg_next ^= flip;
       if (mag != 0) {
-        e_next = niels_load(tv.t + ((size_t)w * tv.nb + j) * tv.E + (mag - 1));
+        e_next = niels_load(sg.t + ((size_t)w * sg.nb + sg.j) * sg.E + (mag - 1));
         have_next = true;
       }
     }
@@ -240,19 +260,19 @@ __device__ __forceinline__ uint32_t carry_into(const fq& s, int w0, int c) {
   return 0u;
 }
 
-// windows [w0, w1) of s * g_j
-__device__ __forceinline__ void table_mul_acc_range(ge_ext& acc, const fq& s_in, const TableView& tv, size_t j, int w0, int w1) {
+// windows [w0, w1) of s * g_j (sg = table_seg(tv, j))
+__device__ __forceinline__ void table_mul_acc_range(ge_ext& acc, const fq& s_in, const TableSeg& sg, int w0, int w1) {
   fq s = s_in;
   const bool flip = fq_fold_sign(s);
-  uint32_t carry = carry_into(s, w0, tv.c);
-  const uint32_t full = 1u << tv.c, half = 1u << (tv.c - 1);
+  uint32_t carry = carry_into(s, w0, sg.c);
+  const uint32_t full = 1u << sg.c, half = 1u << (sg.c - 1);
 #pragma unroll 1
   for (int w = w0; w < w1; w++) {
-    uint32_t v = scalar_digit(s, w, tv.c) + carry;
+    uint32_t v = scalar_digit(s, w, sg.c) + carry;
     bool neg = v > half;
     uint32_t mag = neg ? full - v : v;
     carry = neg ? 1u : 0u;
-    if (mag != 0) acc = ge_add_niels(acc, niels_load(tv.t + ((size_t)w * tv.nb + j) * tv.E + (mag - 1)), neg != flip);
+    if (mag != 0) acc = ge_add_niels(acc, niels_load(sg.t + ((size_t)w * sg.nb + sg.j) * sg.E + (mag - 1)), neg != flip);
   }
 }
 
@@ -272,7 +292,7 @@ __global__ __launch_bounds__(kMsmBlock, 3) void msm_rows_kernel(const fq* __rest
   const size_t total = ncols + (size_t)n_extra;
   // A row of one repeated scalar s: s * (g_0 + ... + g_{ncols-1}) from the prefix-sum base (see gens_sum_kernel).
   // Three probes keep ordinary rows from paying for the full comparison pass.
-  if (gridDim.y == 1 && ncols >= 256 && (ncols & (ncols - 1)) == 0 && ((size_t)1 << (tv.nb - tv.sum0 - 1)) >= ncols) {
+  if (gridDim.y == 1 && ncols >= 256 && (ncols & (ncols - 1)) == 0 && ((size_t)1 << (tv.nbt - tv.sum0 - 1)) >= ncols) {
     const fq* zr = Z + row * stride;
     const fq first = fq_load(zr);
     if (fq_same(first, fq_load(zr + 1)) && fq_same(first, fq_load(zr + ncols / 2)) && fq_same(first, fq_load(zr + ncols - 1))) {
@@ -346,13 +366,15 @@ __global__ __launch_bounds__(kMsmBlock) void msm_wide_kernel(const fq* __restric
                                                              fp* __restrict__ parts_xyzt) {
   const size_t row = blockIdx.y;
   const size_t j = (size_t)blockIdx.x * kWideScalars + (threadIdx.x >> 3);
-  const int grp = threadIdx.x & 7, wpg = (tv.W + 7) / 8;  // this lane's windows [grp*wpg, (grp+1)*wpg)
+  const int grp = threadIdx.x & 7;
   ge_ext acc = ge_identity();
   if (j < ncols) {
     fq s = fq_load(S + row * ncols + j);
     if (!fq_is_zero(s)) {
-      int w0 = grp * wpg, w1 = (w0 + wpg < tv.W) ? w0 + wpg : tv.W;
-      if (w0 < w1) table_mul_acc_range(acc, fq_from_mont(s), tv, j, w0, w1);
+      const TableSeg sg = table_seg(tv, j);
+      const int wpg = (sg.W + 7) / 8;  // this lane's windows [grp*wpg, (grp+1)*wpg)
+      int w0 = grp * wpg, w1 = (w0 + wpg < sg.W) ? w0 + wpg : sg.W;
+      if (w0 < w1) table_mul_acc_range(acc, fq_from_mont(s), sg, w0, w1);
     }
   }
   __shared__ ge_ext sh[kMsmBlock];
@@ -393,13 +415,15 @@ __global__ __launch_bounds__(64) void parts_reduce_kernel(const fp* __restrict__
 __global__ __launch_bounds__(64) void single_base_mul_kernel(const fq* __restrict__ S, size_t n, TableView tv, size_t base,
                                                              ge_ext* __restrict__ out) {
   const size_t i = (size_t)blockIdx.x * 8 + (threadIdx.x >> 3);
-  const int grp = threadIdx.x & 7, wpg = (tv.W + 7) / 8;
+  const int grp = threadIdx.x & 7;
   ge_ext acc = ge_identity();
   if (i < n) {
     fq s = fq_load(S + i);
     if (!fq_is_zero(s)) {
-      int w0 = grp * wpg, w1 = (w0 + wpg < tv.W) ? w0 + wpg : tv.W;
-      if (w0 < w1) table_mul_acc_range(acc, fq_from_mont(s), tv, base, w0, w1);
+      const TableSeg sg = table_seg(tv, base);
+      const int wpg = (sg.W + 7) / 8;
+      int w0 = grp * wpg, w1 = (w0 + wpg < sg.W) ? w0 + wpg : sg.W;
+      if (w0 < w1) table_mul_acc_range(acc, fq_from_mont(s), sg, w0, w1);
     }
   }
   __shared__ ge_ext sh[64];
@@ -476,21 +500,45 @@ static int gens_build(vpin_ctx* c, const uint8_t* gens_xyzt, size_t nb, size_t b
   while (((size_t)2 << (nsum - 1)) <= nb) nsum++;  // S_0 .. S_floor(log2 nb)
   const size_t nbt = nb + (size_t)nsum;
   g->nbt = nbt;
-  // window width by table budget (<= ~24 GB): 12 bits up to ~5k generators, 11 up to ~10k, ... 8 for
-  // the 32k-generator sets of the largest SPARK commitments
-  for (g->c = 12; g->c > 6; g->c--) {
-    g->W = (254 + g->c - 1) / g->c;
-    g->E = 1 << (g->c - 1);
-    if (nb * (size_t)g->W * (size_t)g->E * sizeof(niels_slot) <= budget) break;
+  // Window widths by table budget.  Up to kSplitBases generators: one segment, the widest windows that fit (12 bits
+  // up to ~5k generators under 24 GB, ...).  Longer streams: the first kSplitBases generators -- all that the
+  // per-proof commitments of the largest instance walk (R = 2^14 columns + the two blind bases) -- get 12-bit
+  // windows when the budget allows, the rest 8-bit ones: 71 + 6.4 GB for 32 786 bases, the 77 GB a uniform 11-bit
+  // table took, and 22 instead of 24 table adds per scalar where the time goes.
+  constexpr size_t kSplitBases = 16386;
+  auto fit = [&](size_t n, size_t bud, int cmax, int* c_, int* W_, int* E_) {
+    for (*c_ = cmax; *c_ > 6; (*c_)--) {
+      *W_ = (254 + *c_ - 1) / *c_;
+      *E_ = 1 << (*c_ - 1);
+      if (n * (size_t)*W_ * (size_t)*E_ * sizeof(niels_slot) <= bud) break;
+    }
+  };
+  g->split = nbt;
+  fit(nb, budget, 12, &g->c, &g->W, &g->E);
+  if (nb > kSplitBases && getenv("VPIN_GENS_UNIFORM") == nullptr) {
+    int c2, W2, E2;
+    fit(kSplitBases, budget, 12, &c2, &W2, &E2);
+    const size_t lo_bytes = kSplitBases * (size_t)W2 * E2 * sizeof(niels_slot);
+    if (c2 > g->c && lo_bytes < budget) {
+      g->split = kSplitBases;
+      g->c = c2; g->W = W2; g->E = E2;
+      fit(nbt - kSplitBases, budget - lo_bytes, g->c, &g->c_hi, &g->W_hi, &g->E_hi);
+    }
   }
-  const size_t entries = nbt * (size_t)g->W * g->E;
+  const size_t n_hi = nbt - g->split;
+  const size_t entries = g->split * (size_t)g->W * g->E, entries_hi = n_hi * (size_t)g->W_hi * g->E_hi;
+  const size_t max_entries = entries > entries_hi ? entries : entries_hi;
+  const size_t max_shifts = std::max(g->split * (size_t)g->W, n_hi * (size_t)g->W_hi);
   TraceLap lap(c, "gens_build");
   // temporaries come from the context pool, so the blocks go on to serve proof temporaries instead of being
   // returned to the driver (freed VRAM is wiped before it can be handed out again: tools/ubench_malloc2.hip)
   DevBuf raw(c), b_shifts(c), b_prefix(c);
-  if (raw.alloc(nbt * 128) != VPIN_OK || b_shifts.alloc(nbt * g->W * sizeof(ge_ext)) != VPIN_OK ||
-      b_prefix.alloc(entries * sizeof(fp)) != VPIN_OK || hipMalloc((void**)&g->table, entries * sizeof(niels_slot)) != hipSuccess) {
+  if (raw.alloc(nbt * 128) != VPIN_OK || b_shifts.alloc(max_shifts * sizeof(ge_ext)) != VPIN_OK ||
+      b_prefix.alloc(max_entries * sizeof(fp)) != VPIN_OK || hipMalloc((void**)&g->table, entries * sizeof(niels_slot)) != hipSuccess ||
+      (n_hi && hipMalloc((void**)&g->table_hi, entries_hi * sizeof(niels_slot)) != hipSuccess)) {
     if (g->table) (void)hipFree(g->table);
+  if (g->table_hi) (void)hipFree(g->table_hi);
+    if (g->table_hi) (void)hipFree(g->table_hi);
     delete g;
     return VPIN_ENOMEM;
   }
@@ -501,10 +549,16 @@ static int gens_build(vpin_ctx* c, const uint8_t* gens_xyzt, size_t nb, size_t b
   if (e == hipSuccess) {
     hipLaunchKernelGGL(gens_sum_kernel, dim3((unsigned)nsum), dim3(256), 0, c->stream, (fp*)raw.p, nb);
     hipLaunchKernelGGL(gens_sum_scan_kernel, dim3(1), dim3(64), 0, c->stream, (fp*)raw.p, nb, nsum);
-    hipLaunchKernelGGL(gens_shift_kernel, dim3((unsigned)((nbt + 63) / 64)), dim3(64), 0, c->stream, (const fp*)raw.p, nbt, g->W,
-                       g->c, shifts);
-    hipLaunchKernelGGL(gens_table_kernel, dim3((unsigned)((nbt * g->W + 63) / 64)), dim3(64), 0, c->stream, shifts, nbt, g->W,
+    hipLaunchKernelGGL(gens_shift_kernel, dim3((unsigned)((g->split + 63) / 64)), dim3(64), 0, c->stream, (const fp*)raw.p, g->split,
+                       g->W, g->c, shifts);
+    hipLaunchKernelGGL(gens_table_kernel, dim3((unsigned)((g->split * g->W + 63) / 64)), dim3(64), 0, c->stream, shifts, g->split, g->W,
                        g->E, g->table, prefix);
+    if (n_hi) {  // same temporaries, stream-ordered after the first segment
+      hipLaunchKernelGGL(gens_shift_kernel, dim3((unsigned)((n_hi + 63) / 64)), dim3(64), 0, c->stream,
+                         (const fp*)raw.p + 4 * g->split, n_hi, g->W_hi, g->c_hi, shifts);
+      hipLaunchKernelGGL(gens_table_kernel, dim3((unsigned)((n_hi * g->W_hi + 63) / 64)), dim3(64), 0, c->stream, shifts, n_hi,
+                         g->W_hi, g->E_hi, g->table_hi, prefix);
+    }
     e = hipGetLastError();
   }
   if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
@@ -512,6 +566,7 @@ static int gens_build(vpin_ctx* c, const uint8_t* gens_xyzt, size_t nb, size_t b
   if (e != hipSuccess) {
     set_last_error("vpin_gens_create", e);
     (void)hipFree(g->table);
+    if (g->table_hi) (void)hipFree(g->table_hi);
     delete g;
     return VPIN_EHIP;
   }
@@ -565,6 +620,7 @@ void vpin_gens_shared_clear(void) {
     (void)hipSetDevice(e.device);
     (void)hipDeviceSynchronize();
     if (e.g->table) (void)hipFree(e.g->table);
+    if (e.g->table_hi) (void)hipFree(e.g->table_hi);
     delete e.g;
   }
   g_reg.clear();
@@ -574,6 +630,7 @@ void vpin_gens_free(vpin_ctx* c, vpin_gens* g) {
   if (!g) return;
   if (c) { (void)hipSetDevice(c->device); (void)hipStreamSynchronize(c->stream); }
   if (g->table) (void)hipFree(g->table);
+  if (g->table_hi) (void)hipFree(g->table_hi);
   delete g;
 }
 
@@ -581,7 +638,9 @@ size_t vpin_gens_count(const vpin_gens* g) { return g ? g->nb : 0; }
 size_t vpin_gens_entry_bytes(void) { return sizeof(niels_slot); }
 
 // shared implementation: rows of scalars -> points (kept on device), then optional outputs
-static inline TableView view(const vpin_gens* g) { return TableView{g->table, g->nbt, g->c, g->W, g->E, g->nb}; }
+static inline TableView view(const vpin_gens* g) {
+  return TableView{g->table, g->table_hi, g->split, g->nbt, g->c, g->W, g->E, g->c_hi, g->W_hi, g->E_hi, g->nb};
+}
 
 static int msm_rows(vpin_ctx* c, const vpin_gens* g, const fq* dZ, size_t rows, size_t stride, size_t ncols,
                     const fq* d_extra, int n_extra, size_t extra_base0, ge_ext* d_points) {

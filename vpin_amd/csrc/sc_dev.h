@@ -14,7 +14,7 @@ constexpr int kBlock = 256;
 constexpr int kMinWaves = VPIN_SC_MIN_WAVES;  // waves per SIMD asked of the register allocator
 constexpr int kMaxBlocksCap = 16384;
 inline int max_blocks() {
-  static const int n = [] { const char* e = getenv("VPIN_SC_BLOCKS"); int v = e ? atoi(e) : 2048; return v < 1 ? 1 : v > kMaxBlocksCap ? kMaxBlocksCap : v; }();
+  static const int n = [] { const char* e = getenv("VPIN_SC_BLOCKS"); int v = e ? atoi(e) : 1024; return v < 1 ? 1 : v > kMaxBlocksCap ? kMaxBlocksCap : v; }();
   return n;
 }
 

@@ -469,11 +469,13 @@ int spark_fetch_tops(vpin_ctx* c, const SparkForest* f, size_t cnt) {
 // block partial scratch for up to kSparkMaxInst instances x kRoundBlocks blocks
 constexpr int kRoundBlocks = 4096;  // layout stride of the partial buffer; the launch cap is round_blocks()
 
-// Workgroups per circuit of a round kernel.  Short-lived workgroups matter more than few partials: when several
-// proofs share the device, a high-priority one-workgroup kernel of a small proof can only start when a
-// workgroup of the large proof's kernel retires, and grid-stride workgroups all retire at the kernel's end.
+// Workgroups per circuit of a round kernel (and pairs per thread below which a round gets fewer).  Measured on
+// MI355X (tools/blocks_sweep.sh, profiles/r01m_blocks_sweep.txt): 64 workgroups x 12 circuits with >= 8 pairs per
+// thread beat 512 x 12 with 2 by 10 % on the LeNet step and 4 % on a lone L5-mult proof -- every workgroup ends in
+// an atomic on its circuit's counter and a partial the last workgroup re-reads, and those serialise per address;
+// 32 starves the device when the proof runs alone.
 static inline int round_blocks() {
-  static const int n = [] { const char* e = getenv("VPIN_ROUND_BLOCKS"); int v = e ? atoi(e) : 512; return v < 1 ? 1 : v > kRoundBlocks ? kRoundBlocks : v; }();
+  static const int n = [] { const char* e = getenv("VPIN_ROUND_BLOCKS"); int v = e ? atoi(e) : 64; return v < 1 ? 1 : v > kRoundBlocks ? kRoundBlocks : v; }();
   return n;
 }
 
@@ -484,7 +486,7 @@ static int round_partials(vpin_ctx* c, fq** out) {
 }
 
 static inline int round_grid(size_t pairs) {
-  static const size_t per_thread = [] { const char* e = getenv("VPIN_SPARK_PAIRS_PER_THREAD"); size_t v = e ? (size_t)atoi(e) : 2; return v ? v : 2; }();
+  static const size_t per_thread = [] { const char* e = getenv("VPIN_SPARK_PAIRS_PER_THREAD"); size_t v = e ? (size_t)atoi(e) : 8; return v ? v : 8; }();
   size_t b = (pairs + kBlock * per_thread - 1) / (kBlock * per_thread);
   if (b < 1) b = 1;
   if (b > (size_t)round_blocks()) b = round_blocks();

@@ -659,7 +659,9 @@ static int msm_rows(vpin_ctx* c, const vpin_gens* g, const fq* dZ, size_t rows, 
   }
   {
     ProfScope ps(c, VPIN_K_MSM, 32.0 * nz_est);
-    hipLaunchKernelGGL(msm_rows_kernel, dim3((unsigned)rows, (unsigned)chunks), dim3(kMsmBlock), 0, c->stream, dZ, stride,
+    // VPIN_MSM_LDS_PAD (bytes of unused dynamic LDS) lowers the workgroups per CU: experiment knob
+    static const unsigned pad = [] { const char* e = getenv("VPIN_MSM_LDS_PAD"); return e ? (unsigned)atoi(e) : 0u; }();
+    hipLaunchKernelGGL(msm_rows_kernel, dim3((unsigned)rows, (unsigned)chunks), dim3(kMsmBlock), pad, c->stream, dZ, stride,
                        ncols, d_extra, n_extra, extra_base0, view(g), dst);
   }
   if (chunks > 1)

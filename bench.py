@@ -23,7 +23,7 @@ rank proves its own trace -- independent instances, no data-path collective -> w
 
 Schedule per rank: three host threads / HIP streams -- the largest instance; the other
 point-mult instances; the point-add instances.  The second and third start when the largest
-instance's sat part is done, so its sum-check kernels are timed undisturbed (--sat-only: two
+instance's phase-1 sum-check is done, so its kernels (the roofline sample) are timed undisturbed (--sat-only: two
 lanes, the add lane starts after the largest instance).  `--serial`: one instance at a time.
 
 Beside the headline value the line carries
@@ -70,7 +70,7 @@ def parse():
                     help="streams / host threads for the point-mult instances other than the largest")
     ap.add_argument("--lanes-spec", default=os.environ.get("VPIN_BENCH_LANES"),
                     help="explicit schedule: lanes separated by ';', instance names by ',' (first lane starts at once, the "
-                         "others when its first instance's sat part is done); 'adds' = every point-add instance")
+                         "others when its first instance's phase-1 sum-check is done); 'adds' = every point-add instance")
     ap.add_argument("--pipeline", action="store_true",
                     help="run the K timed steps back to back per lane, the smaller instances of all steps from one shared queue, "
                          "instead of finishing every step before the next starts (measured: 3 %% faster, +15 GB of pooled memory)")
@@ -123,8 +123,8 @@ def main():
     lanes = [mults + adds] if (args.serial or not mults) else [mults, adds]
     if args.snark and not args.serial and len(mults) > 2:
         # whole SNARKs are long enough to be worth three host threads / streams: the largest instance
-        # alone, the other point-mult instances, the point-add instances; lanes 1 and 2 start when the
-        # largest instance's sat part is done, so its sum-check kernels are timed undisturbed
+        # alone, the other point-mult instances, the point-add instances; the other lanes start when the
+        # largest instance's phase-1 sum-check is done, so its kernels (the roofline sample) are timed undisturbed
         rest = [[] for _ in range(max(1, min(args.mult_lanes, len(mults) - 1)))]
         for w in mults[1:]:  # largest first onto the least loaded lane
             min(rest, key=lambda l: sum(x[3] for x in l)).append(w)
@@ -254,7 +254,7 @@ def main():
     # step), so no lane idles at a step boundary while another finishes.  All K x 12 proofs start and end inside the
     # timed region.  Any context can prove any resident instance (read-only); the warm-up lets every context see
     # every instance size once, so no generator view is derived inside the timed region.  The other lanes start when
-    # step 0's largest instance has finished its sat part: its sum-check launches are the roofline sample.
+    # step 0's largest instance has finished its phase-1 sum-check: those launches are the roofline sample.
     pipelined = args.snark and len(lanes) >= 3 and args.pipeline and not args.lanes_spec
     others = sorted([w for lane in lanes[1:] for w in lane], key=lambda w: -w[3]) if pipelined else []
     other_names = [w[0] for w in others]
@@ -293,7 +293,7 @@ def main():
             for name in lane_names[0]:
                 prove(0, name)
             if k == 0 and not warm:
-                lane0_snapshot.update(ctxs[0].prof_read())  # step 0: the largest instance's sat part ran alone
+                lane0_snapshot.update(ctxs[0].prof_read())  # step 0: the largest instance's phase 1 ran alone
         gate.set()
         for t in ts:
             t.join()
@@ -360,10 +360,10 @@ def main():
             "parallelism": f"one trace per rank x {world} rank(s), no collective; per rank "
                            + ("instances proven serially" if len(lanes) == 1 else
                               (f"{len(lanes)} streams, the K timed steps pipelined: the largest instance of every step back to back on one, the "
-                               f"other instances of all steps from a shared queue on {len(lanes) - 1} (started after step 0's largest instance's sat part)"
+                               f"other instances of all steps from a shared queue on {len(lanes) - 1} (started after step 0's largest instance's phase-1 sum-check)"
                                if pipelined else
                                f"{len(lanes)} streams: largest instance | other mult instances on {len(lanes) - 2} | add instances (all but the first "
-                               "start after the largest's sat part)")
+                               "start after the largest's phase-1 sum-check)")
                               if len(lanes) >= 3 else
                               "mult instances serially, add instances on a second stream after the largest"),
             "inputs": "host buffers (PCIe-inclusive, CSR/CSC built per proof)" if args.host_buffers else "resident in HBM",
@@ -372,7 +372,7 @@ def main():
 
     # ---- roofline of the fused sum-check round kernel ----
     # with several streams the event time of a kernel on one stream includes waiting for CUs taken by the
-    # other streams' kernels; lane 0 (the largest instance) runs its sat part before the other lanes
+    # other streams' kernels; lane 0 (the largest instance) runs its phase-1 sum-check before the other lanes
     # start, so the roofline is taken over lane 0's launches only
     k = (stats_lane0 if len(lanes) > 1 else stats).get("sc_cubic_fused")
     k_all = stats.get("sc_cubic_fused")

@@ -56,9 +56,9 @@ int vpin_ctx_create_prio(int device, int priority, vpin_ctx** out);
 void vpin_ctx_destroy(vpin_ctx* ctx);
 /* hipStream_t the ctx launches on (as void*), for callers that time with HIP events */
 void* vpin_ctx_stream(vpin_ctx* ctx);
-/* Optional progress word in host memory: vpin_snark_prove_resident stores 1 to it when the sat part of
- * the proof is complete (bench.py starts its other lanes then, so the largest instance's sum-check
- * kernels are timed undisturbed).  NULL disables. */
+/* Optional progress word in host memory: a proof stores 1 to it when its phase-1 sum-check is over (and again
+ * when the whole sat part is), so that a caller running other proofs on other contexts can hold them back while
+ * the phase-1 kernels of this one are being timed.  NULL clears it. */
 int vpin_ctx_set_progress_flag(vpin_ctx* ctx, int* flag);
 int vpin_ctx_sync(vpin_ctx* ctx);
 

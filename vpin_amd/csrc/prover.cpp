@@ -391,6 +391,7 @@ int sat_prove_core(vpin_ctx* c, const vpin_r1cs_dev* dinst, size_t nv, size_t nc
   rc = zk_sumcheck(c, 4, tabs1, Fq::zero(), Fq::zero(), nrx, sg->gens_1, sg->gens_4, tr, tape, sc1, rx, claims1, blind_post1,
                    &tau, d_pyr);
   if (rc) return rc;
+  if (c->progress_flag) *c->progress_flag = 1;  // phase 1 (the roofline kernel's launches) is over: other streams may start
   g_timings[1] = secs(t0, Clock::now());
 
   const Fq tau_claim = claims1[0], Az_claim = claims1[1], Bz_claim = claims1[2], Cz_claim = claims1[3];

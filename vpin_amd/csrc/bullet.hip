@@ -78,6 +78,13 @@ __global__ __launch_bounds__(kBB) void bullet_fold_kernel(fq* __restrict__ av, f
   }
 }
 
+constexpr size_t kBulletPinned = 64 * 1024;
+
+uint8_t* bullet_pinned(vpin_ctx* c) {
+  if (!c->h_bullet && hipHostMalloc(&c->h_bullet, kBulletPinned, hipHostMallocDefault) != hipSuccess) c->h_bullet = nullptr;
+  return (uint8_t*)c->h_bullet;
+}
+
 void bullet_free(vpin_ctx* c, BulletState* st) {
   if (!st) return;
   for (void* p : {(void*)st->av, (void*)st->bv, (void*)st->sj, (void*)st->rows, (void*)st->partials})
@@ -120,8 +127,13 @@ int bullet_round(vpin_ctx* c, const vpin_gens* g, BulletState* st, size_t n, uin
   VPIN_HIP_TRY(hipGetLastError());
   // only the blocks covering i < n carry non-zero partials
   const int used = (int)((n + kBB - 1) / kBB);
-  std::vector<fq> part((size_t)used * 2);
-  VPIN_HIP_TRY(hipMemcpyAsync(part.data(), st->partials, part.size() * 32, hipMemcpyDeviceToHost, c->stream));
+  // pinned staging (second half of the context's buffer; the caller's partial points use the first half)
+  uint8_t* pin = bullet_pinned(c);
+  std::vector<fq> pageable;
+  fq* part;
+  if (pin && (size_t)used * 64 <= kBulletPinned / 2) part = (fq*)(pin + kBulletPinned / 2);
+  else { pageable.resize((size_t)used * 2); part = pageable.data(); }
+  VPIN_HIP_TRY(hipMemcpyAsync(part, st->partials, (size_t)used * 64, hipMemcpyDeviceToHost, c->stream));
   int rc = gens_msm_parts_dev(c, g, st->rows, 2, st->R, parts_xyzt);  // synchronises the stream
   if (rc) return rc;
   // block partials summed on the host (<= 64 pairs): plain modular additions of Montgomery values

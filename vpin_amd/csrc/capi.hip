@@ -154,6 +154,7 @@ void vpin_ctx_destroy(vpin_ctx* c) {
   if (c->d_partials) (void)hipFree(c->d_partials);
   if (c->d_out) (void)hipFree(c->d_out);
   if (c->h_out) (void)hipHostFree(c->h_out);
+  if (c->h_bullet) (void)hipHostFree(c->h_bullet);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }

@@ -71,6 +71,7 @@ struct vpin_ctx {
   vpin::fq* h_spark = nullptr;  // pinned, kSparkPinned fq; the last element's first word is the completion flag
   uint32_t* d_spark_cnt = nullptr;  // device: per-instance and global "blocks done" counters (self-resetting)
   uint32_t spark_seq = 0;           // sequence number of the last flagged launch group
+  void* h_bullet = nullptr;  // pinned staging of the bullet reduction's per-round results (bullet.hip), 64 KiB
   volatile int* progress_flag = nullptr;  // optional host word: set to 1 when a SNARK's sat part is done
 };
 
@@ -123,6 +124,7 @@ int gens_msm_parts_dev(vpin_ctx* c, const vpin_gens* g, const fq* d_scalars, siz
 struct BulletState;
 int bullet_begin(vpin_ctx* c, const uint8_t* x_mont, const uint8_t* a_mont, size_t R, BulletState** out);
 int bullet_round(vpin_ctx* c, const vpin_gens* g, BulletState* st, size_t n, uint8_t* parts_xyzt, uint8_t cLR[64]);
+uint8_t* bullet_pinned(vpin_ctx* c);  // 64 KiB of pinned host memory owned by the context (nullptr on failure)
 int bullet_fold(vpin_ctx* c, BulletState* st, size_t n, const uint8_t u[32], const uint8_t u_inv[32]);
 int bullet_finish(vpin_ctx* c, const vpin_gens* g, BulletState* st, uint8_t xhat_ahat[64], uint8_t* parts_xyzt);
 void bullet_free(vpin_ctx* c, BulletState* st);

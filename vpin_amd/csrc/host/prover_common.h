@@ -297,7 +297,10 @@ static int dplog_prove(vpin_ctx* c, const PcGens& pc, Transcript& tr, Transcript
   if ((rc = vpin::bullet_begin(c, B(LZ.data()), B(Rv.data()), R, &bs))) return rc;
   struct BsGuard { vpin_ctx* c; vpin::BulletState* s; ~BsGuard() { vpin::bullet_free(c, s); } } bs_guard{c, bs};
   const size_t np = vpin_gens_msm_parts_count(R);
-  std::vector<uint8_t> parts(2 * np * 128);
+  std::vector<uint8_t> parts_pageable;
+  uint8_t* parts_buf = vpin::bullet_pinned(c);  // pinned: the per-round device-to-host copies complete without staging
+  if (!parts_buf || 2 * np * 128 > 32 * 1024) { parts_pageable.resize(2 * np * 128); parts_buf = parts_pageable.data(); }
+  struct { uint8_t* p; uint8_t* data() const { return p; } } parts{parts_buf};
   auto sum_parts = [&](const uint8_t* p) {
     Point acc = Point::from_xyzt(p);
     for (size_t k = 1; k < np; k++) acc = acc + Point::from_xyzt(p + k * 128);

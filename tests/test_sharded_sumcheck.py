@@ -117,6 +117,60 @@ def _worker(rank, world, port, q, n, use_gpu):
     grp.close()
 
 
+def _commit_worker(rank, world, port, q, Ls, Rs, use_gpu):
+    os.environ.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    for p in (ROOT, os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import oracle_lib as O
+    import pymodel as M
+    from vpin_amd.dist import Group, sharded_hyrax_commit
+    grp = Group(backend="gloo")
+    rng = np.random.default_rng(5)
+    Z = M.ints_to_table([int(rng.integers(0, 2**62)) ** 4 % M.Q if rng.random() > 0.3 else 0 for _ in range(Ls * Rs)])
+    blinds = M.ints_to_table([int(rng.integers(0, 2**62)) ** 4 % M.Q for _ in range(Ls)])
+    xyzt, og = O.gens_stream_xyzt(Rs + 2)
+    per = Ls // world
+    zl, bl = Z[rank * per * Rs:(rank + 1) * per * Rs], blinds[rank * per:(rank + 1) * per]
+    if use_gpu:
+        import vpin_amd
+        ctx = vpin_amd.Context(0)
+        g = ctx.gens_create(xyzt)
+        fn = lambda z, b: ctx.hyrax_commit(g, ctx.upload(z), b, Rs + 1)
+    else:
+        fn = lambda z, b: O.hyrax_commit(z, per, b, og, Rs + 1, threads=1)
+    got = sharded_hyrax_commit(grp, fn, zl, bl)
+    if rank == 0:
+        q.put((bool(np.array_equal(got, O.hyrax_commit(Z, Ls, blinds, og, Rs + 1, threads=2))), Ls))
+    grp.barrier()
+    grp.close()
+
+
+def _run_commit(world, Ls, Rs, use_gpu):
+    port = _free_port()
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    procs = [mpc.Process(target=_commit_worker, args=(r, world, port, q, Ls, Rs, use_gpu)) for r in range(world)]
+    for p in procs:
+        p.start()
+    ok, _ = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert ok
+
+
+@pytest.mark.timeout(300)
+def test_row_sharded_commitment_gloo_cpu():
+    _run_commit(2, 8, 16, use_gpu=False)
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(300)
+def test_row_sharded_commitment_two_processes_one_gpu():
+    _run_commit(2, 64, 64, use_gpu=True)
+
+
 def _run(world, n, use_gpu):
     port = _free_port()
     mpc = mp.get_context("spawn")

@@ -179,3 +179,16 @@ def sharded_cubic_sumcheck(grp, ops, shards, challenges):
         tabs = [[(t[i] + r * (t[half + i] - t[i])) % Q for i in range(half)] for t in tabs]
     final = np.stack([_int_to_limbs(t[0] * _R % Q) for t in tabs])
     return evals, final
+
+
+def sharded_hyrax_commit(grp, commit_rows, z_rows_local, blinds_local):
+    """DensePolynomial::commit_inner split across ranks (SURVEY.md 8(e), row H4): the L row commitments are
+    independent MSMs over the same generators, so rank g commits the contiguous rows [g L/P, (g+1) L/P) it holds and
+    the 32-byte results are all-gathered -- no reduction, no point ever crosses a link.
+
+    commit_rows(z_rows_local, blinds_local) -> (L/P, 32) uint8 compressed points (on the GPU: Context.hyrax_commit on
+    the uploaded row block); returns the (L, 32) commitment in row order on every rank."""
+    import numpy as np
+    mine = np.ascontiguousarray(commit_rows(z_rows_local, blinds_local), dtype=np.uint8)
+    parts = grp.gather_objects(mine.tobytes())
+    return np.concatenate([np.frombuffer(p, dtype=np.uint8).reshape(-1, 32) for p in parts])

@@ -143,6 +143,9 @@ def main():
     # kernels are then dispatched ahead of the large instance's queued workgroups instead of behind them
     prios = [0] + [-1] * (len(lanes) - 1) if not os.environ.get("VPIN_BENCH_NO_PRIO") else [0] * len(lanes)
     ctxs = [vpin_amd.Context(local_rank, priority=prios[li]) for li in range(len(lanes))]
+    if len(lanes) > 1:
+        for cx in ctxs:
+            cx.set_shared_device(True)  # the lanes share the GPU: the row-commitment MSM leaves room on every CU
 
     def barrier():
         torch.cuda.synchronize()

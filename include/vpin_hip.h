@@ -60,6 +60,11 @@ void* vpin_ctx_stream(vpin_ctx* ctx);
  * when the whole sat part is), so that a caller running other proofs on other contexts can hold them back while
  * the phase-1 kernels of this one are being timed.  NULL clears it. */
 int vpin_ctx_set_progress_flag(vpin_ctx* ctx, int* flag);
+/* Several contexts prove on this device at the same time (a service, bench.py's lanes): the long VALU-bound kernels of
+ * this context then leave a third of every CU's wave slots to the others (the row-commitment MSM runs 2 instead of 3
+ * workgroups per CU: 3 % slower alone, but a large instance's commitment no longer stalls every other stream for its
+ * whole duration). */
+int vpin_ctx_set_shared_device(vpin_ctx* ctx, int on);
 int vpin_ctx_sync(vpin_ctx* ctx);
 
 /* ---- tables: device-resident Vec<Scalar> ---------------------------------------- */

@@ -80,6 +80,7 @@ def lib():
     L.vpin_ctx_stream.argtypes = [vp]
     L.vpin_ctx_stream.restype = vp
     L.vpin_ctx_sync.argtypes = [vp]
+    L.vpin_ctx_set_shared_device.argtypes = [vp, C.c_int]
     L.vpin_ctx_set_progress_flag.argtypes = [vp, vp]
     L.vpin_table_upload.argtypes = [vp, vp, C.c_size_t, C.POINTER(vp)]
     L.vpin_table_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
@@ -350,6 +351,10 @@ class Context:
 
     def sync(self):
         _chk(lib().vpin_ctx_sync(self.h), "vpin_ctx_sync")
+
+    def set_shared_device(self, on=True):
+        """other contexts prove on this device concurrently: leave them a share of every CU"""
+        _chk(lib().vpin_ctx_set_shared_device(self.h, 1 if on else 0), "vpin_ctx_set_shared_device")
 
     # ---- tables ----
     def upload(self, arr):

@@ -167,6 +167,12 @@ int vpin_ctx_set_progress_flag(vpin_ctx* c, int* flag) {
   return VPIN_OK;
 }
 
+int vpin_ctx_set_shared_device(vpin_ctx* c, int on) {
+  if (!c) return VPIN_EINVAL;
+  c->shared_device = on != 0;
+  return VPIN_OK;
+}
+
 int vpin_ctx_sync(vpin_ctx* c) {
   if (!c) return VPIN_EINVAL;
   VPIN_HIP_TRY(hipStreamSynchronize(c->stream));

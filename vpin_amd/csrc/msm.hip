@@ -659,8 +659,10 @@ static int msm_rows(vpin_ctx* c, const vpin_gens* g, const fq* dZ, size_t rows, 
   }
   {
     ProfScope ps(c, VPIN_K_MSM, 32.0 * nz_est);
-    // VPIN_MSM_LDS_PAD (bytes of unused dynamic LDS) lowers the workgroups per CU: experiment knob
-    static const unsigned pad = [] { const char* e = getenv("VPIN_MSM_LDS_PAD"); return e ? (unsigned)atoi(e) : 0u; }();
+    // unused dynamic LDS lowers the workgroups per CU from 3 to 2 on a shared device (vpin_ctx_set_shared_device);
+    // VPIN_MSM_LDS_PAD overrides (experiments)
+    static const int env_pad = [] { const char* e = getenv("VPIN_MSM_LDS_PAD"); return e ? atoi(e) : -1; }();
+    const unsigned pad = env_pad >= 0 ? (unsigned)env_pad : (c->shared_device ? 20000u : 0u);
     hipLaunchKernelGGL(msm_rows_kernel, dim3((unsigned)rows, (unsigned)chunks), dim3(kMsmBlock), pad, c->stream, dZ, stride,
                        ncols, d_extra, n_extra, extra_base0, view(g), dst);
   }

@@ -430,6 +430,8 @@ def main():
             decomms.pop(name).free()
             dev_insts.pop(name).free()
         if not args.no_span:
+            for cx in ctxs:
+                cx.set_shared_device(False)  # one proof at a time from here on
             span = {}
             ts = time.perf_counter()
             for li, names in enumerate(lane_names):

@@ -49,7 +49,7 @@ def main():
             a = by[(short(r["Kernel_Name"]), r.get("Stream_Id", r.get("Queue_Id", "?")))]
             a[0] += 1
             a[1] += dur
-        top = {x["name"] for x in res.get("kernel_stats", [])[:12]}
+        top = {x["name"] for x in res.get("kernel_stats", [])[:12]} | {k[0] for k in by if "sc_cubic3" in k[0]}  # + the roofline kernel
         res["kernel_stats_by_stream"] = sorted(({"name": k[0], "stream": k[1], "calls": v[0], "total_ns": v[1], "avg_ns": v[1] / v[0]}
                                                 for k, v in by.items() if k[0] in top), key=lambda x: (x["name"], x["stream"]))
     cc = find(d, "*counter_collection.csv")

@@ -255,6 +255,28 @@ __global__ __launch_bounds__(kBlock) void eq_step_kernel(const fq* __restrict__ 
   }
 }
 
+// The first k0 <= 9 doubling steps of EqPolynomial::evals in one workgroup (two LDS buffers of 512 elements), so a
+// table of 2^ell entries costs ell - k0 + 1 launches instead of ell: out[0 .. 2^k0) = eq(r_0..r_{k0-1}, .)
+struct EqHead { fq r[9]; };
+__global__ __launch_bounds__(512) void eq_head_kernel(fq* __restrict__ out, int k0, EqHead rs) {
+  __shared__ fq buf[2][512];
+  if (threadIdx.x == 0) buf[0][0] = fq_one();
+  __syncthreads();
+  int cur = 0;
+  for (int j = 0; j < k0; j++) {
+    const size_t prev = (size_t)1 << j;
+    if (threadIdx.x < prev) {
+      const fq s = buf[cur][threadIdx.x];
+      const fq hi = fq_mul(s, rs.r[j]);
+      buf[cur ^ 1][2 * threadIdx.x + 1] = hi;
+      buf[cur ^ 1][2 * threadIdx.x] = fq_sub(s, hi);
+    }
+    cur ^= 1;
+    __syncthreads();
+  }
+  if (threadIdx.x < ((size_t)1 << k0)) fq_store(out + threadIdx.x, buf[cur][threadIdx.x]);
+}
+
 template <int K>
 static int check_tabs(vpin_ctx* c, const vpin_table* const* t, size_t min_len) {
   if (!c) return VPIN_EINVAL;
@@ -537,17 +559,18 @@ int vpin_eq_table(vpin_ctx* c, const uint8_t* r, int ell, vpin_table** out) {
     rc = table_alloc_uninit(c, n, &b);
     if (rc) { vpin_table_free(c, a); return rc; }
   }
-  // evals[0] = 1 (Montgomery R), then ell doubling steps, ping-ponging a <-> b
-  static const uint32_t kOne[8] = {0x8d98951du, 0xd6ec3174u, 0x737dcf70u, 0xc6ef5bf4u,
-                                   0xfffffffeu, 0xffffffffu, 0xffffffffu, 0x0fffffffu};
-  vpin_table* src = (ell % 2 == 0) ? a : b;  // so that the final result lands in `a`
-  hipError_t e = hipMemcpyAsync(src->d, kOne, 32, hipMemcpyHostToDevice, c->stream);
-  if (e != hipSuccess) { set_last_error("eq init", e); vpin_table_free(c, a); vpin_table_free(c, b); return VPIN_EHIP; }
-  vpin_table* dst = (src == a) ? b : a;
+  // the first k0 = min(ell, 9) steps in one launch (eq_head_kernel), then one launch per step, ping-ponging a <-> b
+  const int k0 = ell < 9 ? ell : 9;
+  vpin_table* src = ((ell - k0) % 2 == 0) ? a : b;  // so that the final result lands in `a`
+  hipError_t e = hipSuccess;
   {
     ProfScope ps(c, VPIN_K_EQ, 32.0 * 3.0 * (double)(n - 1));
-    size_t prev = 1;
-    for (int j = 0; j < ell; j++) {
+    EqHead rs;
+    for (int j = 0; j < k0; j++) rs.r[j] = load_host_fq(r + 32 * (size_t)j);
+    hipLaunchKernelGGL(eq_head_kernel, dim3(1), dim3(512), 0, c->stream, src->d, k0, rs);
+    vpin_table* dst = (src == a) ? b : a;
+    size_t prev = (size_t)1 << k0;
+    for (int j = k0; j < ell; j++) {
       hipLaunchKernelGGL(eq_step_kernel, dim3(grid_for(prev)), dim3(kBlock), 0, c->stream, src->d, dst->d, prev,
                          load_host_fq(r + 32 * (size_t)j));
       prev *= 2;

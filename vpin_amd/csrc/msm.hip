@@ -361,20 +361,26 @@ __global__ __launch_bounds__(kMsmBlock, 3) void msm_rows_kernel(const fq* __rest
 // so the 32 windows of a scalar are spread over 8 threads (4 table adds each) and a 256-thread
 // workgroup covers 32 scalars; the per-workgroup partial points go back to the host, which adds
 // the few dozen partials and compresses (microseconds on a CPU core, ~0.4 ms as a GPU tail).
-constexpr int kWideScalars = 32;  // scalars per workgroup
+constexpr int kWideScalars = 32;  // scalars per workgroup and pass
+// Q passes per workgroup: 32 Q scalars each.  Long rows (>= 8192 scalars) take Q = 4: the 255 tree additions of a
+// workgroup are then spread over four times as many table additions, and a row needs a quarter of the workgroups.
+template <int Q>
 __global__ __launch_bounds__(kMsmBlock) void msm_wide_kernel(const fq* __restrict__ S, size_t ncols, TableView tv,
                                                              fp* __restrict__ parts_xyzt) {
   const size_t row = blockIdx.y;
-  const size_t j = (size_t)blockIdx.x * kWideScalars + (threadIdx.x >> 3);
   const int grp = threadIdx.x & 7;
   ge_ext acc = ge_identity();
-  if (j < ncols) {
-    fq s = fq_load(S + row * ncols + j);
-    if (!fq_is_zero(s)) {
-      const TableSeg sg = table_seg(tv, j);
-      const int wpg = (sg.W + 7) / 8;  // this lane's windows [grp*wpg, (grp+1)*wpg)
-      int w0 = grp * wpg, w1 = (w0 + wpg < sg.W) ? w0 + wpg : sg.W;
-      if (w0 < w1) table_mul_acc_range(acc, fq_from_mont(s), sg, w0, w1);
+#pragma unroll 1
+  for (int q = 0; q < Q; q++) {
+    const size_t j = ((size_t)blockIdx.x * Q + q) * kWideScalars + (threadIdx.x >> 3);
+    if (j < ncols) {
+      fq s = fq_load(S + row * ncols + j);
+      if (!fq_is_zero(s)) {
+        const TableSeg sg = table_seg(tv, j);
+        const int wpg = (sg.W + 7) / 8;  // this lane's windows [grp*wpg, (grp+1)*wpg)
+        int w0 = grp * wpg, w1 = (w0 + wpg < sg.W) ? w0 + wpg : sg.W;
+        if (w0 < w1) table_mul_acc_range(acc, fq_from_mont(s), sg, w0, w1);
+      }
     }
   }
   __shared__ ge_ext sh[kMsmBlock];
@@ -725,7 +731,8 @@ int vpin_hyrax_commit_pair(vpin_ctx* c, const vpin_gens* g, const vpin_table* Za
 // at most kMaxParts per row: longer rows get a second, on-device summation stage (the host would
 // otherwise add a thousand points per row for the 32k-generator evaluation proofs)
 constexpr size_t kMaxParts = 32;
-static inline size_t raw_parts(size_t ncols) { return (ncols + kWideScalars - 1) / kWideScalars; }
+static inline int wide_q(size_t ncols) { return ncols >= 8192 ? 4 : 1; }
+static inline size_t raw_parts(size_t ncols) { const size_t per = (size_t)kWideScalars * wide_q(ncols); return (ncols + per - 1) / per; }
 size_t vpin_gens_msm_parts_count(size_t ncols) { size_t n = raw_parts(ncols); return n < kMaxParts ? n : kMaxParts; }
 
 int vpin_gens_msm_parts(vpin_ctx* c, const vpin_gens* g, const uint8_t* scalars_mont, size_t rows, size_t ncols,
@@ -835,8 +842,12 @@ int gens_msm_parts_dev(vpin_ctx* c, const vpin_gens* g, const fq* d_scalars, siz
   if (dp.alloc(rows * nraw * 128) || (nraw > nparts && dr.alloc(rows * nparts * 128))) return VPIN_ENOMEM;
   {
     ProfScope ps(c, VPIN_K_MSM, 32.0 * (double)rows * (double)ncols);
-    hipLaunchKernelGGL(msm_wide_kernel, dim3((unsigned)nraw, (unsigned)rows), dim3(kMsmBlock), 0, c->stream, d_scalars, ncols,
-                       view(g), (fp*)dp.p);
+    if (wide_q(ncols) == 4)
+      hipLaunchKernelGGL((msm_wide_kernel<4>), dim3((unsigned)nraw, (unsigned)rows), dim3(kMsmBlock), 0, c->stream, d_scalars, ncols,
+                         view(g), (fp*)dp.p);
+    else
+      hipLaunchKernelGGL((msm_wide_kernel<1>), dim3((unsigned)nraw, (unsigned)rows), dim3(kMsmBlock), 0, c->stream, d_scalars, ncols,
+                         view(g), (fp*)dp.p);
   }
   const void* src = dp.p;
   if (nraw > nparts) {

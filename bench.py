@@ -21,8 +21,8 @@ encode_ms.  `--sat-only` times the R1CS satisfiability proof alone (SURVEY.md 8(
 value = unpadded R1CS constraints proven per second, whole job (all ranks).  Multi-GPU: every
 rank proves its own trace -- independent instances, no data-path collective -> weak scaling.
 
-Schedule per rank: three host threads / HIP streams -- the largest instance; the other
-point-mult instances; the point-add instances.  The second and third start when the largest
+Schedule per rank: four host threads / HIP streams -- the largest instance; the other
+point-mult instances on two; the point-add instances.  All but the first start when the largest
 instance's phase-1 sum-check is done, so its kernels (the roofline sample) are timed undisturbed (--sat-only: two
 lanes, the add lane starts after the largest instance).  `--serial`: one instance at a time.
 
@@ -66,7 +66,7 @@ def parse():
                     help="time only the R1CS satisfiability proof (SURVEY.md 8(a) rows H1-H10) instead of the whole SNARK")
     ap.add_argument("--snark", action="store_true", help="(default) whole SNARK: sat proof + inst_evals + SPARK R1CSEvalProof, "
                     "my_lib_prove in full; SNARK::encode runs once per instance before the timed region and is reported beside it")
-    ap.add_argument("--mult-lanes", type=int, default=int(os.environ.get("VPIN_BENCH_MULT_LANES", "1")),
+    ap.add_argument("--mult-lanes", type=int, default=int(os.environ.get("VPIN_BENCH_MULT_LANES", "2")),
                     help="streams / host threads for the point-mult instances other than the largest")
     ap.add_argument("--lanes-spec", default=os.environ.get("VPIN_BENCH_LANES"),
                     help="explicit schedule: lanes separated by ';', instance names by ',' (first lane starts at once, the "

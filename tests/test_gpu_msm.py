@@ -144,6 +144,23 @@ def test_constant_rows_use_the_prefix_sum_base(ctx):
     g.free()
 
 
+def test_shared_device_hint_changes_nothing_but_occupancy(ctx, gens34):
+    """vpin_ctx_set_shared_device only lowers the MSM's workgroups per CU: same commitment bytes"""
+    g, og = gens34
+    rng = np.random.default_rng(31)
+    Ls, Rs = 4, 32
+    Z = M.ints_to_table(structured_scalars(rng, Ls * Rs))
+    blinds = M.ints_to_table([int(rng.integers(0, 2**62)) ** 4 % Q for _ in range(Ls)])
+    dZ = ctx.upload(Z)
+    a = ctx.hyrax_commit(g, dZ, blinds, 33)
+    ctx.set_shared_device(True)
+    try:
+        b = ctx.hyrax_commit(g, dZ, blinds, 33)
+    finally:
+        ctx.set_shared_device(False)
+    assert np.array_equal(a, b) and np.array_equal(a, O.hyrax_commit(Z, Ls, blinds, og, 33))
+
+
 def test_shape_errors(ctx, gens34):
     import vpin_amd
     g, _ = gens34

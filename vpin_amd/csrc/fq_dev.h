@@ -226,6 +226,59 @@ __device__ VPIN_MUL_INLINE fq fq_mul(fq a, fq b) {
 
 __device__ __forceinline__ fq fq_sqr(const fq& a) { return fq_mul(a, a); }
 
+// ---- product with a launch-wide constant ------------------------------------------------------------------------
+// The fold of a sum-check round multiplies every table difference by the same challenge r.  With
+// T_i = r~ * 2^(32 i) * 2^-256 mod q (eight canonical constants, computed once per launch on the host), the
+// Montgomery product is  r~ * d * 2^-256 = sum_i d_i * T_i  (mod q): 64 limb products with no interleaved
+// reduction; the 288-bit sum S is brought into [0, q) with 2^252 = -(q - 2^252): S_lo - (S >> 252) * c, plus q on
+// borrow.  The same element of F_q as fq_mul(r~, d), in canonical form: identical bits.  The constants sit in LDS,
+// transposed (tt[k][i] = limb k of T_i): column k of the sum needs the eight words tt[k][0..7], two 128-bit
+// broadcast reads, so they cost no registers between columns.
+struct fq_const {
+  uint32_t tt[8][8];
+};
+
+__device__ __forceinline__ fq fq_mul_const(const fq& d, const uint32_t (*tt)[8]) {
+  acc96 c{0, 0};
+  uint32_t s[9];
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    const uint4 lo = *reinterpret_cast<const uint4*>(&tt[k][0]);
+    const uint4 hi = *reinterpret_cast<const uint4*>(&tt[k][4]);
+    mac2(c, d.v[0], lo.x, d.v[1], lo.y);
+    mac2(c, d.v[2], lo.z, d.v[3], lo.w);
+    mac2(c, d.v[4], hi.x, d.v[5], hi.y);
+    mac2(c, d.v[6], hi.z, d.v[7], hi.w);
+    s[k] = (uint32_t)c.lo;
+    acc_shift(c);
+  }
+  s[8] = (uint32_t)c.lo;  // S < 8 * 2^32 * q < 2^288
+  const uint32_t h0 = (s[8] << 4) | (s[7] >> 28), h1 = s[8] >> 28;  // S >> 252 = h0 + h1 * 2^32, h1 < 16
+  s[7] &= 0x0fffffffu;
+  // P = (S >> 252) * c, c = q - 2^252 = {Q0, Q1, Q2, Q3}: below 2^161
+  uint32_t P[6];
+  uint64_t t = (uint64_t)h0 * VPIN_Q0;
+  P[0] = (uint32_t)t;
+  t = (uint64_t)h0 * VPIN_Q1 + (t >> 32); P[1] = (uint32_t)t;
+  t = (uint64_t)h0 * VPIN_Q2 + (t >> 32); P[2] = (uint32_t)t;
+  t = (uint64_t)h0 * VPIN_Q3 + (t >> 32); P[3] = (uint32_t)t;
+  P[4] = (uint32_t)(t >> 32);
+  t = (uint64_t)h1 * VPIN_Q0 + P[1]; P[1] = (uint32_t)t;
+  t = (uint64_t)h1 * VPIN_Q1 + P[2] + (t >> 32); P[2] = (uint32_t)t;
+  t = (uint64_t)h1 * VPIN_Q2 + P[3] + (t >> 32); P[3] = (uint32_t)t;
+  t = (uint64_t)h1 * VPIN_Q3 + P[4] + (t >> 32); P[4] = (uint32_t)t;
+  P[5] = (uint32_t)(t >> 32);
+  fq r;
+  unsigned bw = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) r.v[i] = __builtin_subc(s[i], i < 6 ? P[i] : 0u, bw, &bw);
+  fq o;
+  unsigned cy = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) o.v[i] = __builtin_addc(r.v[i], bw ? fq_modulus_limb(i) : 0u, cy, &cy);
+  return o;
+}
+
 // ---- wave / block reductions (64-wide wavefront) ----------------------------------
 
 __device__ __forceinline__ fq fq_shfl_xor(const fq& a, int mask) {

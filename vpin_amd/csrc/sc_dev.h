@@ -149,6 +149,18 @@ __device__ __forceinline__ void fold_pd(fq* __restrict__ t, size_t i, size_t qua
   d = fq_sub(hi, p);
 }
 
+// fold with the launch-wide constant form of r (fq_dev.h fq_mul_const; tt = the constants in LDS)
+__device__ __forceinline__ void fold_pd_c(fq* __restrict__ t, size_t i, size_t quarter, const uint32_t (*tt)[8], fq& p, fq& d) {
+  const size_t half = 2 * quarter;
+  fq a0 = fq_load(t + i), a1 = fq_load(t + half + i);
+  fq b0 = fq_load(t + quarter + i), b1 = fq_load(t + half + quarter + i);
+  p = fq_add(a0, fq_mul_const(fq_sub(a1, a0), tt));
+  fq hi = fq_add(b0, fq_mul_const(fq_sub(b1, b0), tt));
+  fq_store(t + i, p);
+  fq_store(t + quarter + i, hi);
+  d = fq_sub(hi, p);
+}
+
 // Sum nblocks x NE block partials into out[NE].
 template <int NE>
 __global__ __launch_bounds__(kBlock) void sc_finish_kernel(const fq* __restrict__ partials, int nblocks,
@@ -181,6 +193,9 @@ static inline int grid_for(size_t work) {
   if (b > (size_t)max_blocks()) b = max_blocks();
   return (int)b;
 }
+
+// T_i = r~ * 2^(32 i) * 2^-256 mod q for the Montgomery image r~ in `p` (host arithmetic, once per launch), transposed
+fq_const make_fq_const(const uint8_t* p);
 
 static inline fq load_host_fq(const uint8_t* p) {
   fq r;

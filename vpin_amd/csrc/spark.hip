@@ -218,17 +218,25 @@ __device__ __forceinline__ void fold_pd2(const fq* src, fq* dst, size_t i, size_
   d = fq_sub(hi, p);
 }
 
-// LEAD: return sum E*A_0*B_0 and sum E*dA*dB (sc_dev.h lead_bc) instead of the sums at x = 0, 2, 3
+// LEAD: return sum E*A_0*B_0 and sum E*dA*dB (sc_dev.h lead_bc) instead of the sums at x = 0, 2, 3; its folds use the
+// launch-wide constant form of r (fq_dev.h fq_mul_const, constants in LDS)
 template <bool BIND, bool LEAD>
 __global__ __launch_bounds__(kBlock, kMinWaves) void prod_round_kernel(fq* __restrict__ forest, size_t stride, size_t off, size_t h,
-                                                                       const fq* __restrict__ E, size_t pairs, fq r, Finisher fin) {
+                                                                       const fq* __restrict__ E, size_t pairs, fq r, fq_const rc,
+                                                                       Finisher fin) {
+  __shared__ __attribute__((aligned(16))) uint32_t tt[8][8];
+  if (BIND && LEAD) {
+    if (threadIdx.x < 64) tt[threadIdx.x >> 3][threadIdx.x & 7] = rc.tt[threadIdx.x >> 3][threadIdx.x & 7];
+    __syncthreads();
+  }
   fq* A = forest + (size_t)blockIdx.y * stride + off;
   fq* B = A + h;
   Acc<4> acc;
   acc.init();
   for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < pairs; i += (size_t)gridDim.x * kBlock) {
     fq u[3], p1, d1, p2, d2;
-    if (BIND) { fold_pd(A, i, pairs, r, p1, d1); fold_pd(B, i, pairs, r, p2, d2); }
+    if (BIND && LEAD) { fold_pd_c(A, i, pairs, tt, p1, d1); fold_pd_c(B, i, pairs, tt, p2, d2); }
+    else if (BIND) { fold_pd(A, i, pairs, r, p1, d1); fold_pd(B, i, pairs, r, p2, d2); }
     else { load_pd(A, i, pairs, p1, d1); load_pd(B, i, pairs, p2, d2); }
     if (LEAD) {
       acc.lead_bc(p1, d1, p2, d2, fq_load(E + i));
@@ -518,6 +526,7 @@ int spark_prod_round(vpin_ctx* c, const SparkForest* f, int level, size_t len, c
   const size_t pairs = r ? len / 4 : len / 2;
   const int grid = round_grid(pairs);
   const fq rr = r ? load_host_fq(r) : fq{};
+  const fq_const rconst = (r && lead) ? make_fq_const(r) : fq_const{};
   c->spark_seq++;  // a new launch group: this kernel (+ the dot-product kernel that follows when with_dotp)
   Finisher fin = make_finisher(c, partials, 0, f->ncirc + (with_dotp ? 6 : 0));
   {
@@ -527,7 +536,7 @@ int spark_prod_round(vpin_ctx* c, const SparkForest* f, int level, size_t len, c
     ProfScope ps(c, VPIN_K_SPARK_ROUND, bytes);
 #define VPIN_PROD_LAUNCH(B_, L_)                                                                                             \
   hipLaunchKernelGGL((prod_round_kernel<B_, L_>), dim3(grid, f->ncirc), dim3(kBlock), 0, c->stream, f->base, f->stride(), \
-                     f->level_off(level), h, E, pairs, rr, fin)
+                     f->level_off(level), h, E, pairs, rr, rconst, fin)
     if (r) { if (lead) VPIN_PROD_LAUNCH(true, true); else VPIN_PROD_LAUNCH(true, false); }
     else { if (lead) VPIN_PROD_LAUNCH(false, true); else VPIN_PROD_LAUNCH(false, false); }
 #undef VPIN_PROD_LAUNCH

@@ -16,9 +16,25 @@
 #include <cstring>
 
 #include "ctx.h"
+#include "host/field.h"
 #include "sc_dev.h"
 
 namespace vpin {
+
+fq_const make_fq_const(const uint8_t* p) {
+  vpin_host::Fq r;
+  memcpy(r.l, p, 32);
+  fq_const out;
+  for (int i = 0; i < 8; i++) {
+    vpin_host::Fq pw = vpin_host::Fq::zero();
+    pw.l[i / 2] = (uint64_t)1 << (32 * (i & 1));
+    const vpin_host::Fq t = r * pw;  // r~ * 2^(32 i) * R^-1 mod q, canonical
+    uint32_t limbs[8];
+    memcpy(limbs, t.l, 32);
+    for (int k = 0; k < 8; k++) out.tt[k][i] = limbs[k];
+  }
+  return out;
+}
 
 // Round evaluation on tables of live length 2*half: pairs (i, i+half).
 template <int K>
@@ -80,16 +96,22 @@ __global__ __launch_bounds__(kBlock, kMinWaves) void sc_bind_eval_kernel(Tabs<K>
 // quadratic (10 products per pair); without BIND (the first round) also t(1), so the host can check the claim.
 template <bool BIND, bool LEAD>
 __global__ __launch_bounds__(kBlock, kMinWaves) void sc_cubic3_kernel(Tabs<3> tabs, const fq* __restrict__ E, size_t pairs,
-                                                                      fq r, fq* __restrict__ partials) {
+                                                                      fq r, fq_const rc, fq* __restrict__ partials) {
+  __shared__ __attribute__((aligned(16))) uint32_t tt[8][8];
+  if (BIND && LEAD) {
+    if (threadIdx.x < 64) tt[threadIdx.x >> 3][threadIdx.x & 7] = rc.tt[threadIdx.x >> 3][threadIdx.x & 7];
+    __syncthreads();
+  }
   Acc<4> acc;
   acc.init();
   for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < pairs; i += (size_t)gridDim.x * kBlock) {
     fq u[3], p1, d1, p2, d2;
-    if (BIND) { fold_pd(tabs.t[0], i, pairs, r, p1, d1); fold_pd(tabs.t[1], i, pairs, r, p2, d2); }
+    if (BIND && LEAD) { fold_pd_c(tabs.t[0], i, pairs, tt, p1, d1); fold_pd_c(tabs.t[1], i, pairs, tt, p2, d2); }
+    else if (BIND) { fold_pd(tabs.t[0], i, pairs, r, p1, d1); fold_pd(tabs.t[1], i, pairs, r, p2, d2); }
     else { load_pd(tabs.t[0], i, pairs, p1, d1); load_pd(tabs.t[1], i, pairs, p2, d2); }
     if (LEAD) {
       fq p3, d3;
-      if (BIND) fold_pd(tabs.t[2], i, pairs, r, p3, d3);
+      if (BIND) fold_pd_c(tabs.t[2], i, pairs, tt, p3, d3);
       else load_pd(tabs.t[2], i, pairs, p3, d3);
       const fq e = fq_load(E + i);
       acc.lead_bcd(p1, d1, p2, d2, p3, e);
@@ -398,6 +420,7 @@ int sc_cubic3_launch(vpin_ctx* c, vpin_table* const* t, const vpin_table* pyrami
   if (pairs != ((size_t)1 << (ell - level))) return VPIN_ESHAPE;
   const fq* E = pyramid->d + pyramid_offset(ell, level);
   const fq rr = r ? load_host_fq(r) : fq{};
+  const fq_const rconst = (r && lead) ? make_fq_const(r) : fq_const{};
   // algorithmic bytes stay those of the reference formulation (4 tables): SURVEY.md 8(d)
   const double bytes = r ? 4 * 32.0 * ((double)len + (double)len / 2) : 4 * 32.0 * (double)len;
   if (pairs <= kSmallPairs) {
@@ -413,7 +436,7 @@ int sc_cubic3_launch(vpin_ctx* c, vpin_table* const* t, const vpin_table* pyrami
     int grid = grid_for(pairs);
     {
       ProfScope ps(c, r ? VPIN_K_SC_CUBIC_FUSED : VPIN_K_SC_CUBIC, bytes);
-#define VPIN_C3(B_, L_) hipLaunchKernelGGL((sc_cubic3_kernel<B_, L_>), dim3(grid), dim3(kBlock), 0, c->stream, tabs, E, pairs, rr, c->d_partials)
+#define VPIN_C3(B_, L_) hipLaunchKernelGGL((sc_cubic3_kernel<B_, L_>), dim3(grid), dim3(kBlock), 0, c->stream, tabs, E, pairs, rr, rconst, c->d_partials)
       if (r) { if (lead) VPIN_C3(true, true); else VPIN_C3(true, false); }
       else { if (lead) VPIN_C3(false, true); else VPIN_C3(false, false); }
 #undef VPIN_C3

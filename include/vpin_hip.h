@@ -116,6 +116,24 @@ int vpin_sc_cubic3_round(vpin_ctx* ctx, const vpin_table* pyramid, int ell, int 
                          vpin_table* Bz, vpin_table* Cz, uint8_t out_S0_S2_S3[96]);
 int vpin_sc_cubic3_bind_round(vpin_ctx* ctx, const vpin_table* pyramid, int ell, int level, vpin_table* Az,
                               vpin_table* Bz, vpin_table* Cz, const uint8_t r[32], uint8_t out_S0_S2_S3[96]);
+/* Leading-coefficient form of the same round, the one vpin_sat_prove runs while phase 1's claim is consistent: with
+ * the eq factor split off the round polynomial is l(x) * t(x), t(x) = sum_i E[i]*(Az_x*Bz_x - Cz_x)[i] quadratic, and
+ * the kernel returns t(0), the x^2 coefficient sum_i E[i]*(dAz*dBz)[i] and -- only when r == NULL (first round) --
+ * t(1).  The same e0, e2, e3 of Spartan/src/sumcheck.rs:624-652 follow by exact field identities.  r != NULL binds
+ * the tables with r first (dense_mlpoly.rs:229-236). */
+int vpin_sc_cubic3_lead_round(vpin_ctx* ctx, const vpin_table* pyramid, int ell, int level, vpin_table* Az,
+                              vpin_table* Bz, vpin_table* Cz, const uint8_t* r, uint8_t out[96]);
+/* One round of SumcheckInstanceProof::prove_cubic_batched (Spartan/src/sumcheck.rs:273-330,346-370) as
+ * ProductCircuitEvalProofBatched::prove issues it (Spartan/src/product_tree.rs:258-385): `ncirc` product circuits of
+ * `n` leaves each (tree t = forest[t*2n ..), level l at offset 2n - (2n >> l), left/right halves = poly_A/poly_B) proven
+ * in lock-step, eq-factored (E = eq suffix table of this round at E[e_off..], len/2 entries, or len/4 when r != NULL and
+ * the tables are first bound with r).  out: per circuit 3 scalars -- lead == 0: sum_i E[i]*(A_x*B_x)[i] at x = 0, 2, 3;
+ * lead == 1: the value at 0, the x^2 coefficient sum_i E[i]*(dA*dB)[i], and zero.  derefs != NULL (ncirc == 12,
+ * level == 0) adds the six DotProductCircuit halves of Spartan/src/sparse_mlpoly.rs:1103-1125 (A*B*C over derefs row |
+ * col slices (6 x n) and the val slices (3 x n); first fold into scratch, 18 x n/4): out[12..18) = sums at 0, 2, 3. */
+int vpin_spark_batched_round(vpin_ctx* ctx, vpin_table* forest, size_t n, int ncirc, int level, size_t len,
+                             const vpin_table* E, size_t e_off, const uint8_t* r, int lead, const vpin_table* derefs,
+                             const vpin_table* vals, vpin_table* scratch, int first_fold, uint8_t* out);
 
 /* ---- Pedersen generators and fixed-base MSM ----------------------------------------- */
 /* The generator stream of MultiCommitGens::new (Spartan/src/commitments.rs:20-38):
@@ -136,6 +154,10 @@ int vpin_gens_shared(vpin_ctx* ctx, const char* label, const uint8_t* gens_xyzt,
 void vpin_gens_shared_clear(void);
 void vpin_gens_free(vpin_ctx* ctx, vpin_gens* g);
 size_t vpin_gens_count(const vpin_gens* g);
+/* Window layout the table budget chose: out = {c, W, split, c_hi, W_hi, bases}: generators [0, split) have c-bit signed
+ * windows (W per scalar), [split, bases) c_hi-bit ones (0 when the table has a single segment); `bases` counts the
+ * nb generators plus the prefix-sum bases S_k = g_0 + ... + g_{2^k - 1} behind them. */
+int vpin_gens_layout(const vpin_gens* g, size_t out[6]);
 /* bytes per window-table entry (affine Niels point, possibly padded to a cache line) */
 size_t vpin_gens_entry_bytes(void);
 /* DensePolynomial::commit_inner (Spartan/src/dense_mlpoly.rs:160-175): Z viewed as L rows
@@ -218,6 +240,11 @@ size_t vpin_sat_proof_max_bytes(size_t num_cons, size_t num_vars);
 /* R1CSGens::new (Spartan/src/r1csproof.rs:84-89) for this polynomial size ahead of the first proof: host
  * fixed-base tables + the shared device window table (built on demand by the prove calls otherwise). */
 int vpin_sat_prepare(vpin_ctx* ctx, size_t num_vars);
+/* R1CSCommitmentGens::new (Spartan/src/r1csinstance.rs:29-49; SparseMatPolyCommitmentGens::new,
+ * sparse_mlpoly.rs:300-329) for an instance of this shape ahead of the first encode / proof: derives the
+ * b"gens_r1cs_eval" stream and builds (or finds) the shared device window table.  Call it for the LARGEST instance
+ * first: smaller ones then share its table instead of each leaving a superseded one behind. */
+int vpin_spark_prepare(vpin_ctx* ctx, size_t num_cons, size_t num_vars, size_t max_nnz);
 /* wall-clock spans of the last vpin_sat_prove call on this thread's process, seconds:
  * [0] polycommit (uploads + 2 commits + combine)  [1] prove_sc_phase_one (eq table, SpMV, 4 uploads, rounds)
  * [2] prove_sc_phase_two  [3] polyeval  [4] total  [5] generators (0 when cached)
@@ -367,12 +394,17 @@ int vpin_host_commit(const char* label, const uint8_t* v_mont, size_t n, const u
 #define VPIN_K_SC_TAIL 7 /* single-workgroup tail rounds (<= 512 pairs), latency bound */
 #define VPIN_K_SPARK_ROUND 8 /* batched cubic rounds of the product / dot-product circuits (SPARK) */
 #define VPIN_K_SPARK_BUILD 9 /* SPARK gathers, hash layer, product-tree levels, slice evaluations */
+#define VPIN_K_SPARK_ROUND_BIG 10 /* the subset of class 8 with >= 2^20 pairs per circuit: the streaming regime (also counted in 8) */
+#define VPIN_K_MSM_ROWS 11 /* the subset of class 6 that is a row commitment of >= 128 rows (msm_rows_kernel; also counted in 6) */
 #define VPIN_K_COUNT 16
 typedef struct {
   uint64_t launches;
   double ms;         /* sum of event-measured durations */
   double alg_bytes;  /* sum of algorithmic bytes moved by those launches */
+  double units;      /* class 11 under vpin_prof_enable(ctx, 2): affine table additions those launches performed */
 } vpin_kstat;
+/* on = 1: HIP-event bracketing of the kernel classes; on = 2: additionally count the table additions of the row
+ * commitments (an extra counting kernel per commitment: for roofline passes, not for timed regions) */
 int vpin_prof_enable(vpin_ctx* ctx, int on);
 int vpin_prof_reset(vpin_ctx* ctx);
 /* resolves outstanding events; stats must have VPIN_K_COUNT entries */

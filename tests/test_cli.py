@@ -1,4 +1,5 @@
 """vpin_prove: the reference binary's CLI / witness-file contract (VP/main.rs, load_data*.rs)."""
+import hashlib
 import json
 import os
 import subprocess
@@ -56,8 +57,12 @@ def test_cli_proof_matches_oracle(built, tmp_path):
     mult_ops = GM.synthetic_mult_ops(0x5650494E + 2, 1, weights=[(1 << 127) + 12345])
     write_witness(tmp_path, "T", add_ops, mult_ops)
     os.makedirs(tmp_path / "out")
-    seed_c, seed_p = bytes(range(64)), bytes((7 * i + 3) % 256 for i in range(64))
-    r = subprocess.run([BIN, "T", "--seed", (seed_c + seed_p).hex(), "--write-proof", "out"], cwd=tmp_path,
+    master = bytes(range(64)) + bytes((7 * i + 3) % 256 for i in range(64))
+    # every proof draws its own RandomTape seeds (random.rs:14-20 inside each proof_point_*): with --seed the
+    # CLI derives them per proof, SHAKE256(master || domain) -> commit seed | proof seed
+    seeds = {name: hashlib.shake_256(master + dom).digest(128) for name, dom in (("add", b"vPIN/point_add"), ("mult", b"vPIN/point_mult"))}
+    assert seeds["add"] != seeds["mult"]
+    r = subprocess.run([BIN, "T", "--seed", master.hex(), "--write-proof", "out"], cwd=tmp_path,
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     lines = r.stdout.splitlines()
@@ -69,6 +74,7 @@ def test_cli_proof_matches_oracle(built, tmp_path):
     assert lines.count("Proof verification successful!") == 2 and any(l.startswith("Proof verification time: ") for l in lines)
     for name, g in (("add", GM.build_point_add(add_ops)), ("mult", GM.build_point_mult(mult_ops))):
         inst = GM.instance_new(g)
+        seed_c, seed_p = seeds[name][:64], seeds[name][64:]
         exp = O.snark_prove(inst, seed_c, seed_p)  # the CLI proves the whole SNARK, like the reference binary
         got = open(tmp_path / "out" / f"T_{name}.proof", "rb").read()
         assert got == exp["proof"]
@@ -78,10 +84,24 @@ def test_cli_proof_matches_oracle(built, tmp_path):
                    comm_para=np.frombuffer(open(tmp_path / "out" / f"T_{name}.comm_para", "rb").read(), dtype=np.uint8).reshape(-1, 32).copy(),
                    comm_input=np.frombuffer(open(tmp_path / "out" / f"T_{name}.comm_input", "rb").read(), dtype=np.uint8).reshape(-1, 32).copy())
         assert O.snark_verify(inst, res) == 1
+    # the two proofs must not share Hyrax row blinds: the add gadget's vars_para is all zero, so its comm_para rows
+    # are b_i*H; with one shared tape comm_para_mult[i] - comm_para_add[i] would be an unblinded commitment to the
+    # model parameters.  Same tape <=> same first row of the all-zero polynomial's commitment.
+    inst_add = GM.instance_new(GM.build_point_add(add_ops))
+    cp_add = open(tmp_path / "out" / "T_add.comm_para", "rb").read()
+    shared = O.sat_prove(inst_add, seeds["mult"][:64], seeds["mult"][64:])["comm_para"].tobytes()
+    assert cp_add[:32] != shared[:32]
+    # without --seed every proof draws from the OS: two runs differ, and so do the two proofs' tapes
+    os.makedirs(tmp_path / "o1")
+    os.makedirs(tmp_path / "o2")
+    for d in ("o1", "o2"):
+        r = subprocess.run([BIN, "T", "--write-proof", d, "--sat-only"], cwd=tmp_path, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+    rd = lambda d, f: open(tmp_path / d / f, "rb").read()
+    assert rd("o1", "T_add.comm_para") != rd("o2", "T_add.comm_para")
     # --sat-only: the R1CS satisfiability proof alone
     os.makedirs(tmp_path / "out2")
-    r = subprocess.run([BIN, "T", "--seed", (seed_c + seed_p).hex(), "--write-proof", "out2", "--sat-only"], cwd=tmp_path,
+    r = subprocess.run([BIN, "T", "--seed", master.hex(), "--write-proof", "out2", "--sat-only"], cwd=tmp_path,
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
-    inst = GM.instance_new(GM.build_point_add(add_ops))
-    assert open(tmp_path / "out2" / "T_add.proof", "rb").read() == O.sat_prove(inst, seed_c, seed_p)["proof"]
+    assert open(tmp_path / "out2" / "T_add.proof", "rb").read() == O.sat_prove(inst_add, seeds["add"][:64], seeds["add"][64:])["proof"]

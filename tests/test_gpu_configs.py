@@ -1,0 +1,141 @@
+"""Every BASELINE.json configuration at its real size: the HIP path (device-built instance ->
+vpin_snark_prove_dev) against the oracle's digests in tests/golden/config_digests.json
+(tests/golden/make_config_golden.py: witness inputs -> Python gadget model -> C oracle).
+
+Instances: point_mult.rs:27-67 (18 / 98 / 178 / 658 / 300 / 800 / 240 / 168 / 6000 ops),
+point_addition.rs:38-70 and src/LeNet/Server.py:690-698,753-761 for the LeNet layers.
+Byte parity (SHA-256 of the SNARK, of the computation commitment and of both witness commitments) for
+every instance the oracle's prover fits in the build container (up to 2^22 constraints); L5-mult (2^25):
+computation commitment pinned by the oracle's SNARK::encode digest, proof accepted by the oracle's verifier
+(independent code) and tampered proofs rejected.
+"""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+SEED_C = bytes(range(64))
+SEED_P = bytes((7 * i + 3) % 256 for i in range(64))
+
+with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "config_digests.json")) as _f:
+    GOLD = json.load(_f)["cases"]
+
+CONFIG_CASES = {  # BASELINE.json configs[0..4] -> golden cases
+    "conv f=3 32x32": ["3_32-add", "3_32-mult"],
+    "CNN A": ["A-add", "A-mult"],
+    "conv f=7 256x256": ["7_256-add", "7_256-mult"],
+    "CNN E": ["E-add", "E-mult"],
+    "LeNet": ["L1-add", "L1-mult", "L2-add", "L3-add", "L3-mult", "L4-add", "L5-add", "L5-mult", "L6-add", "L6-mult",
+              "L7-add", "L7-mult"],
+}
+
+
+def inputs_digest(kind, inp):
+    h = hashlib.sha256()
+    if kind == "mult":
+        w, x, y = inp
+        h.update(b"".join(int(v).to_bytes(16, "little") for v in w))
+        h.update(x.tobytes())
+        h.update(y.tobytes())
+    else:
+        for a in inp:
+            h.update(a.tobytes())
+    return h.hexdigest()
+
+
+def test_golden_file_covers_every_config():
+    """not gpu: the fixture file names every instance of every BASELINE config, with full digests for all but L5-mult"""
+    for cfg, keys in CONFIG_CASES.items():
+        for k in keys:
+            assert k in GOLD, (cfg, k)
+            assert "comm_sha256" in GOLD[k] and "inputs_sha256" in GOLD[k]
+            if k != "L5-mult":
+                assert "snark_sha256" in GOLD[k], k
+    assert GOLD["L5-mult"]["num_cons"] == 1 << 25 and GOLD["L3-mult"]["num_cons"] == 1 << 22
+
+
+def test_oracle_reproduces_small_config_digests():
+    """not gpu: the oracle still produces the committed digests (the conv f=3 trace; the larger ones take minutes)"""
+    import gadgets_model as GM
+    from vpin_amd import gadgets as G
+    for key in ("3_32-add", "3_32-mult"):
+        g = GOLD[key]
+        inp = G.synthetic_mult_inputs(g["label"]) if g["kind"] == "mult" else G.synthetic_add_inputs(g["label"])
+        assert inputs_digest(g["kind"], inp) == g["inputs_sha256"]
+        ints = lambda a: [int.from_bytes(bytes(r), "little") for r in a]
+        if g["kind"] == "mult":
+            m = GM.build_point_mult(list(zip([int(v) for v in inp[0]], ints(inp[1]), ints(inp[2]))))
+        else:
+            m = GM.build_point_add(list(zip(ints(inp[0]), ints(inp[1]), ints(inp[2]), ints(inp[3]), [int(v) for v in inp[4]])))
+        res = O.snark_prove(GM.instance_new(m), SEED_C, SEED_P)
+        assert hashlib.sha256(res["proof"]).hexdigest() == g["snark_sha256"]
+        assert hashlib.sha256(res["comm"]).hexdigest() == g["comm_sha256"]
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import vpin_amd
+    c = vpin_amd.Context(0)
+    # the generator tables of the largest instance first, so the smaller ones share them instead of each leaving its own
+    # multi-GB table behind (the registry keeps superseded tables alive)
+    g5 = GOLD["L5-mult"]
+    c.spark_prepare(g5["num_cons"], g5["num_vars"], max(g5["nnz"]))
+    c.sat_prepare(g5["num_vars"])
+    yield c
+    c.close()
+
+
+def build_dev(ctx, g):
+    from vpin_amd import gadgets as G
+    inp = G.synthetic_mult_inputs(g["label"]) if g["kind"] == "mult" else G.synthetic_add_inputs(g["label"])
+    assert inputs_digest(g["kind"], inp) == g["inputs_sha256"], "synthetic witness inputs differ from the fixture's"
+    d = ctx.gadget_point_mult_dev(*inp) if g["kind"] == "mult" else ctx.gadget_point_add_dev(*inp)
+    assert (d.num_cons, d.num_vars, d.num_cons_unpadded) == (g["num_cons"], g["num_vars"], g["num_cons_unpadded"])
+    return d
+
+
+FULL = [k for keys in CONFIG_CASES.values() for k in keys if k != "L5-mult"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("key", FULL)
+def test_config_snark_bytes_match_oracle(ctx, key):
+    g = GOLD[key]
+    d = build_dev(ctx, g)
+    try:
+        assert d.is_sat()
+        got = d.snark_prove(SEED_C, SEED_P)
+    finally:
+        d.free()
+    assert len(got["comm"]) == g["comm_len"] and hashlib.sha256(got["comm"]).hexdigest() == g["comm_sha256"], "computation commitment"
+    assert hashlib.sha256(got["comm_para"].tobytes()).hexdigest() == g["comm_para_sha256"], "comm_para"
+    assert hashlib.sha256(got["comm_input"].tobytes()).hexdigest() == g["comm_input_sha256"], "comm_input"
+    assert len(got["proof"]) == g["snark_len"]
+    assert got["proof"][:64].hex() == g["snark_head_hex"], "SNARK differs in its first bytes (sat proof)"
+    assert hashlib.sha256(got["proof"]).hexdigest() == g["snark_sha256"], "SNARK bytes"
+
+
+@pytest.mark.gpu
+def test_l5_mult_commitment_pinned_and_proof_accepted_by_oracle_verifier(ctx):
+    """6000 point-mults, 20,784,000 constraints (2^25 padded): SNARK::encode's commitment equals the oracle's
+    (digest), and the oracle's verifier -- code independent of the product -- accepts the HIP proof against it."""
+    g = GOLD["L5-mult"]
+    d = build_dev(ctx, g)
+    try:
+        got = d.snark_prove(SEED_C, SEED_P)
+        inputs, num_inputs = d.inputs, d.num_inputs
+    finally:
+        d.free()
+    assert len(got["comm"]) == g["comm_len"] and hashlib.sha256(got["comm"]).hexdigest() == g["comm_sha256"]
+    meta = {"inputs": inputs, "num_inputs": num_inputs}
+    assert O.snark_verify(meta, got) == 1
+    assert ctx.snark_verify(meta, got)
+    n = len(got["proof"])
+    for pos in (40, n // 7, n // 2, n - 100):  # sat part, SPARK product layers, hash layer / evaluation proofs
+        bad = bytearray(got["proof"])
+        bad[pos] ^= 2
+        assert O.snark_verify(meta, got, proof=bytes(bad)) == 0, pos

@@ -11,7 +11,7 @@ HEADER = os.path.join(ROOT, "include", "vpin_hip.h")
 
 KERNEL_CLASSES = {
     0: "sc_cubic", 1: "sc_quad", 2: "sc_bind", 3: "sc_cubic_fused", 4: "sc_quad_fused", 5: "eq", 6: "msm", 7: "sc_tail",
-    8: "spark_round", 9: "spark_build",
+    8: "spark_round", 9: "spark_build", 10: "spark_round_big", 11: "msm_rows",
 }
 K_COUNT = 16
 
@@ -47,7 +47,7 @@ def make_r1cs(inst):
 
 
 class KStat(C.Structure):
-    _fields_ = [("launches", C.c_uint64), ("ms", C.c_double), ("alg_bytes", C.c_double)]
+    _fields_ = [("launches", C.c_uint64), ("ms", C.c_double), ("alg_bytes", C.c_double), ("units", C.c_double)]
 
 
 def lib_path():
@@ -420,6 +420,29 @@ class Context:
         _chk(lib().vpin_gens_create(self.h, a.ctypes.data_as(C.c_void_p), a.shape[0], C.byref(h)), "vpin_gens_create")
         return Gens(self, h)
 
+    def gens_shared(self, label, xyzt, budget_gb=0):
+        """vpin_gens_shared: the process-wide window table of `label`'s generator stream (a non-owning handle)."""
+        a = np.ascontiguousarray(xyzt, dtype=np.uint8).reshape(-1, 128)
+        h = C.c_void_p()
+        _chk(lib().vpin_gens_shared(self.h, label.encode(), a.ctypes.data_as(C.c_void_p), a.shape[0], budget_gb, C.byref(h)),
+             "vpin_gens_shared")
+        g = Gens(self, h)
+        g.free = lambda: None  # owned by the registry
+        return g
+
+    def gens_msm_parts(self, gens, scalars, rows, ncols):
+        """vpin_gens_msm_parts: (rows, parts, 128) uint8 partial points X|Y|Z|T; the caller adds them."""
+        L = lib()
+        L.vpin_gens_msm_parts_count.restype = C.c_size_t
+        L.vpin_gens_msm_parts_count.argtypes = [C.c_size_t]
+        s = np.ascontiguousarray(scalars, dtype=np.uint64).reshape(rows * ncols, 4)
+        np_ = L.vpin_gens_msm_parts_count(ncols)
+        out = np.zeros((rows, np_, 128), dtype=np.uint8)
+        L.vpin_gens_msm_parts.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p]
+        _chk(L.vpin_gens_msm_parts(self.h, gens.h, s.ctypes.data_as(C.c_void_p), rows, ncols, out.ctypes.data_as(C.c_void_p)),
+             "vpin_gens_msm_parts")
+        return out
+
     def hyrax_commit(self, gens, Z, blinds, blind_base):
         b = np.ascontiguousarray(blinds, dtype=np.uint64).reshape(-1, 4)
         Ls = b.shape[0]
@@ -538,6 +561,11 @@ class Context:
     def sat_prepare(self, num_vars):
         _chk(lib().vpin_sat_prepare(self.h, num_vars), "vpin_sat_prepare")
 
+    def spark_prepare(self, num_cons, num_vars, max_nnz):
+        L = lib()
+        L.vpin_spark_prepare.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t]
+        _chk(L.vpin_spark_prepare(self.h, num_cons, num_vars, max_nnz), "vpin_spark_prepare")
+
     # ---- SPARK / whole SNARK ----
     def spark_encode(self, inst):
         """SNARK::encode: returns (SparkDecomm, bincode(R1CSCommitment) bytes)."""
@@ -639,7 +667,8 @@ class Context:
 
     # ---- profiling ----
     def prof_enable(self, on=True):
-        _chk(lib().vpin_prof_enable(self.h, 1 if on else 0), "vpin_prof_enable")
+        """on = 2: also count the table additions of the row commitments (vpin_prof_enable level 2)"""
+        _chk(lib().vpin_prof_enable(self.h, int(on)), "vpin_prof_enable")
 
     def prof_reset(self):
         _chk(lib().vpin_prof_reset(self.h), "vpin_prof_reset")
@@ -651,5 +680,5 @@ class Context:
         for k, name in KERNEL_CLASSES.items():
             if arr[k].launches:
                 out[name] = {"launches": int(arr[k].launches), "ms": float(arr[k].ms),
-                             "alg_bytes": float(arr[k].alg_bytes)}
+                             "alg_bytes": float(arr[k].alg_bytes), "units": float(arr[k].units)}
         return out

@@ -24,24 +24,64 @@ static hipEvent_t get_event(vpin_ctx* c) {
   return e;
 }
 
+// live contexts of this process (vpin_ctx_create .. vpin_ctx_destroy): lets a handle freed without a context find
+// out whether its owner still exists, and lets an allocation that fails reclaim the blocks other contexts cache
+static std::mutex g_ctx_mu;
+static std::vector<vpin_ctx*> g_live_ctxs;
+
+void ctx_register(vpin_ctx* c) { std::lock_guard<std::mutex> g(g_ctx_mu); g_live_ctxs.push_back(c); }
+void ctx_unregister(vpin_ctx* c) {
+  std::lock_guard<std::mutex> g(g_ctx_mu);
+  for (size_t i = 0; i < g_live_ctxs.size(); i++)
+    if (g_live_ctxs[i] == c) { g_live_ctxs.erase(g_live_ctxs.begin() + (long)i); break; }
+}
+bool ctx_is_live(vpin_ctx* c) {
+  std::lock_guard<std::mutex> g(g_ctx_mu);
+  for (auto* x : g_live_ctxs) if (x == c) return true;
+  return false;
+}
+
+// cached (free-listed) blocks of one context back to the driver; the caller holds no pool lock
+static void pool_release_locked(vpin_ctx* c) {
+  (void)hipStreamSynchronize(c->stream);  // work that last used the cached blocks is ordered on this stream
+  for (auto& kv : c->pool_free_lists)
+    for (void* p : kv.second) { c->pool_sizes.erase(p); (void)hipFree(p); }
+  c->pool_free_lists.clear();
+}
+
 int dev_alloc(vpin_ctx* c, size_t bytes, void** out) {
   size_t cls = 256;
   while (cls < bytes) cls <<= 1;
   if (cls > (size_t)1 << 22) cls = (bytes + ((size_t)1 << 20) - 1) & ~(((size_t)1 << 20) - 1);  // MiB granularity above 4 MiB
-  // exact class first; for large requests any cached block up to 2x the size will do (proofs of
-  // different instance sizes would otherwise each leave their own multi-GB blocks in the pool)
-  for (auto it = c->pool_free_lists.lower_bound(cls); it != c->pool_free_lists.end(); ++it) {
-    if (it->first != cls && (cls < ((size_t)1 << 22) || it->first > 2 * cls)) break;
-    if (it->second.empty()) continue;
-    *out = it->second.back();
-    it->second.pop_back();
-    return VPIN_OK;
+  {
+    std::lock_guard<std::mutex> g(c->pool_mu);
+    // exact class first; for large requests any cached block up to 2x the size will do (proofs of
+    // different instance sizes would otherwise each leave their own multi-GB blocks in the pool)
+    for (auto it = c->pool_free_lists.lower_bound(cls); it != c->pool_free_lists.end(); ++it) {
+      if (it->first != cls && (cls < ((size_t)1 << 22) || it->first > 2 * cls)) break;
+      if (it->second.empty()) continue;
+      *out = it->second.back();
+      it->second.pop_back();
+      return VPIN_OK;
+    }
   }
   void* p = nullptr;
   if (hipMalloc(&p, cls) != hipSuccess) {
-    dev_pool_release(c);  // give cached blocks back and retry once
-    if (hipMalloc(&p, cls) != hipSuccess) return VPIN_ENOMEM;
+    (void)hipGetLastError();
+    dev_pool_release(c);  // give this context's cached blocks back and retry
+    if (hipMalloc(&p, cls) != hipSuccess) {
+      (void)hipGetLastError();
+      // the other contexts on this device (the lanes of a shared GPU) cache multi-GB blocks too
+      std::vector<vpin_ctx*> others;
+      {
+        std::lock_guard<std::mutex> g(g_ctx_mu);
+        for (auto* x : g_live_ctxs) if (x != c && x->device == c->device) others.push_back(x);
+        for (auto* x : others) { std::lock_guard<std::mutex> gp(x->pool_mu); pool_release_locked(x); }
+      }
+      if (hipMalloc(&p, cls) != hipSuccess) { (void)hipGetLastError(); return VPIN_ENOMEM; }
+    }
   }
+  std::lock_guard<std::mutex> g(c->pool_mu);
   c->pool_sizes[p] = cls;
   *out = p;
   return VPIN_OK;
@@ -49,22 +89,22 @@ int dev_alloc(vpin_ctx* c, size_t bytes, void** out) {
 
 void dev_free(vpin_ctx* c, void* p) {
   if (!p) return;
+  std::lock_guard<std::mutex> g(c->pool_mu);
   auto it = c->pool_sizes.find(p);
   if (it == c->pool_sizes.end()) { (void)hipFree(p); return; }
   c->pool_free_lists[it->second].push_back(p);
 }
 
 void dev_pool_release(vpin_ctx* c) {
-  (void)hipStreamSynchronize(c->stream);
-  for (auto& kv : c->pool_free_lists)
-    for (void* p : kv.second) { c->pool_sizes.erase(p); (void)hipFree(p); }
-  c->pool_free_lists.clear();
+  std::lock_guard<std::mutex> g(c->pool_mu);
+  pool_release_locked(c);
 }
 
-ProfScope::ProfScope(vpin_ctx* c, int kclass, double bytes) : ctx(c) {
+ProfScope::ProfScope(vpin_ctx* c, int kclass, double bytes, int also) : ctx(c) {
   if (!c->prof) return;
   ProfRec r;
   r.kclass = kclass;
+  r.also = also;
   r.bytes = bytes;
   r.start = get_event(c);
   r.stop = get_event(c);
@@ -134,6 +174,7 @@ static int ctx_create(int device, int priority, vpin_ctx** out) {
     vpin_ctx_destroy(c);
     return VPIN_ENOMEM;
   }
+  ctx_register(c);
   *out = c;
   return VPIN_OK;
 }
@@ -146,9 +187,18 @@ void vpin_ctx_destroy(vpin_ctx* c) {
   if (c->spark_cache_free) c->spark_cache_free(c);
   if (c->h_spark) (void)hipHostFree(c->h_spark);
   if (c->d_spark_cnt) (void)hipFree(c->d_spark_cnt);
+  if (c->d_add_count) (void)hipFree(c->d_add_count);
+  ctx_unregister(c);
   dev_pool_release(c);
-  for (auto& kv : c->pool_sizes) (void)hipFree(kv.first);  // blocks still held by leaked handles
-  c->pool_sizes.clear();
+  // Handles (tables, device instances, decommitments) must be freed before their context.  Blocks still out are
+  // released here so the VRAM is not lost; a handle freed later with this (dead) context would touch freed
+  // memory, so say so loudly instead of failing silently.
+  if (!c->pool_sizes.empty()) {
+    fprintf(stderr, "vpin_ctx_destroy: %zu device block(s) still referenced by live handles are released with the context; "
+                    "free tables / instances / decommitments before the context\n", c->pool_sizes.size());
+    for (auto& kv : c->pool_sizes) (void)hipFree(kv.first);
+    c->pool_sizes.clear();
+  }
   for (auto& r : c->recs) { (void)hipEventDestroy(r.start); (void)hipEventDestroy(r.stop); }
   for (auto e : c->free_events) (void)hipEventDestroy(e);
   if (c->d_partials) (void)hipFree(c->d_partials);
@@ -191,6 +241,7 @@ int table_alloc_uninit(vpin_ctx* c, size_t len, vpin_table** out) {
   if (!t) return VPIN_ENOMEM;
   if (dev_alloc(c, len * sizeof(fq), (void**)&t->d) != VPIN_OK) { delete t; return VPIN_ENOMEM; }
   t->len = t->cap = len;
+  t->owner = c;
   *out = t;
   return VPIN_OK;
 }
@@ -205,6 +256,7 @@ int vpin_table_alloc(vpin_ctx* c, size_t len, vpin_table** out) {
   if (!t) return VPIN_ENOMEM;
   if (dev_alloc(c, len * sizeof(fq), (void**)&t->d) != VPIN_OK) { delete t; return VPIN_ENOMEM; }
   t->len = t->cap = len;
+  t->owner = c;
   hipError_t e = hipMemsetAsync(t->d, 0, len * sizeof(fq), c->stream);
   if (e != hipSuccess) { set_last_error("hipMemsetAsync", e); dev_free(c, t->d); delete t; return VPIN_EHIP; }
   *out = t;
@@ -218,6 +270,7 @@ int vpin_table_upload(vpin_ctx* c, const uint8_t* mont32, size_t len, vpin_table
   if (!t) return VPIN_ENOMEM;
   if (dev_alloc(c, len * sizeof(fq), (void**)&t->d) != VPIN_OK) { delete t; return VPIN_ENOMEM; }
   t->len = t->cap = len;
+  t->owner = c;
   hipError_t e = hipMemcpyAsync(t->d, mont32, len * sizeof(fq), hipMemcpyHostToDevice, c->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
   if (e != hipSuccess) { set_last_error("hipMemcpy H2D", e); dev_free(c, t->d); delete t; return VPIN_EHIP; }
@@ -243,6 +296,7 @@ int vpin_table_clone(vpin_ctx* c, const vpin_table* src, vpin_table** out) {
   if (!t) return VPIN_ENOMEM;
   if (dev_alloc(c, src->len * sizeof(fq), (void**)&t->d) != VPIN_OK) { delete t; return VPIN_ENOMEM; }
   t->len = t->cap = src->len;
+  t->owner = c;
   hipError_t e = hipMemcpyAsync(t->d, src->d, src->len * sizeof(fq), hipMemcpyDeviceToDevice, c->stream);
   if (e != hipSuccess) { set_last_error("hipMemcpy D2D", e); dev_free(c, t->d); delete t; return VPIN_EHIP; }
   *out = t;
@@ -252,8 +306,11 @@ int vpin_table_clone(vpin_ctx* c, const vpin_table* src, vpin_table** out) {
 void vpin_table_free(vpin_ctx* c, vpin_table* t) {
   if (!t) return;
   if (t->owned && t->d) {
-    if (c) dev_free(c, t->d);
-    else (void)hipFree(t->d);
+    // the block goes back to the pool it came from; without a context argument that is the table's owner, and if
+    // the owner is gone its destroy already released the block
+    vpin_ctx* pool = c ? c : t->owner;
+    if (pool && (pool == c || ctx_is_live(pool))) dev_free(pool, t->d);
+    else if (!t->owner) (void)hipFree(t->d);
   }
   delete t;
 }
@@ -274,6 +331,12 @@ int vpin_table_read(vpin_ctx* c, const vpin_table* t, size_t off, size_t n, uint
 int vpin_prof_enable(vpin_ctx* c, int on) {
   if (!c) return VPIN_EINVAL;
   c->prof = on != 0;
+  c->prof_count_adds = on >= 2;
+  if (c->prof_count_adds && !c->d_add_count) {
+    (void)hipSetDevice(c->device);
+    VPIN_HIP_TRY(hipMalloc((void**)&c->d_add_count, sizeof(unsigned long long)));
+    VPIN_HIP_TRY(hipMemset(c->d_add_count, 0, sizeof(unsigned long long)));
+  }
   return VPIN_OK;
 }
 
@@ -286,11 +349,23 @@ static int prof_drain(vpin_ctx* c) {
       c->stats[r.kclass].launches += 1;
       c->stats[r.kclass].ms += ms;
       c->stats[r.kclass].alg_bytes += r.bytes;
+      if (r.also >= 0 && r.also < VPIN_K_COUNT) {
+        c->stats[r.also].launches += 1;
+        c->stats[r.also].ms += ms;
+        c->stats[r.also].alg_bytes += r.bytes;
+      }
     }
     c->free_events.push_back(r.start);
     c->free_events.push_back(r.stop);
   }
   c->recs.clear();
+  if (c->d_add_count) {  // table additions counted since the last drain (prof level 2)
+    unsigned long long n = 0;
+    if (hipMemcpy(&n, c->d_add_count, sizeof n, hipMemcpyDeviceToHost) == hipSuccess && n) {
+      c->stats[VPIN_K_MSM_ROWS].units += (double)n;
+      (void)hipMemset(c->d_add_count, 0, sizeof n);
+    }
+  }
   return VPIN_OK;
 }
 

@@ -1,11 +1,17 @@
 // vpin_prove -- command-line prover with the reference binary's contract.
 //   reference: vPIN_proof_generation/src/main.rs:14-46 (`cargo run -- <label>`), witness files read by
 //   load_data.rs:5-63 and load_data_add.rs:5-103 from the cwd-relative directory rust_files/<label>/.
-// Usage: vpin_prove <label> [--seed <hex64bytes>] [--device N] [--write-proof <dir>] [--sat-only]
+// Usage: vpin_prove <label> [--seed <hex>] [--device N] [--write-proof <dir>] [--sat-only]
+// Randomness: like the reference, which builds a fresh RandomTape from OsRng inside every
+// proof_point_add / proof_point_mult (Spartan/src/random.rs:14-20, proof_point_mult.rs:44,
+// commit_test.rs:74), every proof gets its own 128 bytes (commit seed | proof seed) from the OS.
+// With --seed the per-proof seeds are SHAKE256(master || "vPIN/point_add") and
+// SHAKE256(master || "vPIN/point_mult") (master = the hex bytes repeated cyclically to 128): reproducible
+// runs, still independent tapes -- equal tapes would make the two proofs share Hyrax row blinds.
 // Stdout follows the reference line for line (network / gadget banners / counts / proof size / times /
-// totals block).  Differences, all stated on stderr: the proof is the R1CS satisfiability proof only
-// (the SPARK eval proof is not part of this build), and verification is left to the verifier the
-// proof bytes are handed to (--write-proof dumps them with the two commitments and the claims).
+// totals block).  The proof is the whole SNARK (my_lib_prove) and is verified in-process (my_lib_verify) like
+// the reference does; --sat-only proves the R1CS satisfiability proof alone (said on stderr);
+// --write-proof dumps the proof with its commitments.
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -17,6 +23,7 @@
 #include <vector>
 
 #include "../../../include/vpin_hip.h"
+#include "../host/transcript.h"
 
 namespace {
 
@@ -281,9 +288,22 @@ int main(int argc, char** argv) {
       have_seed = true;
     }
   }
-  if (!have_seed) {  // OsRng (Spartan/src/random.rs:17)
+  // one independent 128-byte seed per proof (a shared seed gives both SNARKs the same blinds)
+  uint8_t seeds_add[128], seeds_mult[128];
+  if (!have_seed) {  // OsRng (Spartan/src/random.rs:17), drawn per proof
     std::random_device rd;
-    for (auto& b : seeds) b = (uint8_t)rd();
+    for (auto& b : seeds_add) b = (uint8_t)rd();
+    for (auto& b : seeds_mult) b = (uint8_t)rd();
+  } else {
+    auto derive = [&](const char* domain, uint8_t out[128]) {
+      vpin_host::Shake256 sh;
+      sh.absorb(seeds, 128);
+      sh.absorb(reinterpret_cast<const uint8_t*>(domain), strlen(domain));
+      sh.finalize();
+      sh.squeeze(out, 128);
+    };
+    derive("vPIN/point_add", seeds_add);
+    derive("vPIN/point_mult", seeds_mult);
   }
   fprintf(stderr, g_sat_only ? "vpin_prove: R1CS satisfiability proof only (--sat-only)\n"
                              : "vpin_prove: whole SNARK (sat proof + SPARK evaluation proof)\n");
@@ -312,13 +332,13 @@ int main(int argc, char** argv) {
     vpin_instance* add = nullptr;
     check(vpin_gadget_point_add(apx.data(), apy.data(), arx.data(), ary.data(), arz.data(), n1, &add), "vpin_gadget_point_add");
     lap("gadget_point_add");
-    ra = prove(ctx, add, seeds, add_prefix, t0);
+    ra = prove(ctx, add, seeds_add, add_prefix, t0);
     vpin_instance_free(add);
   } else {
     vpin_dev_instance* add = nullptr;
     check(vpin_gadget_point_add_dev(ctx, apx.data(), apy.data(), arx.data(), ary.data(), arz.data(), n1, &add), "vpin_gadget_point_add_dev");
     lap("gadget_point_add (device)");
-    ra = prove_dev(ctx, add, seeds, add_prefix, t0);
+    ra = prove_dev(ctx, add, seeds_add, add_prefix, t0);
     vpin_dev_instance_free(ctx, add);
   }
   printf("\n");
@@ -348,14 +368,14 @@ int main(int argc, char** argv) {
       check(vpin_gadget_point_mult(w.data(), mpx.data(), mpy.data(), nw, &mult), "vpin_gadget_point_mult");
       lap("gadget_point_mult");
       printf("Still working on...\n");
-      rm = prove(ctx, mult, seeds, mult_prefix, t0);
+      rm = prove(ctx, mult, seeds_mult, mult_prefix, t0);
       vpin_instance_free(mult);
     } else {
       vpin_dev_instance* mult = nullptr;
       check(vpin_gadget_point_mult_dev(ctx, w.data(), mpx.data(), mpy.data(), nw, &mult), "vpin_gadget_point_mult_dev");
       lap("gadget_point_mult (device)");
       printf("Still working on...\n");
-      rm = prove_dev(ctx, mult, seeds, mult_prefix, t0);
+      rm = prove_dev(ctx, mult, seeds_mult, mult_prefix, t0);
       vpin_dev_instance_free(ctx, mult);
     }
   }

@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <map>
+#include <mutex>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -30,15 +31,19 @@ struct ProfRec {
   int kclass;
   double bytes;
   hipEvent_t start, stop;
+  int also = -1;  // a second class the same launch is counted in (a subset class)
 };
 
 }  // namespace vpin
+
+struct vpin_ctx;
 
 struct vpin_table {
   vpin::fq* d = nullptr;  // device pointer
   size_t len = 0;         // live length (halves on bind)
   size_t cap = 0;         // allocated length
   bool owned = true;
+  vpin_ctx* owner = nullptr;  // context whose pool `d` came from (vpin_table_free(NULL, t) returns it there)
 };
 
 struct vpin_gens;
@@ -54,12 +59,17 @@ struct vpin_ctx {
   vpin::fq* h_out = nullptr;  // pinned, 8 fq
   // profiling
   bool prof = false;
+  bool prof_count_adds = false;            // vpin_prof_enable(ctx, 2)
+  unsigned long long* d_add_count = nullptr;  // device counter of msm_count_adds_kernel
   std::vector<vpin::ProfRec> recs;
   std::vector<hipEvent_t> free_events;
   vpin_kstat stats[VPIN_K_COUNT] = {};
   // device memory pool: freed blocks are kept by size class and reused (hipMalloc/hipFree cost
   // hundreds of microseconds and hipFree synchronises the device; one proof makes ~100 of them).
   // All work is issued on `stream`, so a recycled block is only touched by later-ordered work.
+  // pool_mu guards both maps: another context's allocation failure may hand this context's cached blocks back
+  // to the driver (dev_alloc's out-of-memory path)
+  std::mutex pool_mu;
   std::map<size_t, std::vector<void*>> pool_free_lists;
   std::unordered_map<void*, size_t> pool_sizes;
   // host-side prover state (generator sets per polynomial size), owned by prover.cpp
@@ -82,7 +92,7 @@ namespace vpin {
 struct ProfScope {
   vpin_ctx* ctx;
   int rec = -1;
-  ProfScope(vpin_ctx* c, int kclass, double bytes);
+  ProfScope(vpin_ctx* c, int kclass, double bytes, int also = -1);
   ~ProfScope();
 };
 

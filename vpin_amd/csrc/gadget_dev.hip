@@ -645,10 +645,6 @@ static int build_instance(vpin_ctx* c, const TmplSink& ts, int kind, size_t n_op
       return fail(rc);
     if (hipStreamSynchronize(c->stream) != hipSuccess) return fail(VPIN_EHIP);  // host vectors die at scope end
   }
-  {
-    size_t mx = std::max(d->n_chunks[0], std::max(d->n_chunks[1], d->n_chunks[2]));
-    if (dmalloc(c, &d->chunk_partials, mx ? mx : 1)) return fail(VPIN_ENOMEM);
-  }
   if (hipGetLastError() != hipSuccess) return fail(VPIN_EHIP);
 
   // assignment tables, zero-filled (the witness kernels write the live entries)

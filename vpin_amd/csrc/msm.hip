@@ -357,6 +357,56 @@ __global__ __launch_bounds__(kMsmBlock, 3) void msm_rows_kernel(const fq* __rest
   }
 }
 
+// Profiling aid (vpin_prof_enable(ctx, 2)): the affine table additions msm_rows_kernel performs for the same
+// arguments -- non-zero signed digits of every non-zero scalar, one scalar for a constant row -- summed into *count.
+__device__ __forceinline__ uint32_t count_digits(fq s, const TableView& tv, size_t j) {
+  (void)fq_fold_sign(s);
+  const TableSeg sg = table_seg(tv, j);
+  uint32_t carry = 0, n = 0;
+  const uint32_t full = 1u << sg.c, half = 1u << (sg.c - 1);
+  for (int w = 0; w < sg.W; w++) {
+    uint32_t v = scalar_digit(s, w, sg.c) + carry;
+    const bool neg = v > half;
+    const uint32_t mag = neg ? full - v : v;
+    carry = neg ? 1u : 0u;
+    n += mag != 0;
+  }
+  return n;
+}
+__global__ __launch_bounds__(kMsmBlock) void msm_count_adds_kernel(const fq* __restrict__ Z, size_t stride, size_t ncols,
+                                                                   const fq* __restrict__ extra, int n_extra, size_t extra_base0,
+                                                                   TableView tv, unsigned long long* __restrict__ count) {
+  const size_t row = blockIdx.x;
+  const fq* zr = Z + row * stride;
+  uint32_t n = 0;
+  bool constant = false;
+  if (ncols >= 256 && (ncols & (ncols - 1)) == 0 && ((size_t)1 << (tv.nbt - tv.sum0 - 1)) >= ncols) {
+    const fq first = fq_load(zr);
+    int same = 1;
+    for (size_t j = threadIdx.x; j < ncols; j += kMsmBlock) same &= fq_same(first, fq_load(zr + j)) ? 1 : 0;
+    constant = __syncthreads_and(same) != 0;
+    if (constant && threadIdx.x == 0 && !fq_is_zero(first))
+      n += count_digits(fq_from_mont(first), tv, tv.sum0 + (size_t)(63 - __builtin_clzll((unsigned long long)ncols)));
+  }
+  if (!constant)
+    for (size_t j = threadIdx.x; j < ncols; j += kMsmBlock) {
+      const fq s = fq_load(zr + j);
+      if (!fq_is_zero(s)) n += count_digits(fq_from_mont(s), tv, j);
+    }
+  for (int e = threadIdx.x; e < n_extra; e += kMsmBlock) {
+    const fq x = fq_load(extra + row * (size_t)n_extra + e);
+    if (!fq_is_zero(x)) n += count_digits(fq_from_mont(x), tv, extra_base0 + e);
+  }
+  __shared__ uint32_t sh[kMsmBlock];
+  sh[threadIdx.x] = n;
+  __syncthreads();
+  for (int st = kMsmBlock / 2; st >= 1; st >>= 1) {
+    if ((int)threadIdx.x < st) sh[threadIdx.x] += sh[threadIdx.x + st];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0 && sh[0]) atomicAdd(count, (unsigned long long)sh[0]);
+}
+
 // Few-row MSMs (the evaluation proof's bullet rounds: 1-2 rows of R+2 scalars) are latency bound,
 // so the 32 windows of a scalar are spread over 8 threads (4 table adds each) and a 256-thread
 // workgroup covers 32 scalars; the per-workgroup partial points go back to the host, which adds
@@ -543,7 +593,6 @@ static int gens_build(vpin_ctx* c, const uint8_t* gens_xyzt, size_t nb, size_t b
       b_prefix.alloc(max_entries * sizeof(fp)) != VPIN_OK || hipMalloc((void**)&g->table, entries * sizeof(niels_slot)) != hipSuccess ||
       (n_hi && hipMalloc((void**)&g->table_hi, entries_hi * sizeof(niels_slot)) != hipSuccess)) {
     if (g->table) (void)hipFree(g->table);
-  if (g->table_hi) (void)hipFree(g->table_hi);
     if (g->table_hi) (void)hipFree(g->table_hi);
     delete g;
     return VPIN_ENOMEM;
@@ -641,6 +690,13 @@ void vpin_gens_free(vpin_ctx* c, vpin_gens* g) {
 }
 
 size_t vpin_gens_count(const vpin_gens* g) { return g ? g->nb : 0; }
+// window layout chosen by the table budget: out = {c, W, split, c_hi, W_hi, nb + prefix-sum bases}
+int vpin_gens_layout(const vpin_gens* g, size_t out[6]) {
+  if (!g || !out) return VPIN_EINVAL;
+  out[0] = (size_t)g->c; out[1] = (size_t)g->W; out[2] = g->split;
+  out[3] = g->split < g->nbt ? (size_t)g->c_hi : 0; out[4] = g->split < g->nbt ? (size_t)g->W_hi : 0; out[5] = g->nbt;
+  return VPIN_OK;
+}
 size_t vpin_gens_entry_bytes(void) { return sizeof(niels_slot); }
 
 // shared implementation: rows of scalars -> points (kept on device), then optional outputs
@@ -663,8 +719,11 @@ static int msm_rows(vpin_ctx* c, const vpin_gens* g, const fq* dZ, size_t rows, 
     if (parts.alloc(rows * (size_t)chunks * sizeof(ge_ext))) return VPIN_ENOMEM;
     dst = (ge_ext*)parts.p;
   }
+  if (c->prof_count_adds && c->d_add_count && rows >= 128)
+    hipLaunchKernelGGL(msm_count_adds_kernel, dim3((unsigned)rows), dim3(kMsmBlock), 0, c->stream, dZ, stride, ncols, d_extra,
+                       n_extra, extra_base0, view(g), c->d_add_count);
   {
-    ProfScope ps(c, VPIN_K_MSM, 32.0 * nz_est);
+    ProfScope ps(c, VPIN_K_MSM, 32.0 * nz_est, rows >= 128 ? VPIN_K_MSM_ROWS : -1);
     // unused dynamic LDS lowers the workgroups per CU from 3 to 2 on a shared device (vpin_ctx_set_shared_device);
     // VPIN_MSM_LDS_PAD overrides (experiments)
     static const int env_pad = [] { const char* e = getenv("VPIN_MSM_LDS_PAD"); return e ? atoi(e) : -1; }();

@@ -177,7 +177,6 @@ void vpin_r1cs_free(vpin_ctx* c, vpin_r1cs_dev* d) {
     for (void* p : ps)
       if (p) { if (d->pooled && c) dev_free(c, p); else (void)hipFree(p); }
   }
-  if (d->chunk_partials) { if (d->pooled && c) dev_free(c, d->chunk_partials); else (void)hipFree(d->chunk_partials); }
   delete d;
 }
 
@@ -230,10 +229,6 @@ int vpin_r1cs_upload(vpin_ctx* c, const vpin_r1cs* inst, vpin_r1cs_dev** out) {
         (rc = up(c, &d->chunk_k0[m], ck0.data(), ck0.size())) || (rc = up(c, &d->chunk_k1[m], ck1.data(), ck1.size())))
       break;
     if (hipStreamSynchronize(c->stream) != hipSuccess) rc = VPIN_EHIP;  // host vectors die at scope end
-  }
-  if (rc == VPIN_OK) {
-    size_t mx = std::max(d->n_chunks[0], std::max(d->n_chunks[1], d->n_chunks[2]));
-    if (hipMalloc((void**)&d->chunk_partials, (mx ? mx : 1) * sizeof(fq)) != hipSuccess) rc = VPIN_ENOMEM;
   }
   if (rc) { vpin_r1cs_free(c, d); return rc; }
   *out = d;
@@ -295,6 +290,12 @@ int vpin_r1cs_eval_table(vpin_ctx* c, const vpin_r1cs_dev* d, const vpin_table* 
   vpin_table* t = nullptr;
   int rc = table_alloc_uninit(c, ncols, &t);  // matrix A's pass writes every column, B and C accumulate
   if (rc) return rc;
+  // long-column chunk partials: scratch of THIS call from the calling context's pool (the instance is shared,
+  // read-only, by every context / stream that proves it)
+  DevBuf chunk_scratch(c);
+  const size_t max_chunks = std::max(d->n_chunks[0], std::max(d->n_chunks[1], d->n_chunks[2]));
+  if (max_chunks && chunk_scratch.alloc(max_chunks * sizeof(fq))) { vpin_table_free(c, t); return VPIN_ENOMEM; }
+  fq* chunk_partials = (fq*)chunk_scratch.p;
   for (int m = 0; m < 3; m++) {
     fq rc_m;
     memcpy(rc_m.v, r_abc + 32 * m, 32);
@@ -303,9 +304,9 @@ int vpin_r1cs_eval_table(vpin_ctx* c, const vpin_r1cs_dev* d, const vpin_table* 
                        d->csc_row[m], d->csc_val[m], evals_rx->d, ncols, rc_m, accum, t->d);
     if (d->n_long[m]) {
       hipLaunchKernelGGL(long_chunk_kernel, dim3((unsigned)d->n_chunks[m]), dim3(kRB), 0, c->stream, d->chunk_k0[m],
-                         d->chunk_k1[m], d->csc_row[m], d->csc_val[m], evals_rx->d, d->chunk_partials);
+                         d->chunk_k1[m], d->csc_row[m], d->csc_val[m], evals_rx->d, chunk_partials);
       hipLaunchKernelGGL(eval_table_long_finish_kernel, dim3((unsigned)((d->n_long[m] + 63) / 64)), dim3(64), 0, c->stream,
-                         d->long_cols[m], d->long_first[m], d->n_long[m], d->chunk_partials, rc_m, accum, t->d);
+                         d->long_cols[m], d->long_first[m], d->n_long[m], chunk_partials, rc_m, accum, t->d);
     }
   }
   hipError_t e = hipGetLastError();
@@ -321,9 +322,12 @@ int vpin_r1cs_evaluate(vpin_ctx* c, const vpin_r1cs_dev* d, const vpin_table* ev
   if (evals_rx->len != d->num_cons || evals_ry->len != 2 * d->num_vars) return VPIN_ESHAPE;
   (void)hipSetDevice(c->device);
   const size_t ncols = 2 * d->num_vars;
-  DevBuf bo(c);
+  DevBuf bo(c), chunk_scratch(c);
   if (bo.alloc(96)) return VPIN_ENOMEM;
   fq* d_out = (fq*)bo.p;
+  const size_t max_chunks = std::max(d->n_chunks[0], std::max(d->n_chunks[1], d->n_chunks[2]));
+  if (max_chunks && chunk_scratch.alloc(max_chunks * sizeof(fq))) return VPIN_ENOMEM;
+  fq* chunk_partials = (fq*)chunk_scratch.p;
   int grid = (int)std::min<size_t>((ncols + kRB - 1) / kRB, 1024);
   for (int m = 0; m < 3; m++) {
     int nparts = grid + (int)d->n_long[m];
@@ -332,9 +336,9 @@ int vpin_r1cs_evaluate(vpin_ctx* c, const vpin_r1cs_dev* d, const vpin_table* ev
                        evals_rx->d, evals_ry->d, ncols, c->d_partials);
     if (d->n_long[m]) {
       hipLaunchKernelGGL(long_chunk_kernel, dim3((unsigned)d->n_chunks[m]), dim3(kRB), 0, c->stream, d->chunk_k0[m],
-                         d->chunk_k1[m], d->csc_row[m], d->csc_val[m], evals_rx->d, d->chunk_partials);
+                         d->chunk_k1[m], d->csc_row[m], d->csc_val[m], evals_rx->d, chunk_partials);
       hipLaunchKernelGGL(evaluate_long_finish_kernel, dim3((unsigned)((d->n_long[m] + 63) / 64)), dim3(64), 0, c->stream,
-                         d->long_cols[m], d->long_first[m], d->n_long[m], d->chunk_partials, evals_ry->d, c->d_partials + grid);
+                         d->long_cols[m], d->long_first[m], d->n_long[m], chunk_partials, evals_ry->d, c->d_partials + grid);
     }
     hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(kRB), 0, c->stream, c->d_partials, nparts, d_out + m);
   }

@@ -18,7 +18,7 @@ struct vpin_r1cs_dev {
   uint32_t* chunk_k0[3] = {};    // [n_chunks] first entry of the chunk
   uint32_t* chunk_k1[3] = {};    // [n_chunks] end entry
   size_t n_long[3] = {0, 0, 0}, n_chunks[3] = {0, 0, 0};
-  vpin::fq* chunk_partials = nullptr;  // [max n_chunks]
+  // (no mutable scratch here: the instance is immutable and may be proven from several contexts at once)
   bool pooled = false;  // arrays come from the context pool (dev_alloc) instead of hipMalloc
 };
 

@@ -300,7 +300,7 @@ static int batched_prove(vpin_ctx* c, vpin::SparkForest& f, DotpCtx* dotp, Trans
         const vpin::fq* E = pyr->d + pyramid_offset(k, j + 1);
         const uint8_t* rprev = j ? B(&r[j - 1]) : nullptr;
         if ((rc = vpin::spark_prod_round(c, &f, layer_id, len, E, rprev, with_dotp, lead_ok))) return rc;
-        if (with_dotp && (rc = vpin::spark_dotp_round(c, dotp->d, dotp->comb_derefs, dotp->scratch, len, j == 1, rprev))) return rc;
+        if (with_dotp && (rc = vpin::spark_dotp_round(c, dotp->d->N, dotp->d->comb_ops->d + 12 * dotp->d->N, dotp->comb_derefs, dotp->scratch, len, j == 1, rprev))) return rc;
         if ((rc = vpin::spark_wait_flag(c))) return rc;
         const Fq* res = reinterpret_cast<const Fq*>(c->h_spark);
         const Fq rho = rand[j], omr = one - rho;
@@ -582,6 +582,19 @@ size_t vpin_snark_proof_max_bytes(const vpin_r1cs* inst) {
   b += lgM * (lgM * 104 + 64 + 8 * 32 + 64) + 64;
   b += 3 * (16 + 64 * 40 + 128 + 64) + 40 * 32 + 1024;
   return b;
+}
+
+int vpin_spark_prepare(vpin_ctx* c, size_t num_cons, size_t num_vars, size_t max_nnz) {
+  if (!c || !vpin::is_pow2(num_cons) || !vpin::is_pow2(num_vars) || max_nnz == 0) return VPIN_EINVAL;
+  (void)hipSetDevice(c->device);
+  const size_t nnz[3] = {max_nnz, max_nnz, max_nnz};
+  const Shape s = shape_of(num_cons, num_vars, nnz);
+  const PcGens* g = nullptr;
+  int rc = get_view(c, std::max(s.v_ops, s.v_mem), &g);
+  if (!rc) rc = get_view(c, s.v_ops, &g);
+  if (!rc) rc = get_view(c, s.v_mem, &g);
+  if (!rc) rc = get_view(c, s.v_derefs, &g);
+  return rc;
 }
 
 void vpin_spark_decomm_free(vpin_ctx* c, vpin_spark_decomm* d) {

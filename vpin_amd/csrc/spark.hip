@@ -533,7 +533,7 @@ int spark_prod_round(vpin_ctx* c, const SparkForest* f, int level, size_t len, c
     // algorithmic bytes of the reference formulation: A and B of every circuit and the shared eq table read,
     // folded halves written
     const double bytes = (double)f->ncirc * 2 * 32.0 * (r ? (double)len * 1.5 : (double)len) + 32.0 * (r ? (double)len * 1.5 : (double)len);
-    ProfScope ps(c, VPIN_K_SPARK_ROUND, bytes);
+    ProfScope ps(c, VPIN_K_SPARK_ROUND, bytes, pairs >= ((size_t)1 << 20) ? VPIN_K_SPARK_ROUND_BIG : -1);
 #define VPIN_PROD_LAUNCH(B_, L_)                                                                                             \
   hipLaunchKernelGGL((prod_round_kernel<B_, L_>), dim3(grid, f->ncirc), dim3(kBlock), 0, c->stream, f->base, f->stride(), \
                      f->level_off(level), h, E, pairs, rr, rconst, fin)
@@ -545,10 +545,10 @@ int spark_prod_round(vpin_ctx* c, const SparkForest* f, int level, size_t len, c
   return VPIN_OK;
 }
 
-int spark_dotp_round(vpin_ctx* c, const vpin_spark_decomm* d, const fq* comb_derefs, fq* scratch, size_t len, bool first_fold,
+int spark_dotp_round(vpin_ctx* c, size_t N, const fq* vals, const fq* comb_derefs, fq* scratch, size_t len, bool first_fold,
                      const uint8_t* r) {
-  if (!c || !d || !comb_derefs || !scratch) return VPIN_EINVAL;
-  if (len > d->N / 2 || !is_pow2(len) || len < (r ? 4u : 2u) || (first_fold && (!r || len != d->N / 2))) return VPIN_ESHAPE;
+  if (!c || !vals || !comb_derefs || !scratch) return VPIN_EINVAL;
+  if (len > N / 2 || !is_pow2(len) || len < (r ? 4u : 2u) || (first_fold && (!r || len != N / 2))) return VPIN_ESHAPE;
   int rc = spark_pinned(c);
   if (rc) return rc;
   (void)hipSetDevice(c->device);
@@ -557,7 +557,6 @@ int spark_dotp_round(vpin_ctx* c, const vpin_spark_decomm* d, const fq* comb_der
   const size_t pairs = r ? len / 4 : len / 2;
   const int grid = round_grid(pairs);
   const fq rr = r ? load_host_fq(r) : fq{};
-  const fq* vals = d->comb_ops->d + 12 * d->N;
   const bool from_scratch = r && !first_fold;
   // same launch group as the product circuits' kernel just issued: instances 12..17 of 18
   Finisher fin = make_finisher(c, partials + (size_t)12 * kRoundBlocks * 3, 12, 18);
@@ -565,10 +564,10 @@ int spark_dotp_round(vpin_ctx* c, const vpin_spark_decomm* d, const fq* comb_der
     const double bytes = 6 * 3 * 32.0 * (r ? (double)len * 1.5 : (double)len);
     ProfScope ps(c, VPIN_K_SPARK_ROUND, bytes);
     if (r)
-      hipLaunchKernelGGL((dotp_round_kernel<true>), dim3(grid, 6), dim3(kBlock), 0, c->stream, comb_derefs, vals, d->N, scratch,
+      hipLaunchKernelGGL((dotp_round_kernel<true>), dim3(grid, 6), dim3(kBlock), 0, c->stream, comb_derefs, vals, N, scratch,
                          from_scratch, pairs, rr, fin);
     else
-      hipLaunchKernelGGL((dotp_round_kernel<false>), dim3(grid, 6), dim3(kBlock), 0, c->stream, comb_derefs, vals, d->N, scratch,
+      hipLaunchKernelGGL((dotp_round_kernel<false>), dim3(grid, 6), dim3(kBlock), 0, c->stream, comb_derefs, vals, N, scratch,
                          false, pairs, rr, fin);
   }
   VPIN_HIP_TRY(hipGetLastError());
@@ -626,3 +625,27 @@ int spark_slice_evals(vpin_ctx* c, const fq* table, size_t len, int nslices, con
 }
 
 }  // namespace vpin
+
+// Kernel-level C-ABI entry (include/vpin_hip.h): one round of prove_cubic_batched for the product circuits of one forest
+// level and, optionally, the six dot-product circuit halves -- exactly the launch group spark.cpp issues per round.
+extern "C" int vpin_spark_batched_round(vpin_ctx* c, vpin_table* forest, size_t n, int ncirc, int level, size_t len,
+                                        const vpin_table* E, size_t e_off, const uint8_t* r, int lead, const vpin_table* derefs,
+                                        const vpin_table* vals, vpin_table* scratch, int first_fold, uint8_t* out) {
+  using namespace vpin;
+  if (!c || !forest || !E || !out || ncirc < 1 || ncirc > 12 || !is_pow2(n) || n < 4 || level < 0) return VPIN_EINVAL;
+  const bool with_dotp = derefs != nullptr;
+  if (with_dotp && (!vals || !scratch || ncirc != 12 || level != 0)) return VPIN_EINVAL;
+  if (forest->len < (size_t)ncirc * 2 * n) return VPIN_ESHAPE;
+  const size_t pairs = r ? len / 4 : len / 2;
+  if (e_off + pairs > E->len) return VPIN_ESHAPE;
+  if (with_dotp && (derefs->len < 6 * n || vals->len < 3 * n || scratch->len < 18 * (n / 4))) return VPIN_ESHAPE;
+  SparkForest f;
+  f.base = forest->d; f.n = n; f.ncirc = ncirc;
+  int rc = spark_prod_round(c, &f, level, len, E->d + e_off, r, with_dotp, lead != 0);
+  if (!rc && with_dotp) rc = spark_dotp_round(c, n, vals->d, derefs->d, scratch->d, len, first_fold != 0, r);
+  if (!rc) rc = spark_wait_flag(c);
+  if (rc) return rc;
+  memcpy(out, c->h_spark, (size_t)(ncirc + (with_dotp ? 6 : 0)) * 96);
+  return VPIN_OK;
+}
+

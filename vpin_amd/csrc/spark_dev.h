@@ -71,7 +71,8 @@ int spark_prod_round(vpin_ctx* c, const SparkForest* f, int level, size_t len, c
 // writes into `scratch` (18 x N/4 entries) so the committed polynomials stay intact.
 // round 0: r == nullptr, len = N/2.  Results at ctx->h_spark[3*(12+k) + x].  Call right after
 // spark_prod_round(..., with_dotp = true).
-int spark_dotp_round(vpin_ctx* c, const vpin_spark_decomm* d, const fq* comb_derefs, fq* scratch, size_t len, bool first_fold,
+// vals = the three val slices of comb_ops (3 x N), N = leaves of the ops forest.
+int spark_dotp_round(vpin_ctx* c, size_t N, const fq* vals, const fq* comb_derefs, fq* scratch, size_t len, bool first_fold,
                      const uint8_t* r);
 
 // completion of the current launch group: spins on the pinned flag word the last block publishes

@@ -571,6 +571,16 @@ int vpin_sc_cubic3_bind_round(vpin_ctx* c, const vpin_table* pyramid, int ell, i
   return rc ? rc : sc_round_wait(c, 4, out);
 }
 
+// leading-coefficient form of the same round (the kernels the prover runs when phase 1's claim is consistent):
+// out = t(0) | x^2 coefficient of t | t(1) (the last only when r == NULL, i.e. the first round)
+int vpin_sc_cubic3_lead_round(vpin_ctx* c, const vpin_table* pyramid, int ell, int level, vpin_table* Az, vpin_table* Bz,
+                              vpin_table* Cz, const uint8_t* r, uint8_t out[96]) {
+  if (!out) return VPIN_EINVAL;
+  vpin_table* t[3] = {Az, Bz, Cz};
+  int rc = sc_cubic3_launch(c, t, pyramid, ell, level, r, true);
+  return rc ? rc : sc_round_wait(c, 4, out);
+}
+
 int vpin_eq_table(vpin_ctx* c, const uint8_t* r, int ell, vpin_table** out) {
   if (!c || !out || ell < 0 || ell > 40 || (ell > 0 && !r)) return VPIN_EINVAL;
   (void)hipSetDevice(c->device);

@@ -57,7 +57,7 @@ def parse():
     ap.add_argument("--trace", default="lenet", help="lenet (L1..L7) or one label: 3_32, A, 7_256, E, L1..L7")
     ap.add_argument("--label", default=None, help="alias of --trace for a single label")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-mult", type=int, default=18, help="point-mults in the CPU baseline sample")
+    ap.add_argument("--cpu-sample-mult", type=int, default=32, help="point-mults in the CPU baseline sample")
     ap.add_argument("--cpu-sample-add", type=int, default=256)
     ap.add_argument("--serial", action="store_true", help="one instance at a time, one host thread")
     ap.add_argument("--host-buffers", action="store_true",
@@ -78,6 +78,8 @@ def parse():
     ap.add_argument("--only", choices=["mult", "add"], default=None, help="keep only the point-mult / point-add instances of the trace")
     ap.add_argument("--no-verify", action="store_true", help="skip the post-run verification of the last step's SNARKs")
     ap.add_argument("--no-prof", action="store_true", help="no HIP-event bracketing of kernels (no roofline object)")
+    ap.add_argument("--no-roofline-pass", action="store_true",
+                    help="skip the serial pass after the timed region that fills roofline.secondary (largest instance alone)")
     ap.add_argument("--pmc-traffic", type=float, default=None,
                     help="HBM bytes per launch of the roofline kernel from a separate rocprofv3 --pmc pass")
     return ap.parse_args()
@@ -382,16 +384,28 @@ def main():
     if k and k["ms"] > 0:
         achieved = k["alg_bytes"] / (k["ms"] * 1e-3) / 1e9
         traffic = args.pmc_traffic
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-        if traffic is None and os.path.exists(pmc):
-            with open(pmc) as f:
-                ent = json.load(f).get("bench_default", {}).get("sc_cubic3_kernel<true, true>", {})
-            traffic = ent.get("hbm_bytes_per_launch")
+        pmc_all = {}
+        for pmc in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):  # separate rocprofv3 --pmc passes, see the file's _how
+            pth = os.path.join(ROOT, "profiles", pmc)
+            if os.path.exists(pth):
+                with open(pth) as f:
+                    pmc_all = json.load(f).get("bench_default", {})
+                break
+        if traffic is None:
+            traffic = pmc_all.get("sc_cubic3_kernel<true, true>", {}).get("hbm_bytes_per_launch")
+        # bytes the eq-factored kernel really moves per launch: 3 tables read (len) and written (len/2), the suffix
+        # table read once per pair (len/4): 152*len against the 192*len of the reference's 4-table formulation
+        actual = k["alg_bytes"] * 152.0 / 192.0
+        achieved_actual = actual / (k["ms"] * 1e-3) / 1e9
         line["roofline"] = {
             "kernel": "sc_cubic3_kernel<true, true> (fused fold + cubic round evaluation of phase 1, eq-factored, leading-coefficient form; "
                       "rounds with > 512 pairs)",
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+            "achieved_note": "algorithmic bytes of the reference's 4-table formulation (SURVEY.md 8(d): 4*32*1.5*len per launch) / HIP-event time",
+            "achieved_actual": achieved_actual, "frac_actual": achieved_actual / HBM_PEAK_GBPS,
+            "actual_note": "bytes this kernel really moves (3 tables + the suffix table, 152*len: the eq table is never read; PMC "
+                           "agrees, see traffic) / the same time; the kernel sits between the VALU-issue and the HBM limit",
             "launches": k["launches"], "avg_launch_us": k["ms"] * 1e3 / k["launches"],
             "alg_bytes_per_launch": k["alg_bytes"] / k["launches"],
             "scope": ((f"launches of the largest instance ({lane_names[0][0]}) in step 0 of the timed region, before the other lanes start: "
@@ -426,6 +440,60 @@ def main():
         # ---- the reference's own span (proof_point_mult.rs:24-101: witness inputs -> gadget + witness ->
         # is_sat -> SNARK::encode -> my_lib_prove), one instance after the other, generator tables warm; the
         # resident copies are released first.  Same seeds, so the bytes must equal the timed region's proofs.
+        # ---- roofline.secondary: the kernels that own the step, measured on the largest instance proven ALONE (one
+        # stream, nothing else on the device) right after the timed region, so a kernel's event time is its own ----
+        if "roofline" in line and not args.no_roofline_pass and not args.no_prof:
+            big = lane_names[0][0]
+            cx = ctxs[0]
+            cx.set_shared_device(False)
+            cx.prof_reset()
+            cx.prof_enable(2)  # level 2: also count the table additions of the row commitments
+            di, tp, ti, tv_, inp = resident[big]
+            t1 = time.perf_counter()
+            cx.snark_prove_resident(di, decomms[big], tp, ti, tv_, inp, SEED_C, SEED_P)
+            cx.sync()
+            alone_ms = (time.perf_counter() - t1) * 1e3
+            st = cx.prof_read()
+            cx.prof_enable(False)
+            if len(lanes) > 1:
+                cx.set_shared_device(True)
+            sec = []
+            props = torch.cuda.get_device_properties(local_rank)
+            cus, clk = props.multi_processor_count, props.clock_rate * 1e3  # Hz
+            m = st.get("msm_rows")
+            if m and m["ms"] > 0 and m["units"] > 0:
+                # VALU-issue ceiling: one wave-instruction per SIMD per 4 cycles (64 lanes on a 16-lane SIMD); instructions per
+                # affine table addition counted from the ISA of ge_add_niels in msm_rows_kernel (profiles/r02_isa_counts.json)
+                isa = {}
+                pth = os.path.join(ROOT, "profiles", "r02_isa_counts.json")
+                if os.path.exists(pth):
+                    with open(pth) as f:
+                        isa = json.load(f)
+                ipa = isa.get("msm_rows_kernel", {}).get("valu_per_table_add", 1850)
+                peak_adds = cus * 4 * 64 * clk / (4.0 * ipa)
+                adds_s = m["units"] / (m["ms"] * 1e-3)
+                pm = pmc_all.get("msm_rows_kernel", {})
+                sec.append({"kernel": "msm_rows_kernel (row commitments of >= 128 rows: witness, derefs, SNARK::encode shapes)",
+                            "bound": "valu-issue", "achieved": adds_s / 1e9, "peak": peak_adds / 1e9, "unit": "G table adds/s",
+                            "frac": adds_s / peak_adds, "launches": m["launches"], "ms": round(m["ms"], 3),
+                            "table_adds": m["units"], "valu_instructions_per_add": ipa,
+                            "peak_note": f"{cus} CUs x 4 SIMDs x 64 lanes x {clk / 1e9:.2f} GHz / (4 cycles per wave-instruction x {ipa} "
+                                         "VALU instructions per affine table addition)",
+                            "scalars_GBps": m["alg_bytes"] / (m["ms"] * 1e-3) / 1e9,
+                            "traffic_bytes_per_add": (pm.get("hbm_bytes_per_launch") / pm["table_adds_per_launch"]) if pm.get("table_adds_per_launch") else None})
+            p = st.get("spark_round_big")
+            if p and p["ms"] > 0:
+                ach = p["alg_bytes"] / (p["ms"] * 1e-3) / 1e9
+                pp = pmc_all.get("prod_round_kernel<true, true> (>= 2^20 pairs)", {})
+                sec.append({"kernel": "prod_round_kernel<*, true>, launches with >= 2^20 pairs per circuit (12 or 4 circuits per launch)",
+                            "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS,
+                            "launches": p["launches"], "ms": round(p["ms"], 3), "alg_bytes_per_launch": p["alg_bytes"] / p["launches"],
+                            "alg_note": "per launch: circuits x 2 tables x 32 B x 1.5 x len + the shared eq table (32 B x 1.5 x len)",
+                            "traffic": pp.get("hbm_bytes_per_launch")})
+            line["roofline"]["secondary"] = sec
+            line["roofline"]["secondary_scope"] = (f"{big} proven alone after the timed region ({alone_ms:.1f} ms, one stream, HIP events per launch, "
+                                                   "table additions counted by vpin_prof_enable level 2)")
+            line["kernels_largest_instance_alone"] = {name: {"launches": v["launches"], "ms": round(v["ms"], 4)} for name, v in st.items()}
         for name in list(dev_insts):
             decomms.pop(name).free()
             dev_insts.pop(name).free()
@@ -445,6 +513,7 @@ def main():
                     assert r["proof"] == last_proof[name]["proof"], f"{name}: reference-span proof differs from the timed region's"
                     g.free()
             span_s = time.perf_counter() - ts
+            line["value_reference_span"] = total_cons_step / span_s  # the reference's own timed span, see reference_span.scope
             line["reference_span"] = {
                 "ms_per_trace": round(span_s * 1e3, 1), "constraints_per_s": total_cons_step / span_s, "ms": span,
                 "scope": "per instance, serially: witness inputs in host memory -> gadget + witness synthesis + Instance::new "
@@ -454,31 +523,41 @@ def main():
     # ---- CPU baseline: the oracle on a bounded sample, rank 0, N=1 only ----
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         import oracle_lib as O
-        threads = min(os.cpu_count() or 1, 16)
+        all_cores = min(os.cpu_count() or 1, 64)
         lab = "L1" if trace == "lenet" else trace
         sm = G.synthetic_mult_instance(lab, args.cpu_sample_mult) if G.CONFIGS[lab]["n_mult"] else None
         sa = G.synthetic_add_instance(lab, args.cpu_sample_add)
         sample_cons = (sm.num_cons_unpadded if sm else 0) + sa.num_cons_unpadded
-        t0 = time.perf_counter()
-        tm = {}
-        cpu_prove = (lambda dd: O.snark_prove(dd, SEED_C, SEED_P, threads=threads)) if args.snark else \
+        dm, da = (sm.as_dict() if sm else None), sa.as_dict()
+
+        def cpu_run(threads):
+            """the C oracle (restated reference prover) on the sample; SNARK::encode excluded on both sides"""
+            os.environ["OMP_NUM_THREADS"] = str(threads)
+            t0 = time.perf_counter()
+            tm, enc_s = {}, 0.0
+            prove = (lambda dd: O.snark_prove(dd, SEED_C, SEED_P, threads=threads)) if args.snark else \
                     (lambda dd: O.sat_prove(dd, SEED_C, SEED_P, threads=threads))
-        enc_s = 0.0
-        if sm:
-            r1 = cpu_prove(sm.as_dict())
-            tm = dict(O.sat_timings(), **({"spark_" + k: v for k, v in O.spark_timings().items()} if args.snark else {}))
+            if dm is not None:
+                assert len(prove(dm)["proof"])
+                tm = dict(O.sat_timings(), **({"spark_" + k: v for k, v in O.spark_timings().items()} if args.snark else {}))
+                enc_s += O.spark_timings()["encode"] if args.snark else 0.0
+            assert len(prove(da)["proof"])
             enc_s += O.spark_timings()["encode"] if args.snark else 0.0
-            assert len(r1["proof"])
-        r2 = cpu_prove(sa.as_dict())
-        enc_s += O.spark_timings()["encode"] if args.snark else 0.0
-        cpu_s = time.perf_counter() - t0 - enc_s  # SNARK::encode excluded on both sides
-        assert len(r2["proof"])
+            return time.perf_counter() - t0 - enc_s, tm
+
+        s_all, tm_all = cpu_run(all_cores)
+        s_one, tm_one = cpu_run(1)
         line["cpu_baseline"] = {
-            "value": sample_cons / cpu_s, "unit": "constraints/s", "cores": threads, "kind": "port",
+            "value": sample_cons / s_all, "unit": "constraints/s", "cores": all_cores, "kind": "port",
             "sample": f"{args.cpu_sample_mult if sm else 0} point-mults + {sa.num_cons_unpadded // 10} point-adds drawn like layer {lab} "
-                      f"({sample_cons} constraints), C oracle (restated reference prover), OpenMP rows in the commitment "
-                      f"(as rayon in the reference), single-threaded sum-checks; {cpu_s:.1f} s",
-            "spans_ms_mult": {kk: round(vv * 1e3, 1) for kk, vv in tm.items()},
+                      f"({sample_cons} constraints; 2^17 padded for the point-mult instance), C oracle (restated reference prover): OpenMP "
+                      f"over the commitment rows (as rayon in the reference), single-threaded sum-checks; {s_all:.1f} s on {all_cores} "
+                      f"threads, {s_one:.1f} s on 1",
+            "single_thread": {"value": sample_cons / s_one, "cores": 1, "seconds": round(s_one, 2),
+                              "note": "comparable with the single-core profile of Spartan/README.md:338-377 (2^20 constraints: "
+                                      "SNARK::prove 39.1 s = 26.8 k constraints/s on one i7-1065G7 core)"},
+            "spans_ms_mult": {kk: round(vv * 1e3, 1) for kk, vv in tm_all.items()},
+            "spans_ms_mult_single_thread": {kk: round(vv * 1e3, 1) for kk, vv in tm_one.items()},
         }
 
     if rank == 0:

@@ -65,6 +65,8 @@ int vpin_ctx_set_progress_flag(vpin_ctx* ctx, int* flag);
  * workgroups per CU: 3 % slower alone, but a large instance's commitment no longer stalls every other stream for its
  * whole duration). */
 int vpin_ctx_set_shared_device(vpin_ctx* ctx, int on);
+/* free / total HBM of the context's device, bytes (the table budgets are chosen from `total`) */
+int vpin_ctx_mem_info(vpin_ctx* ctx, size_t* free_bytes, size_t* total_bytes);
 int vpin_ctx_sync(vpin_ctx* ctx);
 
 /* ---- tables: device-resident Vec<Scalar> ---------------------------------------- */
@@ -79,6 +81,8 @@ size_t vpin_table_len(const vpin_table* t); /* DensePolynomial::len(), halves on
 void* vpin_table_device_ptr(const vpin_table* t);
 /* Index<usize> for DensePolynomial (dense_mlpoly.rs:295-302): read n scalars from off */
 int vpin_table_read(vpin_ctx* ctx, const vpin_table* t, size_t off, size_t n, uint8_t* out);
+/* the reverse: n scalars from host memory into the table's allocation at element offset `off` (len is unchanged) */
+int vpin_table_write(vpin_ctx* ctx, vpin_table* t, size_t off, size_t n, const uint8_t* src);
 
 /* ---- sum-check round reductions -------------------------------------------------- */
 /* Round evaluation loop of ZKSumcheckInstanceProof::prove_cubic_with_additive_term
@@ -396,6 +400,7 @@ int vpin_host_commit(const char* label, const uint8_t* v_mont, size_t n, const u
 #define VPIN_K_SPARK_BUILD 9 /* SPARK gathers, hash layer, product-tree levels, slice evaluations */
 #define VPIN_K_SPARK_ROUND_BIG 10 /* the subset of class 8 with >= 2^20 pairs per circuit: the streaming regime (also counted in 8) */
 #define VPIN_K_MSM_ROWS 11 /* the subset of class 6 that is a row commitment of >= 128 rows (msm_rows_kernel; also counted in 6) */
+#define VPIN_K_SPARK_TAIL 12 /* persistent tail launches (all the small rounds of one layer; time includes the host's turn-arounds) */
 #define VPIN_K_COUNT 16
 typedef struct {
   uint64_t launches;

@@ -151,15 +151,12 @@ def next_pow2(x):
 
 
 def dev_table(ctx, host=None, rows=None):
-    """device tensor (rows rounded up to a power of two, zero filled, `host` copied to its front) and a vpin_table
-    view on it (vpin_table_wrap); torch is only the device-memory plumbing here"""
-    import torch
+    """zero-filled device table of rows rounded up to a power of two, `host` copied to its front"""
     rows = next_pow2(rows if rows is not None else host.shape[0])
-    t = torch.zeros((rows, 4), dtype=torch.int64, device="cuda")
+    t = ctx.alloc(rows)
     if host is not None:
-        t[:host.shape[0]] = torch.from_numpy(np.ascontiguousarray(host).view(np.int64)).cuda()
-    torch.cuda.synchronize()
-    return t, ctx.wrap(t.data_ptr(), rows)
+        t.write(0, host)
+    return t
 
 
 def batched_round(ctx, forest_v, n, ncirc, length, E_v, e_off, r, lead, dotp=None, first_fold=0):
@@ -180,31 +177,27 @@ def batched_round(ctx, forest_v, n, ncirc, length, E_v, e_off, r, lead, dotp=Non
 def test_spark_batched_rounds_vs_oracle(ctx, lg_pairs, ncirc, with_dotp, lead):
     """three consecutive rounds of prove_cubic_batched on level 0 of a forest: round 0 unbound (<false,*>), then two
     bound rounds (<true,*>; the dot-product tables fold into scratch first, then in place)"""
-    import torch
     rng = np.random.default_rng(7000 + lg_pairs * 16 + ncirc + 2 * lead)
     h = 2 << lg_pairs  # entries per half: pairs = h/2 in round 0
     n = 2 * h
     zeros = np.zeros((h, 4), dtype=np.uint64)
     A = [fast_table(rng, h, zero_frac=0.1) for _ in range(ncirc)]
     B = [fast_table(rng, h, zero_frac=0.1) for _ in range(ncirc)]
-    forest, forest_v = dev_table(ctx, rows=ncirc * 2 * n)
+    forest_v = dev_table(ctx, rows=ncirc * 2 * n)
     for t in range(ncirc):
-        forest[t * 2 * n:t * 2 * n + h] = torch.from_numpy(A[t].view(np.int64)).cuda()
-        forest[t * 2 * n + h:t * 2 * n + n] = torch.from_numpy(B[t].view(np.int64)).cuda()
-    torch.cuda.synchronize()
+        forest_v.write(t * 2 * n, A[t])
+        forest_v.write(t * 2 * n + h, B[t])
     k = lg_pairs + 1  # rounds of this layer; E_j = eq(rand[j+1..]) has h >> (j+1) entries
     rand = fast_table(rng, k)
     Es = [O.eq_evals(rand[j + 1:]) for j in range(3)]
-    E_dev, E_v = dev_table(ctx, np.concatenate(Es))
+    E_v = dev_table(ctx, np.concatenate(Es))
     e_offs = [0, len(Es[0]), len(Es[0]) + len(Es[1])]
     dotp = None
     if with_dotp:
         N = n
         derefs = fast_table(rng, 6 * N, zero_frac=0.05)
         vals = fast_table(rng, 3 * N, zero_frac=0.4)
-        pairs_tv = [dev_table(ctx, derefs), dev_table(ctx, vals), dev_table(ctx, rows=18 * (N // 4))]
-        keep = [x[0] for x in pairs_tv]
-        dotp = [x[1] for x in pairs_tv]
+        dotp = [dev_table(ctx, derefs), dev_table(ctx, vals), dev_table(ctx, rows=18 * (N // 4))]
         hN = N // 2
         D = []  # per dot-product circuit half k = 2m + half: (L, R, W)
         for kk in range(6):
@@ -237,17 +230,16 @@ def test_spark_batched_rounds_vs_oracle(ctx, lg_pairs, ncirc, with_dotp, lead):
             length //= 2
         r = rand_scalar(rng)
     # folded tables on the device = the oracle's folds (live length after two binds: h/4)
-    torch.cuda.synchronize()
     live = len(A[0])
-    f_host = forest.cpu().numpy().view(np.uint64)
     for t in range(ncirc):
         o = t * 2 * n
-        assert np.array_equal(f_host[o:o + live], A[t]) and np.array_equal(f_host[o + h:o + h + live], B[t]), f"circuit {t}"
+        assert np.array_equal(forest_v.read(o, live), A[t]) and np.array_equal(forest_v.read(o + h, live), B[t]), f"circuit {t}"
     if with_dotp:
-        s_host = keep[2].cpu().numpy().view(np.uint64)
         q4 = N // 4
         for kk in range(6):
             for tt in range(3):
-                assert np.array_equal(s_host[(3 * kk + tt) * q4:(3 * kk + tt) * q4 + live], D[kk][tt])
+                assert np.array_equal(dotp[2].read((3 * kk + tt) * q4, live), D[kk][tt])
         # the committed polynomials were not touched by the first fold
-        assert np.array_equal(keep[0].cpu().numpy().view(np.uint64)[:6 * N], derefs)
+        assert np.array_equal(dotp[0].read(0, 6 * N), derefs)
+    for t in [forest_v, E_v] + (dotp or []):
+        t.free()

@@ -30,10 +30,8 @@ def ctx():
 
 @pytest.fixture(scope="module")
 def big(ctx):
-    import torch
     xyzt, og = O.gens_stream_xyzt(NB, b"gens_r1cs_eval")
-    total = torch.cuda.mem_get_info(0)[1]
-    g = ctx.gens_shared("gens_r1cs_eval", xyzt, 80 if total >= (200 << 30) else 24)
+    g = ctx.gens_shared("gens_r1cs_eval", xyzt, 80 if ctx.device_total_bytes() >= (200 << 30) else 24)
     import vpin_amd
     lay = (C.c_size_t * 6)()
     L = vpin_amd.lib()
@@ -79,12 +77,11 @@ def sum_parts(parts_row):
     return bytes(out)
 
 
-def test_table_has_two_segments_on_a_288gb_part(big):
+def test_table_has_two_segments_on_a_288gb_part(ctx, big):
     g, og, lay = big
     c, W, split, c_hi, W_hi, bases = lay
     assert bases >= NB
-    import torch
-    if torch.cuda.mem_get_info(0)[1] >= (200 << 30):
+    if ctx.device_total_bytes() >= (200 << 30):
         assert split == 16386 and c == 12 and 6 < c_hi < 12, lay  # the layout DESIGN.md section 3 describes
 
 

@@ -11,7 +11,7 @@ HEADER = os.path.join(ROOT, "include", "vpin_hip.h")
 
 KERNEL_CLASSES = {
     0: "sc_cubic", 1: "sc_quad", 2: "sc_bind", 3: "sc_cubic_fused", 4: "sc_quad_fused", 5: "eq", 6: "msm", 7: "sc_tail",
-    8: "spark_round", 9: "spark_build", 10: "spark_round_big", 11: "msm_rows",
+    8: "spark_round", 9: "spark_build", 10: "spark_round_big", 11: "msm_rows", 12: "spark_tail",
 }
 K_COUNT = 16
 
@@ -212,6 +212,12 @@ class Table:
         _chk(lib().vpin_table_read(self.ctx.h, self.h, off, n, out.ctypes.data_as(C.c_void_p)), "vpin_table_read")
         return out
 
+    def write(self, off, arr):
+        a = np.ascontiguousarray(arr, dtype=np.uint64).reshape(-1, 4)
+        L = lib()
+        L.vpin_table_write.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p]
+        _chk(L.vpin_table_write(self.ctx.h, self.h, off, a.shape[0], a.ctypes.data_as(C.c_void_p)), "vpin_table_write")
+
     def clone(self):
         h = C.c_void_p()
         _chk(lib().vpin_table_clone(self.ctx.h, self.h, C.byref(h)), "vpin_table_clone")
@@ -351,6 +357,13 @@ class Context:
 
     def sync(self):
         _chk(lib().vpin_ctx_sync(self.h), "vpin_ctx_sync")
+
+    def device_total_bytes(self):
+        f, t = C.c_size_t(), C.c_size_t()
+        L = lib()
+        L.vpin_ctx_mem_info.argtypes = [C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+        _chk(L.vpin_ctx_mem_info(self.h, C.byref(f), C.byref(t)), "vpin_ctx_mem_info")
+        return t.value
 
     def set_shared_device(self, on=True):
         """other contexts prove on this device concurrently: leave them a share of every CU"""

@@ -223,6 +223,13 @@ int vpin_ctx_set_shared_device(vpin_ctx* c, int on) {
   return VPIN_OK;
 }
 
+int vpin_ctx_mem_info(vpin_ctx* c, size_t* free_bytes, size_t* total_bytes) {
+  if (!c || !free_bytes || !total_bytes) return VPIN_EINVAL;
+  (void)hipSetDevice(c->device);
+  VPIN_HIP_TRY(hipMemGetInfo(free_bytes, total_bytes));
+  return VPIN_OK;
+}
+
 int vpin_ctx_sync(vpin_ctx* c) {
   if (!c) return VPIN_EINVAL;
   VPIN_HIP_TRY(hipStreamSynchronize(c->stream));
@@ -324,6 +331,16 @@ int vpin_table_read(vpin_ctx* c, const vpin_table* t, size_t off, size_t n, uint
   if (n == 0) return VPIN_OK;
   (void)hipSetDevice(c->device);
   VPIN_HIP_TRY(hipMemcpyAsync(out, t->d + off, n * sizeof(fq), hipMemcpyDeviceToHost, c->stream));
+  VPIN_HIP_TRY(hipStreamSynchronize(c->stream));
+  return VPIN_OK;
+}
+
+int vpin_table_write(vpin_ctx* c, vpin_table* t, size_t off, size_t n, const uint8_t* src) {
+  if (!c || !t || !src) return VPIN_EINVAL;
+  if (off + n > t->cap) return VPIN_ESHAPE;
+  if (n == 0) return VPIN_OK;
+  (void)hipSetDevice(c->device);
+  VPIN_HIP_TRY(hipMemcpyAsync(t->d + off, src, n * sizeof(fq), hipMemcpyHostToDevice, c->stream));
   VPIN_HIP_TRY(hipStreamSynchronize(c->stream));
   return VPIN_OK;
 }

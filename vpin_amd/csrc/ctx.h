@@ -81,6 +81,8 @@ struct vpin_ctx {
   vpin::fq* h_spark = nullptr;  // pinned, kSparkPinned fq; the last element's first word is the completion flag
   uint32_t* d_spark_cnt = nullptr;  // device: per-instance and global "blocks done" counters (self-resetting)
   uint32_t spark_seq = 0;           // sequence number of the last flagged launch group
+  uint32_t tail_seq = 0;            // persistent tail kernel (spark.hip): sequence base of the current / next launch
+  int tail_rounds = 0;
   bool shared_device = false;  // other contexts prove on this device at the same time (vpin_ctx_set_shared_device)
   void* h_bullet = nullptr;  // pinned staging of the bullet reduction's per-round results (bullet.hip), 64 KiB
   volatile int* progress_flag = nullptr;  // optional host word: set to 1 when a SNARK's sat part is done

@@ -295,14 +295,35 @@ static int batched_prove(vpin_ctx* c, vpin::SparkForest& f, DotpCtx* dotp, Trans
       }
       Fq cn = Fq::zero();
       for (int t = 0; t < npc; t++) cn = cn + claims[t] * coeffs[t];
+      // Rounds with at most spark_tail_pairs() pairs per circuit are proven by ONE resident launch (spark.hip, persistent
+      // tail): the kernel publishes a round's sums to pinned memory and polls a pinned mailbox for the challenge this
+      // loop derives from the transcript.  Larger rounds take one launch each.
+      const size_t tail_pairs = lead_ok ? vpin::spark_tail_pairs() : 0;
+      bool tail_on = false;
+      int tail_j0 = 0;
+      const int ninst = npc + (with_dotp ? 6 : 0);
       for (int j = 0; j < k; j++) {
         const size_t len = j == 0 ? h : (h >> (j - 1));  // live length before this round's launch
         const vpin::fq* E = pyr->d + pyramid_offset(k, j + 1);
         const uint8_t* rprev = j ? B(&r[j - 1]) : nullptr;
-        if ((rc = vpin::spark_prod_round(c, &f, layer_id, len, E, rprev, with_dotp, lead_ok))) return rc;
-        if (with_dotp && (rc = vpin::spark_dotp_round(c, dotp->d->N, dotp->d->comb_ops->d + 12 * dotp->d->N, dotp->comb_derefs, dotp->scratch, len, j == 1, rprev))) return rc;
-        if ((rc = vpin::spark_wait_flag(c))) return rc;
-        const Fq* res = reinterpret_cast<const Fq*>(c->h_spark);
+        if (!tail_on && (h >> (j + 1)) <= tail_pairs) {
+          if ((rc = vpin::spark_tail_launch(c, &f, layer_id, k, j, len, pyr->d, rprev, with_dotp ? dotp->d->N : 0,
+                                            with_dotp ? dotp->d->comb_ops->d + 12 * dotp->d->N : nullptr,
+                                            with_dotp ? dotp->comb_derefs : nullptr, with_dotp ? dotp->scratch : nullptr)))
+            return rc;
+          tail_on = true;
+          tail_j0 = j;
+        }
+        const Fq* res;
+        if (tail_on) {
+          if ((rc = vpin::spark_tail_wait(c, j - tail_j0, ninst))) return rc;
+          res = reinterpret_cast<const Fq*>(vpin::spark_tail_sums(c));
+        } else {
+          if ((rc = vpin::spark_prod_round(c, &f, layer_id, len, E, rprev, with_dotp, lead_ok))) return rc;
+          if (with_dotp && (rc = vpin::spark_dotp_round(c, dotp->d->N, dotp->d->comb_ops->d + 12 * dotp->d->N, dotp->comb_derefs, dotp->scratch, len, j == 1, rprev))) return rc;
+          if ((rc = vpin::spark_wait_flag(c))) return rc;
+          res = reinterpret_cast<const Fq*>(c->h_spark);
+        }
         const Fq rho = rand[j], omr = one - rho;
         Fq S0 = Fq::zero(), S2 = Fq::zero(), S3 = Fq::zero(), T1 = Fq::zero(), Sinf = Fq::zero();
         if (lead_ok) {
@@ -327,6 +348,7 @@ static int batched_prove(vpin_ctx* c, vpin::SparkForest& f, DotpCtx* dotp, Trans
         unipoly_from_evals(evals, 4, cf);
         append_unipoly(tr, cf, 4);
         Fq rj = tr.challenge_scalar("challenge_nextround");
+        if (tail_on && j + 1 < k) vpin::spark_tail_reply(c, j - tail_j0, B(&rj));  // the kernel folds while the host finishes the round
         r[j] = rj;
         e = unipoly_eval(cf, 4, rj);
         if (lead_ok) cn = S0 + rj * ((T1 - S0 - Sinf) + rj * Sinf);   // T(r_j)
@@ -334,20 +356,37 @@ static int batched_prove(vpin_ctx* c, vpin::SparkForest& f, DotpCtx* dotp, Trans
         polys[3 * j] = cf[0]; polys[3 * j + 1] = cf[2]; polys[3 * j + 2] = cf[3];
       }
       // final fold of the two live entries per table with r_{k-1}
-      if ((rc = vpin::spark_collect(c, &f, layer_id, with_dotp ? dotp->d : nullptr, with_dotp ? dotp->comb_derefs : nullptr,
-                                    with_dotp ? dotp->scratch : nullptr, with_dotp, k >= 2)))
-        return rc;
-      const Fq* res = reinterpret_cast<const Fq*>(c->h_spark);
       const Fq rl = r[k - 1];
-      for (int t = 0; t < npc; t++) {
-        cl[t] = res[4 * t] + rl * (res[4 * t + 1] - res[4 * t]);
-        cr[t] = res[4 * t + 2] + rl * (res[4 * t + 3] - res[4 * t + 2]);
-      }
-      if (with_dotp) {
-        const Fq* q = reinterpret_cast<const Fq*>(c->h_spark) + 64;
-        for (int t = 0; t < 3; t++) out.dotp[t].resize(6);
-        for (int i = 0; i < 6; i++)
-          for (int t = 0; t < 3; t++) out.dotp[t][i] = q[6 * i + 2 * t] + rl * (q[6 * i + 2 * t + 1] - q[6 * i + 2 * t]);
+      if (tail_on) {
+        const Fq* fin = reinterpret_cast<const Fq*>(vpin::spark_tail_final(c));
+        for (int t = 0; t < npc; t++) {
+          cl[t] = fin[6 * t] + rl * (fin[6 * t + 1] - fin[6 * t]);
+          cr[t] = fin[6 * t + 2] + rl * (fin[6 * t + 3] - fin[6 * t + 2]);
+        }
+        if (with_dotp) {
+          for (int t = 0; t < 3; t++) out.dotp[t].resize(6);
+          for (int i = 0; i < 6; i++)
+            for (int t = 0; t < 3; t++) {
+              const Fq* q = fin + 6 * (npc + i) + 2 * t;
+              out.dotp[t][i] = q[0] + rl * (q[1] - q[0]);
+            }
+        }
+        vpin::spark_tail_end(c);
+      } else {
+        if ((rc = vpin::spark_collect(c, &f, layer_id, with_dotp ? dotp->d : nullptr, with_dotp ? dotp->comb_derefs : nullptr,
+                                      with_dotp ? dotp->scratch : nullptr, with_dotp, k >= 2)))
+          return rc;
+        const Fq* res = reinterpret_cast<const Fq*>(c->h_spark);
+        for (int t = 0; t < npc; t++) {
+          cl[t] = res[4 * t] + rl * (res[4 * t + 1] - res[4 * t]);
+          cr[t] = res[4 * t + 2] + rl * (res[4 * t + 3] - res[4 * t + 2]);
+        }
+        if (with_dotp) {
+          const Fq* q = reinterpret_cast<const Fq*>(c->h_spark) + 64;
+          for (int t = 0; t < 3; t++) out.dotp[t].resize(6);
+          for (int i = 0; i < 6; i++)
+            for (int t = 0; t < 3; t++) out.dotp[t][i] = q[6 * i + 2 * t] + rl * (q[6 * i + 2 * t + 1] - q[6 * i + 2 * t]);
+        }
       }
     }
 

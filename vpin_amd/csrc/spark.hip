@@ -20,6 +20,7 @@
 // sum_i E[i]*(A_x*B_x)[i] for x = 0,2,3 with E the read-only suffix table of the round, and the
 // host applies the per-round scalar.  Per pair: fold 2 tables (4 products), 3 products A_x*B_x,
 // 3 products by E: 10 Montgomery products, 9 loads, 4 stores.  HBM-streaming integer work.
+#include <chrono>
 #include <cstdlib>
 
 #include "sc_dev.h"
@@ -623,6 +624,264 @@ int spark_slice_evals(vpin_ctx* c, const fq* table, size_t len, int nslices, con
   VPIN_HIP_TRY(hipGetLastError());
   return spark_wait(c);
 }
+
+
+// ---- persistent tail: all the small rounds of a layer in ONE launch ---------------------------------------------
+// Once a layer's tables are down to kTailPairs pairs per circuit every further round is latency, not bandwidth:
+// the classic path pays a launch, a finisher and a pinned-flag round trip per round (25-35 us measured).  The tail
+// kernel stays resident for the rest of the layer instead: one workgroup per circuit (plus one per dot-product
+// half on layer 0) folds and evaluates its own tables, publishes its three scalars and a sequence word to pinned
+// host memory, then polls a pinned host mailbox for the round's challenge.  The transcript stays on the host:
+// Keccak-f[1600] costs 5.8 us on 25 lanes of a wave and 8.8-11 us on one (two permutations per round), the
+// mailbox round trip 2.9 us (tools/ubench_fs.hip, profiles/r02_ubench_fs.txt).  No workgroup depends on another one
+// (the circuits only share the challenge), so there is no grid barrier and nothing to deadlock on; every poll loop is
+// bounded and watches an abort word, so the grid always drains.
+struct TailArgs {
+  fq* forest; size_t stride, off, h; int ncirc;  // product circuits: blockIdx.x < ncirc
+  const fq* pyr; int k;                           // suffix pyramid of the layer's k rounds
+  int j0; size_t len0;                            // first round of the tail, live length before it
+  fq r_prev;                                      // r_{j0-1} (j0 > 0)
+  const fq* derefs; const fq* vals; fq* scratch; size_t N;  // dot-product halves: blockIdx.x - ncirc = 0..5
+  fq* up_sums;             // pinned [inst][3]
+  fq* up_final;            // pinned [inst][6]: the two live entries of every table after the last round
+  uint32_t* up_seq;        // pinned [inst]
+  const uint32_t* down;    // pinned, 3 chunks of {seq, w, w, w}: the challenge in 16-byte pieces
+  const uint32_t* abort_flag;
+  uint32_t seq0;           // round j publishes / waits for seq0 + (j - j0) + 1
+  unsigned long long* trace;  // VPIN_TAIL_TRACE: pinned, per round {start, published, reply seen, -} in 100 MHz ticks (instance 0)
+};
+
+constexpr int kTailBlock = 512;
+constexpr long kTailSpinLimit = 4000000;  // ~10 s of polling: a lost host ends the kernel instead of hanging the GPU
+
+// the three 16-byte pieces of the host's reply in one go: three uncached (system-scope) loads in flight, one wait
+__device__ __forceinline__ void load48_system(const uint32_t* p, uint4& c0, uint4& c1, uint4& c2) {
+  asm volatile(
+      "global_load_dwordx4 %0, %3, off sc0 sc1\n\t"
+      "global_load_dwordx4 %1, %3, off offset:16 sc0 sc1\n\t"
+      "global_load_dwordx4 %2, %3, off offset:32 sc0 sc1\n\t"
+      "s_waitcnt vmcnt(0)"
+      : "=&v"(c0), "=&v"(c1), "=&v"(c2)
+      : "v"(p)
+      : "memory");
+}
+
+__device__ __forceinline__ fq tail_block_sum3(fq* e) {
+  __shared__ fq sh[kTailBlock / 64][3];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    fq t = fq_wave_sum(e[k]);
+    if (lane == 0) sh[wave][k] = t;
+  }
+  __syncthreads();
+  fq t = fq_zero();
+  if (threadIdx.x < 3) {
+    t = sh[0][threadIdx.x];
+#pragma unroll
+    for (int w = 1; w < kTailBlock / 64; w++) t = fq_add(t, sh[w][threadIdx.x]);
+  }
+  __syncthreads();
+  return t;
+}
+
+__global__ __launch_bounds__(kTailBlock) void spark_tail_kernel(TailArgs a) {
+  const int inst = blockIdx.x;
+  const bool is_dotp = inst >= a.ncirc;
+  __shared__ fq sh_r;
+  __shared__ int sh_stop;
+  fq r = a.r_prev;
+  size_t len = a.len0;
+  fq* A = nullptr;
+  fq* Bt = nullptr;
+  const fq* src[3] = {nullptr, nullptr, nullptr};
+  fq* dst[3] = {nullptr, nullptr, nullptr};
+  if (!is_dotp) {
+    A = a.forest + (size_t)inst * a.stride + a.off;
+    Bt = A + a.h;
+  } else {
+    const int kk = inst - a.ncirc, m = kk >> 1, half = kk & 1;
+    const size_t hN = a.N / 2, q4 = a.N / 4;
+    src[0] = a.derefs + (size_t)m * a.N + (size_t)half * hN;
+    src[1] = a.derefs + (size_t)(3 + m) * a.N + (size_t)half * hN;
+    src[2] = a.vals + (size_t)m * a.N + (size_t)half * hN;
+#pragma unroll
+    for (int t = 0; t < 3; t++) dst[t] = a.scratch + (size_t)(3 * kk + t) * q4;
+  }
+  for (int j = a.j0; j < a.k; j++) {
+    const bool bind = j > 0;
+    const size_t pairs = bind ? len / 4 : len / 2;
+    const fq* E = a.pyr + ((((size_t)1) << a.k) - (((size_t)2) << (a.k - (j + 1))));  // pyramid level j + 1
+    Acc<4> acc;
+    acc.init();
+    if (a.trace && inst == 0 && threadIdx.x == 0) a.trace[4 * (j - a.j0)] = wall_clock64();
+    if (!is_dotp) {
+      for (size_t i = threadIdx.x; i < pairs; i += kTailBlock) {
+        fq p1, d1, p2, d2;
+        if (bind) { fold_pd(A, i, pairs, r, p1, d1); fold_pd(Bt, i, pairs, r, p2, d2); }
+        else { load_pd(A, i, pairs, p1, d1); load_pd(Bt, i, pairs, p2, d2); }
+        acc.lead_bc(p1, d1, p2, d2, fq_load(E + i));
+      }
+    } else {
+      // round 0 reads the committed polynomials as they are, round 1 folds them into scratch, later rounds fold scratch in place
+      const bool from_src = j <= 1;
+      for (size_t i = threadIdx.x; i < pairs; i += kTailBlock) {
+        fq u[3], p1, d1, p2, d2;
+        if (bind) {
+          fold_pd2(from_src ? src[0] : dst[0], dst[0], i, pairs, r, p1, d1);
+          fold_pd2(from_src ? src[1] : dst[1], dst[1], i, pairs, r, p2, d2);
+        } else { load_pd(src[0], i, pairs, p1, d1); load_pd(src[1], i, pairs, p2, d2); }
+        acc.stage_bc(u, p1, d1, p2, d2);
+        if (bind) fold_pd2(from_src ? src[2] : dst[2], dst[2], i, pairs, r, p1, d1);
+        else load_pd(src[2], i, pairs, p1, d1);
+        acc.stage_a(u, p1, d1);
+      }
+    }
+    if (bind) len /= 2;
+    fq t = tail_block_sum3(acc.e);  // its barriers also order this round's folds before the next round's loads
+    if (threadIdx.x < 3) fq_store(&a.up_sums[3 * (size_t)inst + threadIdx.x], t);
+    if (j == a.k - 1) {
+      // live length is 2: both entries of every table, for the host to bind with the last challenge
+      const int ne = is_dotp ? 6 : 4;
+      if ((int)threadIdx.x < ne) {
+        const int tt = threadIdx.x >> 1, e = threadIdx.x & 1;
+        const fq* tab;
+        if (!is_dotp) tab = tt ? Bt : A;
+        else tab = (a.k >= 2) ? dst[tt] : src[tt];  // no fold has happened in a one-round layer
+        fq_store(&a.up_final[6 * (size_t)inst + threadIdx.x], fq_load(tab + e));
+      }
+    }
+    if (threadIdx.x < 8) __threadfence_system();  // the threads that wrote to host memory
+    __syncthreads();
+    if (a.trace && inst == 0 && threadIdx.x == 0) a.trace[4 * (j - a.j0) + 1] = wall_clock64();
+    if (threadIdx.x == 0)
+      __hip_atomic_store(&a.up_seq[inst], a.seq0 + (uint32_t)(j - a.j0) + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (j == a.k - 1) break;
+    if (threadIdx.x == 0) {
+      const uint32_t want = a.seq0 + (uint32_t)(j - a.j0) + 1u;
+      int stop = 1;
+      for (long spin = 0; spin < kTailSpinLimit; spin++) {
+        uint4 c0, c1, c2;
+        load48_system(a.down, c0, c1, c2);
+        if (c0.x == want && c1.x == want && c2.x == want) {
+          fq rr;
+          rr.v[0] = c0.y; rr.v[1] = c0.z; rr.v[2] = c0.w; rr.v[3] = c1.y; rr.v[4] = c1.z; rr.v[5] = c1.w; rr.v[6] = c2.y; rr.v[7] = c2.z;
+          sh_r = rr;
+          stop = 0;
+          break;
+        }
+        if (__hip_atomic_load(a.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) break;
+      }
+      sh_stop = stop;
+      if (a.trace && inst == 0) a.trace[4 * (j - a.j0) + 2] = wall_clock64();
+    }
+    __syncthreads();
+    if (sh_stop) return;
+    r = sh_r;
+  }
+}
+
+// pinned mailbox carved out of ctx->h_spark (kSparkPinned fq = 256 KiB): element offsets
+constexpr size_t kTailTrace = 4096 + 256;  // 64 rounds x 4 x u64
+constexpr size_t kTailSums = 4096, kTailFinal = 4096 + 64, kTailWords = 4096 + 192;  // words: up_seq[32] | abort | .. | down[12] at +64
+static inline uint32_t* tail_words(vpin_ctx* c) { return reinterpret_cast<uint32_t*>(c->h_spark + kTailWords); }
+
+size_t spark_tail_pairs() {
+  static const size_t n = [] { const char* e = getenv("VPIN_SPARK_TAIL_PAIRS"); long v = e ? atol(e) : 1024; return (size_t)(v < 0 ? 0 : v); }();
+  return n;  // 0 disables the persistent tail (classic per-round launches only)
+}
+
+int spark_tail_launch(vpin_ctx* c, const SparkForest* f, int level, int k, int j0, size_t len0, const fq* pyr, const uint8_t* r_prev,
+                      size_t N, const fq* vals, const fq* comb_derefs, fq* scratch) {
+  if (!c || !f || !f->base || !pyr || k < 1 || j0 < 0 || j0 >= k || (j0 > 0 && !r_prev) || f->ncirc > 12) return VPIN_EINVAL;
+  const bool with_dotp = vals != nullptr;
+  if (with_dotp && (!comb_derefs || !scratch || f->ncirc != 12 || level != 0 || N != f->n)) return VPIN_EINVAL;
+  const size_t h = f->n >> (level + 1);
+  if (h != ((size_t)1 << k) || len0 != (j0 == 0 ? h : (h >> (j0 - 1)))) return VPIN_ESHAPE;
+  int rc = spark_pinned(c);
+  if (rc) return rc;
+  (void)hipSetDevice(c->device);
+  TailArgs a{};
+  a.forest = f->base; a.stride = f->stride(); a.off = f->level_off(level); a.h = h; a.ncirc = f->ncirc;
+  a.pyr = pyr; a.k = k; a.j0 = j0; a.len0 = len0;
+  if (r_prev) a.r_prev = load_host_fq(r_prev);
+  a.derefs = comb_derefs; a.vals = vals; a.scratch = scratch; a.N = N;
+  a.up_sums = c->h_spark + kTailSums;
+  a.up_final = c->h_spark + kTailFinal;
+  uint32_t* w = tail_words(c);
+  a.up_seq = w; a.abort_flag = w + 32; a.down = w + 64;
+  w[32] = 0;
+  a.seq0 = c->tail_seq;
+  static const bool trace_on = getenv("VPIN_TAIL_TRACE") != nullptr;
+  a.trace = trace_on ? reinterpret_cast<unsigned long long*>(c->h_spark + kTailTrace) : nullptr;
+  if (trace_on) memset(c->h_spark + kTailTrace, 0, 64 * 32);
+  c->tail_rounds = k - j0;
+  const int ninst = f->ncirc + (with_dotp ? 6 : 0);
+  {
+    ProfScope ps(c, VPIN_K_SPARK_TAIL, 0.0);
+    hipLaunchKernelGGL(spark_tail_kernel, dim3(ninst), dim3(kTailBlock), 0, c->stream, a);
+  }
+  VPIN_HIP_TRY(hipGetLastError());
+  return VPIN_OK;
+}
+
+// results of tail round `idx` (0-based within the tail) of all `ninst` instances: sums at ctx->h_spark[kTailSums + 3*inst + x]
+int spark_tail_wait(vpin_ctx* c, int idx, int ninst) {
+  volatile uint32_t* up = tail_words(c);
+  const uint32_t want = c->tail_seq + (uint32_t)idx + 1u;
+  const auto t0 = std::chrono::steady_clock::now();
+  for (long spins = 0;; spins++) {
+    int done = 0;
+    for (int i = 0; i < ninst; i++) done += (up[i] == want);
+    if (done == ninst) return VPIN_OK;
+    __builtin_ia32_pause();
+    if ((spins & 0xfff) == 0xfff) {
+      (void)hipStreamQuery(c->stream);  // nudges runtimes / profilers that submit lazily
+      if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 20.0) {
+        tail_words(c)[32] = 1;  // abort: every workgroup leaves its poll loop
+        (void)hipStreamSynchronize(c->stream);
+        set_last_error("spark_tail_wait: the persistent round kernel did not answer", hipErrorUnknown);
+        return VPIN_EHIP;
+      }
+    }
+  }
+}
+
+// challenge of tail round `idx` to the kernel: three 16-byte stores {seq, 3 words} (single-copy atomic on x86-64), so a
+// poll that sees the sequence number in all three pieces holds the whole scalar
+void spark_tail_reply(vpin_ctx* c, int idx, const uint8_t r[32]) {
+  uint32_t* down = tail_words(c) + 64;
+  const uint32_t seq = c->tail_seq + (uint32_t)idx + 1u;
+  uint32_t wv[8];
+  memcpy(wv, r, 32);
+  typedef uint32_t v4 __attribute__((vector_size(16), aligned(16)));
+  v4 c0 = {seq, wv[0], wv[1], wv[2]}, c1 = {seq, wv[3], wv[4], wv[5]}, c2 = {seq, wv[6], wv[7], 0u};
+  __atomic_thread_fence(__ATOMIC_RELEASE);
+  *reinterpret_cast<volatile v4*>(down) = c0;
+  *reinterpret_cast<volatile v4*>(down + 4) = c1;
+  *reinterpret_cast<volatile v4*>(down + 8) = c2;
+  __atomic_thread_fence(__ATOMIC_SEQ_CST);
+}
+
+// after the last round's results were taken: retire the sequence numbers of this tail
+void spark_tail_end(vpin_ctx* c) {
+  static const bool trace_on = getenv("VPIN_TAIL_TRACE") != nullptr;
+  if (trace_on) {
+    (void)hipStreamSynchronize(c->stream);
+    const unsigned long long* t = reinterpret_cast<const unsigned long long*>(c->h_spark + kTailTrace);
+    fprintf(stderr, "[tail] %d rounds:", c->tail_rounds);
+    for (int i = 0; i < c->tail_rounds && i < 64; i++) {
+      const double comp = (double)(t[4 * i + 1] - t[4 * i]) * 0.01, wait = t[4 * i + 2] ? (double)(t[4 * i + 2] - t[4 * i + 1]) * 0.01 : 0.0;
+      fprintf(stderr, " %.1f+%.1f", comp, wait);
+    }
+    fprintf(stderr, " us (compute+publish, wait for reply)\n");
+  }
+  c->tail_seq += (uint32_t)c->tail_rounds + 1u;
+  c->tail_rounds = 0;
+}
+
+const fq* spark_tail_sums(vpin_ctx* c) { return c->h_spark + kTailSums; }
+const fq* spark_tail_final(vpin_ctx* c) { return c->h_spark + kTailFinal; }
 
 }  // namespace vpin
 

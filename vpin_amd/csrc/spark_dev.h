@@ -89,6 +89,20 @@ int spark_collect(vpin_ctx* c, const SparkForest* f, int level, const vpin_spark
 // over the N/2 entries of half k; synchronises
 int spark_triple_sums(vpin_ctx* c, const vpin_spark_decomm* d, const fq* comb_derefs);
 
+// Persistent tail (spark.hip): rounds j0..k-1 of forest level `level` (h = 2^k entries per half) in ONE launch, one workgroup per
+// circuit (+ the six dot-product halves when vals != nullptr), leading-coefficient form.  The host keeps the transcript:
+// per round spark_tail_wait(idx) -> sums at spark_tail_sums()[3*inst + x] -> spark_tail_reply(idx, r_j) (not after the last
+// round, which also leaves the two live entries of every table at spark_tail_final()[6*inst + 2*table + e]); spark_tail_end
+// retires the launch's sequence numbers.  len0 = live length before round j0; r_prev = r_{j0-1} when j0 > 0.
+size_t spark_tail_pairs();  // rounds with at most this many pairs per circuit go to the tail (0 = never)
+int spark_tail_launch(vpin_ctx* c, const SparkForest* f, int level, int k, int j0, size_t len0, const fq* pyr, const uint8_t* r_prev,
+                      size_t N, const fq* vals, const fq* comb_derefs, fq* scratch);
+int spark_tail_wait(vpin_ctx* c, int idx, int ninst);
+void spark_tail_reply(vpin_ctx* c, int idx, const uint8_t r[32]);
+void spark_tail_end(vpin_ctx* c);
+const fq* spark_tail_sums(vpin_ctx* c);
+const fq* spark_tail_final(vpin_ctx* c);
+
 int spark_wait(vpin_ctx* c);  // stream sync
 
 // out[s] = sum_i table[s*len + i] * eq[i], s < nslices (DensePolynomial::evaluate of every slice at

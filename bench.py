@@ -458,8 +458,7 @@ def main():
             if len(lanes) > 1:
                 cx.set_shared_device(True)
             sec = []
-            props = torch.cuda.get_device_properties(local_rank)
-            cus, clk = props.multi_processor_count, props.clock_rate * 1e3  # Hz
+            cus, clk = cx.device_props()  # compute units, shader clock in Hz
             m = st.get("msm_rows")
             if m and m["ms"] > 0 and m["units"] > 0:
                 # VALU-issue ceiling: one wave-instruction per SIMD per 4 cycles (64 lanes on a 16-lane SIMD); instructions per

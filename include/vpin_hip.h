@@ -65,6 +65,8 @@ int vpin_ctx_set_progress_flag(vpin_ctx* ctx, int* flag);
  * workgroups per CU: 3 % slower alone, but a large instance's commitment no longer stalls every other stream for its
  * whole duration). */
 int vpin_ctx_set_shared_device(vpin_ctx* ctx, int on);
+/* compute units and shader clock (kHz) of the context's device: the VALU-issue ceiling bench.py prices the MSM against */
+int vpin_ctx_device_props(vpin_ctx* ctx, int* num_cus, int* clock_khz);
 /* free / total HBM of the context's device, bytes (the table budgets are chosen from `total`) */
 int vpin_ctx_mem_info(vpin_ctx* ctx, size_t* free_bytes, size_t* total_bytes);
 int vpin_ctx_sync(vpin_ctx* ctx);

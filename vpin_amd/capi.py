@@ -358,6 +358,14 @@ class Context:
     def sync(self):
         _chk(lib().vpin_ctx_sync(self.h), "vpin_ctx_sync")
 
+    def device_props(self):
+        """(compute units, shader clock in Hz)"""
+        cus, khz = C.c_int(), C.c_int()
+        L = lib()
+        L.vpin_ctx_device_props.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        _chk(L.vpin_ctx_device_props(self.h, C.byref(cus), C.byref(khz)), "vpin_ctx_device_props")
+        return cus.value, khz.value * 1e3
+
     def device_total_bytes(self):
         f, t = C.c_size_t(), C.c_size_t()
         L = lib()

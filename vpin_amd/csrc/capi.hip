@@ -223,6 +223,15 @@ int vpin_ctx_set_shared_device(vpin_ctx* c, int on) {
   return VPIN_OK;
 }
 
+int vpin_ctx_device_props(vpin_ctx* c, int* num_cus, int* clock_khz) {
+  if (!c || !num_cus || !clock_khz) return VPIN_EINVAL;
+  hipDeviceProp_t prop;
+  VPIN_HIP_TRY(hipGetDeviceProperties(&prop, c->device));
+  *num_cus = prop.multiProcessorCount;
+  *clock_khz = prop.clockRate;
+  return VPIN_OK;
+}
+
 int vpin_ctx_mem_info(vpin_ctx* c, size_t* free_bytes, size_t* total_bytes) {
   if (!c || !free_bytes || !total_bytes) return VPIN_EINVAL;
   (void)hipSetDevice(c->device);

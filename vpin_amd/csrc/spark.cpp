@@ -191,6 +191,9 @@ struct DotpCtx {  // the six DotProductCircuit halves ride along on layer 0 of t
 
 static int batched_prove(vpin_ctx* c, vpin::SparkForest& f, DotpCtx* dotp, Transcript& tr, Batched& out, std::vector<Fq>& rand) {
   const int npc = f.ncirc, ndotp = dotp ? 6 : 0;
+  static const bool fine = getenv("VPIN_SPARK_TRACE") && atoi(getenv("VPIN_SPARK_TRACE")) >= 2;
+  double t_setup = 0, t_first = 0, t_rounds = 0, t_epi = 0, t_host = 0;
+  auto tl0 = Clock::now();
   const int num_layers = (int)log2z(f.n);
   int rc;
   // host copies of the small top levels
@@ -217,6 +220,7 @@ static int batched_prove(vpin_ctx* c, vpin::SparkForest& f, DotpCtx* dotp, Trans
       for (int i = 0; i < 6; i++) claims[npc + i] = dotp->claims[i];
       nclaims += 6;
     }
+    if (fine) tl0 = Clock::now();
     coeffs = tr.challenge_vector("rand_coeffs_next_layer", nclaims);
     Fq e = Fq::zero();
     for (int i = 0; i < nclaims; i++) e = e + claims[i] * coeffs[i];
@@ -302,6 +306,7 @@ static int batched_prove(vpin_ctx* c, vpin::SparkForest& f, DotpCtx* dotp, Trans
       bool tail_on = false;
       int tail_j0 = 0;
       const int ninst = npc + (with_dotp ? 6 : 0);
+      if (fine) { auto t = Clock::now(); t_setup += secs(tl0, t); tl0 = t; }
       for (int j = 0; j < k; j++) {
         const size_t len = j == 0 ? h : (h >> (j - 1));  // live length before this round's launch
         const vpin::fq* E = pyr->d + pyramid_offset(k, j + 1);
@@ -324,6 +329,7 @@ static int batched_prove(vpin_ctx* c, vpin::SparkForest& f, DotpCtx* dotp, Trans
           if ((rc = vpin::spark_wait_flag(c))) return rc;
           res = reinterpret_cast<const Fq*>(c->h_spark);
         }
+        if (fine) { auto t = Clock::now(); (j == 0 ? t_first : t_rounds) += secs(tl0, t); if (k >= 11) fprintf(stderr, " w%.1f", secs(tl0, t) * 1e6); tl0 = t; }
         const Fq rho = rand[j], omr = one - rho;
         Fq S0 = Fq::zero(), S2 = Fq::zero(), S3 = Fq::zero(), T1 = Fq::zero(), Sinf = Fq::zero();
         if (lead_ok) {
@@ -354,7 +360,9 @@ static int batched_prove(vpin_ctx* c, vpin::SparkForest& f, DotpCtx* dotp, Trans
         if (lead_ok) cn = S0 + rj * ((T1 - S0 - Sinf) + rj * Sinf);   // T(r_j)
         s = s * (rho * rj + omr * (one - rj));
         polys[3 * j] = cf[0]; polys[3 * j + 1] = cf[2]; polys[3 * j + 2] = cf[3];
+        if (fine) { auto t = Clock::now(); t_host += secs(tl0, t); if (k >= 11) fprintf(stderr, " m%.1f", secs(tl0, t) * 1e6); tl0 = t; }
       }
+      if (fine && k >= 11) fprintf(stderr, "\n");
       // final fold of the two live entries per table with r_{k-1}
       const Fq rl = r[k - 1];
       if (tail_on) {
@@ -409,7 +417,11 @@ static int batched_prove(vpin_ctx* c, vpin::SparkForest& f, DotpCtx* dotp, Trans
     ext.push_back(r_layer);
     ext.insert(ext.end(), r.begin(), r.end());
     rand.swap(ext);
+    if (fine) { auto t = Clock::now(); t_epi += secs(tl0, t); tl0 = t; }
   }
+  if (fine)
+    fprintf(stderr, "[spark]   forest of %d x 2^%d: setup %.3f  first result %.3f  later results %.3f  host per-round math %.3f  epilogue %.3f ms\n",
+            npc, num_layers, t_setup * 1e3, t_first * 1e3, t_rounds * 1e3, t_host * 1e3, t_epi * 1e3);
   return VPIN_OK;
 }
 

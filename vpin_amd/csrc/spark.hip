@@ -494,8 +494,12 @@ static int round_partials(vpin_ctx* c, fq** out) {
   return VPIN_OK;
 }
 
+// Pairs per thread: at least VPIN_SPARK_PAIRS_PER_THREAD (default 1) until the launch reaches round_blocks() workgroups per
+// circuit, grid-stride beyond.  A thread's pairs are serial work (~7 us each in a lone wave), so mid-size rounds (2^11..2^16
+// pairs), which cannot fill the device anyway, get one pair per thread: 75 -> ~25 us per round measured on the 2^16 instance;
+// the streaming rounds (>= 2^17 pairs per circuit) sit at the cap either way and keep their 8+ pairs per thread.
 static inline int round_grid(size_t pairs) {
-  static const size_t per_thread = [] { const char* e = getenv("VPIN_SPARK_PAIRS_PER_THREAD"); size_t v = e ? (size_t)atoi(e) : 8; return v ? v : 8; }();
+  static const size_t per_thread = [] { const char* e = getenv("VPIN_SPARK_PAIRS_PER_THREAD"); size_t v = e ? (size_t)atoi(e) : 1; return v ? v : 1; }();
   size_t b = (pairs + kBlock * per_thread - 1) / (kBlock * per_thread);
   if (b < 1) b = 1;
   if (b > (size_t)round_blocks()) b = round_blocks();

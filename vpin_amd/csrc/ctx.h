@@ -83,6 +83,8 @@ struct vpin_ctx {
   uint32_t spark_seq = 0;           // sequence number of the last flagged launch group
   uint32_t tail_seq = 0;            // persistent tail kernel (spark.hip): sequence base of the current / next launch
   int tail_rounds = 0;
+  vpin::fq tail_sums[3 * 18];   // host copies of the current tail round's results (assembled from the mailbox pieces)
+  vpin::fq tail_final[6 * 18];
   bool shared_device = false;  // other contexts prove on this device at the same time (vpin_ctx_set_shared_device)
   void* h_bullet = nullptr;  // pinned staging of the bullet reduction's per-round results (bullet.hip), 64 KiB
   volatile int* progress_flag = nullptr;  // optional host word: set to 1 when a SNARK's sat part is done

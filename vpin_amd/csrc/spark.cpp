@@ -321,7 +321,7 @@ static int batched_prove(vpin_ctx* c, vpin::SparkForest& f, DotpCtx* dotp, Trans
         }
         const Fq* res;
         if (tail_on) {
-          if ((rc = vpin::spark_tail_wait(c, j - tail_j0, ninst))) return rc;
+          if ((rc = vpin::spark_tail_wait(c, j - tail_j0, ninst, npc))) return rc;
           res = reinterpret_cast<const Fq*>(vpin::spark_tail_sums(c));
         } else {
           if ((rc = vpin::spark_prod_round(c, &f, layer_id, len, E, rprev, with_dotp, lead_ok))) return rc;

@@ -646,20 +646,24 @@ struct TailArgs {
   int j0; size_t len0;                            // first round of the tail, live length before it
   fq r_prev;                                      // r_{j0-1} (j0 > 0)
   const fq* derefs; const fq* vals; fq* scratch; size_t N;  // dot-product halves: blockIdx.x - ncirc = 0..5
-  fq* up_sums;             // pinned [inst][3]
-  fq* up_final;            // pinned [inst][6]: the two live entries of every table after the last round
-  uint32_t* up_seq;        // pinned [inst]
-  const uint32_t* down;    // pinned, 3 chunks of {seq, w, w, w}: the challenge in 16-byte pieces
+  // Mailbox in pinned host memory.  Every 32-byte scalar travels as three 16-byte pieces {seq, w, w, w}: a 16-byte store
+  // (GPU -> host) or load (host -> GPU) is one bus transaction, so a piece that carries the expected sequence number is
+  // whole and current -- no fence, no flag, no second round trip.
+  uint32_t* up;            // [inst][kTailUpChunks][4]: sums 0..2, then the 6 final entries
+  const uint32_t* down;    // 3 pieces: the challenge
   const uint32_t* abort_flag;
   uint32_t seq0;           // round j publishes / waits for seq0 + (j - j0) + 1
   unsigned long long* trace;  // VPIN_TAIL_TRACE: pinned, per round {start, published, reply seen, -} in 100 MHz ticks (instance 0)
 };
 
 constexpr int kTailBlock = 512;
-constexpr long kTailSpinLimit = 4000000;  // ~10 s of polling: a lost host ends the kernel instead of hanging the GPU
+constexpr int kTailUpChunks = 32;             // 16-byte pieces per instance: 9 for the sums, 18 for the final entries
+constexpr long kTailSpinLimit = 4000000;      // ~10 s of polling: a lost host ends the kernel instead of hanging the GPU
+constexpr size_t kTailQuadPairs = kTailBlock / 4;  // rounds with at most this many pairs run four lanes per pair
 
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 // the three 16-byte pieces of the host's reply in one go: three uncached (system-scope) loads in flight, one wait
-__device__ __forceinline__ void load48_system(const uint32_t* p, uint4& c0, uint4& c1, uint4& c2) {
+__device__ __forceinline__ void load48_system(const uint32_t* p, u32x4& c0, u32x4& c1, u32x4& c2) {
   asm volatile(
       "global_load_dwordx4 %0, %3, off sc0 sc1\n\t"
       "global_load_dwordx4 %1, %3, off offset:16 sc0 sc1\n\t"
@@ -669,21 +673,38 @@ __device__ __forceinline__ void load48_system(const uint32_t* p, uint4& c0, uint
       : "v"(p)
       : "memory");
 }
+__device__ __forceinline__ void store16_system(uint32_t* p, u32x4 v) {
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void publish_scalar(uint32_t* slot, const fq& v, uint32_t seq) {
+  store16_system(slot, u32x4{seq, v.v[0], v.v[1], v.v[2]});
+  store16_system(slot + 4, u32x4{seq, v.v[3], v.v[4], v.v[5]});
+  store16_system(slot + 8, u32x4{seq, v.v[6], v.v[7], 0u});
+}
+__device__ __forceinline__ fq fq_shfl_from(const fq& a, int src) {
+  fq r;
+#pragma unroll
+  for (int i = 0; i < 8; i++) r.v[i] = __shfl(a.v[i], src, 64);
+  return r;
+}
 
-__device__ __forceinline__ fq tail_block_sum3(fq* e) {
+// sums of e[0..2] over the first `nw` waves of the block; valid in threads 0..2
+__device__ __forceinline__ fq tail_block_sum3(fq* e, int nw, int lo_off) {
   __shared__ fq sh[kTailBlock / 64][3];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (wave < nw) {
 #pragma unroll
-  for (int k = 0; k < 3; k++) {
-    fq t = fq_wave_sum(e[k]);
-    if (lane == 0) sh[wave][k] = t;
+    for (int k = 0; k < 3; k++) {
+      fq t = e[k];
+      for (int off = 32; off >= lo_off; off >>= 1) t = fq_add(t, fq_shfl_xor(t, off));
+      if (lane == 0) sh[wave][k] = t;
+    }
   }
   __syncthreads();
   fq t = fq_zero();
   if (threadIdx.x < 3) {
     t = sh[0][threadIdx.x];
-#pragma unroll
-    for (int w = 1; w < kTailBlock / 64; w++) t = fq_add(t, sh[w][threadIdx.x]);
+    for (int w = 1; w < nw; w++) t = fq_add(t, sh[w][threadIdx.x]);
   }
   __syncthreads();
   return t;
@@ -712,20 +733,53 @@ __global__ __launch_bounds__(kTailBlock) void spark_tail_kernel(TailArgs a) {
 #pragma unroll
     for (int t = 0; t < 3; t++) dst[t] = a.scratch + (size_t)(3 * kk + t) * q4;
   }
+  uint32_t* up = a.up + (size_t)inst * kTailUpChunks * 4;
   for (int j = a.j0; j < a.k; j++) {
-    const bool bind = j > 0;
+    const bool bind = j > 0, last = j == a.k - 1;
     const size_t pairs = bind ? len / 4 : len / 2;
+    const uint32_t seq = a.seq0 + (uint32_t)(j - a.j0) + 1u;
     const fq* E = a.pyr + ((((size_t)1) << a.k) - (((size_t)2) << (a.k - (j + 1))));  // pyramid level j + 1
     Acc<4> acc;
     acc.init();
     if (a.trace && inst == 0 && threadIdx.x == 0) a.trace[4 * (j - a.j0)] = wall_clock64();
-    if (!is_dotp) {
+    int nw = kTailBlock / 64, lo_off = 1;
+    fq mine = fq_zero();  // quad mode: this lane's folded entry (A[i], A[q+i], B[i], B[q+i] by role)
+    if (!is_dotp && pairs <= kTailQuadPairs) {
+      // Four lanes per pair: each folds ONE of the pair's four entries (a lone wave issues one modular product in
+      // ~0.7 us whatever its lanes do, so eight products per lane are eight times that), then lane 0 of the quad
+      // forms E*A_0*B_0 and lane 1 E*dA*dB.
+      const int role = threadIdx.x & 3;
+      const size_t pi = threadIdx.x >> 2;
+      if (pi < pairs) {
+        fq* T = (role & 2) ? Bt : A;
+        const size_t idx = (role & 1) ? pairs + pi : pi;
+        if (bind) {
+          const fq x0 = fq_load(T + idx), x1 = fq_load(T + 2 * pairs + idx);
+          mine = fq_add(x0, fq_mul(r, fq_sub(x1, x0)));
+          fq_store(T + idx, mine);
+        } else {
+          mine = fq_load(T + idx);
+        }
+      }
+      const int lbase = (threadIdx.x & 63) & ~3;  // lane of the quad's role 0
+      const fq pA = fq_shfl_from(mine, lbase), hA = fq_shfl_from(mine, lbase + 1), pB = fq_shfl_from(mine, lbase + 2),
+               hB = fq_shfl_from(mine, lbase + 3);
+      if (pi < pairs && role < 2) {
+        const fq u = role ? fq_mul(fq_sub(hA, pA), fq_sub(hB, pB)) : fq_mul(pA, pB);
+        acc.e[role] = fq_mul(fq_load(E + pi), u);
+      }
+      nw = (int)((4 * pairs + 63) / 64);
+      lo_off = 4;  // after the strides 32..4 lane 0 of a wave holds the role-0 sum, lane 1 the role-1 sum
+      // e[0] lives in role-0 lanes, e[1] in role-1 lanes: bring both to the layout tail_block_sum3 reduces
+      // (every lane may hold all three; foreign roles hold zero, so the quad-strided sums are already right)
+    } else if (!is_dotp) {
       for (size_t i = threadIdx.x; i < pairs; i += kTailBlock) {
         fq p1, d1, p2, d2;
         if (bind) { fold_pd(A, i, pairs, r, p1, d1); fold_pd(Bt, i, pairs, r, p2, d2); }
         else { load_pd(A, i, pairs, p1, d1); load_pd(Bt, i, pairs, p2, d2); }
         acc.lead_bc(p1, d1, p2, d2, fq_load(E + i));
       }
+      if (pairs < (size_t)kTailBlock) nw = (int)((pairs + 63) / 64);
     } else {
       // round 0 reads the committed polynomials as they are, round 1 folds them into scratch, later rounds fold scratch in place
       const bool from_src = j <= 1;
@@ -740,34 +794,52 @@ __global__ __launch_bounds__(kTailBlock) void spark_tail_kernel(TailArgs a) {
         else load_pd(src[2], i, pairs, p1, d1);
         acc.stage_a(u, p1, d1);
       }
+      if (pairs < (size_t)kTailBlock) nw = (int)((pairs + 63) / 64);
     }
     if (bind) len /= 2;
-    fq t = tail_block_sum3(acc.e);  // its barriers also order this round's folds before the next round's loads
-    if (threadIdx.x < 3) fq_store(&a.up_sums[3 * (size_t)inst + threadIdx.x], t);
-    if (j == a.k - 1) {
+    fq t;
+    if (lo_off == 4) {
+      // quad mode: lanes of role 0 carry e[0], role 1 e[1]; reduce each over its own lanes, then lane 1's e[1] joins lane 0
+      fq v = (threadIdx.x & 1) ? acc.e[1] : acc.e[0];
+      __shared__ fq shq[kTailBlock / 64][2];
+      const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+      if (wave < nw) {
+        for (int off = 32; off >= 4; off >>= 1) v = fq_add(v, fq_shfl_xor(v, off));
+        if (lane < 2) shq[wave][lane] = v;
+      }
+      __syncthreads();  // also orders this round's folds before the next round's loads
+      t = fq_zero();
+      if (threadIdx.x < 2) {
+        t = shq[0][threadIdx.x];
+        for (int w = 1; w < nw; w++) t = fq_add(t, shq[w][threadIdx.x]);
+      }
+    } else {
+      t = tail_block_sum3(acc.e, nw, 1);  // its barriers also order this round's folds before the next round's loads
+    }
+    if (threadIdx.x < 3) publish_scalar(up + 12 * threadIdx.x, t, seq);
+    if (last) {
       // live length is 2: both entries of every table, for the host to bind with the last challenge
-      const int ne = is_dotp ? 6 : 4;
-      if ((int)threadIdx.x < ne) {
-        const int tt = threadIdx.x >> 1, e = threadIdx.x & 1;
-        const fq* tab;
-        if (!is_dotp) tab = tt ? Bt : A;
-        else tab = (a.k >= 2) ? dst[tt] : src[tt];  // no fold has happened in a one-round layer
-        fq_store(&a.up_final[6 * (size_t)inst + threadIdx.x], fq_load(tab + e));
+      if (!is_dotp && lo_off == 4) {
+        if (threadIdx.x < 4) publish_scalar(up + 36 + 12 * threadIdx.x, mine, seq);  // A[0], A[1], B[0], B[1]
+      } else {
+        const int ne = is_dotp ? 6 : 4;
+        if ((int)threadIdx.x < ne) {
+          const int tt = threadIdx.x >> 1, e = threadIdx.x & 1;
+          const fq* tab;
+          if (!is_dotp) tab = tt ? Bt : A;
+          else tab = (a.k >= 2) ? dst[tt] : src[tt];  // no fold has happened in a one-round layer
+          publish_scalar(up + 36 + 12 * threadIdx.x, fq_load(tab + e), seq);
+        }
       }
     }
-    if (threadIdx.x < 8) __threadfence_system();  // the threads that wrote to host memory
-    __syncthreads();
     if (a.trace && inst == 0 && threadIdx.x == 0) a.trace[4 * (j - a.j0) + 1] = wall_clock64();
-    if (threadIdx.x == 0)
-      __hip_atomic_store(&a.up_seq[inst], a.seq0 + (uint32_t)(j - a.j0) + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    if (j == a.k - 1) break;
+    if (last) break;
     if (threadIdx.x == 0) {
-      const uint32_t want = a.seq0 + (uint32_t)(j - a.j0) + 1u;
       int stop = 1;
       for (long spin = 0; spin < kTailSpinLimit; spin++) {
-        uint4 c0, c1, c2;
+        u32x4 c0, c1, c2;
         load48_system(a.down, c0, c1, c2);
-        if (c0.x == want && c1.x == want && c2.x == want) {
+        if (c0.x == seq && c1.x == seq && c2.x == seq) {
           fq rr;
           rr.v[0] = c0.y; rr.v[1] = c0.z; rr.v[2] = c0.w; rr.v[3] = c1.y; rr.v[4] = c1.z; rr.v[5] = c1.w; rr.v[6] = c2.y; rr.v[7] = c2.z;
           sh_r = rr;
@@ -785,10 +857,12 @@ __global__ __launch_bounds__(kTailBlock) void spark_tail_kernel(TailArgs a) {
   }
 }
 
-// pinned mailbox carved out of ctx->h_spark (kSparkPinned fq = 256 KiB): element offsets
-constexpr size_t kTailTrace = 4096 + 256;  // 64 rounds x 4 x u64
-constexpr size_t kTailSums = 4096, kTailFinal = 4096 + 64, kTailWords = 4096 + 192;  // words: up_seq[32] | abort | .. | down[12] at +64
+// pinned mailbox carved out of ctx->h_spark (kSparkPinned fq = 256 KiB), offsets in fq elements (32 B)
+constexpr size_t kTailUp = 4096;                     // kSparkMaxInst x kTailUpChunks x 16 B = 18 x 512 B = 288 fq
+constexpr size_t kTailWords = 4096 + 320;            // uint32 words: abort at [0], the reply's three pieces at [16..28)
+constexpr size_t kTailTrace = 4096 + 384;            // 64 rounds x 4 x u64
 static inline uint32_t* tail_words(vpin_ctx* c) { return reinterpret_cast<uint32_t*>(c->h_spark + kTailWords); }
+static inline uint32_t* tail_up(vpin_ctx* c) { return reinterpret_cast<uint32_t*>(c->h_spark + kTailUp); }
 
 size_t spark_tail_pairs() {
   static const size_t n = [] { const char* e = getenv("VPIN_SPARK_TAIL_PAIRS"); long v = e ? atol(e) : 1024; return (size_t)(v < 0 ? 0 : v); }();
@@ -810,11 +884,10 @@ int spark_tail_launch(vpin_ctx* c, const SparkForest* f, int level, int k, int j
   a.pyr = pyr; a.k = k; a.j0 = j0; a.len0 = len0;
   if (r_prev) a.r_prev = load_host_fq(r_prev);
   a.derefs = comb_derefs; a.vals = vals; a.scratch = scratch; a.N = N;
-  a.up_sums = c->h_spark + kTailSums;
-  a.up_final = c->h_spark + kTailFinal;
+  a.up = tail_up(c);
   uint32_t* w = tail_words(c);
-  a.up_seq = w; a.abort_flag = w + 32; a.down = w + 64;
-  w[32] = 0;
+  a.abort_flag = w; a.down = w + 16;
+  w[0] = 0;
   a.seq0 = c->tail_seq;
   static const bool trace_on = getenv("VPIN_TAIL_TRACE") != nullptr;
   a.trace = trace_on ? reinterpret_cast<unsigned long long*>(c->h_spark + kTailTrace) : nullptr;
@@ -829,20 +902,43 @@ int spark_tail_launch(vpin_ctx* c, const SparkForest* f, int level, int k, int j
   return VPIN_OK;
 }
 
-// results of tail round `idx` (0-based within the tail) of all `ninst` instances: sums at ctx->h_spark[kTailSums + 3*inst + x]
-int spark_tail_wait(vpin_ctx* c, int idx, int ninst) {
-  volatile uint32_t* up = tail_words(c);
+typedef uint32_t tail_v4 __attribute__((vector_size(16), aligned(16)));
+
+// one scalar out of its three pieces; false while a piece still carries an older sequence number
+static inline bool tail_take(const uint32_t* slot, uint32_t want, fq* out) {
+  const tail_v4 c0 = *reinterpret_cast<const volatile tail_v4*>(slot), c1 = *reinterpret_cast<const volatile tail_v4*>(slot + 4),
+                c2 = *reinterpret_cast<const volatile tail_v4*>(slot + 8);
+  if (c0[0] != want || c1[0] != want || c2[0] != want) return false;
+  out->v[0] = c0[1]; out->v[1] = c0[2]; out->v[2] = c0[3]; out->v[3] = c1[1]; out->v[4] = c1[2]; out->v[5] = c1[3];
+  out->v[6] = c2[1]; out->v[7] = c2[2];
+  return true;
+}
+
+// results of tail round `idx` (0-based within the tail) of all `ninst` instances: sums -> spark_tail_sums()[3*inst + x] and,
+// after the tail's last round, the live entries -> spark_tail_final()[6*inst + e]
+int spark_tail_wait(vpin_ctx* c, int idx, int ninst, int ncirc) {
   const uint32_t want = c->tail_seq + (uint32_t)idx + 1u;
+  const bool last = idx == c->tail_rounds - 1;
+  const uint32_t* up = tail_up(c);
   const auto t0 = std::chrono::steady_clock::now();
+  unsigned done_mask = 0;
+  const unsigned all = (1u << ninst) - 1u;
   for (long spins = 0;; spins++) {
-    int done = 0;
-    for (int i = 0; i < ninst; i++) done += (up[i] == want);
-    if (done == ninst) return VPIN_OK;
+    for (int i = 0; i < ninst; i++) {
+      if (done_mask >> i & 1u) continue;
+      const uint32_t* u = up + (size_t)i * kTailUpChunks * 4;
+      bool ok = true;
+      for (int k = 0; k < 3 && ok; k++) ok = tail_take(u + 12 * k, want, &c->tail_sums[3 * i + k]);
+      const int ne = i < ncirc ? 4 : 6;
+      for (int e = 0; last && e < ne && ok; e++) ok = tail_take(u + 36 + 12 * e, want, &c->tail_final[6 * i + e]);
+      if (ok) done_mask |= 1u << i;
+    }
+    if (done_mask == all) return VPIN_OK;
     __builtin_ia32_pause();
     if ((spins & 0xfff) == 0xfff) {
       (void)hipStreamQuery(c->stream);  // nudges runtimes / profilers that submit lazily
       if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 20.0) {
-        tail_words(c)[32] = 1;  // abort: every workgroup leaves its poll loop
+        tail_words(c)[0] = 1;  // abort: every workgroup leaves its poll loop
         (void)hipStreamSynchronize(c->stream);
         set_last_error("spark_tail_wait: the persistent round kernel did not answer", hipErrorUnknown);
         return VPIN_EHIP;
@@ -854,16 +950,14 @@ int spark_tail_wait(vpin_ctx* c, int idx, int ninst) {
 // challenge of tail round `idx` to the kernel: three 16-byte stores {seq, 3 words} (single-copy atomic on x86-64), so a
 // poll that sees the sequence number in all three pieces holds the whole scalar
 void spark_tail_reply(vpin_ctx* c, int idx, const uint8_t r[32]) {
-  uint32_t* down = tail_words(c) + 64;
+  uint32_t* down = tail_words(c) + 16;
   const uint32_t seq = c->tail_seq + (uint32_t)idx + 1u;
   uint32_t wv[8];
   memcpy(wv, r, 32);
-  typedef uint32_t v4 __attribute__((vector_size(16), aligned(16)));
-  v4 c0 = {seq, wv[0], wv[1], wv[2]}, c1 = {seq, wv[3], wv[4], wv[5]}, c2 = {seq, wv[6], wv[7], 0u};
-  __atomic_thread_fence(__ATOMIC_RELEASE);
-  *reinterpret_cast<volatile v4*>(down) = c0;
-  *reinterpret_cast<volatile v4*>(down + 4) = c1;
-  *reinterpret_cast<volatile v4*>(down + 8) = c2;
+  tail_v4 c0 = {seq, wv[0], wv[1], wv[2]}, c1 = {seq, wv[3], wv[4], wv[5]}, c2 = {seq, wv[6], wv[7], 0u};
+  *reinterpret_cast<volatile tail_v4*>(down) = c0;
+  *reinterpret_cast<volatile tail_v4*>(down + 4) = c1;
+  *reinterpret_cast<volatile tail_v4*>(down + 8) = c2;
   __atomic_thread_fence(__ATOMIC_SEQ_CST);
 }
 
@@ -884,8 +978,8 @@ void spark_tail_end(vpin_ctx* c) {
   c->tail_rounds = 0;
 }
 
-const fq* spark_tail_sums(vpin_ctx* c) { return c->h_spark + kTailSums; }
-const fq* spark_tail_final(vpin_ctx* c) { return c->h_spark + kTailFinal; }
+const fq* spark_tail_sums(vpin_ctx* c) { return c->tail_sums; }
+const fq* spark_tail_final(vpin_ctx* c) { return c->tail_final; }
 
 }  // namespace vpin
 

@@ -97,7 +97,7 @@ int spark_triple_sums(vpin_ctx* c, const vpin_spark_decomm* d, const fq* comb_de
 size_t spark_tail_pairs();  // rounds with at most this many pairs per circuit go to the tail (0 = never)
 int spark_tail_launch(vpin_ctx* c, const SparkForest* f, int level, int k, int j0, size_t len0, const fq* pyr, const uint8_t* r_prev,
                       size_t N, const fq* vals, const fq* comb_derefs, fq* scratch);
-int spark_tail_wait(vpin_ctx* c, int idx, int ninst);
+int spark_tail_wait(vpin_ctx* c, int idx, int ninst, int ncirc);
 void spark_tail_reply(vpin_ctx* c, int idx, const uint8_t r[32]);
 void spark_tail_end(vpin_ctx* c);
 const fq* spark_tail_sums(vpin_ctx* c);

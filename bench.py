@@ -384,15 +384,17 @@ def main():
     if k and k["ms"] > 0:
         achieved = k["alg_bytes"] / (k["ms"] * 1e-3) / 1e9
         traffic = args.pmc_traffic
-        pmc_all = {}
+        pmc_all, pmc_l5 = {}, {}
         for pmc in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):  # separate rocprofv3 --pmc passes, see the file's _how
             pth = os.path.join(ROOT, "profiles", pmc)
             if os.path.exists(pth):
                 with open(pth) as f:
-                    pmc_all = json.load(f).get("bench_default", {})
+                    doc = json.load(f)
+                pmc_all, pmc_l5 = doc.get("bench_default", {}), doc.get("bench_L5_mult", {})
                 break
         if traffic is None:
-            traffic = pmc_all.get("sc_cubic3_kernel<true, true>", {}).get("hbm_bytes_per_launch")
+            # the largest instance's launches alone (bench_L5_mult section): the default run's average mixes every instance's
+            traffic = (pmc_l5 or pmc_all).get("sc_cubic3_kernel<true, true>", {}).get("hbm_bytes_per_launch")
         # bytes the eq-factored kernel really moves per launch: 3 tables read (len) and written (len/2), the suffix
         # table read once per pair (len/4): 152*len against the 192*len of the reference's 4-table formulation
         actual = k["alg_bytes"] * 152.0 / 192.0
@@ -459,19 +461,19 @@ def main():
                 cx.set_shared_device(True)
             sec = []
             cus, clk = cx.device_props()  # compute units, shader clock in Hz
+            # VALU-issue ceiling: one wave-instruction per SIMD per 4 cycles (64 lanes on a 16-lane SIMD); instructions per
+            # affine table addition / per pair counted from the ISA of the kernels' hot loops (profiles/r02_isa_counts.json)
+            isa = {}
+            pth = os.path.join(ROOT, "profiles", "r02_isa_counts.json")
+            if os.path.exists(pth):
+                with open(pth) as f:
+                    isa = json.load(f)
             m = st.get("msm_rows")
             if m and m["ms"] > 0 and m["units"] > 0:
-                # VALU-issue ceiling: one wave-instruction per SIMD per 4 cycles (64 lanes on a 16-lane SIMD); instructions per
-                # affine table addition counted from the ISA of ge_add_niels in msm_rows_kernel (profiles/r02_isa_counts.json)
-                isa = {}
-                pth = os.path.join(ROOT, "profiles", "r02_isa_counts.json")
-                if os.path.exists(pth):
-                    with open(pth) as f:
-                        isa = json.load(f)
                 ipa = isa.get("msm_rows_kernel", {}).get("valu_per_table_add", 1850)
                 peak_adds = cus * 4 * 64 * clk / (4.0 * ipa)
                 adds_s = m["units"] / (m["ms"] * 1e-3)
-                pm = pmc_all.get("msm_rows_kernel", {})
+                pm = pmc_l5.get("msm_rows_kernel (>= 1 GB fetched)", {})
                 sec.append({"kernel": "msm_rows_kernel (row commitments of >= 128 rows: witness, derefs, SNARK::encode shapes)",
                             "bound": "valu-issue", "achieved": adds_s / 1e9, "peak": peak_adds / 1e9, "unit": "G table adds/s",
                             "frac": adds_s / peak_adds, "launches": m["launches"], "ms": round(m["ms"], 3),
@@ -479,16 +481,26 @@ def main():
                             "peak_note": f"{cus} CUs x 4 SIMDs x 64 lanes x {clk / 1e9:.2f} GHz / (4 cycles per wave-instruction x {ipa} "
                                          "VALU instructions per affine table addition)",
                             "scalars_GBps": m["alg_bytes"] / (m["ms"] * 1e-3) / 1e9,
-                            "traffic_bytes_per_add": (pm.get("hbm_bytes_per_launch") / pm["table_adds_per_launch"]) if pm.get("table_adds_per_launch") else None})
+                            "traffic_bytes_per_add": pm.get("bytes_per_table_add"),
+                            "traffic_note": "PMC FETCH_SIZE + WRITE_SIZE of the largest instance's row commitments / their table additions "
+                                            "(profiles/r02_pmc_traffic.json, bench_L5_mult)"})
             p = st.get("spark_round_big")
             if p and p["ms"] > 0:
                 ach = p["alg_bytes"] / (p["ms"] * 1e-3) / 1e9
-                pp = pmc_all.get("prod_round_kernel<true, true> (>= 2^20 pairs)", {})
+                pp = pmc_l5.get("prod_round_kernel<true, true> (>= 2^20 pairs)", {})
+                ipp = isa.get("prod_round_kernel<true, true>", {}).get("valu_per_pair", 2224)
+                peak_pairs = cus * 4 * 64 * clk / (4.0 * ipp)
+                pairs_s = p["units"] / (p["ms"] * 1e-3)
                 sec.append({"kernel": "prod_round_kernel<*, true>, launches with >= 2^20 pairs per circuit (12 or 4 circuits per launch)",
                             "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS,
+                            "valu_issue": {"achieved": pairs_s / 1e9, "peak": peak_pairs / 1e9, "unit": "G pair evaluations/s",
+                                           "frac": pairs_s / peak_pairs, "valu_instructions_per_pair": ipp,
+                                           "note": "the limiter: 8 products mod q per pair; same ceiling model as the MSM entry"},
                             "launches": p["launches"], "ms": round(p["ms"], 3), "alg_bytes_per_launch": p["alg_bytes"] / p["launches"],
                             "alg_note": "per launch: circuits x 2 tables x 32 B x 1.5 x len + the shared eq table (32 B x 1.5 x len)",
-                            "traffic": pp.get("hbm_bytes_per_launch")})
+                            "traffic": pp.get("hbm_bytes_per_launch"),
+                            "traffic_note": "PMC bytes per launch of the <true, true> launches of this class (16 of the 25 per proof; their "
+                                            "algorithmic bytes average 6.4 GB per launch)"})
             line["roofline"]["secondary"] = sec
             line["roofline"]["secondary_scope"] = (f"{big} proven alone after the timed region ({alone_ms:.1f} ms, one stream, HIP events per launch, "
                                                    "table additions counted by vpin_prof_enable level 2)")

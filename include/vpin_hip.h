@@ -171,6 +171,12 @@ size_t vpin_gens_entry_bytes(void);
  * blinds = L x 32 B Montgomery scalars on the host. */
 int vpin_hyrax_commit(vpin_ctx* ctx, const vpin_gens* g, const vpin_table* Z, const uint8_t* blinds,
                       size_t L, size_t blind_base, uint8_t* out_compressed /* L*32 */);
+/* Rows [row0, row0 + nrows) of the same commitment (Z viewed as L rows; blinds = nrows x 32 B for those rows, or NULL
+ * for DensePolynomial::commit(gens, None)).  The L row commitments are independent MSMs over shared generators
+ * (rayon's into_par_iter at dense_mlpoly.rs:166-173), so a commitment splits across GPUs by rows: every rank commits
+ * a contiguous block and the 32-byte results are all-gathered -- no point crosses a link. */
+int vpin_hyrax_commit_rows(vpin_ctx* ctx, const vpin_gens* g, const vpin_table* Z, size_t L, size_t row0, size_t nrows,
+                           const uint8_t* blinds, size_t blind_base, uint8_t* out_compressed);
 /* The two commitments of proof_point_{add,mult}.rs:44-52 plus their row-wise sum
  * (:75-80) in one call: out_sum[i] = compress(decompress(a[i]) + decompress(b[i])). */
 int vpin_hyrax_commit_pair(vpin_ctx* ctx, const vpin_gens* g, const vpin_table* Za, const vpin_table* Zb,
@@ -251,6 +257,7 @@ int vpin_sat_prepare(vpin_ctx* ctx, size_t num_vars);
  * b"gens_r1cs_eval" stream and builds (or finds) the shared device window table.  Call it for the LARGEST instance
  * first: smaller ones then share its table instead of each leaving a superseded one behind. */
 int vpin_spark_prepare(vpin_ctx* ctx, size_t num_cons, size_t num_vars, size_t max_nnz);
+
 /* wall-clock spans of the last vpin_sat_prove call on this thread's process, seconds:
  * [0] polycommit (uploads + 2 commits + combine)  [1] prove_sc_phase_one (eq table, SpMV, 4 uploads, rounds)
  * [2] prove_sc_phase_two  [3] polyeval  [4] total  [5] generators (0 when cached)
@@ -265,6 +272,26 @@ void vpin_sat_last_timings(double out[8]);
 /* ComputationDecommitment (Spartan/src/lib.rs:70-73): MultiSparseMatPolynomialAsDense
  * (Spartan/src/sparse_mlpoly.rs:285-292) resident in HBM. */
 typedef struct vpin_spark_decomm vpin_spark_decomm;
+
+/* ---- one large commitment split across GPUs (the derefs commitment of R1CSEvalProof::prove, the single largest MSM
+ * of a SNARK: 6N full-width scalars, sparse_mlpoly.rs:525-531,56-79) -------------------------------------------------
+ * The proving rank installs two hooks on its context.  vpin_snark_prove_* then (1) hands (rx, ry) to `begin` as soon
+ * as the sat proof has produced them, so the helper ranks can rebuild the derefs polynomial from their own copy of
+ * the computation decommitment while the prover builds its own, and (2) asks `commit` for the L compressed row
+ * commitments of that polynomial instead of computing them all locally; `commit` commits a block of rows with
+ * vpin_hyrax_commit_rows (Z = the prover's polynomial) and gathers the other blocks from the helpers, which produce
+ * theirs with vpin_spark_derefs_commit_rows.  The exchange itself (all-gather of 32-byte rows: RCCL over xGMI on a GPU
+ * node, gloo in the CPU tests) belongs to the caller (vpin_amd/dist.py).  Polynomials shorter than min_len scalars
+ * are committed locally.  Proof bytes are identical to the single-GPU proof. */
+typedef int (*vpin_split_begin_fn)(void* user, const uint8_t* rx, size_t nx, const uint8_t* ry, size_t ny);
+typedef int (*vpin_split_commit_fn)(void* user, const vpin_table* Z, size_t L, size_t R, uint8_t* out_compressed);
+int vpin_ctx_set_split_hooks(vpin_ctx* ctx, vpin_split_begin_fn begin, vpin_split_commit_fn commit, void* user, size_t min_len);
+/* the b"gens_r1cs_eval" view a polynomial of 2^ell scalars is committed under (PolyCommitmentGens::new(ell, ..)) */
+int vpin_spark_gens_view(vpin_ctx* ctx, size_t ell, const vpin_gens** out, size_t* L, size_t* R);
+/* helper side: Derefs::new (sparse_mlpoly.rs:525-531) for (rx, ry) from this rank's copy of the decommitment, then the
+ * commitment rows [row0, row0 + nrows) of it (zero blinds, as commit(gens, None)) */
+int vpin_spark_derefs_commit_rows(vpin_ctx* ctx, const vpin_spark_decomm* decomm, const uint8_t* rx, size_t nx,
+                                  const uint8_t* ry, size_t ny, size_t row0, size_t nrows, uint8_t* out_compressed);
 
 /* bincode size of R1CSCommitment (Spartan/src/r1csinstance.rs:53-58) for this instance. */
 size_t vpin_spark_comm_bytes(const vpin_r1cs* inst);
@@ -408,7 +435,8 @@ typedef struct {
   uint64_t launches;
   double ms;         /* sum of event-measured durations */
   double alg_bytes;  /* sum of algorithmic bytes moved by those launches */
-  double units;      /* class 11 under vpin_prof_enable(ctx, 2): affine table additions those launches performed */
+  double units;      /* classes 8 / 10: pair evaluations (circuits x pairs); class 11 under vpin_prof_enable(ctx, 2): affine
+                      * table additions those launches performed */
 } vpin_kstat;
 /* on = 1: HIP-event bracketing of the kernel classes; on = 2: additionally count the table additions of the row
  * commitments (an extra counting kernel per commitment: for roofline passes, not for timed regions) */

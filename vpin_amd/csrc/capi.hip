@@ -100,11 +100,12 @@ void dev_pool_release(vpin_ctx* c) {
   pool_release_locked(c);
 }
 
-ProfScope::ProfScope(vpin_ctx* c, int kclass, double bytes, int also) : ctx(c) {
+ProfScope::ProfScope(vpin_ctx* c, int kclass, double bytes, int also, double units) : ctx(c) {
   if (!c->prof) return;
   ProfRec r;
   r.kclass = kclass;
   r.also = also;
+  r.units = units;
   r.bytes = bytes;
   r.start = get_event(c);
   r.stop = get_event(c);
@@ -214,6 +215,12 @@ void* vpin_ctx_stream(vpin_ctx* c) { return c ? (void*)c->stream : nullptr; }
 int vpin_ctx_set_progress_flag(vpin_ctx* c, int* flag) {
   if (!c) return VPIN_EINVAL;
   c->progress_flag = flag;
+  return VPIN_OK;
+}
+
+int vpin_ctx_set_split_hooks(vpin_ctx* c, vpin_split_begin_fn begin, vpin_split_commit_fn commit, void* user, size_t min_len) {
+  if (!c || (begin == nullptr) != (commit == nullptr)) return VPIN_EINVAL;
+  c->split_begin = begin; c->split_commit = commit; c->split_user = user; c->split_min_len = min_len;
   return VPIN_OK;
 }
 
@@ -375,10 +382,12 @@ static int prof_drain(vpin_ctx* c) {
       c->stats[r.kclass].launches += 1;
       c->stats[r.kclass].ms += ms;
       c->stats[r.kclass].alg_bytes += r.bytes;
+      c->stats[r.kclass].units += r.units;
       if (r.also >= 0 && r.also < VPIN_K_COUNT) {
         c->stats[r.also].launches += 1;
         c->stats[r.also].ms += ms;
         c->stats[r.also].alg_bytes += r.bytes;
+        c->stats[r.also].units += r.units;
       }
     }
     c->free_events.push_back(r.start);

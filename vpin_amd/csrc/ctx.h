@@ -32,6 +32,7 @@ struct ProfRec {
   double bytes;
   hipEvent_t start, stop;
   int also = -1;  // a second class the same launch is counted in (a subset class)
+  double units = 0.0;
 };
 
 }  // namespace vpin
@@ -87,6 +88,11 @@ struct vpin_ctx {
   vpin::fq tail_final[6 * 18];
   bool shared_device = false;  // other contexts prove on this device at the same time (vpin_ctx_set_shared_device)
   void* h_bullet = nullptr;  // pinned staging of the bullet reduction's per-round results (bullet.hip), 64 KiB
+  // one large commitment split across ranks (include/vpin_hip.h, vpin_ctx_set_split_hooks)
+  vpin_split_begin_fn split_begin = nullptr;
+  vpin_split_commit_fn split_commit = nullptr;
+  void* split_user = nullptr;
+  size_t split_min_len = 0;
   volatile int* progress_flag = nullptr;  // optional host word: set to 1 when a SNARK's sat part is done
 };
 
@@ -96,7 +102,7 @@ namespace vpin {
 struct ProfScope {
   vpin_ctx* ctx;
   int rec = -1;
-  ProfScope(vpin_ctx* c, int kclass, double bytes, int also = -1);
+  ProfScope(vpin_ctx* c, int kclass, double bytes, int also = -1, double units = 0.0);
   ~ProfScope();
 };
 

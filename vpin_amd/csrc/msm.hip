@@ -758,6 +758,26 @@ int vpin_hyrax_commit(vpin_ctx* c, const vpin_gens* g, const vpin_table* Z, cons
   return VPIN_OK;
 }
 
+int vpin_hyrax_commit_rows(vpin_ctx* c, const vpin_gens* g, const vpin_table* Z, size_t L, size_t row0, size_t nrows,
+                           const uint8_t* blinds, size_t blind_base, uint8_t* out_compressed) {
+  if (!c || !g || !Z || !Z->d || !out_compressed || L == 0 || nrows == 0) return VPIN_EINVAL;
+  if (Z->len % L != 0 || row0 + nrows > L) return VPIN_ESHAPE;
+  const size_t R = Z->len / L;
+  if (R > g->nb || (blinds && blind_base >= g->nb)) return VPIN_ESHAPE;
+  (void)hipSetDevice(c->device);
+  DevBuf dbl(c), dpts(c), dout(c);
+  if ((blinds && dbl.alloc(nrows * 32)) || dpts.alloc(nrows * sizeof(ge_ext)) || dout.alloc(nrows * 32)) return VPIN_ENOMEM;
+  if (blinds) VPIN_HIP_TRY(hipMemcpyAsync(dbl.p, blinds, nrows * 32, hipMemcpyHostToDevice, c->stream));
+  int rc = msm_rows(c, g, Z->d + row0 * R, nrows, R, R, blinds ? (const fq*)dbl.p : nullptr, blinds ? 1 : 0, blind_base, (ge_ext*)dpts.p);
+  if (rc) return rc;
+  hipLaunchKernelGGL(ge_compress_kernel, dim3((unsigned)((nrows + 63) / 64)), dim3(64), 0, c->stream, (const ge_ext*)dpts.p, nrows,
+                     (fp*)dout.p, (fp*)nullptr);
+  VPIN_HIP_TRY(hipGetLastError());
+  VPIN_HIP_TRY(hipMemcpyAsync(out_compressed, dout.p, nrows * 32, hipMemcpyDeviceToHost, c->stream));
+  VPIN_HIP_TRY(hipStreamSynchronize(c->stream));
+  return VPIN_OK;
+}
+
 int vpin_hyrax_commit_pair(vpin_ctx* c, const vpin_gens* g, const vpin_table* Za, const vpin_table* Zb,
                            const uint8_t* blinds_a, const uint8_t* blinds_b, size_t L, size_t blind_base,
                            uint8_t* out_a, uint8_t* out_b, uint8_t* out_sum) {

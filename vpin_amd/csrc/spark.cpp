@@ -442,6 +442,9 @@ static int spark_prove(vpin_ctx* c, const vpin_spark_decomm* d, const std::vecto
   TableGuard tg(c);
   auto t0 = Clock::now();
 
+  // a split derefs commitment (vpin_ctx_set_split_hooks): the helper ranks get (rx, ry) before anything else happens here
+  const bool split = c->split_begin && c->split_commit && 8 * N >= c->split_min_len;
+  if (split && (rc = c->split_begin(c->split_user, B(rx.data()), rx.size(), B(ry.data()), ry.size()))) return rc;
   tr.append_protocol_name("Sparse polynomial evaluation proof");
   // equalize (sparse_mlpoly.rs:1448-1465) + the two memories eq(rx_ext, .), eq(ry_ext, .)
   const size_t nm = std::max(d->nx, d->ny);
@@ -458,7 +461,12 @@ static int spark_prove(vpin_ctx* c, const vpin_spark_decomm* d, const std::vecto
   tg.add(comb);
   if ((rc = vpin::spark_gather_derefs(c, d, mem_rx->d, mem_ry->d, comb->d))) return rc;
   std::vector<CG> comm_derefs;
-  if ((rc = commit_noblind(c, g_derefs, comb, comm_derefs))) return rc;
+  if (split) {
+    comm_derefs.resize(g_derefs->L);
+    if ((rc = c->split_commit(c->split_user, comb, g_derefs->L, g_derefs->R, comm_derefs[0].b))) return rc;
+  } else if ((rc = commit_noblind(c, g_derefs, comb, comm_derefs))) {
+    return rc;
+  }
   tr.append_message("derefs_commitment", "begin_derefs_commitment");  // DerefsCommitment::append_to_transcript (:216-222)
   append_polycomm(tr, "comm_poly_row_col_ops_val", comm_derefs);
   tr.append_message("derefs_commitment", "end_derefs_commitment");
@@ -646,6 +654,42 @@ int vpin_spark_prepare(vpin_ctx* c, size_t num_cons, size_t num_vars, size_t max
   if (!rc) rc = get_view(c, s.v_mem, &g);
   if (!rc) rc = get_view(c, s.v_derefs, &g);
   return rc;
+}
+
+int vpin_spark_gens_view(vpin_ctx* c, size_t ell, const vpin_gens** out, size_t* L, size_t* R) {
+  if (!c || !out || !L || !R || ell < 2 || ell > 40) return VPIN_EINVAL;
+  (void)hipSetDevice(c->device);
+  const PcGens* g = nullptr;
+  int rc = get_view(c, ell, &g);
+  if (rc) return rc;
+  *out = g->dev; *L = g->L; *R = g->R;
+  return VPIN_OK;
+}
+
+int vpin_spark_derefs_commit_rows(vpin_ctx* c, const vpin_spark_decomm* d, const uint8_t* rx, size_t nx, const uint8_t* ry, size_t ny,
+                                  size_t row0, size_t nrows, uint8_t* out_compressed) {
+  if (!c || !d || !rx || !ry || !out_compressed || nrows == 0) return VPIN_EINVAL;
+  if (nx != d->nx || ny != d->ny) return VPIN_ESHAPE;
+  (void)hipSetDevice(c->device);
+  const size_t N = d->N, lgN = log2z(N);
+  const PcGens* g_derefs = nullptr;
+  int rc = get_view(c, lgN + 3, &g_derefs);
+  if (rc) return rc;
+  if (row0 + nrows > g_derefs->L) return VPIN_ESHAPE;
+  TableGuard tg(c);
+  const size_t nm = std::max(d->nx, d->ny);
+  std::vector<Fq> rx_ext(nm, Fq::zero()), ry_ext(nm, Fq::zero());
+  memcpy(rx_ext.data() + (nm - nx), rx, nx * 32);
+  memcpy(ry_ext.data() + (nm - ny), ry, ny * 32);
+  vpin_table *mem_rx = nullptr, *mem_ry = nullptr, *comb = nullptr;
+  if ((rc = vpin_eq_table(c, B(rx_ext.data()), (int)nm, &mem_rx))) return rc;
+  tg.add(mem_rx);
+  if ((rc = vpin_eq_table(c, B(ry_ext.data()), (int)nm, &mem_ry))) return rc;
+  tg.add(mem_ry);
+  if ((rc = vpin::table_alloc_uninit(c, 8 * N, &comb))) return rc;
+  tg.add(comb);
+  if ((rc = vpin::spark_gather_derefs(c, d, mem_rx->d, mem_ry->d, comb->d))) return rc;
+  return vpin_hyrax_commit_rows(c, g_derefs->dev, comb, g_derefs->L, row0, nrows, nullptr, g_derefs->R + 1, out_compressed);
 }
 
 void vpin_spark_decomm_free(vpin_ctx* c, vpin_spark_decomm* d) {

@@ -538,7 +538,7 @@ int spark_prod_round(vpin_ctx* c, const SparkForest* f, int level, size_t len, c
     // algorithmic bytes of the reference formulation: A and B of every circuit and the shared eq table read,
     // folded halves written
     const double bytes = (double)f->ncirc * 2 * 32.0 * (r ? (double)len * 1.5 : (double)len) + 32.0 * (r ? (double)len * 1.5 : (double)len);
-    ProfScope ps(c, VPIN_K_SPARK_ROUND, bytes, pairs >= ((size_t)1 << 20) ? VPIN_K_SPARK_ROUND_BIG : -1);
+    ProfScope ps(c, VPIN_K_SPARK_ROUND, bytes, pairs >= ((size_t)1 << 20) ? VPIN_K_SPARK_ROUND_BIG : -1, (double)f->ncirc * (double)pairs);
 #define VPIN_PROD_LAUNCH(B_, L_)                                                                                             \
   hipLaunchKernelGGL((prod_round_kernel<B_, L_>), dim3(grid, f->ncirc), dim3(kBlock), 0, c->stream, f->base, f->stride(), \
                      f->level_off(level), h, E, pairs, rr, rconst, fin)

@@ -78,6 +78,10 @@ def parse():
     ap.add_argument("--only", choices=["mult", "add"], default=None, help="keep only the point-mult / point-add instances of the trace")
     ap.add_argument("--no-verify", action="store_true", help="skip the post-run verification of the last step's SNARKs")
     ap.add_argument("--no-prof", action="store_true", help="no HIP-event bracketing of kernels (no roofline object)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak (default): every rank proves its own trace; strong: ONE trace over all ranks -- its instances "
+                         "LPT-sharded, the largest instance's derefs commitment (the single largest MSM) split by rows across the ranks")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend of the N>1 runs (gloo: rehearsal with ranks sharing a GPU)")
     ap.add_argument("--no-roofline-pass", action="store_true",
                     help="skip the serial pass after the timed region that fills roofline.secondary (largest instance alone)")
     ap.add_argument("--pmc-traffic", type=float, default=None,
@@ -85,8 +89,128 @@ def parse():
     return ap.parse_args()
 
 
+def main_strong(args):
+    """--scaling strong: one trace, all ranks.  The 12 instances are LPT-sharded by constraint count (vpin_amd.dist.plan_shards);
+    the largest instance is proven by rank 0 with its derefs commitment split by rows over every rank (vpin_amd.dist.SplitCommit:
+    broadcast of (rx, ry), all-gather of 32-byte rows; the other ranks serve their block from a side thread / stream while they
+    prove their own shard).  value = the trace's constraints x steps / slowest rank's time."""
+    import threading
+    import torch
+    import vpin_amd
+    from vpin_amd import gadgets as G
+    from vpin_amd.dist import Group, SplitCommit, SplitEngine, env_rank, plan_shards
+
+    rank, local_rank, world = env_rank()
+    ndev = torch.cuda.device_count()
+    dev = local_rank % max(1, ndev)
+    use_nccl = args.backend == "nccl" and world > 1
+    if use_nccl:
+        torch.cuda.set_device(dev)
+    grp = Group(backend=args.backend, device=torch.device("cuda", dev) if use_nccl else None)
+    trace = args.label or args.trace
+    labels = list(G.LENET) if trace == "lenet" else [trace]
+    work = []
+    for lab in labels:
+        m = G.synthetic_mult_inputs(lab)
+        if m is not None:
+            work.append((f"{lab}-mult", "mult", m, 3464 * len(m[0])))
+        a = G.synthetic_add_inputs(lab)
+        work.append((f"{lab}-add", "add", a, 10 * len(a[4])))
+    work.sort(key=lambda w: -w[3])
+    total_cons = sum(w[3] for w in work)
+    big = work[0]
+    # rank 0 owns the largest instance; about 40 % of its time is the split commitment, so it weighs 0.6 of its constraints
+    costs = [int(0.6 * big[3])] + [w[3] for w in work[1:]]
+    shards = plan_shards(costs, world)
+    assert 0 in shards[0]
+    mine = [work[i] for i in shards[rank] if i != 0]
+
+    ctx = vpin_amd.Context(dev)
+    ctx_h = vpin_amd.Context(dev) if (world > 1 and rank != 0) else None  # helper stream: serves the owner's request
+    if ctx_h is not None:
+        ctx.set_shared_device(True)
+        ctx_h.set_shared_device(True)
+
+    def build(cx, w):
+        g = cx.gadget_point_mult_dev(*w[2]) if w[1] == "mult" else cx.gadget_point_add_dev(*w[2])
+        cx.sat_prepare(g.num_vars)
+        dec, _ = g.spark_encode()
+        return g, dec
+
+    gb, decb = build(ctx_h if ctx_h is not None else ctx, big)  # every rank holds the largest circuit's decommitment
+    N = 1
+    while N < max(lib_nnz(gb)):
+        N *= 2
+    ell = (N.bit_length() - 1) + 3
+    L = 1 << (ell // 2)
+    own = {w[0]: build(ctx, w) for w in mine}
+    sc = SplitCommit(grp, SplitEngine(ctx_h if ctx_h is not None else ctx, decomm=decb, derefs_ell=ell), owner=0)
+    if rank == 0 and world > 1:
+        ctx.set_split(sc, min_len=1 << 22)
+
+    def prove(cx, g, dec):
+        return cx.snark_prove_resident(g.r1cs, dec, g.vars_para, g.vars_input, g.vars, g.inputs, SEED_C, SEED_P)
+
+    proof_bytes = {}
+
+    def step():
+        t = None
+        if ctx_h is not None:
+            t = threading.Thread(target=lambda: sc.serve_one(L))
+            t.start()
+        if rank == 0:
+            proof_bytes[big[0]] = len(prove(ctx, gb, decb)["proof"])
+        for name, (g, dec) in own.items():
+            proof_bytes[name] = len(prove(ctx, g, dec)["proof"])
+        if t is not None:
+            t.join()
+
+    def barrier():
+        torch.cuda.synchronize()
+        grp.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    ctx.sync()
+    barrier()
+    elapsed = grp.max_over_ranks(time.perf_counter() - t0)
+    names = grp.gather_objects([w[0] for w in mine] + ([big[0]] if rank == 0 else []))
+    if rank == 0:
+        print(json.dumps({
+            "metric": "R1CS constraints/sec, whole Spartan SNARK (sat proof + SPARK evaluation proof; vPIN point-mult + point-add instances)",
+            "value": total_cons * args.steps / elapsed, "unit": "constraints/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "u256 (mod q = 2^252+..., mod p = 2^255-19; 32-bit limbs)", "data": "synthetic",
+            "config": {"workload": f"ONE vPIN trace '{trace}' over {world} rank(s): {len(work)} SNARKs per step",
+                       "constraints_unpadded_per_step": total_cons,
+                       "parallelism": f"instances LPT-sharded over {world} rank(s) by constraint count; {big[0]}'s derefs commitment "
+                                      f"({L} rows) split by rows over all ranks: broadcast of (rx, ry), all-gather of 32-byte rows over "
+                                      f"{args.backend}; no other data-path collective",
+                       "shards": names},
+            "proof_bytes": proof_bytes}))
+    ctx.set_split(None)
+    grp.close()
+
+
+def lib_nnz(g):
+    import vpin_amd
+    L = vpin_amd.lib()
+    return [int(L.vpin_dev_instance_nnz(g.h, m)) for m in range(3)]
+
+
 def main():
     args = parse()
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    if world_env > 1 and "VPIN_HOST_THREADS" not in os.environ:
+        # the library's OpenMP teams (blind terms, generator derivation) are sized per lane; N ranks x 4 lanes share the node's cores
+        os.environ["VPIN_HOST_THREADS"] = str(max(2, min(8, (os.cpu_count() or 8) // (world_env * 4))))
+    if args.scaling == "strong":
+        return main_strong(args)
     args.snark = not args.sat_only and not args.host_buffers
     import torch
     import vpin_amd

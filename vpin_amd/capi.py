@@ -582,6 +582,70 @@ class Context:
     def sat_prepare(self, num_vars):
         _chk(lib().vpin_sat_prepare(self.h, num_vars), "vpin_sat_prepare")
 
+    # ---- a large commitment split across ranks (vpin_ctx_set_split_hooks; orchestration in vpin_amd/dist.py) ----
+    def spark_commit_rows(self, z_handle, ell, L, row0, nrows):
+        """rows [row0, row0+nrows) of the commitment of the polynomial behind the raw vpin_table handle `z_handle`
+        (2^ell scalars) under the b"gens_r1cs_eval" view, zero blinds"""
+        Lb = lib()
+        g, Lv, Rv = C.c_void_p(), C.c_size_t(), C.c_size_t()
+        Lb.vpin_spark_gens_view.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+        _chk(Lb.vpin_spark_gens_view(self.h, ell, C.byref(g), C.byref(Lv), C.byref(Rv)), "vpin_spark_gens_view")
+        assert Lv.value == L
+        out = np.zeros((nrows, 32), dtype=np.uint8)
+        Lb.vpin_hyrax_commit_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p,
+                                              C.c_size_t, C.c_void_p]
+        _chk(Lb.vpin_hyrax_commit_rows(self.h, g, z_handle, L, row0, nrows, None, Rv.value + 1, out.ctypes.data_as(C.c_void_p)),
+             "vpin_hyrax_commit_rows")
+        return out
+
+    def spark_derefs_commit_rows(self, decomm, rx, ry, row0, nrows):
+        rx = np.ascontiguousarray(rx, dtype=np.uint64).reshape(-1, 4)
+        ry = np.ascontiguousarray(ry, dtype=np.uint64).reshape(-1, 4)
+        out = np.zeros((nrows, 32), dtype=np.uint8)
+        Lb = lib()
+        Lb.vpin_spark_derefs_commit_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t,
+                                                     C.c_size_t, C.c_void_p]
+        p = lambda a: a.ctypes.data_as(C.c_void_p)
+        _chk(Lb.vpin_spark_derefs_commit_rows(self.h, decomm.h, p(rx), rx.shape[0], p(ry), ry.shape[0], row0, nrows, p(out)),
+             "vpin_spark_derefs_commit_rows")
+        return out
+
+    def set_split(self, split, min_len=1 << 20):
+        """install (split = a dist.SplitCommit) or clear (None) the split-commitment hooks of this context"""
+        Lb = lib()
+        BEGIN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t)
+        COMMIT = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p)
+        Lb.vpin_ctx_set_split_hooks.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+        if split is None:
+            _chk(Lb.vpin_ctx_set_split_hooks(self.h, None, None, None, 0), "vpin_ctx_set_split_hooks")
+            self._split_keep = None
+            return
+
+        def _begin(_user, rx, nx, ry, ny):
+            try:
+                a = np.ctypeslib.as_array(C.cast(rx, C.POINTER(C.c_uint64)), shape=(nx, 4)).copy()
+                b = np.ctypeslib.as_array(C.cast(ry, C.POINTER(C.c_uint64)), shape=(ny, 4)).copy()
+                split.begin(a, b)
+                return 0
+            except Exception as e:  # an exception must not unwind through the C frames
+                self._split_error = e
+                return -4
+
+        def _commit(_user, z, L, R, out):
+            try:
+                rows = split.commit(C.c_void_p(z), L, R)
+                C.memmove(out, np.ascontiguousarray(rows, dtype=np.uint8).ctypes.data, L * 32)
+                return 0
+            except Exception as e:
+                self._split_error = e
+                return -4
+
+        cb = (BEGIN(_begin), COMMIT(_commit))
+        self._split_keep = cb  # keep the trampolines alive while installed
+        self._split_error = None
+        _chk(Lb.vpin_ctx_set_split_hooks(self.h, C.cast(cb[0], C.c_void_p), C.cast(cb[1], C.c_void_p), None, min_len),
+             "vpin_ctx_set_split_hooks")
+
     def spark_prepare(self, num_cons, num_vars, max_nnz):
         L = lib()
         L.vpin_spark_prepare.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t]

@@ -72,123 +72,113 @@ class Group:
             self.dist.destroy_process_group()
 
 
-# ---- one large sum-check split across ranks ------------------------------------------
-# The folds pair entry i with i + len/2, so a STRIDED partition (rank g owns the indices i = g mod P) keeps both
-# members of every pair on one rank for as long as len/2 >= P: tables never move.  In local indexing the shard is
-# again a table folded top variable first, so the single-GPU round kernels run unchanged on it; per round every rank
-# contributes its partial (e0, e2, e3) -- 96 bytes -- and the sums are taken mod q.  Field addition is not a
-# collective reduce op, so the exchange is an all-gather of the partials plus a local modular sum (the transcript
-# needs them on the host anyway).  When the shards are down to one entry (len = P) the remaining log2 P rounds run
-# on the gathered P entries per table, on every rank alike.
+# ---- one large commitment split across ranks (BASELINE configs[4] "split MSM") ---------------
+# The L row commitments of a Hyrax commitment are independent MSMs over shared generators, so the single largest MSM of a
+# SNARK -- the derefs commitment of R1CSEvalProof::prove, 6N full-width scalars -- splits by rows: rank g commits the
+# contiguous block [g L/P, (g+1) L/P) and the 32-byte compressed rows are all-gathered; no point crosses a link and
+# nothing is reduced (group addition is not a collective reduce op anyway).  The proving rank drives this through the
+# two hooks of vpin_ctx_set_split_hooks (include/vpin_hip.h): `begin` broadcasts (rx, ry) the moment the sat proof has
+# produced them, so the helpers rebuild the derefs polynomial from their own copy of the computation decommitment while
+# the prover builds its own; `commit` commits the prover's block and gathers the others.  Collectives: torch.distributed
+# on the group's backend -- "nccl" (RCCL over xGMI) on a GPU node, "gloo" in the CPU tests; payloads are 32 bytes per
+# row and two challenge vectors, so the links carry kilobytes.  All arithmetic stays in the library.
 
-Q = 2**252 + 27742317777372353535851937790883648493
-_R = 1 << 256
-_RINV = pow(_R, -1, Q)
-
-
-def _limbs_to_int(a):
-    return sum(int(x) << (64 * i) for i, x in enumerate(a))
+_HDR = 16  # int64 words of the broadcast header: [nx, ny, L, R, stop]
 
 
-def _int_to_limbs(v):
-    import numpy as np
-    return np.array([(v >> (64 * i)) & (2**64 - 1) for i in range(4)], dtype=np.uint64)
+class SplitCommit:
+    """Row-split of the derefs commitment over the ranks of `grp`.
+
+    engine: the per-rank calls into the library (on a GPU box: SplitEngine below):
+      commit_rows(Z_handle, L, row0, nrows) -> (nrows, 32) uint8      prover's block from its own polynomial
+      derefs_commit_rows(rx, ry, row0, nrows) -> (nrows, 32) uint8    helper's block, derefs rebuilt from (rx, ry)
+    """
+
+    def __init__(self, grp, engine, owner=0):
+        self.grp, self.engine, self.owner = grp, engine, owner
+        self._pending = None
+
+    # ---- tensors on the backend's device ----
+    def _tensor(self, arr):
+        import torch
+        t = torch.from_numpy(arr)
+        return t.to(self.grp.device) if self.grp.device is not None else t
+
+    def _bcast(self, arr):
+        """arr: numpy array (filled on the owner, any content elsewhere) -> the owner's content on every rank"""
+        t = self._tensor(arr)
+        self.grp.dist.broadcast(t, src=self.owner)
+        return t.cpu().numpy()
+
+    def _allgather_rows(self, mine):
+        import numpy as np
+        import torch
+        t = self._tensor(np.ascontiguousarray(mine))
+        outs = [torch.empty_like(t) for _ in range(self.grp.world)]
+        self.grp.dist.all_gather(outs, t)
+        return np.concatenate([o.cpu().numpy() for o in outs])
+
+    @staticmethod
+    def block(L, rank, world):
+        per = L // world
+        return rank * per, per
+
+    # ---- prover side (called from inside vpin_snark_prove_* through the hooks) ----
+    def begin(self, rx, ry):
+        import numpy as np
+        rx = np.ascontiguousarray(rx, dtype=np.uint64).reshape(-1, 4)
+        ry = np.ascontiguousarray(ry, dtype=np.uint64).reshape(-1, 4)
+        hdr = np.zeros(_HDR + 4 * 128, dtype=np.int64)
+        hdr[0], hdr[1] = rx.shape[0], ry.shape[0]
+        hdr[_HDR:_HDR + rx.size] = rx.reshape(-1).view(np.int64)
+        hdr[_HDR + 256:_HDR + 256 + ry.size] = ry.reshape(-1).view(np.int64)
+        if self.grp.dist is not None:
+            self._bcast(hdr)
+
+    def commit(self, z_handle, L, R):
+        import numpy as np
+        world = self.grp.world
+        if L % world:
+            raise ValueError("rows do not divide over the ranks")
+        row0, nrows = self.block(L, self.grp.rank, world)
+        mine = self.engine.commit_rows(z_handle, L, row0, nrows)
+        if self.grp.dist is None:
+            return mine
+        return self._allgather_rows(np.ascontiguousarray(mine, dtype=np.uint8))
+
+    def stop(self):
+        """prover: tell the helpers no further request follows"""
+        import numpy as np
+        if self.grp.dist is not None:
+            hdr = np.zeros(_HDR + 4 * 128, dtype=np.int64)
+            hdr[4] = 1
+            self._bcast(hdr)
+
+    # ---- helper side ----
+    def serve_one(self, L):
+        """wait for the prover's (rx, ry), commit this rank's block of the derefs polynomial, join the all-gather.
+        Returns False when the prover said stop."""
+        import numpy as np
+        hdr = self._bcast(np.zeros(_HDR + 4 * 128, dtype=np.int64))
+        if hdr[4]:
+            return False
+        nx, ny = int(hdr[0]), int(hdr[1])
+        rx = hdr[_HDR:_HDR + 4 * nx].view(np.uint64).reshape(nx, 4).copy()
+        ry = hdr[_HDR + 256:_HDR + 256 + 4 * ny].view(np.uint64).reshape(ny, 4).copy()
+        row0, nrows = self.block(L, self.grp.rank, self.grp.world)
+        mine = self.engine.derefs_commit_rows(rx, ry, row0, nrows)
+        self._allgather_rows(np.ascontiguousarray(mine, dtype=np.uint8))
+        return True
 
 
-def strided_shard(table, rank, world):
-    """rank's shard of a table of Montgomery scalars ((n,4) uint64): the entries with index = rank mod world"""
-    return table[rank::world].copy()
+class SplitEngine:
+    """The library calls behind SplitCommit on a GPU rank (vpin_hyrax_commit_rows / vpin_spark_derefs_commit_rows)."""
 
+    def __init__(self, ctx, decomm=None, derefs_ell=None):
+        self.ctx, self.decomm, self.derefs_ell = ctx, decomm, derefs_ell
 
-def _gather_sum(grp, partial):
-    """partial: (k,4) uint64 Montgomery scalars of this rank -> their sums mod q over all ranks (Montgomery form is
-    linear, so the images add)"""
-    import numpy as np
-    parts = grp.gather_objects(np.ascontiguousarray(partial, dtype=np.uint64).tobytes())
-    out = np.zeros_like(np.asarray(partial, dtype=np.uint64))
-    for k in range(out.shape[0]):
-        s = 0
-        for p in parts:
-            s += _limbs_to_int(np.frombuffer(p, dtype=np.uint64).reshape(-1, 4)[k])
-        out[k] = _int_to_limbs(s % Q)
-    return out
+    def commit_rows(self, z_handle, L, row0, nrows):
+        return self.ctx.spark_commit_rows(z_handle, self.derefs_ell, L, row0, nrows)
 
-
-def _host_cubic_round(tabs):
-    """(e0, e2, e3) of sum_i A(B C - D) on host integers; tabs: 4 lists of canonical ints of equal even length
-    (sumcheck.rs:624-652, comb r1csproof.rs:104-108)"""
-    half = len(tabs[0]) // 2
-    e = [0, 0, 0]
-    for i in range(half):
-        lo = [t[i] for t in tabs]
-        d = [(t[half + i] - t[i]) % Q for t in tabs]
-        for k, x in enumerate((0, 2, 3)):
-            a, b, c, dd = [(lo[j] + x * d[j]) % Q for j in range(4)]
-            e[k] = (e[k] + a * (b * c - dd)) % Q
-    return e
-
-
-def sharded_cubic_sumcheck(grp, ops, shards, challenges):
-    """Cubic sum-check rounds over four tables split across grp's ranks by `strided_shard`.
-
-    ops: the local round engine on this rank's shard handles -- `length(tab)`, `round(tabs) -> (3,4)`,
-         `bind_round(tabs, r) -> (3,4)` (fold with r, then evaluate), `bind(tabs, r)`, `read(tab) -> (n,4)` -- all in
-         Montgomery limbs; on the GPU these are
-         Context.sc_cubic_round / sc_cubic_bind_round / Table.read, i.e. the same kernels a single GPU runs.
-    shards: the four local table handles (tau, Az, Bz, Cz), local length a power of two.
-    challenges: one Montgomery scalar per round ((rounds,4) uint64); in a proof they come from the transcript on
-         rank 0 and are broadcast, 32 bytes per round.
-    Returns (list of per-round (3,4) evaluations -- the global e0, e2, e3 --, final (4,4) values of the four tables
-    at the challenge point)."""
-    import numpy as np
-    world = grp.world
-    local_len = ops.length(shards[0])
-    total = local_len * world
-    rounds = total.bit_length() - 1
-    assert len(challenges) == rounds
-    evals = []
-    r_prev = None
-    j = 0
-    while local_len >= 2:  # both members of every pair are local
-        if r_prev is None:
-            part = ops.round(shards)
-        elif local_len >= 4:
-            part = ops.bind_round(shards, r_prev)  # fused fold + evaluation of the next round
-            local_len //= 2
-        else:
-            ops.bind(shards, r_prev)  # the last local fold: the shards are single entries afterwards
-            local_len //= 2
-            break
-        evals.append(_gather_sum(grp, part))
-        r_prev = challenges[j]
-        j += 1
-    # finish on the gathered world-sized tables (rank g holds entry g of each)
-    vals = [ops.read(t)[:1] for t in shards]
-    gathered = grp.gather_objects(np.concatenate(vals).tobytes())
-    tabs = [[0] * world for _ in range(4)]
-    for g, blob in enumerate(gathered):
-        a = np.frombuffer(blob, dtype=np.uint64).reshape(4, 4)
-        for t in range(4):
-            tabs[t][g] = _limbs_to_int(a[t]) * _RINV % Q  # index = g mod world: rank g holds entry g
-    while len(tabs[0]) >= 2:
-        e = _host_cubic_round(tabs)
-        evals.append(np.stack([_int_to_limbs(x * _R % Q) for x in e]))
-        r = _limbs_to_int(challenges[j]) * _RINV % Q
-        j += 1
-        half = len(tabs[0]) // 2
-        tabs = [[(t[i] + r * (t[half + i] - t[i])) % Q for i in range(half)] for t in tabs]
-    final = np.stack([_int_to_limbs(t[0] * _R % Q) for t in tabs])
-    return evals, final
-
-
-def sharded_hyrax_commit(grp, commit_rows, z_rows_local, blinds_local):
-    """DensePolynomial::commit_inner split across ranks (SURVEY.md 8(e), row H4): the L row commitments are
-    independent MSMs over the same generators, so rank g commits the contiguous rows [g L/P, (g+1) L/P) it holds and
-    the 32-byte results are all-gathered -- no reduction, no point ever crosses a link.
-
-    commit_rows(z_rows_local, blinds_local) -> (L/P, 32) uint8 compressed points (on the GPU: Context.hyrax_commit on
-    the uploaded row block); returns the (L, 32) commitment in row order on every rank."""
-    import numpy as np
-    mine = np.ascontiguousarray(commit_rows(z_rows_local, blinds_local), dtype=np.uint8)
-    parts = grp.gather_objects(mine.tobytes())
-    return np.concatenate([np.frombuffer(p, dtype=np.uint8).reshape(-1, 32) for p in parts])
+    def derefs_commit_rows(self, rx, ry, row0, nrows):
+        return self.ctx.spark_derefs_commit_rows(self.decomm, rx, ry, row0, nrows)

@@ -218,9 +218,11 @@ def main():
     from vpin_amd.dist import Group, env_rank
 
     rank, local_rank, world = env_rank()
+    if args.backend != "nccl":  # rehearsal: ranks share the visible GPU(s), the control path goes over gloo
+        local_rank = local_rank % max(1, torch.cuda.device_count())
     if world > 1:
         torch.cuda.set_device(local_rank)
-    grp = Group(backend="nccl", device=torch.device("cuda", local_rank) if world > 1 else None)
+    grp = Group(backend=args.backend, device=torch.device("cuda", local_rank) if (world > 1 and args.backend == "nccl") else None)
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     trace = args.label or args.trace
@@ -654,6 +656,34 @@ def main():
                 "scope": "per instance, serially: witness inputs in host memory -> gadget + witness synthesis + Instance::new "
                          "(device) -> is_sat -> SNARK::encode -> my_lib_prove -> proof bytes on the host; generator tables warm",
             }
+            if len(lanes) > 1:
+                # the same span with the trace's instances on the bench's lanes (streams) instead of one after the other
+                for cx in ctxs:
+                    cx.set_shared_device(True)
+                errs = []
+
+                def span_lane(li):
+                    try:
+                        for name in lane_names[li]:
+                            kind, inp = inputs_of[name]
+                            g = build_instance(ctxs[li], kind, inp)
+                            assert g.is_sat()
+                            r = g.snark_prove(SEED_C, SEED_P)
+                            assert r["proof"] == last_proof[name]["proof"], name
+                            g.free()
+                    except Exception as e:  # noqa: BLE001
+                        errs.append(repr(e))
+                ts = time.perf_counter()
+                th = [threading.Thread(target=span_lane, args=(li,)) for li in range(len(lanes))]
+                for t in th:
+                    t.start()
+                for t in th:
+                    t.join()
+                lanes_s = time.perf_counter() - ts
+                assert not errs, errs
+                line["reference_span"]["lanes"] = {
+                    "ms_per_trace": round(lanes_s * 1e3, 1), "constraints_per_s": total_cons_step / lanes_s,
+                    "scope": f"the same per-instance span with the trace's instances on {len(lanes)} streams / host threads at once"}
 
     # ---- CPU baseline: the oracle on a bounded sample, rank 0, N=1 only ----
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -299,6 +299,124 @@ __global__ __launch_bounds__(512) void eq_head_kernel(fq* __restrict__ out, int 
   if (threadIdx.x < ((size_t)1 << k0)) fq_store(out + threadIdx.x, buf[cur][threadIdx.x]);
 }
 
+// ---- one-launch eq tables -----------------------------------------------------------------------------------------
+// A doubling step per launch makes an eq table of 2^ell entries cost ell - 8 dependent launches and three times its size
+// in HBM traffic; the factorisation  E[h * 512 + i] = H[h] * Lo[i]  (Lo = the table of the last nine variables, built by
+// doubling in LDS by every workgroup; H[h] = the product of the h-bits' factors, ell - 9 products by one thread) writes
+// every entry once from ONE launch.  Field values are canonical, so the bytes equal the doubling construction's.
+struct TauAll { fq t[32]; };
+constexpr int kEqLoVars = 9, kEqChunk = 1 << kEqLoVars;
+
+// lo[cur][0..512) = eq(t[first..first+9), .) with t[first] the most significant index bit (new variable = LSB: EqPolynomial::evals)
+__device__ __forceinline__ int eq_lo_build_lsb(fq (*buf)[kEqChunk], const TauAll& ts, int first) {
+  if (threadIdx.x == 0) buf[0][0] = fq_one();
+  __syncthreads();
+  int cur = 0;
+  for (int j = 0; j < kEqLoVars; j++) {
+    const int prev = 1 << j;
+    if ((int)threadIdx.x < prev) {
+      const fq s = buf[cur][threadIdx.x];
+      const fq hi = fq_mul(s, ts.t[first + j]);
+      buf[cur ^ 1][2 * threadIdx.x + 1] = hi;
+      buf[cur ^ 1][2 * threadIdx.x] = fq_sub(s, hi);
+    }
+    cur ^= 1;
+    __syncthreads();
+  }
+  return cur;
+}
+
+// EqPolynomial::evals (dense_mlpoly.rs:78-94) of ell >= 10 variables in one launch.  A workgroup writes up to 32
+// consecutive chunks of 512 entries: E[((b*32 + m) * 512) + i] = Hhi[b] * Hmid[m] * Lo[i]  (Hmid over the five variables
+// above Lo's nine, Hhi over the rest: index MSB <-> r_0), so the per-workgroup set-up is shared by 16384 outputs.
+constexpr int kEqMidVars = 5, kEqMid = 1 << kEqMidVars;
+__global__ __launch_bounds__(kEqChunk) void eq_table_fused_kernel(fq* __restrict__ out, int ell, int nmid, TauAll rs) {
+  __shared__ fq buf[2][kEqChunk];
+  __shared__ fq hm[kEqMid];
+  const int cur = eq_lo_build_lsb(buf, rs, ell - kEqLoVars);
+  // nmid: variables r_{ell-9-nmid .. ell-10} (chunks per workgroup = 2^nmid, chosen by the launcher)
+  const int nhi = ell - kEqLoVars - nmid;                                              // variables r_0 .. r_{nhi-1}
+  const fq one = fq_one();
+  if ((int)threadIdx.x < (1 << nmid)) {
+    // Hhi[b] * Hmid[m]: m's bit (nmid-1-j) pairs with r_{nhi+j}; b's bit (nhi-1-j) with r_j
+    fq run = one;
+    const size_t bidx = blockIdx.x;
+    for (int j = 0; j < nhi; j++) run = fq_mul(run, ((bidx >> (nhi - 1 - j)) & 1) ? rs.t[j] : fq_sub(one, rs.t[j]));
+    const int m = threadIdx.x;
+    for (int j = 0; j < nmid; j++) run = fq_mul(run, ((m >> (nmid - 1 - j)) & 1) ? rs.t[nhi + j] : fq_sub(one, rs.t[nhi + j]));
+    hm[m] = run;
+  }
+  __syncthreads();
+  const fq lo = buf[cur][threadIdx.x];
+  fq* dst = out + ((size_t)blockIdx.x << (nmid + kEqLoVars)) + threadIdx.x;
+  for (int m = 0; m < (1 << nmid); m++) fq_store(dst + (size_t)m * kEqChunk, fq_mul(hm[m], lo));
+}
+
+// All suffix tables of ell >= 11 variables (vpin_eq_suffix_tables' layout) in one launch.  Level k = eq(tau_k.., .) has
+// 2^(ell-k) entries, tau_k on the most significant index bit; its chunk c (512 entries) is P_k(c) * Lo with Lo = level
+// ell-9 and P_k(c) the product of the factors of c's low (ell-k-9) bits (bit j <-> tau_{ell-10-j}).  A workgroup covers
+// 32 consecutive chunk indices c = 32 b + m and writes chunk c of every level that has one; workgroup 0 also writes the
+// levels of fewer than 512 entries.  Prefix products: pm[m][j] over m's bits j < 5, pb[j] over b's bits above them.
+__global__ __launch_bounds__(kEqChunk) void eq_pyramid_fused_kernel(fq* __restrict__ base, int ell, int nlow, TauAll ts) {
+  __shared__ fq buf[2][kEqChunk];
+  __shared__ fq pm[kEqMid][kEqMidVars];
+  __shared__ fq pb[32];
+  const size_t n = (size_t)1 << ell;
+  if (threadIdx.x == 0) {
+    buf[0][0] = fq_one();
+    if (blockIdx.x == 0) fq_store(base + (n - 2), fq_one());  // level ell
+  }
+  __syncthreads();
+  int cur = 0;
+  for (int s = 1; s <= kEqLoVars; s++) {  // Lo by doubling from the last variable, newest variable on top
+    const int k = ell - s, m = 1 << (s - 1);
+    if ((int)threadIdx.x < m) {
+      const fq v = buf[cur][threadIdx.x];
+      const fq hi = fq_mul(v, ts.t[k]);
+      buf[cur ^ 1][threadIdx.x] = fq_sub(v, hi);
+      buf[cur ^ 1][m + threadIdx.x] = hi;
+    }
+    cur ^= 1;
+    __syncthreads();
+    if (blockIdx.x == 0 && (int)threadIdx.x < 2 * m)
+      fq_store(base + (n - ((size_t)2 << (ell - k))) + threadIdx.x, buf[cur][threadIdx.x]);  // level k, 2m entries
+  }
+  const int nbits = ell - kEqLoVars - 1;  // bits of a chunk index of level 1
+  const fq one = fq_one();
+  if ((int)threadIdx.x < (1 << nlow)) {
+    fq run = one;
+    for (int j = 0; j < nlow; j++) {
+      const fq& t = ts.t[ell - kEqLoVars - 1 - j];
+      run = fq_mul(run, ((threadIdx.x >> j) & 1) ? t : fq_sub(one, t));
+      pm[threadIdx.x][j] = run;
+    }
+  } else if (threadIdx.x == 64) {
+    fq run = one;
+    const size_t bidx = blockIdx.x;
+    for (int j = nlow; j < nbits; j++) {
+      const fq& t = ts.t[ell - kEqLoVars - 1 - j];
+      run = fq_mul(run, ((bidx >> (j - nlow)) & 1) ? t : fq_sub(one, t));
+      pb[j] = run;
+    }
+  }
+  __syncthreads();
+  const fq lo = buf[cur][threadIdx.x];
+  for (int k = 1; k <= ell - kEqLoVars - 1; k++) {
+    const int nb = ell - k - kEqLoVars;  // level k has 2^nb chunks
+    fq* lvl = base + (n - ((size_t)2 << (ell - k))) + threadIdx.x;
+    if (nb <= nlow) {
+      if (blockIdx.x != 0) continue;
+      for (int m = 0; m < (1 << nb); m++) fq_store(lvl + (size_t)m * kEqChunk, fq_mul(pm[m][nb - 1], lo));
+    } else {
+      if (((size_t)blockIdx.x >> (nb - nlow)) != 0) continue;
+      const fq hb = fq_mul(pb[nb - 1], lo);
+      if (nlow == 0) { fq_store(lvl + (size_t)blockIdx.x * kEqChunk, hb); continue; }
+      for (int m = 0; m < (1 << nlow); m++)
+        fq_store(lvl + (((size_t)blockIdx.x << nlow) + m) * kEqChunk, fq_mul(pm[m][nlow - 1], hb));
+    }
+  }
+}
+
 template <int K>
 static int check_tabs(vpin_ctx* c, const vpin_table* const* t, size_t min_len) {
   if (!c) return VPIN_EINVAL;
@@ -537,16 +655,24 @@ int vpin_eq_suffix_tables(vpin_ctx* c, const uint8_t* tau, int ell, vpin_table**
   hipError_t e = hipSuccess;
   {
     ProfScope ps(c, VPIN_K_EQ, 32.0 * 3.0 * (double)(((size_t)1 << (ell - 1)) - 1));
-    // levels of up to 512 elements (k >= ell-9) in one launch, the larger ones one launch each
-    const int k_lo = ell - 9 > 1 ? ell - 9 : 1;
-    TauPack tp;
-    for (int k = k_lo; k <= ell - 1; k++) tp.t[k - k_lo] = load_host_fq(tau + 32 * (size_t)k);
-    hipLaunchKernelGGL(eq_pyramid_top_kernel, dim3(1), dim3(512), 0, c->stream, t->d, ell, k_lo, tp);
-    for (int k = k_lo - 1; k >= 1; k--) {  // level k from level k+1
-      size_t m = (size_t)1 << (ell - k - 1);
-      hipLaunchKernelGGL(eq_pyramid_step_kernel, dim3(grid_for(m)), dim3(kBlock), 0, c->stream,
-                         (const fq*)(t->d + pyramid_offset(ell, k + 1)), t->d + pyramid_offset(ell, k), m,
-                         load_host_fq(tau + 32 * (size_t)k));
+    static const bool fused = getenv("VPIN_EQ_STEPWISE") == nullptr;
+    if (fused && ell >= kEqLoVars + 2 && ell <= 32) {
+      TauAll ta;
+      for (int k = 0; k < ell; k++) ta.t[k] = load_host_fq(tau + 32 * (size_t)k);
+      const int nbits = ell - kEqLoVars - 1, nlow = std::min(kEqMidVars, std::max(0, nbits - 8));
+      hipLaunchKernelGGL(eq_pyramid_fused_kernel, dim3((unsigned)((size_t)1 << (nbits - nlow))), dim3(kEqChunk), 0, c->stream, t->d, ell, nlow, ta);
+    } else {
+      // levels of up to 512 elements (k >= ell-9) in one launch, the larger ones one launch each
+      const int k_lo = ell - 9 > 1 ? ell - 9 : 1;
+      TauPack tp;
+      for (int k = k_lo; k <= ell - 1; k++) tp.t[k - k_lo] = load_host_fq(tau + 32 * (size_t)k);
+      hipLaunchKernelGGL(eq_pyramid_top_kernel, dim3(1), dim3(512), 0, c->stream, t->d, ell, k_lo, tp);
+      for (int k = k_lo - 1; k >= 1; k--) {  // level k from level k+1
+        size_t m = (size_t)1 << (ell - k - 1);
+        hipLaunchKernelGGL(eq_pyramid_step_kernel, dim3(grid_for(m)), dim3(kBlock), 0, c->stream,
+                           (const fq*)(t->d + pyramid_offset(ell, k + 1)), t->d + pyramid_offset(ell, k), m,
+                           load_host_fq(tau + 32 * (size_t)k));
+      }
     }
     e = hipGetLastError();
   }
@@ -585,6 +711,25 @@ int vpin_eq_table(vpin_ctx* c, const uint8_t* r, int ell, vpin_table** out) {
   if (!c || !out || ell < 0 || ell > 40 || (ell > 0 && !r)) return VPIN_EINVAL;
   (void)hipSetDevice(c->device);
   size_t n = (size_t)1 << ell;
+  static const bool fused = getenv("VPIN_EQ_STEPWISE") == nullptr;
+  if (fused && ell >= kEqLoVars + 1 && ell <= 32) {
+    // one launch, every entry written once (eq_table_fused_kernel)
+    vpin_table* t = nullptr;
+    int rc1 = table_alloc_uninit(c, n, &t);
+    if (rc1) return rc1;
+    TauAll ra;
+    for (int j = 0; j < ell; j++) ra.t[j] = load_host_fq(r + 32 * (size_t)j);
+    {
+      ProfScope ps(c, VPIN_K_EQ, 32.0 * (double)n);
+      // chunks per workgroup: one while the table has at most 256 chunks (latency), up to 32 for the large ones (set-up amortised)
+      const int nmid = std::min(kEqMidVars, std::max(0, ell - kEqLoVars - 8));
+      hipLaunchKernelGGL(eq_table_fused_kernel, dim3((unsigned)(n >> (kEqLoVars + nmid))), dim3(kEqChunk), 0, c->stream, t->d, ell, nmid, ra);
+    }
+    hipError_t e1 = hipGetLastError();  // no temporaries: nothing to wait for, later work is ordered on the stream
+    if (e1 != hipSuccess) { set_last_error("eq_table", e1); vpin_table_free(c, t); return VPIN_EHIP; }
+    *out = t;
+    return VPIN_OK;
+  }
   vpin_table *a = nullptr, *b = nullptr;
   int rc = table_alloc_uninit(c, n, &a);  // every element is written by the doubling steps
   if (rc) return rc;

@@ -156,7 +156,11 @@ def main_strong(args):
     def step():
         t = None
         if ctx_h is not None:
-            t = threading.Thread(target=lambda: sc.serve_one(L))
+            def serve():
+                if use_nccl:
+                    torch.cuda.set_device(dev)  # the current device is per thread
+                sc.serve_one(L)
+            t = threading.Thread(target=serve)
             t.start()
         if rank == 0:
             proof_bytes[big[0]] = len(prove(ctx, gb, decb)["proof"])

@@ -168,3 +168,45 @@ def test_shape_errors(ctx, gens34):
     with pytest.raises(vpin_amd.VpinError) as ei:
         ctx.hyrax_commit(g, Z, np.zeros((1, 4), dtype=np.uint64), 33)  # R = 64 > 34 generators
     assert ei.value.code == -5
+
+
+def test_commit_rows_blocks_equal_the_whole_commitment(ctx, gens34):
+    """vpin_hyrax_commit_rows: any block of rows, with or without blinds, equals the same rows of vpin_hyrax_commit
+    and of the oracle (the row split of vpin_amd/dist.py rests on this)"""
+    import ctypes as C
+    import vpin_amd
+    L = vpin_amd.lib()
+    L.vpin_hyrax_commit_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p,
+                                         C.c_size_t, C.c_void_p]
+    g, og = gens34
+    rng = np.random.default_rng(77)
+    Ls, Rs = 16, 32
+    Z = M.ints_to_table(structured_scalars(rng, Ls * Rs))
+    blinds = M.ints_to_table([int(rng.integers(0, 2**62)) ** 4 % Q for _ in range(Ls)])
+    dZ = ctx.upload(Z)
+    whole = ctx.hyrax_commit(g, dZ, blinds, 33)
+    assert np.array_equal(whole, O.hyrax_commit(Z, Ls, blinds, og, 33))
+    zero = np.zeros((Ls, 4), dtype=np.uint64)
+    whole0 = O.hyrax_commit(Z, Ls, zero, og, 33)
+    for row0, nrows in ((0, 16), (0, 4), (4, 4), (13, 3), (15, 1)):
+        out = np.zeros((nrows, 32), dtype=np.uint8)
+        b = np.ascontiguousarray(blinds[row0:row0 + nrows])
+        assert L.vpin_hyrax_commit_rows(ctx.h, g.h, dZ.h, Ls, row0, nrows, b.ctypes.data_as(C.c_void_p), 33,
+                                        out.ctypes.data_as(C.c_void_p)) == 0
+        assert np.array_equal(out, whole[row0:row0 + nrows]), (row0, nrows)
+        assert L.vpin_hyrax_commit_rows(ctx.h, g.h, dZ.h, Ls, row0, nrows, None, 33, out.ctypes.data_as(C.c_void_p)) == 0
+        assert np.array_equal(out, whole0[row0:row0 + nrows]), (row0, nrows)
+    out = np.zeros((4, 32), dtype=np.uint8)
+    assert L.vpin_hyrax_commit_rows(ctx.h, g.h, dZ.h, Ls, 14, 4, None, 33, out.ctypes.data_as(C.c_void_p)) == -5  # rows past L
+
+
+def test_table_write_roundtrip(ctx):
+    t = ctx.alloc(64)
+    a = M.ints_to_table(list(range(1, 17)))
+    t.write(8, a)
+    got = t.read()
+    assert np.array_equal(got[8:24], a) and not got[:8].any() and not got[24:].any()
+    import vpin_amd
+    with pytest.raises(vpin_amd.VpinError):
+        t.write(60, a)
+    t.free()

@@ -228,3 +228,29 @@ def test_eq_factored_phase1_matches_reference_form(ctx, ell):
     host = [O.bound_top(t, r) for t in host]
     assert M.table_to_ints(host[0]) == [s]
     L.vpin_table_free(ctx.h, pyr)
+
+
+@pytest.mark.parametrize("ell", [10, 11, 14, 15, 19, 20, 23])
+def test_one_launch_eq_tables_and_pyramids_vs_oracle(ctx, ell):
+    """eq_table_fused_kernel / eq_pyramid_fused_kernel (H[h] * Lo[i] factorisation, 1..32 chunks per workgroup) against
+    EqPolynomial::evals of the oracle: the full table and every suffix level"""
+    import ctypes as C
+    import vpin_amd
+    L = vpin_amd.lib()
+    vp = C.c_void_p
+    L.vpin_eq_suffix_tables.argtypes = [vp, vp, C.c_int, C.POINTER(vp)]
+    L.vpin_table_read.argtypes = [vp, vp, C.c_size_t, C.c_size_t, vp]
+    rng = np.random.default_rng(600 + ell)
+    tau = rand_table(rng, ell)
+    exp = O.eq_evals(tau)
+    assert np.array_equal(ctx.eq_table(tau).read(), exp)
+    pyr = vp()
+    assert L.vpin_eq_suffix_tables(ctx.h, tau.ctypes.data_as(vp), ell, C.byref(pyr)) == 0
+    out = np.zeros(((1 << ell), 4), dtype=np.uint64)
+    assert L.vpin_table_read(ctx.h, pyr, 0, 1 << ell, out.ctypes.data_as(vp)) == 0
+    n = 1 << ell
+    for k in range(1, ell + 1):  # level k = eq(tau_k.., .) at offset n - 2^(ell-k+1)
+        off = n - (2 << (ell - k))
+        lvl = O.eq_evals(tau[k:]) if k < ell else M.ints_to_table([1])
+        assert np.array_equal(out[off:off + (1 << (ell - k))], lvl), f"level {k}"
+    L.vpin_table_free(ctx.h, pyr)

@@ -344,16 +344,22 @@ __global__ __launch_bounds__(kBlock) void fetch_tops_kernel(const fq* __restrict
   }
 }
 
-// blockIdx.y = slice: partial sums of <table[slice], eq>
-__global__ __launch_bounds__(kBlock) void slice_dot_kernel(const fq* __restrict__ table, size_t len, const fq* __restrict__ eq,
-                                                           fq* __restrict__ partials) {
-  const fq* t = table + (size_t)blockIdx.y * len;
-  fq acc = fq_zero();
+// Three slices per workgroup row: the eq table is read once per three slices instead of once per slice (the hash layer
+// evaluates 6 + 15 + 2 slices against two eq tables of N and M entries: 23 -> 9 reads of an eq table).
+// blockIdx.y = group g: slices 3g .. 3g+2; partial k of the group is slice 3g + k.
+__global__ __launch_bounds__(kBlock) void slice_dot3_kernel(const fq* __restrict__ table, size_t len, int nslices,
+                                                            const fq* __restrict__ eq, fq* __restrict__ partials) {
+  const int s0 = 3 * blockIdx.y;
+  const fq* t0 = table + (size_t)s0 * len;
+  const bool has1 = s0 + 1 < nslices, has2 = s0 + 2 < nslices;
+  fq e[3] = {fq_zero(), fq_zero(), fq_zero()};
   for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < len; i += (size_t)gridDim.x * kBlock) {
-    fq v = fq_load(t + i);
-    if (!fq_is_zero(v)) acc = fq_add(acc, fq_mul(v, fq_load(eq + i)));
+    const fq q = fq_load(eq + i);
+    fq v = fq_load(t0 + i);
+    if (!fq_is_zero(v)) e[0] = fq_add(e[0], fq_mul(v, q));
+    if (has1) { v = fq_load(t0 + len + i); if (!fq_is_zero(v)) e[1] = fq_add(e[1], fq_mul(v, q)); }
+    if (has2) { v = fq_load(t0 + 2 * len + i); if (!fq_is_zero(v)) e[2] = fq_add(e[2], fq_mul(v, q)); }
   }
-  fq e[3] = {acc, fq_zero(), fq_zero()};
   block_reduce_store<3>(e, partials + (size_t)blockIdx.y * gridDim.x * 3);
 }
 
@@ -620,13 +626,19 @@ int spark_slice_evals(vpin_ctx* c, const fq* table, size_t len, int nslices, con
   fq* partials = nullptr;
   if ((rc = round_partials(c, &partials))) return rc;
   const int grid = round_grid(len);
+  const int groups = (nslices + 2) / 3;
   {
     ProfScope ps(c, VPIN_K_SPARK_BUILD, (double)nslices * 32.0 * (double)len + 32.0 * (double)len);
-    hipLaunchKernelGGL(slice_dot_kernel, dim3(grid, nslices), dim3(kBlock), 0, c->stream, table, len, eq, partials);
+    hipLaunchKernelGGL(slice_dot3_kernel, dim3(grid, groups), dim3(kBlock), 0, c->stream, table, len, nslices, eq, partials);
   }
-  hipLaunchKernelGGL(inst_finish_kernel, dim3(nslices), dim3(kBlock), 0, c->stream, (const fq*)partials, grid, 0, c->h_spark);
+  hipLaunchKernelGGL(inst_finish_kernel, dim3(groups), dim3(kBlock), 0, c->stream, (const fq*)partials, grid, 0, c->h_spark);
   VPIN_HIP_TRY(hipGetLastError());
-  return spark_wait(c);
+  if ((rc = spark_wait(c))) return rc;
+  // group g's three sums sit at h_spark[3g + k] = slice 3g + k: spread them to the h_spark[3 * slice] layout of the callers
+  fq tmp[kSparkMaxInst];
+  for (int i = 0; i < nslices; i++) tmp[i] = c->h_spark[i];
+  for (int i = 0; i < nslices; i++) c->h_spark[3 * i] = tmp[i];
+  return VPIN_OK;
 }
 
 

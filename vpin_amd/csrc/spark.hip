@@ -625,7 +625,9 @@ int spark_slice_evals(vpin_ctx* c, const fq* table, size_t len, int nslices, con
   (void)hipSetDevice(c->device);
   fq* partials = nullptr;
   if ((rc = round_partials(c, &partials))) return rc;
-  const int grid = round_grid(len);
+  // a streaming read: enough workgroups to keep HBM busy whatever the number of slice groups (the round kernels' cap of
+  // 64 per circuit is sized for their finisher, not for this)
+  const int grid = (int)std::min<size_t>(512, std::max<size_t>(1, (len + kBlock * 8 - 1) / (kBlock * 8)));
   const int groups = (nslices + 2) / 3;
   {
     ProfScope ps(c, VPIN_K_SPARK_BUILD, (double)nslices * 32.0 * (double)len + 32.0 * (double)len);

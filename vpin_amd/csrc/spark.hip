@@ -504,11 +504,19 @@ static int round_partials(vpin_ctx* c, fq** out) {
 // circuit, grid-stride beyond.  A thread's pairs are serial work (~7 us each in a lone wave), so mid-size rounds (2^11..2^16
 // pairs), which cannot fill the device anyway, get one pair per thread: 75 -> ~25 us per round measured on the 2^16 instance;
 // the streaming rounds (>= 2^17 pairs per circuit) sit at the cap either way and keep their 8+ pairs per thread.
-static inline int round_grid(size_t pairs) {
+static inline int round_grid(size_t pairs, int ncirc = 12, bool shared_device = false) {
   static const size_t per_thread = [] { const char* e = getenv("VPIN_SPARK_PAIRS_PER_THREAD"); size_t v = e ? (size_t)atoi(e) : 1; return v ? v : 1; }();
   size_t b = (pairs + kBlock * per_thread - 1) / (kBlock * per_thread);
   if (b < 1) b = 1;
-  if (b > (size_t)round_blocks()) b = round_blocks();
+  // A proof that has the device to itself caps the LAUNCH, not the circuit: round_blocks() x 12 workgroups = 3 per CU fills
+  // the device for the 12 "ops" circuits, so the 4 "mem" circuits and the 6 dot-product halves get proportionally more
+  // workgroups each (the mem forest's streaming rounds ran at one workgroup per CU: the 2^25 instance alone 385 -> 379 ms).
+  // On a shared device (vpin_ctx_set_shared_device: other contexts prove at the same time) the per-circuit cap stays: the
+  // leftover CUs are the other streams', and more, shorter-lived workgroups cost the step 6 % (537 against 507 ms, same box).
+  const size_t cap0 = (size_t)round_blocks();
+  size_t cap = shared_device ? cap0 : cap0 * 12 / (size_t)(ncirc < 1 ? 1 : ncirc > 12 ? 12 : ncirc);
+  if (cap > (size_t)kRoundBlocks) cap = kRoundBlocks;
+  if (b > cap) b = cap;
   return (int)b;
 }
 
@@ -535,7 +543,7 @@ int spark_prod_round(vpin_ctx* c, const SparkForest* f, int level, size_t len, c
   fq* partials = nullptr;
   if ((rc = round_partials(c, &partials))) return rc;
   const size_t pairs = r ? len / 4 : len / 2;
-  const int grid = round_grid(pairs);
+  const int grid = round_grid(pairs, f->ncirc, c->shared_device);
   const fq rr = r ? load_host_fq(r) : fq{};
   const fq_const rconst = (r && lead) ? make_fq_const(r) : fq_const{};
   c->spark_seq++;  // a new launch group: this kernel (+ the dot-product kernel that follows when with_dotp)
@@ -566,7 +574,7 @@ int spark_dotp_round(vpin_ctx* c, size_t N, const fq* vals, const fq* comb_deref
   fq* partials = nullptr;
   if ((rc = round_partials(c, &partials))) return rc;
   const size_t pairs = r ? len / 4 : len / 2;
-  const int grid = round_grid(pairs);
+  const int grid = round_grid(pairs, 6, c->shared_device);
   const fq rr = r ? load_host_fq(r) : fq{};
   const bool from_scratch = r && !first_fold;
   // same launch group as the product circuits' kernel just issued: instances 12..17 of 18
@@ -607,7 +615,7 @@ int spark_triple_sums(vpin_ctx* c, const vpin_spark_decomm* d, const fq* comb_de
   (void)hipSetDevice(c->device);
   fq* partials = nullptr;
   if ((rc = round_partials(c, &partials))) return rc;
-  const int grid = round_grid(d->N / 2);
+  const int grid = round_grid(d->N / 2, 6, c->shared_device);
   {
     ProfScope ps(c, VPIN_K_SPARK_BUILD, 9.0 * 32.0 * (double)d->N);
     hipLaunchKernelGGL(triple_sum_kernel, dim3(grid, 6), dim3(kBlock), 0, c->stream, comb_derefs,

@@ -617,7 +617,7 @@ def main():
             p = st.get("spark_round_big")
             if p and p["ms"] > 0:
                 ach = p["alg_bytes"] / (p["ms"] * 1e-3) / 1e9
-                pp = pmc_l5.get("prod_round_kernel<true, true> (>= 2^20 pairs)", {})
+                pp = pmc_l5.get("prod_round_kernel<*, true, true> (>= 2^20 pairs)", {})
                 ipp = isa.get("prod_round_kernel<true, true>", {}).get("valu_per_pair", 2224)
                 peak_pairs = cus * 4 * 64 * clk / (4.0 * ipp)
                 pairs_s = p["units"] / (p["ms"] * 1e-3)
@@ -629,8 +629,8 @@ def main():
                             "launches": p["launches"], "ms": round(p["ms"], 3), "alg_bytes_per_launch": p["alg_bytes"] / p["launches"],
                             "alg_note": "per launch: circuits x 2 tables x 32 B x 1.5 x len + the shared eq table (32 B x 1.5 x len)",
                             "traffic": pp.get("hbm_bytes_per_launch"),
-                            "traffic_note": "PMC bytes per launch of the <true, true> launches of this class (16 of the 25 per proof; their "
-                                            "algorithmic bytes average 6.4 GB per launch)"})
+                            "traffic_note": "PMC bytes per launch of the same launches (kernel names prod_round_kernel<*, true, true>), "
+                                            "profiles/r02_pmc_traffic.json section bench_L5_mult"})
             line["roofline"]["secondary"] = sec
             line["roofline"]["secondary_scope"] = (f"{big} proven alone after the timed region ({alone_ms:.1f} ms, one stream, HIP events per launch, "
                                                    "table additions counted by vpin_prof_enable level 2)")

@@ -67,7 +67,7 @@ def main():
     res["sc_cubic3_kernel<true, true>"] = {"valu_per_pair": big["valu"], "v_mad_u64_u32_per_pair": big["v_mad_u64_u32"],
                                            "loads_per_pair": big["vmem_loads"], "stores_per_pair": big["vmem_stores"]}
     sp = isa(os.path.join(ROOT, "vpin_amd", "csrc", "spark.hip"))
-    ls = loops(kernel_body(sp, "_ZN4vpin17prod_round_kernelILb1ELb1EE"))
+    ls = loops(kernel_body(sp, "_ZN4vpin17prod_round_kernelILb1ELb1ELb1EE"))
     big = max(ls, key=lambda l: l["valu"])
     res["prod_round_kernel<true, true>"] = {"valu_per_pair": big["valu"], "v_mad_u64_u32_per_pair": big["v_mad_u64_u32"],
                                             "loads_per_pair": big["vmem_loads"], "stores_per_pair": big["vmem_stores"]}

@@ -4,8 +4,8 @@ usage: pmc_summary.py <section> <fetch_dir> <write_dir> [bench_json_of_the_same_
 The counters are in KiB.  On gfx950 FETCH_SIZE counts half the bytes of wide coalesced reads (MI355X_MICROARCH.md, HBM
 section), so hbm_bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024.  The correction is calibrated for 16-byte-per-lane
 streaming reads; for the MSM's 96-byte random table gathers it is an upper bound (noted in the entry).
-prod_round_kernel<true, true> is split by launch size: the class ">= 2^20 pairs" is recognised by the dispatch's grid
-(gridDim.y = circuits) and its traffic against the algorithmic bytes of 2^20 pairs.
+The product rounds of >= 2^20 pairs run under their own kernel names (prod_round_kernel<*, true, true>), so their class
+is the one bench.py's roofline.secondary times.
 """
 import csv
 import glob
@@ -49,18 +49,6 @@ def main():
         n = min(len(d["f"]), len(d["w"]))
         if n == 0:
             continue
-        if name.startswith("prod_round_kernel<true, true>"):
-            big_f, big_w = [], []
-            for i in range(n):
-                ncirc = max(1, d["grid"][i] // (64 * 256))  # launches at the 64-block cap: grid = 64 x 256 x circuits threads
-                alg_2_20 = ncirc * 2 * 32 * 1.5 * (4 << 20) + 32 * 1.5 * (4 << 20)
-                if (2 * d["f"][i] + d["w"][i]) * 1024 >= 0.6 * alg_2_20 and d["grid"][i] >= 64 * 256:
-                    big_f.append(d["f"][i])
-                    big_w.append(d["w"][i])
-            if big_f:
-                res["prod_round_kernel<true, true> (>= 2^20 pairs)"] = {
-                    "dispatches": len(big_f), "FETCH_SIZE_avg_KiB": sum(big_f) / len(big_f), "WRITE_SIZE_avg_KiB": sum(big_w) / len(big_w),
-                    "hbm_bytes_per_launch": (2 * sum(big_f) / len(big_f) + sum(big_w) / len(big_w)) * 1024}
         if name.startswith("msm_rows_kernel"):
             big = [i for i in range(n) if d["f"][i] * 1024 >= 1e9]  # the row commitments of the large polynomials
             if big:
@@ -75,6 +63,15 @@ def main():
         if name.startswith("msm_"):
             ent["note"] = "96-byte random table gathers: the x2 FETCH_SIZE correction is calibrated for streaming reads only, so this is an upper bound"
         res[name] = ent
+    # the >= 2^20-pair launches of the product rounds run under their own kernel names (template parameter BIG)
+    bigs = [v for k, v in per.items() if k.startswith("prod_round_kernel<") and k.rstrip().endswith("true>") and k.count("true") + k.count("false") == 3]
+    if bigs:
+        fs = [x for d in bigs for x in d["f"]]
+        ws = [x for d in bigs for x in d["w"]]
+        n = min(len(fs), len(ws))
+        res["prod_round_kernel<*, true, true> (>= 2^20 pairs)"] = {
+            "dispatches": n, "FETCH_SIZE_avg_KiB": sum(fs[:n]) / n, "WRITE_SIZE_avg_KiB": sum(ws[:n]) / n,
+            "hbm_bytes_per_launch": (2 * sum(fs[:n]) / n + sum(ws[:n]) / n) * 1024}
     if bench:
         for s in bench.get("roofline", {}).get("secondary", []):
             key = "msm_rows_kernel (>= 1 GB fetched)"
@@ -92,6 +89,12 @@ def main():
     if os.path.exists(OUT):
         doc = json.load(open(OUT))
     doc[section] = dict(sorted(res.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["dispatches"])[:24])
+    json.dump(doc, open(OUT, "w"), indent=1)
+    for k, v in doc[section].items():
+        if k.startswith("prod_round") and "(>=" in k and bench:
+            for s_ in bench.get("roofline", {}).get("secondary", []):
+                if s_["kernel"].startswith("prod_round") and section != "bench_default":
+                    v["algorithmic_bytes_per_launch"] = s_["alg_bytes_per_launch"]
     json.dump(doc, open(OUT, "w"), indent=1)
     print(json.dumps({k: v for k, v in doc[section].items() if "cubic3" in k or "prod_round" in k or "msm_rows" in k}, indent=1))
 

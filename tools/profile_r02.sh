@@ -7,7 +7,7 @@ O=$R/gpurun_out/r02p
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 python3 $R/bench.py --trace L5 --only mult --serial --steps 1 --warmup 1 --no-cpu-baseline --no-span --no-verify > $O/bench_L5_mult.json 2> $O/bench_L5_mult.err || exit 1
-timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ktrace -o kt -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/ktrace.log || exit 2
+timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ktrace -o kt -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-span > $O/bench_under_rocprof.json 2> $O/ktrace.log || exit 2
 for ctr in FETCH_SIZE WRITE_SIZE; do
   timeout -k 10 500 rocprofv3 --pmc $ctr --output-format csv -d $O/pmc_default_$ctr -o p -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-span --no-verify --no-roofline-pass > $O/pmc_default_$ctr.json 2> $O/pmc_default_$ctr.log || exit 3
   timeout -k 10 500 rocprofv3 --pmc $ctr --output-format csv -d $O/pmc_L5_$ctr -o p -- python3 $R/bench.py --trace L5 --only mult --serial --steps 1 --warmup 1 --no-cpu-baseline --no-span --no-verify --no-roofline-pass > $O/pmc_L5_$ctr.json 2> $O/pmc_L5_$ctr.log || exit 4

@@ -221,7 +221,9 @@ __device__ __forceinline__ void fold_pd2(const fq* src, fq* dst, size_t i, size_
 
 // LEAD: return sum E*A_0*B_0 and sum E*dA*dB (sc_dev.h lead_bc) instead of the sums at x = 0, 2, 3; its folds use the
 // launch-wide constant form of r (fq_dev.h fq_mul_const, constants in LDS)
-template <bool BIND, bool LEAD>
+// BIG: the same code under its own name for launches of >= 2^20 pairs per circuit (the streaming regime), so profilers
+// report that class separately (bench.py roofline.secondary, tools/pmc_summary.py)
+template <bool BIND, bool LEAD, bool BIG = false>
 __global__ __launch_bounds__(kBlock, kMinWaves) void prod_round_kernel(fq* __restrict__ forest, size_t stride, size_t off, size_t h,
                                                                        const fq* __restrict__ E, size_t pairs, fq r, fq_const rc,
                                                                        Finisher fin) {
@@ -553,11 +555,12 @@ int spark_prod_round(vpin_ctx* c, const SparkForest* f, int level, size_t len, c
     // folded halves written
     const double bytes = (double)f->ncirc * 2 * 32.0 * (r ? (double)len * 1.5 : (double)len) + 32.0 * (r ? (double)len * 1.5 : (double)len);
     ProfScope ps(c, VPIN_K_SPARK_ROUND, bytes, pairs >= ((size_t)1 << 20) ? VPIN_K_SPARK_ROUND_BIG : -1, (double)f->ncirc * (double)pairs);
-#define VPIN_PROD_LAUNCH(B_, L_)                                                                                             \
-  hipLaunchKernelGGL((prod_round_kernel<B_, L_>), dim3(grid, f->ncirc), dim3(kBlock), 0, c->stream, f->base, f->stride(), \
+#define VPIN_PROD_LAUNCH(B_, L_, G_)                                                                                              \
+  hipLaunchKernelGGL((prod_round_kernel<B_, L_, G_>), dim3(grid, f->ncirc), dim3(kBlock), 0, c->stream, f->base, f->stride(), \
                      f->level_off(level), h, E, pairs, rr, rconst, fin)
-    if (r) { if (lead) VPIN_PROD_LAUNCH(true, true); else VPIN_PROD_LAUNCH(true, false); }
-    else { if (lead) VPIN_PROD_LAUNCH(false, true); else VPIN_PROD_LAUNCH(false, false); }
+    const bool big = lead && pairs >= ((size_t)1 << 20);
+    if (r) { if (big) VPIN_PROD_LAUNCH(true, true, true); else if (lead) VPIN_PROD_LAUNCH(true, true, false); else VPIN_PROD_LAUNCH(true, false, false); }
+    else { if (big) VPIN_PROD_LAUNCH(false, true, true); else if (lead) VPIN_PROD_LAUNCH(false, true, false); else VPIN_PROD_LAUNCH(false, false, false); }
 #undef VPIN_PROD_LAUNCH
   }
   VPIN_HIP_TRY(hipGetLastError());

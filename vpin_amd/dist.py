@@ -1,8 +1,10 @@
-"""Multi-GPU plumbing: one process per GPU, instances sharded across ranks, no data-path collective.
+"""Multi-GPU plumbing: one process per GPU.
 
-vPIN's proofs are independent per gadget instance (2 per trace, 12 for LeNet: SURVEY.md F1), so the
-N-GPU path is a work partition plus a barrier and a max-reduce of the wall time.  torch.distributed
-(backend "nccl" = RCCL on the GPU box, "gloo" in the CPU tests) is used for exactly those two things.
+vPIN's proofs are independent per gadget instance (2 per trace, 12 for LeNet: SURVEY.md F1), so the default
+N-GPU path is a work partition plus a barrier and a max-reduce of the wall time -- no data-path collective.
+The one exchange step that exists is the row split of a single large commitment (SplitCommit below): a broadcast
+of two challenge vectors and an all-gather of 32-byte rows.  torch.distributed carries both (backend "nccl" =
+RCCL on a GPU node, "gloo" in the CPU tests); no field or group arithmetic lives in this module.
 """
 import os
 
@@ -96,7 +98,6 @@ class SplitCommit:
 
     def __init__(self, grp, engine, owner=0):
         self.grp, self.engine, self.owner = grp, engine, owner
-        self._pending = None
 
     # ---- tensors on the backend's device ----
     def _tensor(self, arr):

@@ -20,6 +20,8 @@ struct BulletState {
   fq *av = nullptr, *bv = nullptr, *sj = nullptr;  // [R] each
   fq* rows = nullptr;                              // [2][R]: scalars of L and R over g_0..g_{R-1}
   fq* partials = nullptr;                          // [nblk][2] block partials of the two inner products
+  void* msm_scratch = nullptr;                     // partial points of the round's two-row MSM (gens_msm_parts_launch)
+  hipEvent_t ev_partials = nullptr;                // the inner products have reached the host
   size_t R = 0;
   int nblk = 0;
 };
@@ -87,8 +89,9 @@ uint8_t* bullet_pinned(vpin_ctx* c) {
 
 void bullet_free(vpin_ctx* c, BulletState* st) {
   if (!st) return;
-  for (void* p : {(void*)st->av, (void*)st->bv, (void*)st->sj, (void*)st->rows, (void*)st->partials})
+  for (void* p : {(void*)st->av, (void*)st->bv, (void*)st->sj, (void*)st->rows, (void*)st->partials, st->msm_scratch})
     if (p) dev_free(c, p);
+  if (st->ev_partials) (void)hipEventDestroy(st->ev_partials);
   delete st;
 }
 
@@ -101,7 +104,9 @@ int bullet_begin(vpin_ctx* c, const uint8_t* x_mont, const uint8_t* a_mont, size
   st->R = R;
   st->nblk = (int)((R + kBB - 1) / kBB);
   if (dev_alloc(c, R * 32, (void**)&st->av) || dev_alloc(c, R * 32, (void**)&st->bv) || dev_alloc(c, R * 32, (void**)&st->sj) ||
-      dev_alloc(c, 2 * R * 32, (void**)&st->rows) || dev_alloc(c, (size_t)st->nblk * 64, (void**)&st->partials)) {
+      dev_alloc(c, 2 * R * 32, (void**)&st->rows) || dev_alloc(c, (size_t)st->nblk * 64, (void**)&st->partials) ||
+      dev_alloc(c, gens_msm_parts_scratch_bytes(2, R), &st->msm_scratch) ||
+      hipEventCreateWithFlags(&st->ev_partials, hipEventDisableTiming) != hipSuccess) {
     bullet_free(c, st);
     return VPIN_ENOMEM;
   }
@@ -117,9 +122,12 @@ int bullet_begin(vpin_ctx* c, const uint8_t* x_mont, const uint8_t* a_mont, size
   return VPIN_OK;
 }
 
-// One round at half length n: partial points of L and R (2 x vpin_gens_msm_parts_count(R) x 128 B, over the R
-// stream generators only; the c*Q and blind*H terms are the caller's) and the inner products c_L, c_R.
-int bullet_round(vpin_ctx* c, const vpin_gens* g, BulletState* st, size_t n, uint8_t* parts_xyzt, uint8_t cLR[64]) {
+// One round at half length n, in two halves so the host's work overlaps the MSM:
+//   bullet_round_begin : rows kernel, inner products to the host (event), the two-row MSM and its copy enqueued;
+//                        returns the inner products c_L, c_R as soon as THEY are there (the MSM is still running)
+//   bullet_round_end   : waits for the partial points of L and R (2 x vpin_gens_msm_parts_count(R) x 128 B, over the R
+//                        stream generators only; the c*Q and blind*H terms are the caller's, computed in between)
+int bullet_round_begin(vpin_ctx* c, const vpin_gens* g, BulletState* st, size_t n, uint8_t* parts_xyzt, uint8_t cLR[64]) {
   if (!c || !g || !st || !parts_xyzt || !cLR || n == 0 || 2 * n > st->R) return VPIN_EINVAL;
   (void)hipSetDevice(c->device);
   hipLaunchKernelGGL(bullet_rows_kernel, dim3(st->nblk), dim3(kBB), 0, c->stream, (const fq*)st->av, (const fq*)st->bv,
@@ -134,8 +142,16 @@ int bullet_round(vpin_ctx* c, const vpin_gens* g, BulletState* st, size_t n, uin
   if (pin && (size_t)used * 64 <= kBulletPinned / 2) part = (fq*)(pin + kBulletPinned / 2);
   else { pageable.resize((size_t)used * 2); part = pageable.data(); }
   VPIN_HIP_TRY(hipMemcpyAsync(part, st->partials, (size_t)used * 64, hipMemcpyDeviceToHost, c->stream));
-  int rc = gens_msm_parts_dev(c, g, st->rows, 2, st->R, parts_xyzt);  // synchronises the stream
+  VPIN_HIP_TRY(hipEventRecord(st->ev_partials, c->stream));
+  int rc = gens_msm_parts_launch(c, g, st->rows, 2, st->R, st->msm_scratch, parts_xyzt);
   if (rc) return rc;
+  // spin on the event: a blocking wait costs more than the ~10 us this copy takes
+  for (long spins = 0;; spins++) {
+    const hipError_t q = hipEventQuery(st->ev_partials);
+    if (q == hipSuccess) break;
+    if (q != hipErrorNotReady) { set_last_error("bullet_round_begin: hipEventQuery", q); return VPIN_EHIP; }
+    if (spins > 2000000) { VPIN_HIP_TRY(hipEventSynchronize(st->ev_partials)); break; }
+  }
   // block partials summed on the host (<= 64 pairs): plain modular additions of Montgomery values
   auto add = [](fq& a, const fq& b) {
     uint64_t cy = 0;
@@ -149,6 +165,17 @@ int bullet_round(vpin_ctx* c, const vpin_gens* g, BulletState* st, size_t n, uin
   fq sums[2] = {part[0], part[1]};
   for (int b = 1; b < used; b++) { add(sums[0], part[2 * (size_t)b]); add(sums[1], part[2 * (size_t)b + 1]); }
   memcpy(cLR, sums, 64);
+  return VPIN_OK;
+}
+
+int bullet_round_end(vpin_ctx* c) {
+  for (long spins = 0;; spins++) {
+    const hipError_t q = hipStreamQuery(c->stream);
+    if (q == hipSuccess) return VPIN_OK;
+    if (q != hipErrorNotReady) { set_last_error("bullet_round_end: hipStreamQuery", q); return VPIN_EHIP; }
+    if (spins > 2000000) break;
+  }
+  VPIN_HIP_TRY(hipStreamSynchronize(c->stream));
   return VPIN_OK;
 }
 

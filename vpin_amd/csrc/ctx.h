@@ -140,11 +140,16 @@ inline bool is_pow2(size_t x) { return x && !(x & (x - 1)); }
 // few-row fixed-base MSM over device-resident scalars (msm.hip): rows x ncols Montgomery scalars ->
 // rows x vpin_gens_msm_parts_count(ncols) partial points (canonical X|Y|Z|T) in host memory; synchronises
 int gens_msm_parts_dev(vpin_ctx* c, const vpin_gens* g, const fq* d_scalars, size_t rows, size_t ncols, uint8_t* parts_xyzt);
+// the same without the synchronisation (the caller provides the device scratch and waits on the stream itself)
+size_t gens_msm_parts_scratch_bytes(size_t rows, size_t ncols);
+int gens_msm_parts_launch(vpin_ctx* c, const vpin_gens* g, const fq* d_scalars, size_t rows, size_t ncols, void* scratch,
+                          uint8_t* parts_xyzt);
 
 // device side of the bullet reduction (bullet.hip)
 struct BulletState;
 int bullet_begin(vpin_ctx* c, const uint8_t* x_mont, const uint8_t* a_mont, size_t R, BulletState** out);
-int bullet_round(vpin_ctx* c, const vpin_gens* g, BulletState* st, size_t n, uint8_t* parts_xyzt, uint8_t cLR[64]);
+int bullet_round_begin(vpin_ctx* c, const vpin_gens* g, BulletState* st, size_t n, uint8_t* parts_xyzt, uint8_t cLR[64]);
+int bullet_round_end(vpin_ctx* c);
 uint8_t* bullet_pinned(vpin_ctx* c);  // 64 KiB of pinned host memory owned by the context (nullptr on failure)
 int bullet_fold(vpin_ctx* c, BulletState* st, size_t n, const uint8_t u[32], const uint8_t u_inv[32]);
 int bullet_finish(vpin_ctx* c, const vpin_gens* g, BulletState* st, uint8_t xhat_ahat[64], uint8_t* parts_xyzt);

@@ -307,21 +307,40 @@ static int dplog_prove(vpin_ctx* c, const PcGens& pc, Transcript& tr, Transcript
     return acc;
   };
   size_t n = R;
+  static const bool fine = getenv("VPIN_SPARK_TRACE") && atoi(getenv("VPIN_SPARK_TRACE")) >= 3;
+  double tb[6] = {0, 0, 0, 0, 0, 0};
   for (size_t round = 0; round < lgR; round++) {
     n /= 2;
     Fq cLR[2];
-    if ((rc = vpin::bullet_round(c, pc.dev, bs, n, parts.data(), B(cLR)))) return rc;
-    Point lr[2] = {sum_parts(parts.data()), sum_parts(parts.data() + np * 128)};
-    pc.fb_gR.mul_acc(lr[0], cLR[0] * r_); pc.fb_h.mul_acc(lr[0], bv1[round]);  // c_L * Q + blind_L * H
-    pc.fb_gR.mul_acc(lr[1], cLR[1] * r_); pc.fb_h.mul_acc(lr[1], bv2[round]);
+    auto t0 = Clock::now();
+    if ((rc = vpin::bullet_round_begin(c, pc.dev, bs, n, parts.data(), B(cLR)))) return rc;
+    auto t1 = Clock::now();
+    // c_L * Q + blind_L * H and c_R * Q + blind_R * H on the host while the device is still summing the stream terms
+    Point qh[2] = {Point::identity(), Point::identity()};
+    pc.fb_gR.mul_acc(qh[0], cLR[0] * r_); pc.fb_h.mul_acc(qh[0], bv1[round]);
+    pc.fb_gR.mul_acc(qh[1], cLR[1] * r_); pc.fb_h.mul_acc(qh[1], bv2[round]);
+    auto t2 = Clock::now();
+    if ((rc = vpin::bullet_round_end(c))) return rc;
+    auto t3 = Clock::now();
+    Point lr[2] = {sum_parts(parts.data()) + qh[0], sum_parts(parts.data() + np * 128) + qh[1]};
+    auto t4 = Clock::now();
     out.Lvec[round] = compress(lr[0]);
     out.Rvec[round] = compress(lr[1]);
     tr.append_point("L", out.Lvec[round].b);
     tr.append_point("R", out.Rvec[round].b);
     Fq u = tr.challenge_scalar("u"), u_inv = u.invert();
+    auto t5 = Clock::now();
     if ((rc = vpin::bullet_fold(c, bs, n, B(&u), B(&u_inv)))) return rc;
     blind_fin = blind_fin + bv1[round] * u * u + bv2[round] * u_inv * u_inv;
+    if (fine) {
+      auto t6 = Clock::now();
+      tb[0] += secs(t0, t1); tb[1] += secs(t1, t2); tb[2] += secs(t2, t3); tb[3] += secs(t3, t4); tb[4] += secs(t4, t5); tb[5] += secs(t5, t6);
+    }
   }
+  if (fine)
+    fprintf(stderr, "[dplog] R=%zu, %zu rounds, us per round: rows+inner products %.1f | host Q,H terms %.1f | wait for the MSM %.1f | "
+            "sum %zu parts x2 %.1f | compress x2 + transcript + invert %.1f | fold launch %.1f\n", R, lgR, tb[0] / lgR * 1e6,
+            tb[1] / lgR * 1e6, tb[2] / lgR * 1e6, np, tb[3] / lgR * 1e6, tb[4] / lgR * 1e6, tb[5] / lgR * 1e6);
   Fq xa[2];
   // g_hat = sum_j s_j g_j
   if ((rc = vpin::bullet_finish(c, pc.dev, bs, B(xa), parts.data()))) return rc;

@@ -809,7 +809,7 @@ int vpin_hyrax_commit_pair(vpin_ctx* c, const vpin_gens* g, const vpin_table* Za
 // partial points of few-row MSMs: parts_xyzt must hold rows * vpin_gens_msm_parts_count(ncols) * 128 bytes
 // at most kMaxParts per row: longer rows get a second, on-device summation stage (the host would
 // otherwise add a thousand points per row for the 32k-generator evaluation proofs)
-constexpr size_t kMaxParts = 32;
+constexpr size_t kMaxParts = 128;  // the host adds up to 128 partial points per row (~20 us) rather than wait for a second kernel
 static inline int wide_q(size_t ncols) { return ncols >= 8192 ? 4 : 1; }
 static inline size_t raw_parts(size_t ncols) { const size_t per = (size_t)kWideScalars * wide_q(ncols); return (ncols + per - 1) / per; }
 size_t vpin_gens_msm_parts_count(size_t ncols) { size_t n = raw_parts(ncols); return n < kMaxParts ? n : kMaxParts; }
@@ -911,6 +911,37 @@ int vpin_gens_msm(vpin_ctx* c, const vpin_gens* g, const uint8_t* scalars_mont, 
 }  // extern "C"
 
 namespace vpin {
+
+// asynchronous form: kernels and the device-to-host copy are enqueued on the context's stream; `scratch` must hold
+// rows * (raw_parts(ncols) + nparts) * 128 bytes and outlive them (gens_msm_parts_scratch_bytes)
+size_t gens_msm_parts_scratch_bytes(size_t rows, size_t ncols) { return rows * (raw_parts(ncols) + vpin_gens_msm_parts_count(ncols)) * 128; }
+int gens_msm_parts_launch(vpin_ctx* c, const vpin_gens* g, const fq* d_scalars, size_t rows, size_t ncols, void* scratch,
+                          uint8_t* parts_xyzt) {
+  if (!c || !g || !d_scalars || !parts_xyzt || !scratch || rows == 0 || ncols == 0) return VPIN_EINVAL;
+  if (ncols > g->nb) return VPIN_ESHAPE;
+  (void)hipSetDevice(c->device);
+  const size_t nraw = raw_parts(ncols), nparts = vpin_gens_msm_parts_count(ncols);
+  fp* dp = (fp*)scratch;
+  fp* dr = (fp*)((uint8_t*)scratch + rows * nraw * 128);
+  {
+    ProfScope ps(c, VPIN_K_MSM, 32.0 * (double)rows * (double)ncols);
+    if (wide_q(ncols) == 4)
+      hipLaunchKernelGGL((msm_wide_kernel<4>), dim3((unsigned)nraw, (unsigned)rows), dim3(kMsmBlock), 0, c->stream, d_scalars, ncols,
+                         view(g), dp);
+    else
+      hipLaunchKernelGGL((msm_wide_kernel<1>), dim3((unsigned)nraw, (unsigned)rows), dim3(kMsmBlock), 0, c->stream, d_scalars, ncols,
+                         view(g), dp);
+  }
+  const void* src = dp;
+  if (nraw > nparts) {
+    hipLaunchKernelGGL(parts_reduce_kernel, dim3((unsigned)((rows * nparts + 63) / 64)), dim3(64), 0, c->stream, (const fp*)dp, rows,
+                       nraw, (int)nparts, dr);
+    src = dr;
+  }
+  VPIN_HIP_TRY(hipGetLastError());
+  VPIN_HIP_TRY(hipMemcpyAsync(parts_xyzt, src, rows * nparts * 128, hipMemcpyDeviceToHost, c->stream));
+  return VPIN_OK;
+}
 
 int gens_msm_parts_dev(vpin_ctx* c, const vpin_gens* g, const fq* d_scalars, size_t rows, size_t ncols, uint8_t* parts_xyzt) {
   if (!c || !g || !d_scalars || !parts_xyzt || rows == 0 || ncols == 0) return VPIN_EINVAL;

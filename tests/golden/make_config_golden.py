@@ -125,6 +125,33 @@ def l5_comm():
     print(json.dumps(ent))
 
 
+def l5_sat():
+    """L5-mult: the oracle's R1CS satisfiability proof (my_R1CSProof_prove, commit_test.rs:136-334) fits this container
+    where its whole SNARK does not.  A SNARK's first bytes ARE that proof (lib.rs:330-338: r1cs_sat_proof is the first field),
+    so its digest pins the sat half of the HIP SNARK -- both ZK sum-checks at 2^25 constraints, the witness commitments,
+    the evaluation proof -- byte for byte."""
+    import oracle_lib as O
+    from vpin_amd import gadgets as G
+    t0 = time.time()
+    inp = G.synthetic_mult_inputs("L5")
+    inst = model_instance("mult", inp)
+    t1 = time.time()
+    res = O.sat_prove(inst, SEED_C, SEED_P, threads=os.cpu_count() or 1)
+    assert O.sat_verify(inst, res) == 1
+    with open(OUT) as f:
+        doc = json.load(f)
+    ent = doc["cases"]["L5-mult"]
+    assert ent["inputs_sha256"] == inputs_digest("mult", inp)
+    ent.update({"sat_len": len(res["proof"]), "sat_sha256": hashlib.sha256(res["proof"]).hexdigest(),
+                "comm_para_sha256": hashlib.sha256(res["comm_para"].tobytes()).hexdigest(),
+                "comm_input_sha256": hashlib.sha256(res["comm_input"].tobytes()).hexdigest(),
+                "inst_evals_sha256": hashlib.sha256(res["inst_evals"].tobytes()).hexdigest(),
+                "oracle_sat_s": {"model_instance": round(t1 - t0, 1), "sat_prove": round(time.time() - t1, 1),
+                                 "maxrss_gb": round(resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1e6, 1)}})
+    merge("L5-mult", ent)
+    print(json.dumps(ent))
+
+
 def merge(key, ent):
     doc = {"_source": "oracle/ (C restatement of SNARK::encode + my_lib_prove) on instances built by tests/gadgets_model.py "
                       "from the synthetic witness inputs of vpin_amd/gadgets.py CONFIGS; seed_commit = bytes(range(64)), "
@@ -144,5 +171,7 @@ if __name__ == "__main__":
             subprocess.check_call([sys.executable, os.path.abspath(__file__), lab, kind])
     elif sys.argv[1] == "l5":
         l5_comm()
+    elif sys.argv[1] == "l5sat":
+        l5_sat()
     else:
         one(sys.argv[1], sys.argv[2])

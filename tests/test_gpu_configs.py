@@ -56,6 +56,7 @@ def test_golden_file_covers_every_config():
             if k != "L5-mult":
                 assert "snark_sha256" in GOLD[k], k
     assert GOLD["L5-mult"]["num_cons"] == 1 << 25 and GOLD["L3-mult"]["num_cons"] == 1 << 22
+    assert "sat_sha256" in GOLD["L5-mult"] and "inst_evals_sha256" in GOLD["L5-mult"]
 
 
 def test_oracle_reproduces_small_config_digests():
@@ -121,8 +122,10 @@ def test_config_snark_bytes_match_oracle(ctx, key):
 
 @pytest.mark.gpu
 def test_l5_mult_commitment_pinned_and_proof_accepted_by_oracle_verifier(ctx):
-    """6000 point-mults, 20,784,000 constraints (2^25 padded): SNARK::encode's commitment equals the oracle's
-    (digest), and the oracle's verifier -- code independent of the product -- accepts the HIP proof against it."""
+    """6000 point-mults, 20,784,000 constraints (2^25 padded): SNARK::encode's commitment and the whole sat half of the
+    SNARK (R1CSProof + inst_evals + both witness commitments) equal the oracle's byte for byte (digests), and the oracle's
+    verifier -- code independent of the product -- accepts the HIP proof (whose SPARK half the oracle's prover cannot
+    reproduce in 62 GB) against that commitment."""
     g = GOLD["L5-mult"]
     d = build_dev(ctx, g)
     try:
@@ -131,6 +134,13 @@ def test_l5_mult_commitment_pinned_and_proof_accepted_by_oracle_verifier(ctx):
     finally:
         d.free()
     assert len(got["comm"]) == g["comm_len"] and hashlib.sha256(got["comm"]).hexdigest() == g["comm_sha256"]
+    # the sat half byte for byte: a SNARK starts with its R1CSProof (lib.rs:330-338), then the three inst_evals; the oracle's
+    # sat prover fits the build container at this size (tests/golden/make_config_golden.py l5sat)
+    n_sat = g["sat_len"]
+    assert hashlib.sha256(got["proof"][:n_sat]).hexdigest() == g["sat_sha256"], "R1CS satisfiability proof (both ZK sum-checks at 2^25)"
+    assert hashlib.sha256(got["proof"][n_sat:n_sat + 96]).hexdigest() == g["inst_evals_sha256"], "inst_evals"
+    assert hashlib.sha256(got["comm_para"].tobytes()).hexdigest() == g["comm_para_sha256"]
+    assert hashlib.sha256(got["comm_input"].tobytes()).hexdigest() == g["comm_input_sha256"]
     meta = {"inputs": inputs, "num_inputs": num_inputs}
     assert O.snark_verify(meta, got) == 1
     assert ctx.snark_verify(meta, got)

@@ -714,14 +714,14 @@ __device__ __forceinline__ fq fq_shfl_from(const fq& a, int src) {
 }
 
 // sums of e[0..2] over the first `nw` waves of the block; valid in threads 0..2
-__device__ __forceinline__ fq tail_block_sum3(fq* e, int nw, int lo_off) {
+__device__ __forceinline__ fq tail_block_sum3(fq* e, int nw) {
   __shared__ fq sh[kTailBlock / 64][3];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (wave < nw) {
 #pragma unroll
     for (int k = 0; k < 3; k++) {
       fq t = e[k];
-      for (int off = 32; off >= lo_off; off >>= 1) t = fq_add(t, fq_shfl_xor(t, off));
+      for (int off = 32; off >= 1; off >>= 1) t = fq_add(t, fq_shfl_xor(t, off));
       if (lane == 0) sh[wave][k] = t;
     }
   }
@@ -794,9 +794,7 @@ __global__ __launch_bounds__(kTailBlock) void spark_tail_kernel(TailArgs a) {
         acc.e[role] = fq_mul(fq_load(E + pi), u);
       }
       nw = (int)((4 * pairs + 63) / 64);
-      lo_off = 4;  // after the strides 32..4 lane 0 of a wave holds the role-0 sum, lane 1 the role-1 sum
-      // e[0] lives in role-0 lanes, e[1] in role-1 lanes: bring both to the layout tail_block_sum3 reduces
-      // (every lane may hold all three; foreign roles hold zero, so the quad-strided sums are already right)
+      lo_off = 4;  // quad layout: e[0] lives in the role-0 lanes, e[1] in the role-1 lanes (reduced over strides 32..4 below)
     } else if (!is_dotp) {
       for (size_t i = threadIdx.x; i < pairs; i += kTailBlock) {
         fq p1, d1, p2, d2;
@@ -824,7 +822,7 @@ __global__ __launch_bounds__(kTailBlock) void spark_tail_kernel(TailArgs a) {
     if (bind) len /= 2;
     fq t;
     if (lo_off == 4) {
-      // quad mode: lanes of role 0 carry e[0], role 1 e[1]; reduce each over its own lanes, then lane 1's e[1] joins lane 0
+      // quad layout: every lane reduces the sum of its own role over the lanes of that role (strides 32..4)
       fq v = (threadIdx.x & 1) ? acc.e[1] : acc.e[0];
       __shared__ fq shq[kTailBlock / 64][2];
       const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -839,7 +837,7 @@ __global__ __launch_bounds__(kTailBlock) void spark_tail_kernel(TailArgs a) {
         for (int w = 1; w < nw; w++) t = fq_add(t, shq[w][threadIdx.x]);
       }
     } else {
-      t = tail_block_sum3(acc.e, nw, 1);  // its barriers also order this round's folds before the next round's loads
+      t = tail_block_sum3(acc.e, nw);  // its barriers also order this round's folds before the next round's loads
     }
     if (threadIdx.x < 3) publish_scalar(up + 12 * threadIdx.x, t, seq);
     if (last) {

@@ -698,6 +698,11 @@ __device__ __forceinline__ void load48_system(const uint32_t* p, u32x4& c0, u32x
       : "v"(p)
       : "memory");
 }
+__device__ __forceinline__ u32x4 load16_system(const uint32_t* p) {
+  u32x4 v;
+  asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(p) : "memory");
+  return v;
+}
 __device__ __forceinline__ void store16_system(uint32_t* p, u32x4 v) {
   asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(p), "v"(v) : "memory");
 }
@@ -839,7 +844,7 @@ __global__ __launch_bounds__(kTailBlock) void spark_tail_kernel(TailArgs a) {
     } else {
       t = tail_block_sum3(acc.e, nw);  // its barriers also order this round's folds before the next round's loads
     }
-    if (threadIdx.x < 3) publish_scalar(up + 12 * threadIdx.x, t, seq);
+    if ((int)threadIdx.x < (is_dotp ? 3 : 2)) publish_scalar(up + 12 * threadIdx.x, t, seq);  // a product circuit has two sums
     if (last) {
       // live length is 2: both entries of every table, for the host to bind with the last challenge
       if (!is_dotp && lo_off == 4) {
@@ -860,7 +865,13 @@ __global__ __launch_bounds__(kTailBlock) void spark_tail_kernel(TailArgs a) {
     if (threadIdx.x == 0) {
       int stop = 1;
       for (long spin = 0; spin < kTailSpinLimit; spin++) {
-        u32x4 c0, c1, c2;
+        // one 16-byte read per poll (12-18 workgroups poll the same three pieces: a third of the PCIe reads); the other two
+        // pieces only once the first carries the round's sequence number
+        u32x4 c0 = load16_system(a.down), c1, c2;
+        if (c0.x != seq) {
+          if ((spin & 15) == 15 && __hip_atomic_load(a.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) break;
+          continue;
+        }
         load48_system(a.down, c0, c1, c2);
         if (c0.x == seq && c1.x == seq && c2.x == seq) {
           fq rr;
@@ -926,6 +937,7 @@ int spark_tail_launch(vpin_ctx* c, const SparkForest* f, int level, int k, int j
 }
 
 typedef uint32_t tail_v4 __attribute__((vector_size(16), aligned(16)));
+static inline fq fq_zero_host() { fq z; memset(z.v, 0, sizeof z.v); return z; }
 
 // one scalar out of its three pieces; false while a piece still carries an older sequence number
 static inline bool tail_take(const uint32_t* slot, uint32_t want, fq* out) {
@@ -951,7 +963,9 @@ int spark_tail_wait(vpin_ctx* c, int idx, int ninst, int ncirc) {
       if (done_mask >> i & 1u) continue;
       const uint32_t* u = up + (size_t)i * kTailUpChunks * 4;
       bool ok = true;
-      for (int k = 0; k < 3 && ok; k++) ok = tail_take(u + 12 * k, want, &c->tail_sums[3 * i + k]);
+      const int nsum = i < ncirc ? 2 : 3;  // leading-coefficient form: two sums per product circuit, three per dot-product half
+      for (int k = 0; k < nsum && ok; k++) ok = tail_take(u + 12 * k, want, &c->tail_sums[3 * i + k]);
+      if (nsum == 2) c->tail_sums[3 * i + 2] = fq_zero_host();
       const int ne = i < ncirc ? 4 : 6;
       for (int e = 0; last && e < ne && ok; e++) ok = tail_take(u + 36 + 12 * e, want, &c->tail_final[6 * i + e]);
       if (ok) done_mask |= 1u << i;

@@ -149,3 +149,19 @@ def test_l5_mult_commitment_pinned_and_proof_accepted_by_oracle_verifier(ctx):
         bad = bytearray(got["proof"])
         bad[pos] ^= 2
         assert O.snark_verify(meta, got, proof=bytes(bad)) == 0, pos
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("key", ["3_32-mult", "A-add", "7_256-mult"])
+def test_host_built_instances_give_the_same_bytes(ctx, key):
+    """the other entry of the boundary: instance and witness built on the HOST (vpin_gadget_point_*), uploaded and proven
+    through vpin_snark_prove -- same oracle digests as the device-built path"""
+    from vpin_amd import gadgets as G
+    g = GOLD[key]
+    inst = G.synthetic_mult_instance(g["label"]) if g["kind"] == "mult" else G.synthetic_add_instance(g["label"])
+    d = inst.as_dict()
+    inst.free()
+    got = ctx.snark_prove(d, SEED_C, SEED_P)
+    assert hashlib.sha256(got["comm"]).hexdigest() == g["comm_sha256"]
+    assert hashlib.sha256(got["proof"]).hexdigest() == g["snark_sha256"]
+    assert hashlib.sha256(got["comm_para"].tobytes()).hexdigest() == g["comm_para_sha256"]

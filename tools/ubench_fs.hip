@@ -160,6 +160,14 @@ int main() {
   hipEvent_t e0, e1;
   hipEventCreate(&e0); hipEventCreate(&e1);
   const int n = 200;
+  {
+    // known answer: Keccak-f[1600] of the all-zero state starts with lane 0 = f1258f7940e1dde7 (FIPS 202 test vectors)
+    hipMemset(d, 0, 200);
+    hipLaunchKernelGGL(k_keccak_wave, dim3(1), dim3(64), 0, s, d, 1);
+    hipStreamSynchronize(s);
+    hipMemcpy(h0, d, 200, hipMemcpyDeviceToHost);
+    printf("keccak-f(0) lane 0 = %016llx (%s)\n", (unsigned long long)h0[0], h0[0] == 0xf1258f7940e1dde7ULL ? "matches FIPS 202" : "WRONG");
+  }
   for (int rep = 0; rep < 2; rep++) {
     float ms_a, ms_b, ms_c;
     hipMemset(d, 1, 200);

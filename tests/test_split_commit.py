@@ -146,8 +146,8 @@ def _gpu_worker(rank, world, port, q, n_ops):
 
 @pytest.mark.gpu
 @pytest.mark.timeout(600)
-def test_split_derefs_commitment_two_processes_one_gpu():
-    world = 2
+@pytest.mark.parametrize("world", [2, 4])
+def test_split_derefs_commitment_processes_sharing_one_gpu(world):
     port = _free_port()
     mpc = mp.get_context("spawn")
     q = mpc.Queue()

@@ -23,7 +23,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 
-OUT = os.path.join(HERE, "config_digests.json")
+OUT = os.environ.get("VPIN_GOLDEN_OUT", os.path.join(HERE, "config_digests.json"))
 SEED_C = bytes(range(64))
 SEED_P = bytes((7 * i + 3) % 256 for i in range(64))
 
@@ -152,6 +152,47 @@ def l5_sat():
     print(json.dumps(ent))
 
 
+def l5_full():
+    """L5-mult, the whole SNARK: ~95 GB and ~25 core-minutes in the oracle, more than the build container has, so this
+    mode is run on the GPU box's HOST cores (322 GB, 16 cores; nothing touches the GPU):
+        gpurun --timeout 1200 -- 'VPIN_GOLDEN_OUT=gpurun_out/l5full.json python tests/golden/make_config_golden.py l5full'
+    and the entry it prints is merged into config_digests.json here.  Same chain as every other case (Python gadget model ->
+    oracle); it re-derives the commitment and sat-half digests the container produced and refuses to write if they differ."""
+    import threading
+    import oracle_lib as O
+    from vpin_amd import gadgets as G
+    stop = threading.Event()
+
+    def beat():
+        t = time.time()
+        while not stop.wait(60):
+            print(f"[l5full] {time.time() - t:.0f} s, maxrss {resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1e6:.1f} GB", flush=True)
+    threading.Thread(target=beat, daemon=True).start()
+    t0 = time.time()
+    inp = G.synthetic_mult_inputs("L5")
+    inst = model_instance("mult", inp)
+    t1 = time.time()
+    print(f"[l5full] instance built in {t1 - t0:.0f} s", flush=True)
+    res = O.snark_prove(inst, SEED_C, SEED_P, threads=int(os.environ.get("VPIN_ORACLE_THREADS", os.cpu_count() or 1)))
+    t2 = time.time()
+    print(f"[l5full] proved in {t2 - t1:.0f} s", flush=True)
+    ok = O.snark_verify(inst, res)
+    stop.set()
+    assert ok == 1
+    with open(os.path.join(HERE, "config_digests.json")) as f:
+        ent = json.load(f)["cases"]["L5-mult"]
+    assert ent["inputs_sha256"] == inputs_digest("mult", inp)
+    assert ent["comm_sha256"] == hashlib.sha256(res["comm"]).hexdigest(), "computation commitment differs from the container's"
+    assert ent["sat_sha256"] == hashlib.sha256(res["proof"][:ent["sat_len"]]).hexdigest(), "sat half differs from the container's"
+    ent.update({"snark_len": len(res["proof"]), "snark_sha256": hashlib.sha256(res["proof"]).hexdigest(),
+                "snark_head_hex": res["proof"][:64].hex(), "snark_tail_hex": res["proof"][-64:].hex(),
+                "oracle_full_s": {"where": "GPU box host cores (EPYC 9575F share)", "model_instance": round(t1 - t0, 1),
+                                  "encode_prove": round(t2 - t1, 1), "verify": round(time.time() - t2, 1),
+                                  "maxrss_gb": round(resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1e6, 1)}})
+    merge("L5-mult", ent)
+    print(json.dumps(ent))
+
+
 def merge(key, ent):
     doc = {"_source": "oracle/ (C restatement of SNARK::encode + my_lib_prove) on instances built by tests/gadgets_model.py "
                       "from the synthetic witness inputs of vpin_amd/gadgets.py CONFIGS; seed_commit = bytes(range(64)), "
@@ -173,5 +214,7 @@ if __name__ == "__main__":
         l5_comm()
     elif sys.argv[1] == "l5sat":
         l5_sat()
+    elif sys.argv[1] == "l5full":
+        l5_full()
     else:
         one(sys.argv[1], sys.argv[2])

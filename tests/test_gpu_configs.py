@@ -4,10 +4,10 @@ vpin_snark_prove_dev) against the oracle's digests in tests/golden/config_digest
 
 Instances: point_mult.rs:27-67 (18 / 98 / 178 / 658 / 300 / 800 / 240 / 168 / 6000 ops),
 point_addition.rs:38-70 and src/LeNet/Server.py:690-698,753-761 for the LeNet layers.
-Byte parity (SHA-256 of the SNARK, of the computation commitment and of both witness commitments) for
-every instance the oracle's prover fits in the build container (up to 2^22 constraints); L5-mult (2^25):
-computation commitment pinned by the oracle's SNARK::encode digest, proof accepted by the oracle's verifier
-(independent code) and tampered proofs rejected.
+Byte parity (SHA-256 of the SNARK, of the computation commitment and of both witness commitments) for EVERY instance,
+L5-mult (2^25 constraints) included: its whole-SNARK digest was produced by the oracle on the GPU box's host cores
+(93 GB; make_config_golden.py l5full), its commitment and sat-half digests in the build container, and the two runs agree.
+On top, the oracle's verifier (independent code) accepts the HIP L5 proof and rejects tampered ones.
 """
 import hashlib
 import json
@@ -48,13 +48,12 @@ def inputs_digest(kind, inp):
 
 
 def test_golden_file_covers_every_config():
-    """not gpu: the fixture file names every instance of every BASELINE config, with full digests for all but L5-mult"""
+    """not gpu: the fixture file names every instance of every BASELINE config, with whole-SNARK digests for all of them"""
     for cfg, keys in CONFIG_CASES.items():
         for k in keys:
             assert k in GOLD, (cfg, k)
             assert "comm_sha256" in GOLD[k] and "inputs_sha256" in GOLD[k]
-            if k != "L5-mult":
-                assert "snark_sha256" in GOLD[k], k
+            assert "snark_sha256" in GOLD[k] and "snark_len" in GOLD[k], k
     assert GOLD["L5-mult"]["num_cons"] == 1 << 25 and GOLD["L3-mult"]["num_cons"] == 1 << 22
     assert "sat_sha256" in GOLD["L5-mult"] and "inst_evals_sha256" in GOLD["L5-mult"]
 
@@ -99,7 +98,7 @@ def build_dev(ctx, g):
     return d
 
 
-FULL = [k for keys in CONFIG_CASES.values() for k in keys if k != "L5-mult"]
+FULL = [k for keys in CONFIG_CASES.values() for k in keys]
 
 
 @pytest.mark.gpu
@@ -122,10 +121,10 @@ def test_config_snark_bytes_match_oracle(ctx, key):
 
 @pytest.mark.gpu
 def test_l5_mult_commitment_pinned_and_proof_accepted_by_oracle_verifier(ctx):
-    """6000 point-mults, 20,784,000 constraints (2^25 padded): SNARK::encode's commitment and the whole sat half of the
-    SNARK (R1CSProof + inst_evals + both witness commitments) equal the oracle's byte for byte (digests), and the oracle's
-    verifier -- code independent of the product -- accepts the HIP proof (whose SPARK half the oracle's prover cannot
-    reproduce in 62 GB) against that commitment."""
+    """6000 point-mults, 20,784,000 constraints (2^25 padded), beyond the whole-SNARK digest of the parametrised test:
+    SNARK::encode's commitment and the sat half (R1CSProof + inst_evals + both witness commitments) against the digests the
+    oracle produced in the build container, and the oracle's verifier -- code independent of the product -- accepts the
+    HIP proof against that commitment and rejects tampered ones."""
     g = GOLD["L5-mult"]
     d = build_dev(ctx, g)
     try:
@@ -141,6 +140,7 @@ def test_l5_mult_commitment_pinned_and_proof_accepted_by_oracle_verifier(ctx):
     assert hashlib.sha256(got["proof"][n_sat:n_sat + 96]).hexdigest() == g["inst_evals_sha256"], "inst_evals"
     assert hashlib.sha256(got["comm_para"].tobytes()).hexdigest() == g["comm_para_sha256"]
     assert hashlib.sha256(got["comm_input"].tobytes()).hexdigest() == g["comm_input_sha256"]
+    assert len(got["proof"]) == g["snark_len"] and hashlib.sha256(got["proof"]).hexdigest() == g["snark_sha256"], "SNARK bytes"
     meta = {"inputs": inputs, "num_inputs": num_inputs}
     assert O.snark_verify(meta, got) == 1
     assert ctx.snark_verify(meta, got)

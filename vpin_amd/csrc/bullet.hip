@@ -6,11 +6,13 @@
 // cross inner products <a_L, b_R>, <a_R, b_L> and the folds of a, b, s with the round challenge all live on the
 // device (R <= 32768 elements: launch-latency bound); a round moves only the partial points of L and R, the two
 // inner products and the challenge across PCIe.
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
 
 #include "ctx.h"
+#include "mailbox_dev.h"
 
 namespace vpin {
 
@@ -18,6 +20,8 @@ constexpr int kBB = 256;
 
 struct BulletState {
   fq *av = nullptr, *bv = nullptr, *sj = nullptr;  // [R] each
+  fq *av2 = nullptr, *bv2 = nullptr;               // fused rounds: the folded vectors are double-buffered
+  int cur = 0;                                     // fused rounds: 0 = the live vectors are in av / bv, 1 = in av2 / bv2
   fq* rows = nullptr;                              // [2][R]: scalars of L and R over g_0..g_{R-1}
   fq* partials = nullptr;                          // [nblk][2] block partials of the two inner products
   void* msm_scratch = nullptr;                     // partial points of the round's two-row MSM (gens_msm_parts_launch)
@@ -35,7 +39,7 @@ __global__ __launch_bounds__(kBB) void bullet_init_kernel(fq* __restrict__ sj, s
 // partials[blk] = block sums of a_L[i]*b_R[i] and a_R[i]*b_L[i].
 __global__ __launch_bounds__(kBB) void bullet_rows_kernel(const fq* __restrict__ av, const fq* __restrict__ bv,
                                                           const fq* __restrict__ sj, size_t n, size_t R, fq* __restrict__ rows,
-                                                          fq* __restrict__ partials) {
+                                                          fq* __restrict__ partials, int used) {
   const size_t j = (size_t)blockIdx.x * kBB + threadIdx.x;
   fq pl = fq_zero(), pr = fq_zero();
   if (j < R) {
@@ -59,7 +63,7 @@ __global__ __launch_bounds__(kBB) void bullet_rows_kernel(const fq* __restrict__
   pr = fq_wave_sum(pr);
   if (lane == 0) { sh[wave][0] = pl; sh[wave][1] = pr; }
   __syncthreads();
-  if (threadIdx.x < 2) {
+  if (threadIdx.x < 2 && (int)blockIdx.x < used) {  // the blocks past i < n hold zeros nobody reads
     fq s = sh[0][threadIdx.x];
 #pragma unroll
     for (int w = 1; w < kBB / 64; w++) s = fq_add(s, sh[w][threadIdx.x]);
@@ -83,13 +87,23 @@ __global__ __launch_bounds__(kBB) void bullet_fold_kernel(fq* __restrict__ av, f
 constexpr size_t kBulletPinned = 64 * 1024;
 
 uint8_t* bullet_pinned(vpin_ctx* c) {
-  if (!c->h_bullet && hipHostMalloc(&c->h_bullet, kBulletPinned, hipHostMallocDefault) != hipSuccess) c->h_bullet = nullptr;
+  if (!c->h_bullet) {
+    if (hipHostMalloc(&c->h_bullet, kBulletPinned, hipHostMallocDefault) != hipSuccess) c->h_bullet = nullptr;
+    else memset(c->h_bullet, 0, kBulletPinned);  // mailbox pieces start with sequence number 0 = never published
+  }
   return (uint8_t*)c->h_bullet;
+}
+
+constexpr size_t kFusedMaxR = 4096;  // 2 x R/32 partial points of 128 B fill the first half of the pinned buffer
+bool bullet_fused(const BulletState* st) {
+  static const bool off = getenv("VPIN_BULLET_CLASSIC") != nullptr;
+  return st && !off && st->av2 && st->R % 32 == 0 && st->R <= kFusedMaxR;
 }
 
 void bullet_free(vpin_ctx* c, BulletState* st) {
   if (!st) return;
-  for (void* p : {(void*)st->av, (void*)st->bv, (void*)st->sj, (void*)st->rows, (void*)st->partials, st->msm_scratch})
+  for (void* p : {(void*)st->av, (void*)st->bv, (void*)st->sj, (void*)st->rows, (void*)st->partials, st->msm_scratch, (void*)st->av2,
+                  (void*)st->bv2})
     if (p) dev_free(c, p);
   if (st->ev_partials) (void)hipEventDestroy(st->ev_partials);
   delete st;
@@ -103,10 +117,12 @@ int bullet_begin(vpin_ctx* c, const uint8_t* x_mont, const uint8_t* a_mont, size
   if (!st) return VPIN_ENOMEM;
   st->R = R;
   st->nblk = (int)((R + kBB - 1) / kBB);
-  if (dev_alloc(c, R * 32, (void**)&st->av) || dev_alloc(c, R * 32, (void**)&st->bv) || dev_alloc(c, R * 32, (void**)&st->sj) ||
+  const bool want_fused = R % 32 == 0 && R <= kFusedMaxR && bullet_pinned(c) != nullptr;
+  if ((want_fused && (dev_alloc(c, R * 32, (void**)&st->av2) || dev_alloc(c, R * 32, (void**)&st->bv2))) ||
+      dev_alloc(c, R * 32, (void**)&st->av) || dev_alloc(c, R * 32, (void**)&st->bv) || dev_alloc(c, R * 32, (void**)&st->sj) ||
       dev_alloc(c, 2 * R * 32, (void**)&st->rows) || dev_alloc(c, (size_t)st->nblk * 64, (void**)&st->partials) ||
       dev_alloc(c, gens_msm_parts_scratch_bytes(2, R), &st->msm_scratch) ||
-      hipEventCreateWithFlags(&st->ev_partials, hipEventDisableTiming) != hipSuccess) {
+      hipEventCreateWithFlags(&st->ev_partials, hipEventDisableTiming | hipEventReleaseToSystem) != hipSuccess) {
     bullet_free(c, st);
     return VPIN_ENOMEM;
   }
@@ -130,20 +146,23 @@ int bullet_begin(vpin_ctx* c, const uint8_t* x_mont, const uint8_t* a_mont, size
 int bullet_round_begin(vpin_ctx* c, const vpin_gens* g, BulletState* st, size_t n, uint8_t* parts_xyzt, uint8_t cLR[64]) {
   if (!c || !g || !st || !parts_xyzt || !cLR || n == 0 || 2 * n > st->R) return VPIN_EINVAL;
   (void)hipSetDevice(c->device);
-  hipLaunchKernelGGL(bullet_rows_kernel, dim3(st->nblk), dim3(kBB), 0, c->stream, (const fq*)st->av, (const fq*)st->bv,
-                     (const fq*)st->sj, n, st->R, st->rows, st->partials);
-  VPIN_HIP_TRY(hipGetLastError());
   // only the blocks covering i < n carry non-zero partials
   const int used = (int)((n + kBB - 1) / kBB);
-  // pinned staging (second half of the context's buffer; the caller's partial points use the first half)
+  // Pinned staging (second half of the context's buffer; the caller's partial points use the first half).  Pinned host
+  // memory is device-addressable: the kernels store the block partials and the partial points straight into it, so a
+  // round has no copy command at all (each costs ~10 us of latency here).
   uint8_t* pin = bullet_pinned(c);
+  const bool direct = pin && (size_t)used * 64 <= kBulletPinned / 2;
   std::vector<fq> pageable;
   fq* part;
-  if (pin && (size_t)used * 64 <= kBulletPinned / 2) part = (fq*)(pin + kBulletPinned / 2);
+  if (direct) part = (fq*)(pin + kBulletPinned / 2);
   else { pageable.resize((size_t)used * 2); part = pageable.data(); }
-  VPIN_HIP_TRY(hipMemcpyAsync(part, st->partials, (size_t)used * 64, hipMemcpyDeviceToHost, c->stream));
+  hipLaunchKernelGGL(bullet_rows_kernel, dim3(st->nblk), dim3(kBB), 0, c->stream, (const fq*)st->av, (const fq*)st->bv,
+                     (const fq*)st->sj, n, st->R, st->rows, direct ? part : st->partials, used);
+  VPIN_HIP_TRY(hipGetLastError());
+  if (!direct) VPIN_HIP_TRY(hipMemcpyAsync(part, st->partials, (size_t)used * 64, hipMemcpyDeviceToHost, c->stream));
   VPIN_HIP_TRY(hipEventRecord(st->ev_partials, c->stream));
-  int rc = gens_msm_parts_launch(c, g, st->rows, 2, st->R, st->msm_scratch, parts_xyzt);
+  int rc = gens_msm_parts_launch(c, g, st->rows, 2, st->R, st->msm_scratch, parts_xyzt, pin && parts_xyzt == pin);
   if (rc) return rc;
   // spin on the event: a blocking wait costs more than the ~10 us this copy takes
   for (long spins = 0;; spins++) {
@@ -188,6 +207,76 @@ int bullet_fold(vpin_ctx* c, BulletState* st, size_t n, const uint8_t u[32], con
   hipLaunchKernelGGL(bullet_fold_kernel, dim3(st->nblk), dim3(kBB), 0, c->stream, st->av, st->bv, st->sj, n, st->R, fu, fi);
   VPIN_HIP_TRY(hipGetLastError());
   return VPIN_OK;
+}
+
+
+// ---- fused rounds: one launch each (msm.hip bullet_step_kernel) ---------------------------------------------------
+static inline uint32_t* fused_up(vpin_ctx* c) { return reinterpret_cast<uint32_t*>((uint8_t*)c->h_bullet + kBulletPinned / 2); }
+
+static int fused_take(vpin_ctx* c, int nslots, uint32_t seq, fq sums[2]) {
+  const uint32_t* up = fused_up(c);
+  auto add = [](fq& a, const fq& b) {
+    uint64_t cy = 0;
+    uint32_t t[8];
+    for (int i = 0; i < 8; i++) { cy += (uint64_t)a.v[i] + b.v[i]; t[i] = (uint32_t)cy; cy >>= 32; }
+    uint32_t d[8];
+    int64_t bw = 0;
+    for (int i = 0; i < 8; i++) { bw += (int64_t)t[i] - (int64_t)fq_modulus_limb(i); d[i] = (uint32_t)bw; bw >>= 32; }
+    for (int i = 0; i < 8; i++) a.v[i] = bw ? t[i] : d[i];
+  };
+  for (int b = 0; b < nslots; b++)
+    for (int k = 0; k < 2; k++) {
+      fq v;
+      for (long spins = 0; !tail_take(up + (2 * (size_t)b + k) * 12, seq, &v); spins++) {
+        __builtin_ia32_pause();
+        if ((spins & 0xffff) == 0xffff) {
+          const hipError_t q = hipStreamQuery(c->stream);  // a finished stream without the scalars = a failed launch
+          if (q != hipErrorNotReady && !tail_take(up + (2 * (size_t)b + k) * 12, seq, &v)) {
+            set_last_error("bullet_step: the round kernel ended without publishing its inner products", q);
+            return VPIN_EHIP;
+          }
+        }
+      }
+      if (b == 0) sums[k] = v; else add(sums[k], v);
+    }
+  return VPIN_OK;
+}
+
+int bullet_step(vpin_ctx* c, const vpin_gens* g, BulletState* st, size_t n, const uint8_t* u_prev, const uint8_t* u_inv_prev,
+                uint8_t cLR[64]) {
+  if (!c || !g || !st || !cLR || !bullet_fused(st) || n == 0 || 2 * n > st->R) return VPIN_EINVAL;
+  uint8_t* pin = bullet_pinned(c);
+  if (!pin) return VPIN_ENOMEM;
+  const uint32_t seq = ++c->bullet_seq;
+  fq* ap = st->cur ? st->av2 : st->av; fq* bp = st->cur ? st->bv2 : st->bv;
+  fq* an = st->cur ? st->av : st->av2; fq* bn = st->cur ? st->bv : st->bv2;
+  int rc = bullet_step_launch(c, g, ap, bp, an, bn, st->sj, n, st->R, u_prev != nullptr, false, u_prev, u_inv_prev, pin, fused_up(c), seq);
+  if (rc) return rc;
+  st->cur ^= 1;
+  fq sums[2];
+  if ((rc = fused_take(c, (int)((n + 255) / 256), seq, sums))) return rc;
+  memcpy(cLR, sums, 64);
+  return VPIN_OK;
+}
+
+const uint8_t* bullet_parts(vpin_ctx* c, const BulletState* st, size_t* nblk) {
+  if (nblk) *nblk = st->R / 32;
+  return (const uint8_t*)c->h_bullet;
+}
+
+int bullet_finish_fused(vpin_ctx* c, const vpin_gens* g, BulletState* st, const uint8_t u[32], const uint8_t u_inv[32],
+                        uint8_t xhat_ahat[64]) {
+  if (!c || !g || !st || !u || !u_inv || !xhat_ahat || !bullet_fused(st)) return VPIN_EINVAL;
+  uint8_t* pin = bullet_pinned(c);
+  if (!pin) return VPIN_ENOMEM;
+  const uint32_t seq = ++c->bullet_seq;
+  fq* ap = st->cur ? st->av2 : st->av; fq* bp = st->cur ? st->bv2 : st->bv;
+  int rc = bullet_step_launch(c, g, ap, bp, nullptr, nullptr, st->sj, 0, st->R, false, true, u, u_inv, pin, fused_up(c), seq);
+  if (rc) return rc;
+  fq sums[2];
+  if ((rc = fused_take(c, 1, seq, sums))) return rc;
+  memcpy(xhat_ahat, sums, 64);
+  return bullet_round_end(c);
 }
 
 // after the last fold: x_hat = a[0], a_hat = b[0] and the partial points of g_hat = sum_j s_j g_j

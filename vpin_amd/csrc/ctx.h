@@ -88,6 +88,7 @@ struct vpin_ctx {
   vpin::fq tail_final[6 * 18];
   bool shared_device = false;  // other contexts prove on this device at the same time (vpin_ctx_set_shared_device)
   void* h_bullet = nullptr;  // pinned staging of the bullet reduction's per-round results (bullet.hip), 64 KiB
+  uint32_t bullet_seq = 0;   // sequence number of the last fused bullet round (mailbox_dev.h)
   // one large commitment split across ranks (include/vpin_hip.h, vpin_ctx_set_split_hooks)
   vpin_split_begin_fn split_begin = nullptr;
   vpin_split_commit_fn split_commit = nullptr;
@@ -143,7 +144,7 @@ int gens_msm_parts_dev(vpin_ctx* c, const vpin_gens* g, const fq* d_scalars, siz
 // the same without the synchronisation (the caller provides the device scratch and waits on the stream itself)
 size_t gens_msm_parts_scratch_bytes(size_t rows, size_t ncols);
 int gens_msm_parts_launch(vpin_ctx* c, const vpin_gens* g, const fq* d_scalars, size_t rows, size_t ncols, void* scratch,
-                          uint8_t* parts_xyzt);
+                          uint8_t* parts_xyzt, bool host_mapped = false);
 
 // device side of the bullet reduction (bullet.hip)
 struct BulletState;
@@ -154,6 +155,17 @@ uint8_t* bullet_pinned(vpin_ctx* c);  // 64 KiB of pinned host memory owned by t
 int bullet_fold(vpin_ctx* c, BulletState* st, size_t n, const uint8_t u[32], const uint8_t u_inv[32]);
 int bullet_finish(vpin_ctx* c, const vpin_gens* g, BulletState* st, uint8_t xhat_ahat[64], uint8_t* parts_xyzt);
 void bullet_free(vpin_ctx* c, BulletState* st);
+// one launch per round (msm.hip bullet_step_kernel) when the state allows it: R a multiple of 32, at most 4096
+bool bullet_fused(const BulletState* st);
+int bullet_step(vpin_ctx* c, const vpin_gens* g, BulletState* st, size_t n, const uint8_t* u_prev, const uint8_t* u_inv_prev,
+                uint8_t cLR[64]);
+// partial points of the last bullet_step / bullet_finish_fused after bullet_round_end: [2][*nblk] x 128 B, row 0 = L
+const uint8_t* bullet_parts(vpin_ctx* c, const BulletState* st, size_t* nblk);
+int bullet_finish_fused(vpin_ctx* c, const vpin_gens* g, BulletState* st, const uint8_t u[32], const uint8_t u_inv[32],
+                        uint8_t xhat_ahat[64]);
+int bullet_step_launch(vpin_ctx* c, const vpin_gens* g, const fq* a_prev, const fq* b_prev, fq* a_next, fq* b_next, fq* sj, size_t n,
+                       size_t R, bool fold, bool finish, const uint8_t* u, const uint8_t* u_inv, uint8_t* parts_pinned,
+                       uint32_t* up_pinned, uint32_t seq);
 
 // VPIN_CLI_TRACE=1: wall-clock laps of the cold (one-shot CLI) path on stderr; each lap drains the stream
 struct TraceLap {

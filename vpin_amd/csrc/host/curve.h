@@ -131,34 +131,73 @@ struct Point {
   Point mul(const Fq& s) const { uint8_t b[32]; s.to_bytes(b); return mul_bytes(b); }
 };
 
-// Fixed-base 8-bit signed-window table for one generator: 32 x 128 cached multiples.
+// Fixed-base signed-window table for one generator: 26 windows of 10 bits, 512 AFFINE multiples each as
+// (y+x, y-x, 2dxy) -- 1.6 MB per generator, 26 mixed additions of 7 products per scalar.  The per-round commitments of
+// the ZK sum-checks (8 scalar multiplications per round, sumcheck.rs:655-758) are the host's share of a round and, for
+// instances below ~2^20 constraints, longer than the round's kernel.
+struct Niels { Fe ypx, ymx, xy2d; };
+
 struct FixedBase {
-  std::vector<Cached> t;  // [32][128]
+  static constexpr int kBits = 10, kWindows = 26, kEntries = 1 << (kBits - 1);
+  std::vector<Niels> t;  // [kWindows][kEntries]
   Point base;
   FixedBase() {}
-  explicit FixedBase(const Point& p) : t(32 * 128), base(p) {
+  explicit FixedBase(const Point& p) : t((size_t)kWindows * kEntries), base(p) {
+    std::vector<Point> m((size_t)kWindows * kEntries);
     Point s = p;
-    for (int w = 0; w < 32; w++) {
+    for (int w = 0; w < kWindows; w++) {
       Cached sc = s.cached();
       Point q = s;
-      t[w * 128] = sc;
-      for (int k = 1; k < 128; k++) { q = q.add(sc); t[w * 128 + k] = q.cached(); }
-      for (int k = 0; k < 8; k++) s = s.dbl();
+      m[(size_t)w * kEntries] = s;
+      for (int k = 1; k < kEntries; k++) { q = q.add(sc); m[(size_t)w * kEntries + k] = q; }
+      for (int k = 0; k < kBits; k++) s = s.dbl();
     }
+    // one inversion for all Z (Montgomery's trick)
+    std::vector<Fe> pre(m.size());
+    Fe acc = Fe::one();
+    for (size_t i = 0; i < m.size(); i++) { pre[i] = acc; acc = acc * m[i].Z; }
+    acc = acc.invert();
+    for (size_t i = m.size(); i-- > 0;) {
+      Fe zi = acc * pre[i];
+      acc = acc * m[i].Z;
+      Fe x = m[i].X * zi, y = m[i].Y * zi;
+      t[i] = Niels{y + x, y - x, x * y * K().d2};
+    }
+  }
+  static Point add_niels(const Point& p, const Niels& q, bool negq) {
+    Fe PP = p.Y.add_lazy(p.X) * (negq ? q.ymx : q.ypx), MM = p.Y.sub_lazy(p.X) * (negq ? q.ypx : q.ymx);
+    Fe TT = p.T * q.xy2d, ZZ2 = p.Z.add_lazy(p.Z);
+    Fe E = PP.sub_lazy(MM), H = PP.add_lazy(MM);
+    Fe G = negq ? ZZ2.sub_lazy(TT) : ZZ2.add_lazy(TT), F = negq ? ZZ2.add_lazy(TT) : ZZ2.sub_lazy(TT);
+    return Point{E * F, G * H, F * G, E * H};
   }
   // acc += s * base
   void mul_acc(Point& acc, const Fq& s) const {
     if (s.is_zero()) return;
-    uint8_t b[32];
+    uint8_t b[40] = {0};
     s.to_bytes(b);
+    const Niels* e[kWindows + 1];
+    bool neg[kWindows + 1];
+    int n = 0;
     unsigned carry = 0;
-    for (int w = 0; w < 32; w++) {
-      unsigned v = b[w] + carry;
-      bool neg = v > 128;
-      unsigned mag = neg ? 256 - v : v;
-      carry = neg ? 1 : 0;
-      if (mag) acc = acc.add(t[w * 128 + mag - 1], neg);
+    for (int w = 0; w < kWindows; w++) {
+      const int off = w * kBits;
+      uint32_t word;
+      memcpy(&word, b + (off >> 3), 4);
+      unsigned v = ((word >> (off & 7)) & ((1u << kBits) - 1u)) + carry;
+      const bool ng = v > (unsigned)kEntries;
+      const unsigned mag = ng ? (1u << kBits) - v : v;
+      carry = ng ? 1 : 0;
+      if (mag) {
+        e[n] = &t[(size_t)w * kEntries + mag - 1];
+        neg[n] = ng;
+        __builtin_prefetch(e[n]);
+        __builtin_prefetch(reinterpret_cast<const char*>(e[n]) + 64);
+        n++;
+      }
     }
+    // a canonical scalar is below 2^253 < 2^(10*26 - 1): no carry leaves the top window
+    for (int i = 0; i < n; i++) acc = add_niels(acc, *e[i], neg[i]);
   }
   Point mul(const Fq& s) const { Point a = Point::identity(); mul_acc(a, s); return a; }
 };

@@ -171,6 +171,19 @@ struct Fe {
     return r;
   }
   Fe neg() const { return zero() - *this; }
+  // Uncarried sum / difference for operands that go straight into a product: limbs stay below 2^54 when both inputs are
+  // carried values or single lazy sums, and operator* takes limbs up to 2^54 (5 x 2^54 x 19 x 2^54 < 2^128).
+  Fe add_lazy(const Fe& o) const {
+    Fe r;
+    for (int i = 0; i < 5; i++) r.l[i] = l[i] + o.l[i];
+    return r;
+  }
+  Fe sub_lazy(const Fe& o) const {  // + 4p; o's limbs must be below 2^53
+    Fe r;
+    r.l[0] = l[0] + 4 * (MASK - 18) - o.l[0];
+    for (int i = 1; i < 5; i++) r.l[i] = l[i] + 4 * MASK - o.l[i];
+    return r;
+  }
   Fe operator*(const Fe& o) const {
     const uint64_t* x = l;
     const uint64_t* y = o.l;
@@ -191,7 +204,25 @@ struct Fe {
     c = r.l[0] >> 51; r.l[0] &= MASK; r.l[1] += c;
     return r;
   }
-  Fe square() const { return *this * *this; }
+  Fe square() const {  // 15 products instead of 25
+    const uint64_t* x = l;
+    const uint64_t d0 = 2 * x[0], d1 = 2 * x[1], x3_19 = 19 * x[3], x4_19 = 19 * x[4];
+    u128 t0 = (u128)x[0] * x[0] + (u128)d1 * x4_19 + (u128)(2 * x[2]) * x3_19;
+    u128 t1 = (u128)d0 * x[1] + (u128)(2 * x[2]) * x4_19 + (u128)x[3] * x3_19;
+    u128 t2 = (u128)d0 * x[2] + (u128)x[1] * x[1] + (u128)(2 * x[3]) * x4_19;
+    u128 t3 = (u128)d0 * x[3] + (u128)d1 * x[2] + (u128)x[4] * x4_19;
+    u128 t4 = (u128)d0 * x[4] + (u128)d1 * x[3] + (u128)x[2] * x[2];
+    Fe r;
+    t1 += (uint64_t)(t0 >> 51); r.l[0] = (uint64_t)t0 & MASK;
+    t2 += (uint64_t)(t1 >> 51); r.l[1] = (uint64_t)t1 & MASK;
+    t3 += (uint64_t)(t2 >> 51); r.l[2] = (uint64_t)t2 & MASK;
+    t4 += (uint64_t)(t3 >> 51); r.l[3] = (uint64_t)t3 & MASK;
+    uint64_t c = (uint64_t)(t4 >> 51);
+    r.l[4] = (uint64_t)t4 & MASK;
+    r.l[0] += 19 * c;
+    c = r.l[0] >> 51; r.l[0] &= MASK; r.l[1] += c;
+    return r;
+  }
   Fe sqn(int n) const {
     Fe r = *this;
     for (int i = 0; i < n; i++) r = r.square();
@@ -233,6 +264,11 @@ struct Fe {
   bool is_zero() const { return equals(zero()); }
   Fe abs() const { return is_negative() ? neg() : *this; }
 
+  // z^(p-2)
+  Fe invert() const {
+    Fe t = pow_p58().sqn(3);  // z^(2^255 - 24)
+    return t * (square() * *this);  // * z^3 -> z^(2^255 - 21)
+  }
   // z^(2^252 - 3)
   Fe pow_p58() const {
     const Fe& z = *this;

@@ -309,11 +309,28 @@ static int dplog_prove(vpin_ctx* c, const PcGens& pc, Transcript& tr, Transcript
   size_t n = R;
   static const bool fine = getenv("VPIN_SPARK_TRACE") && atoi(getenv("VPIN_SPARK_TRACE")) >= 3;
   double tb[6] = {0, 0, 0, 0, 0, 0};
+  // Fused rounds (R <= 4096): one launch folds the previous challenge in, runs the round's MSM and publishes the inner
+  // products; its partial points arrive as [2][R/32], a workgroup of 32 generators holding one side while n >= 32.
+  const bool fused = vpin::bullet_fused(bs);
+  size_t fblk = 0;
+  const uint8_t* fparts = fused ? vpin::bullet_parts(c, bs, &fblk) : nullptr;
+  auto sum_side = [&](int row, size_t nn) {  // row 0 = L (generators with pos >= nn), row 1 = R
+    Point acc = Point::identity();
+    for (size_t b = 0; b < fblk; b++) {
+      const bool is_L = ((b * 32) & (2 * nn - 1)) >= nn;
+      if (nn >= 32 && is_L != (row == 0)) continue;
+      acc = acc + Point::from_xyzt(fparts + ((size_t)row * fblk + b) * 128);
+    }
+    return acc;
+  };
+  Fq u_prev = Fq::zero(), u_inv_prev = Fq::zero();
   for (size_t round = 0; round < lgR; round++) {
     n /= 2;
     Fq cLR[2];
     auto t0 = Clock::now();
-    if ((rc = vpin::bullet_round_begin(c, pc.dev, bs, n, parts.data(), B(cLR)))) return rc;
+    if (fused) rc = vpin::bullet_step(c, pc.dev, bs, n, round ? B(&u_prev) : nullptr, round ? B(&u_inv_prev) : nullptr, B(cLR));
+    else rc = vpin::bullet_round_begin(c, pc.dev, bs, n, parts.data(), B(cLR));
+    if (rc) return rc;
     auto t1 = Clock::now();
     // c_L * Q + blind_L * H and c_R * Q + blind_R * H on the host while the device is still summing the stream terms
     Point qh[2] = {Point::identity(), Point::identity()};
@@ -322,7 +339,8 @@ static int dplog_prove(vpin_ctx* c, const PcGens& pc, Transcript& tr, Transcript
     auto t2 = Clock::now();
     if ((rc = vpin::bullet_round_end(c))) return rc;
     auto t3 = Clock::now();
-    Point lr[2] = {sum_parts(parts.data()) + qh[0], sum_parts(parts.data() + np * 128) + qh[1]};
+    Point lr[2] = {(fused ? sum_side(0, n) : sum_parts(parts.data())) + qh[0],
+                   (fused ? sum_side(1, n) : sum_parts(parts.data() + np * 128)) + qh[1]};
     auto t4 = Clock::now();
     out.Lvec[round] = compress(lr[0]);
     out.Rvec[round] = compress(lr[1]);
@@ -330,7 +348,8 @@ static int dplog_prove(vpin_ctx* c, const PcGens& pc, Transcript& tr, Transcript
     tr.append_point("R", out.Rvec[round].b);
     Fq u = tr.challenge_scalar("u"), u_inv = u.invert();
     auto t5 = Clock::now();
-    if ((rc = vpin::bullet_fold(c, bs, n, B(&u), B(&u_inv)))) return rc;
+    if (fused) { u_prev = u; u_inv_prev = u_inv; }  // folded in by the next round's launch
+    else if ((rc = vpin::bullet_fold(c, bs, n, B(&u), B(&u_inv)))) return rc;
     blind_fin = blind_fin + bv1[round] * u * u + bv2[round] * u_inv * u_inv;
     if (fine) {
       auto t6 = Clock::now();
@@ -343,9 +362,17 @@ static int dplog_prove(vpin_ctx* c, const PcGens& pc, Transcript& tr, Transcript
             tb[1] / lgR * 1e6, tb[2] / lgR * 1e6, np, tb[3] / lgR * 1e6, tb[4] / lgR * 1e6, tb[5] / lgR * 1e6);
   Fq xa[2];
   // g_hat = sum_j s_j g_j
-  if ((rc = vpin::bullet_finish(c, pc.dev, bs, B(xa), parts.data()))) return rc;
+  if (fused) rc = vpin::bullet_finish_fused(c, pc.dev, bs, B(&u_prev), B(&u_inv_prev), B(xa));
+  else rc = vpin::bullet_finish(c, pc.dev, bs, B(xa), parts.data());
+  if (rc) return rc;
   const Fq x_hat = xa[0], a_hat = xa[1], y_hat = x_hat * a_hat;
-  Point g_hat = sum_parts(parts.data());
+  Point g_hat;
+  if (fused) {
+    g_hat = Point::identity();
+    for (size_t b = 0; b < fblk; b++) g_hat = g_hat + Point::from_xyzt(fparts + b * 128);
+  } else {
+    g_hat = sum_parts(parts.data());
+  }
   {
     Point p = g_hat.mul(d_);  // d.commit(&r_delta, {G:[g_hat], h})
     pc.fb_h.mul_acc(p, r_delta);

@@ -25,6 +25,7 @@
 
 #include "ctx.h"
 #include "fp_dev.h"
+#include "mailbox_dev.h"
 
 #ifndef VPIN_NIELS_SLOT
 #define VPIN_NIELS_SLOT 96  // bytes per table entry: 96 (packed) or 128 (one entry per 128-byte line)
@@ -279,6 +280,60 @@ __device__ __forceinline__ void table_mul_acc_range(ge_ext& acc, const fq& s_in,
 // ---- row-batched commitment -------------------------------------------------------------
 
 constexpr int kMsmBlock = 256;
+// ---- block tree with four lanes per addition -----------------------------------------------------------------
+// The few-row MSMs are latency bound: one wave per SIMD issues a modular product in ~0.5 us, and an addition of two
+// extended points is nine of them in a row on one lane.  Here the four products of each half of the addition
+// (add-2008-hwcd-3: A,B,C,D then X3,Y3,Z3,T3) run on the four lanes of a quad -- same code path, operands picked by the
+// lane's role, the halves exchanged with lane shuffles -- so a level costs three products instead of nine.
+__device__ __forceinline__ fp fp_shfl_from(const fp& a, int src) {
+  fp r;
+#pragma unroll
+  for (int i = 0; i < 8; i++) r.v[i] = __shfl(a.v[i], src, 64);
+  return r;
+}
+__device__ __forceinline__ fp fp_pick(bool c, const fp& a, const fp& b) {
+  fp r;
+#pragma unroll
+  for (int i = 0; i < 8; i++) r.v[i] = c ? a.v[i] : b.v[i];
+  return r;
+}
+// sh[0] = sum of sh[0..n) (n a power of two, n <= blockDim.x); every thread of the block calls it.
+// split > 0 (a power of two below n): the entries alternate in runs of `split` between two sums (index & split); the
+// level that would mix them is skipped and the levels below it reduce both runs: sh[0] = sum of the entries with
+// (index & split) == 0, sh[split] = sum of the others.
+__device__ __forceinline__ void ge_tree_quad(ge_ext* sh, int n, int split = 0) {
+  const int role = threadIdx.x & 3, qbase = (threadIdx.x & 63) & ~3;
+  const fp* shf = reinterpret_cast<const fp*>(sh);
+  fp* shw = reinterpret_cast<fp*>(sh);
+  for (int s = n / 2; s >= 1; s >>= 1) {
+    if (s == split) continue;
+    const int items = s < split ? 2 * s : s;
+    for (int w = threadIdx.x >> 2; w < items; w += (int)(blockDim.x >> 2)) {
+      const int i = w < s ? w : split + (w - s);
+      // role 0: (Y1-X1)(Y2-X2)   role 1: (Y1+X1)(Y2+X2)   role 2: 2d T1 T2   role 3: 2 Z1 Z2
+      const int f0 = role < 2 ? 1 : (role == 2 ? 3 : 2);  // Y | T | Z
+      const fp p0 = shf[4 * i + f0], q0 = shf[4 * (i + s) + f0];
+      fp u = p0, v = q0;
+      if (role < 2) {  // uniform per quad pair: both take the same instructions, the select below is per lane
+        const fp p1 = shf[4 * i], q1 = shf[4 * (i + s)];
+        u = fp_pick(role == 0, fp_sub(p0, p1), fp_add(p0, p1));
+        v = fp_pick(role == 0, fp_sub(q0, q1), fp_add(q0, q1));
+      }
+      fp m = fp_mul(u, v);
+      m = fp_mul(m, fp_pick(role == 2, FP_D2(), fp_one()));
+      m = fp_pick(role == 3, fp_add(m, m), m);
+      const fp a = fp_shfl_from(m, qbase), b = fp_shfl_from(m, qbase + 1), c = fp_shfl_from(m, qbase + 2),
+               d = fp_shfl_from(m, qbase + 3);
+      const fp E = fp_sub(b, a), H = fp_add(b, a), F = fp_sub(d, c), G = fp_add(d, c);
+      // X3 = E F, Y3 = G H, Z3 = F G, T3 = E H
+      u = fp_pick(role == 0 || role == 3, E, fp_pick(role == 1, G, F));
+      v = fp_pick(role == 0, F, fp_pick(role == 2, G, H));
+      shw[4 * i + role] = fp_mul(u, v);
+    }
+    __syncthreads();
+  }
+}
+
 
 // rows x (ncols scalars from Z with row stride `stride`) + optional extra scalars on bases
 // [extra_base0, extra_base0 + n_extra).  out[row] = sum_j s[row][j] * g_j  (extended coords)
@@ -344,14 +399,9 @@ __global__ __launch_bounds__(kMsmBlock, 3) void msm_rows_kernel(const fq* __rest
   __shared__ ge_ext sh[kMsmBlock];
   sh[threadIdx.x] = acc;
   __syncthreads();
-  for (int s = kMsmBlock / 2; s >= 1; s >>= 1) {
-    if ((int)threadIdx.x < s) {
-      acc = ge_add(acc, sh[threadIdx.x + s]);
-      sh[threadIdx.x] = acc;
-    }
-    __syncthreads();
-  }
+  ge_tree_quad(sh, kMsmBlock);
   if (threadIdx.x == 0) {
+    acc = sh[0];
     ge_ext* o = out + row * gridDim.y + blockIdx.y;
     fp_store(&o->X, acc.X); fp_store(&o->Y, acc.Y); fp_store(&o->Z, acc.Z); fp_store(&o->T, acc.T);
   }
@@ -436,16 +486,120 @@ __global__ __launch_bounds__(kMsmBlock) void msm_wide_kernel(const fq* __restric
   __shared__ ge_ext sh[kMsmBlock];
   sh[threadIdx.x] = acc;
   __syncthreads();
-  for (int st = kMsmBlock / 2; st >= 1; st >>= 1) {
-    if ((int)threadIdx.x < st) {
-      acc = ge_add(acc, sh[threadIdx.x + st]);
-      sh[threadIdx.x] = acc;
-    }
-    __syncthreads();
-  }
+  ge_tree_quad(sh, kMsmBlock);
   if (threadIdx.x == 0) {
+    acc = sh[0];
     fp* o = parts_xyzt + 4 * (row * gridDim.x + blockIdx.x);
     fp_store(o, fp_freeze(acc.X)); fp_store(o + 1, fp_freeze(acc.Y)); fp_store(o + 2, fp_freeze(acc.Z)); fp_store(o + 3, fp_freeze(acc.T));
+  }
+}
+
+
+// ---- one kernel per round of the bullet reduction (host side: bullet.hip) ------------------------------------------
+// BulletReductionProof::prove (nizk/bullet.rs:32-132), round with half length n, everything the device does for it:
+//   * fold the previous round's challenge into a, b and the generator coefficients s_j (bullet.rs:99-109);
+//   * L = <a_L, G_R>, R = <a_R, G_L> over the stream generators as fixed-base MSMs with scalars a'[.] * s'_j
+//     (bullet.hip: G is never folded) -- workgroups [0, nmsm), 32 generators each, eight lanes per scalar;
+//   * the cross inner products c_L = <a_L, b_R>, c_R = <a_R, b_L> and the folded a, b for the next round -- workgroups
+//     [nmsm, gridDim.x), published through the pinned mailbox so the host forms c*Q + blind*H while the MSM runs.
+// No workgroup reads what another one writes (a, b are double-buffered; s_j belongs to its eight lanes), so one launch
+// replaces the fold, rows and MSM launches and both copies of a round.  finish = 1: the last fold only --
+// g_hat = sum_j s_j g_j, x_hat, a_hat.
+struct BulletStep {
+  const fq* a_prev; const fq* b_prev;  // live length 4n when fold (2n otherwise)
+  fq* a_next; fq* b_next;              // live length 2n after this launch
+  fq* sj;                              // [R]
+  size_t n, R;
+  int fold, finish, nmsm;
+  fq u, u_inv;                         // the previous round's challenge (fold / finish)
+  fp* parts;                           // pinned: [2][nmsm] points X|Y|Z|T, row 0 = L, row 1 = R
+  uint32_t* up;                        // pinned: two scalars per inner-product workgroup, 12 words each
+  uint32_t seq;
+};
+
+__global__ __launch_bounds__(kMsmBlock) void bullet_step_kernel(BulletStep a, TableView tv) {
+  const size_t n = a.n;
+  if ((int)blockIdx.x >= a.nmsm) {
+    // ---- inner products + the folded vectors ----
+    const int ib = (int)blockIdx.x - a.nmsm;
+    const size_t i = (size_t)ib * kMsmBlock + threadIdx.x;
+    fq pl = fq_zero(), pr = fq_zero();
+    if (a.finish) {
+      if (ib == 0 && threadIdx.x == 0) {
+        pl = fq_add(fq_mul(fq_load(a.a_prev), a.u), fq_mul(a.u_inv, fq_load(a.a_prev + 1)));  // x_hat
+        pr = fq_add(fq_mul(fq_load(a.b_prev), a.u_inv), fq_mul(a.u, fq_load(a.b_prev + 1)));  // a_hat
+      }
+    } else if (i < n) {
+      fq a0, a1, b0, b1;
+      if (a.fold) {
+        a0 = fq_add(fq_mul(fq_load(a.a_prev + i), a.u), fq_mul(a.u_inv, fq_load(a.a_prev + 2 * n + i)));
+        a1 = fq_add(fq_mul(fq_load(a.a_prev + n + i), a.u), fq_mul(a.u_inv, fq_load(a.a_prev + 3 * n + i)));
+        b0 = fq_add(fq_mul(fq_load(a.b_prev + i), a.u_inv), fq_mul(a.u, fq_load(a.b_prev + 2 * n + i)));
+        b1 = fq_add(fq_mul(fq_load(a.b_prev + n + i), a.u_inv), fq_mul(a.u, fq_load(a.b_prev + 3 * n + i)));
+      } else {
+        a0 = fq_load(a.a_prev + i); a1 = fq_load(a.a_prev + n + i);
+        b0 = fq_load(a.b_prev + i); b1 = fq_load(a.b_prev + n + i);
+      }
+      fq_store(a.a_next + i, a0); fq_store(a.a_next + n + i, a1);
+      fq_store(a.b_next + i, b0); fq_store(a.b_next + n + i, b1);
+      pl = fq_mul(a0, b1);
+      pr = fq_mul(a1, b0);
+    }
+    __shared__ fq shp[kMsmBlock / 64][2];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    pl = fq_wave_sum(pl);
+    pr = fq_wave_sum(pr);
+    if (lane == 0) { shp[wave][0] = pl; shp[wave][1] = pr; }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+      fq t = shp[0][threadIdx.x];
+#pragma unroll
+      for (int w = 1; w < kMsmBlock / 64; w++) t = fq_add(t, shp[w][threadIdx.x]);
+      publish_scalar(a.up + (2 * (size_t)ib + threadIdx.x) * 12, t, a.seq);
+    }
+    return;
+  }
+  // ---- the round's MSM: 32 generators per workgroup, the W windows of a scalar over eight lanes ----
+  const int g = threadIdx.x >> 3, grp = threadIdx.x & 7;
+  const size_t j = (size_t)blockIdx.x * kWideScalars + g;
+  ge_ext acc = ge_identity();
+  if (j < a.R) {
+    fq sc = fq_load(a.sj + j);
+    if (a.fold || a.finish) {
+      const size_t hp = a.finish ? 1 : 2 * n;  // half length of the vectors the challenge folded
+      sc = fq_mul(sc, ((j & (2 * hp - 1)) < hp) ? a.u_inv : a.u);
+      if (grp == 0) fq_store(a.sj + j, sc);  // the eight lanes of j read s_j in the same instruction, before this store
+    }
+    if (!a.finish) {
+      const size_t pos = j & (2 * n - 1);
+      const size_t idx = pos >= n ? pos - n : n + pos;  // L: a_L[pos - n] on G_R; R: a_R[pos] on G_L
+      fq av = a.fold ? fq_add(fq_mul(fq_load(a.a_prev + idx), a.u), fq_mul(a.u_inv, fq_load(a.a_prev + 2 * n + idx)))
+                     : fq_load(a.a_prev + idx);
+      sc = fq_mul(av, sc);
+    }
+    if (!fq_is_zero(sc)) {
+      const TableSeg sg = table_seg(tv, j);
+      const int wpg = (sg.W + 7) / 8;
+      const int w0 = grp * wpg, w1 = (w0 + wpg < sg.W) ? w0 + wpg : sg.W;
+      if (w0 < w1) table_mul_acc_range(acc, fq_from_mont(sc), sg, w0, w1);
+    }
+  }
+  // entry grp*32 + g: the first three levels add up the eight lanes of a generator, the rest runs over the generators
+  __shared__ ge_ext sh[kMsmBlock];
+  sh[grp * kWideScalars + g] = acc;
+  __syncthreads();
+  // generators alternate between R (pos < n) and L (pos >= n) in runs of n: one side per workgroup while n >= 32
+  const int split = (a.finish || n >= (size_t)kWideScalars) ? 0 : (int)n;
+  ge_tree_quad(sh, kMsmBlock, split);
+  if (threadIdx.x < 2) {
+    // thread 0 stores sh[0]; with a split, thread 1 stores sh[split] (the L run)
+    const bool first_is_L = a.finish || (((size_t)blockIdx.x * kWideScalars) & (2 * n - 1)) >= n;
+    if (threadIdx.x == 0 || split) {
+      const ge_ext p = sh[threadIdx.x ? split : 0];
+      const int row = threadIdx.x ? 0 : ((split || !first_is_L) ? 1 : 0);
+      fp* o = a.parts + 4 * ((size_t)row * a.nmsm + blockIdx.x);
+      fp_store(o, fp_freeze(p.X)); fp_store(o + 1, fp_freeze(p.Y)); fp_store(o + 2, fp_freeze(p.Z)); fp_store(o + 3, fp_freeze(p.T));
+    }
   }
 }
 
@@ -916,30 +1070,57 @@ namespace vpin {
 // rows * (raw_parts(ncols) + nparts) * 128 bytes and outlive them (gens_msm_parts_scratch_bytes)
 size_t gens_msm_parts_scratch_bytes(size_t rows, size_t ncols) { return rows * (raw_parts(ncols) + vpin_gens_msm_parts_count(ncols)) * 128; }
 int gens_msm_parts_launch(vpin_ctx* c, const vpin_gens* g, const fq* d_scalars, size_t rows, size_t ncols, void* scratch,
-                          uint8_t* parts_xyzt) {
+                          uint8_t* parts_xyzt, bool host_mapped) {
   if (!c || !g || !d_scalars || !parts_xyzt || !scratch || rows == 0 || ncols == 0) return VPIN_EINVAL;
   if (ncols > g->nb) return VPIN_ESHAPE;
   (void)hipSetDevice(c->device);
   const size_t nraw = raw_parts(ncols), nparts = vpin_gens_msm_parts_count(ncols);
+  // host_mapped: parts_xyzt is pinned host memory, which the device addresses directly -- the last stage stores its
+  // partial points there and the ~10 us copy command per call goes away (the caller waits for the stream instead)
   fp* dp = (fp*)scratch;
   fp* dr = (fp*)((uint8_t*)scratch + rows * nraw * 128);
+  fp* first_out = (host_mapped && nraw == nparts) ? (fp*)parts_xyzt : dp;
   {
     ProfScope ps(c, VPIN_K_MSM, 32.0 * (double)rows * (double)ncols);
     if (wide_q(ncols) == 4)
       hipLaunchKernelGGL((msm_wide_kernel<4>), dim3((unsigned)nraw, (unsigned)rows), dim3(kMsmBlock), 0, c->stream, d_scalars, ncols,
-                         view(g), dp);
+                         view(g), first_out);
     else
       hipLaunchKernelGGL((msm_wide_kernel<1>), dim3((unsigned)nraw, (unsigned)rows), dim3(kMsmBlock), 0, c->stream, d_scalars, ncols,
-                         view(g), dp);
+                         view(g), first_out);
   }
-  const void* src = dp;
+  const void* src = first_out;
   if (nraw > nparts) {
+    fp* second_out = host_mapped ? (fp*)parts_xyzt : dr;
     hipLaunchKernelGGL(parts_reduce_kernel, dim3((unsigned)((rows * nparts + 63) / 64)), dim3(64), 0, c->stream, (const fp*)dp, rows,
-                       nraw, (int)nparts, dr);
-    src = dr;
+                       nraw, (int)nparts, second_out);
+    src = second_out;
   }
   VPIN_HIP_TRY(hipGetLastError());
-  VPIN_HIP_TRY(hipMemcpyAsync(parts_xyzt, src, rows * nparts * 128, hipMemcpyDeviceToHost, c->stream));
+  if (src != (const void*)parts_xyzt) VPIN_HIP_TRY(hipMemcpyAsync(parts_xyzt, src, rows * nparts * 128, hipMemcpyDeviceToHost, c->stream));
+  return VPIN_OK;
+}
+
+// one launch per bullet round (bullet_step_kernel); parts/up are pinned host memory.  R must be a multiple of 32.
+int bullet_step_launch(vpin_ctx* c, const vpin_gens* g, const fq* a_prev, const fq* b_prev, fq* a_next, fq* b_next, fq* sj, size_t n,
+                       size_t R, bool fold, bool finish, const uint8_t* u, const uint8_t* u_inv, uint8_t* parts_pinned,
+                       uint32_t* up_pinned, uint32_t seq) {
+  if (!c || !g || !a_prev || !b_prev || !sj || !parts_pinned || !up_pinned || R % kWideScalars || R > g->nb) return VPIN_EINVAL;
+  if (!finish && (n == 0 || 2 * n > R || !a_next || !b_next)) return VPIN_EINVAL;
+  if ((fold || finish) && (!u || !u_inv)) return VPIN_EINVAL;
+  (void)hipSetDevice(c->device);
+  BulletStep a{};
+  a.a_prev = a_prev; a.b_prev = b_prev; a.a_next = a_next; a.b_next = b_next; a.sj = sj;
+  a.n = finish ? 0 : n; a.R = R; a.fold = fold ? 1 : 0; a.finish = finish ? 1 : 0;
+  a.nmsm = (int)(R / kWideScalars);
+  if (u) { memcpy(a.u.v, u, 32); memcpy(a.u_inv.v, u_inv, 32); }
+  a.parts = (fp*)parts_pinned; a.up = up_pinned; a.seq = seq;
+  const int nip = finish ? 1 : (int)((n + kMsmBlock - 1) / kMsmBlock);
+  {
+    ProfScope ps(c, VPIN_K_MSM, 32.0 * 2.0 * (double)R);
+    hipLaunchKernelGGL(bullet_step_kernel, dim3((unsigned)(a.nmsm + nip)), dim3(kMsmBlock), 0, c->stream, a, view(g));
+  }
+  VPIN_HIP_TRY(hipGetLastError());
   return VPIN_OK;
 }
 

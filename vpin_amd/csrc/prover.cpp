@@ -164,9 +164,12 @@ static int zk_sumcheck(vpin_ctx* c, int K, vpin_table** tabs, const Fq& claim, c
   int rc = factored ? vpin::sc_cubic3_launch(c, tabs, pyramid, rounds, 1, nullptr, lead) : vpin::sc_round_launch(c, K, tabs, nullptr);
   if (rc) return rc;
   Fq r_j = Fq::zero();
+  static const bool fine = getenv("VPIN_SPARK_TRACE") && atoi(getenv("VPIN_SPARK_TRACE")) >= 2;
+  Clock::time_point tp0 = Clock::now();
   for (int j = 0; j < rounds; j++) {
     Fq e[3];
     if ((rc = vpin::sc_round_wait(c, K, B(e)))) return rc;
+    Clock::time_point tp1 = Clock::now();
     bool lead_next = lead;
     Fq t0, t1, tinf;
     if (factored) {
@@ -202,6 +205,7 @@ static int zk_sumcheck(vpin_ctx* c, int K, vpin_table** tabs, const Fq& claim, c
       rc = factored ? vpin::sc_cubic3_launch(c, tabs, pyramid, rounds, j + 2, B(&r_j), lead_next) : vpin::sc_round_launch(c, K, tabs, B(&r_j));
       if (rc) return rc;
     }
+    Clock::time_point tp2 = Clock::now();
     if (lead) cn = t0 + r_j * ((t1 - t0 - tinf) + r_j * tinf);  // t(r_j)
     lead = lead_next;
     if (factored) {  // s_{j+1} = s_j * eq1(tau_j, r_j)
@@ -249,6 +253,12 @@ static int zk_sumcheck(vpin_ctx* c, int K, vpin_table** tabs, const Fq& claim, c
     comm_claim = comm_eval;
     r_out.push_back(r_j);
     pf.comm_evals.push_back(comm_eval);
+    if (fine) {  // w = wait for the round's sums, c = comm_poly .. next launch (critical path), h = the rest of the host's round
+      Clock::time_point tp3 = Clock::now();
+      fprintf(stderr, " w%.1f c%.1f h%.1f", 1e6 * secs(tp0, tp1), 1e6 * secs(tp1, tp2), 1e6 * secs(tp2, tp3));
+      if (j == rounds - 1) fprintf(stderr, "\n");
+      tp0 = tp3;
+    }
   }
   // last fold (sumcheck.rs:673-676 of the final round), then the final claims P[0]
   rc = vpin_sc_bind(c, tabs, ntab, B(&r_j));
@@ -497,6 +507,11 @@ int sat_prove_core(vpin_ctx* c, const vpin_r1cs_dev* dinst, size_t nv, size_t nc
   if (tr_out) *tr_out = tr;
   if (tape_out) *tape_out = tape;
   g_timings[4] = secs(t_begin, Clock::now());
+  static const bool trace_on = getenv("VPIN_SPARK_TRACE") && atoi(getenv("VPIN_SPARK_TRACE")) >= 2;
+  if (trace_on)
+    fprintf(stderr, "[sat] 2^%d: polycommit %.3f  phase 1 %.3f  phase 2 %.3f  polyeval %.3f  inst.evaluate %.3f  (sparse products %.3f)  total %.3f ms\n",
+            nrx, 1e3 * g_timings[0], 1e3 * g_timings[1], 1e3 * g_timings[2], 1e3 * g_timings[3], 1e3 * g_timings[7],
+            1e3 * g_timings[6], 1e3 * g_timings[4]);
   return VPIN_OK;
 }
 

@@ -23,6 +23,7 @@
 #include <chrono>
 #include <cstdlib>
 
+#include "mailbox_dev.h"
 #include "sc_dev.h"
 #include "spark_dev.h"
 
@@ -686,31 +687,6 @@ constexpr int kTailUpChunks = 32;             // 16-byte pieces per instance: 9 
 constexpr long kTailSpinLimit = 4000000;      // ~10 s of polling: a lost host ends the kernel instead of hanging the GPU
 constexpr size_t kTailQuadPairs = kTailBlock / 4;  // rounds with at most this many pairs run four lanes per pair
 
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-// the three 16-byte pieces of the host's reply in one go: three uncached (system-scope) loads in flight, one wait
-__device__ __forceinline__ void load48_system(const uint32_t* p, u32x4& c0, u32x4& c1, u32x4& c2) {
-  asm volatile(
-      "global_load_dwordx4 %0, %3, off sc0 sc1\n\t"
-      "global_load_dwordx4 %1, %3, off offset:16 sc0 sc1\n\t"
-      "global_load_dwordx4 %2, %3, off offset:32 sc0 sc1\n\t"
-      "s_waitcnt vmcnt(0)"
-      : "=&v"(c0), "=&v"(c1), "=&v"(c2)
-      : "v"(p)
-      : "memory");
-}
-__device__ __forceinline__ u32x4 load16_system(const uint32_t* p) {
-  u32x4 v;
-  asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(p) : "memory");
-  return v;
-}
-__device__ __forceinline__ void store16_system(uint32_t* p, u32x4 v) {
-  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(p), "v"(v) : "memory");
-}
-__device__ __forceinline__ void publish_scalar(uint32_t* slot, const fq& v, uint32_t seq) {
-  store16_system(slot, u32x4{seq, v.v[0], v.v[1], v.v[2]});
-  store16_system(slot + 4, u32x4{seq, v.v[3], v.v[4], v.v[5]});
-  store16_system(slot + 8, u32x4{seq, v.v[6], v.v[7], 0u});
-}
 __device__ __forceinline__ fq fq_shfl_from(const fq& a, int src) {
   fq r;
 #pragma unroll
@@ -934,19 +910,6 @@ int spark_tail_launch(vpin_ctx* c, const SparkForest* f, int level, int k, int j
   }
   VPIN_HIP_TRY(hipGetLastError());
   return VPIN_OK;
-}
-
-typedef uint32_t tail_v4 __attribute__((vector_size(16), aligned(16)));
-static inline fq fq_zero_host() { fq z; memset(z.v, 0, sizeof z.v); return z; }
-
-// one scalar out of its three pieces; false while a piece still carries an older sequence number
-static inline bool tail_take(const uint32_t* slot, uint32_t want, fq* out) {
-  const tail_v4 c0 = *reinterpret_cast<const volatile tail_v4*>(slot), c1 = *reinterpret_cast<const volatile tail_v4*>(slot + 4),
-                c2 = *reinterpret_cast<const volatile tail_v4*>(slot + 8);
-  if (c0[0] != want || c1[0] != want || c2[0] != want) return false;
-  out->v[0] = c0[1]; out->v[1] = c0[2]; out->v[2] = c0[3]; out->v[3] = c1[1]; out->v[4] = c1[2]; out->v[5] = c1[3];
-  out->v[6] = c2[1]; out->v[7] = c2[2];
-  return true;
 }
 
 // results of tail round `idx` (0-based within the tail) of all `ninst` instances: sums -> spark_tail_sums()[3*inst + x] and,

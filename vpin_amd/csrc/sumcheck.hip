@@ -492,7 +492,14 @@ static int launch_bind_eval(vpin_ctx* c, vpin_table* const* t, const uint8_t* r,
 }
 
 static int fetch(vpin_ctx* c, int ne, uint8_t* out) {
-  VPIN_HIP_TRY(hipStreamSynchronize(c->stream));
+  // spin on the stream's status: a blocking wait costs ~10 us even when the round's kernel has long finished, which is
+  // the usual case below ~2^18 pairs (the host's share of a ZK round is longer than the kernel)
+  for (long spins = 0;; spins++) {
+    const hipError_t q = hipStreamQuery(c->stream);
+    if (q == hipSuccess) break;
+    if (q != hipErrorNotReady) { set_last_error("sum-check round: hipStreamQuery", q); return VPIN_EHIP; }
+    if (spins > 4000000) { VPIN_HIP_TRY(hipStreamSynchronize(c->stream)); break; }
+  }
   memcpy(out, c->h_out, (size_t)ne * sizeof(fq));
   return VPIN_OK;
 }

@@ -165,3 +165,22 @@ def test_host_built_instances_give_the_same_bytes(ctx, key):
     assert hashlib.sha256(got["comm"]).hexdigest() == g["comm_sha256"]
     assert hashlib.sha256(got["proof"]).hexdigest() == g["snark_sha256"]
     assert hashlib.sha256(got["comm_para"].tobytes()).hexdigest() == g["comm_para_sha256"]
+
+
+@pytest.mark.gpu
+def test_classic_bullet_rounds_give_the_same_bytes():
+    """the per-round launches of the bullet reduction (rows, MSM, fold) that rows longer than 4096 scalars still use, forced
+    for a small instance (VPIN_BULLET_CLASSIC is read once per process, hence the child): same oracle digest as the fused
+    one-launch rounds the parametrised test above ran"""
+    import subprocess
+    import sys
+    g = GOLD["3_32-mult"]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import hashlib, sys; sys.path.insert(0, %r); import vpin_amd; from vpin_amd import gadgets as G\n"
+            "c = vpin_amd.Context(0); d = c.gadget_point_mult_dev(*G.synthetic_mult_inputs('3_32'))\n"
+            "r = d.snark_prove(bytes(range(64)), bytes((7 * i + 3) %% 256 for i in range(64)))\n"
+            "print(hashlib.sha256(r['proof']).hexdigest()); d.free(); c.close()\n" % root)
+    env = dict(os.environ, VPIN_BULLET_CLASSIC="1")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout.strip().splitlines()[-1] == g["snark_sha256"]

@@ -132,7 +132,8 @@ int bullet_begin(vpin_ctx* c, const uint8_t* x_mont, const uint8_t* a_mont, size
     hipLaunchKernelGGL(bullet_init_kernel, dim3(st->nblk), dim3(kBB), 0, c->stream, st->sj, R);
     e = hipGetLastError();
   }
-  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);  // caller buffers
+  // no wait here: x_mont / a_mont must stay valid until the first round's results are back (dplog_prove's vectors do), and
+  // the uploads overlap the host's transcript work before the first round
   if (e != hipSuccess) { set_last_error("bullet_begin", e); bullet_free(c, st); return VPIN_EHIP; }
   *out = st;
   return VPIN_OK;

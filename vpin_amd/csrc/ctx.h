@@ -133,6 +133,7 @@ int commit_pair_finish(vpin_ctx* c, const vpin_gens* g, CommitPairState* st, con
 // asynchronous round launch / collect (sumcheck.hip), for the host prover's overlap
 int sc_round_launch(vpin_ctx* c, int K, vpin_table* const* tabs, const uint8_t* r);
 int sc_round_wait(vpin_ctx* c, int K, uint8_t* out);
+int sc_final_claims(vpin_ctx* c, vpin_table* const* tables, int k, const uint8_t r[32], uint8_t* out);
 int sc_cubic3_launch(vpin_ctx* c, vpin_table* const* t, const vpin_table* pyramid, int ell, int level, const uint8_t* r,
                      bool lead = false);
 

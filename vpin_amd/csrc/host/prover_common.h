@@ -272,6 +272,16 @@ static int dplog_prove(vpin_ctx* c, const PcGens& pc, Transcript& tr, Transcript
   std::vector<Fq> bv2 = tape.challenge_vector("blinds_vec_2", 2 * lgR);
   const size_t ncols = R + 2;  // scalars over g[0..R) | g[R] | g[R+1]=h
   std::vector<Fq> srow(2 * ncols, Fq::zero());
+  // The vectors a, b and the generator coefficients s_j stay on the device (bullet.hip); per round the GPU
+  // returns the partial points of  a_L . G_R  and  a_R . G_L  over the stream generators and the two cross
+  // inner products; the c*Q + blind*H terms (Q = r * g[R]) are two fixed-base multiplications each here.
+  // Uploaded first (no wait): the copies run while the host hashes the R scalars of `a` into the transcript.
+  vpin::BulletState* bs = nullptr;
+  if ((rc = vpin::bullet_begin(c, B(LZ.data()), B(Rv.data()), R, &bs))) return rc;
+  struct BsGuard {  // an early return may leave the uploads in flight: wait before the buffers go back to the pool
+    vpin_ctx* c; vpin::BulletState* s; bool done;
+    ~BsGuard() { if (!done) (void)hipStreamSynchronize(c->stream); vpin::bullet_free(c, s); }
+  } bs_guard{c, bs, false};
   CG Cx;
   {
     memcpy(srow.data(), LZ.data(), R * 32);
@@ -290,12 +300,6 @@ static int dplog_prove(vpin_ctx* c, const PcGens& pc, Transcript& tr, Transcript
   Fq blind_Gamma = LZ_blind + r_ * blind_y;
   out.Lvec.resize(lgR); out.Rvec.resize(lgR);
   Fq blind_fin = blind_Gamma;
-  // The vectors a, b and the generator coefficients s_j stay on the device (bullet.hip); per round the GPU
-  // returns the partial points of  a_L . G_R  and  a_R . G_L  over the stream generators and the two cross
-  // inner products; the c*Q + blind*H terms (Q = r * g[R]) are two fixed-base multiplications each here.
-  vpin::BulletState* bs = nullptr;
-  if ((rc = vpin::bullet_begin(c, B(LZ.data()), B(Rv.data()), R, &bs))) return rc;
-  struct BsGuard { vpin_ctx* c; vpin::BulletState* s; ~BsGuard() { vpin::bullet_free(c, s); } } bs_guard{c, bs};
   const size_t np = vpin_gens_msm_parts_count(R);
   std::vector<uint8_t> parts_pageable;
   uint8_t* parts_buf = vpin::bullet_pinned(c);  // pinned: the per-round device-to-host copies complete without staging
@@ -386,6 +390,7 @@ static int dplog_prove(vpin_ctx* c, const PcGens& pc, Transcript& tr, Transcript
   Fq c_ = tr.challenge_scalar("c");
   out.z1 = d_ + c_ * y_hat;
   out.z2 = a_hat * (c_ * blind_fin + r_beta) + r_delta;
+  bs_guard.done = true;  // bullet_finish* waited for the stream
   return VPIN_OK;
 }
 

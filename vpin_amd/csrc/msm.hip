@@ -347,7 +347,7 @@ __global__ __launch_bounds__(kMsmBlock, 3) void msm_rows_kernel(const fq* __rest
   const size_t total = ncols + (size_t)n_extra;
   // A row of one repeated scalar s: s * (g_0 + ... + g_{ncols-1}) from the prefix-sum base (see gens_sum_kernel).
   // Three probes keep ordinary rows from paying for the full comparison pass.
-  if (gridDim.y == 1 && ncols >= 256 && (ncols & (ncols - 1)) == 0 && ((size_t)1 << (tv.nbt - tv.sum0 - 1)) >= ncols) {
+  if (ncols >= 256 && (ncols & (ncols - 1)) == 0 && ((size_t)1 << (tv.nbt - tv.sum0 - 1)) >= ncols) {
     const fq* zr = Z + row * stride;
     const fq first = fq_load(zr);
     if (fq_same(first, fq_load(zr + 1)) && fq_same(first, fq_load(zr + ncols / 2)) && fq_same(first, fq_load(zr + ncols - 1))) {
@@ -355,12 +355,14 @@ __global__ __launch_bounds__(kMsmBlock, 3) void msm_rows_kernel(const fq* __rest
       for (size_t j = threadIdx.x; j < ncols; j += kMsmBlock) same &= fq_same(first, fq_load(zr + j)) ? 1 : 0;
       if (__syncthreads_and(same)) {
         if (threadIdx.x == 0) {
-          if (!fq_is_zero(first)) table_mul_acc(acc, fq_from_mont(first), tv, tv.sum0 + (size_t)(63 - __builtin_clzll((unsigned long long)ncols)));
-          for (int e = 0; e < n_extra; e++) {
-            const fq x = fq_load(extra + row * (size_t)n_extra + e);
-            if (!fq_is_zero(x)) table_mul_acc(acc, fq_from_mont(x), tv, extra_base0 + e);
+          if (blockIdx.y == 0) {  // with column chunks every chunk sees the same row: the first one owns it, the others add nothing
+            if (!fq_is_zero(first)) table_mul_acc(acc, fq_from_mont(first), tv, tv.sum0 + (size_t)(63 - __builtin_clzll((unsigned long long)ncols)));
+            for (int e = 0; e < n_extra; e++) {
+              const fq x = fq_load(extra + row * (size_t)n_extra + e);
+              if (!fq_is_zero(x)) table_mul_acc(acc, fq_from_mont(x), tv, extra_base0 + e);
+            }
           }
-          ge_ext* o = out + row;
+          ge_ext* o = out + row * gridDim.y + blockIdx.y;
           fp_store(&o->X, acc.X); fp_store(&o->Y, acc.Y); fp_store(&o->Z, acc.Z); fp_store(&o->T, acc.T);
         }
         return;
@@ -866,6 +868,13 @@ static int msm_rows(vpin_ctx* c, const vpin_gens* g, const fq* dZ, size_t rows, 
   if (rows < 128) {  // spread a few rows over the chip: ~one scalar per thread, <= 64 chunks per row
     size_t want = (total + kMsmBlock - 1) / kMsmBlock * 4;
     chunks = (int)(want < 1 ? 1 : want > 64 ? 64 : want);
+  } else if (rows < 768 && total >= 2 * (size_t)kMsmBlock) {
+    // Fewer than three workgroups per CU: a wave's 22-addition chains run at ~13 us per addition instead of ~9.5 us
+    // with the SIMDs full, and every thread walks several of them.  Split the rows into column chunks until the chip is
+    // full or a thread is down to one scalar (the 2^15..2^17-constraint instances' derefs commitment: 573 -> ~300 us).
+    size_t want = (768 + rows - 1) / rows, most = total / kMsmBlock;
+    chunks = (int)(want < most ? want : most);
+    if (chunks < 1) chunks = 1;
   }
   DevBuf parts(c);
   ge_ext* dst = d_points;

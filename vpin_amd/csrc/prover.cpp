@@ -261,12 +261,17 @@ static int zk_sumcheck(vpin_ctx* c, int K, vpin_table** tabs, const Fq& claim, c
     }
   }
   // last fold (sumcheck.rs:673-676 of the final round), then the final claims P[0]
-  rc = vpin_sc_bind(c, tabs, ntab, B(&r_j));
-  if (rc) return rc;
   if (factored) final_claims[0] = s_eq;  // tau(rx) = prod_i eq1(tau_i, r_i)
-  for (int k = 0; k < ntab; k++) {
-    rc = vpin_table_read(c, tabs[k], 0, 1, B(&final_claims[factored ? k + 1 : k]));
+  if (tabs[0]->len == 2) {
+    rc = vpin::sc_final_claims(c, tabs, ntab, B(&r_j), B(&final_claims[factored ? 1 : 0]));
     if (rc) return rc;
+  } else {
+    rc = vpin_sc_bind(c, tabs, ntab, B(&r_j));
+    if (rc) return rc;
+    for (int k = 0; k < ntab; k++) {
+      rc = vpin_table_read(c, tabs[k], 0, 1, B(&final_claims[factored ? k + 1 : k]));
+      if (rc) return rc;
+    }
   }
   blind_last = blinds_evals[rounds - 1];
   return VPIN_OK;

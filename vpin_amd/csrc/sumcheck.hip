@@ -252,6 +252,17 @@ __global__ __launch_bounds__(512) void eq_pyramid_top_kernel(fq* __restrict__ ba
 }
 
 // Plain fold of K tables (live length 2*half).
+// last fold of a sum-check (live length 2): the k bound values go to the tables AND to pinned host memory, so the final
+// claims cost one launch and one wait instead of a bind, its sync and k synchronous 32-byte copies (~25 us each)
+__global__ __launch_bounds__(64) void sc_final_kernel(Tabs<4> tabs, int k, fq r, fq* __restrict__ out) {
+  const int i = threadIdx.x;
+  if (i >= k) return;
+  const fq a0 = fq_load(tabs.t[i]), a1 = fq_load(tabs.t[i] + 1);
+  const fq v = fq_add(a0, fq_mul(r, fq_sub(a1, a0)));
+  fq_store(tabs.t[i], v);
+  fq_store(out + i, v);
+}
+
 template <int K>
 __global__ __launch_bounds__(kBlock) void sc_bind_kernel(Tabs<K> tabs, size_t half, fq r) {
   for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < half; i += (size_t)gridDim.x * kBlock) {
@@ -575,6 +586,24 @@ int sc_cubic3_launch(vpin_ctx* c, vpin_table* const* t, const vpin_table* pyrami
   return VPIN_OK;
 }
 
+
+// tables of live length 2 -> length 1 with r; the k (<= 4) bound values in `out` (k x 32 bytes)
+int sc_final_claims(vpin_ctx* c, vpin_table* const* tables, int k, const uint8_t r[32], uint8_t* out) {
+  if (!c || !tables || !r || !out || k < 1 || k > 4) return VPIN_EINVAL;
+  Tabs<4> t4{};
+  for (int i = 0; i < k; i++) {
+    if (!tables[i] || !tables[i]->d || tables[i]->len != 2) return VPIN_ESHAPE;
+    t4.t[i] = tables[i]->d;
+  }
+  (void)hipSetDevice(c->device);
+  {
+    ProfScope ps(c, VPIN_K_SC_BIND, (double)k * 96.0);
+    hipLaunchKernelGGL(sc_final_kernel, dim3(1), dim3(64), 0, c->stream, t4, k, load_host_fq(r), c->h_out);
+  }
+  VPIN_HIP_TRY(hipGetLastError());
+  for (int i = 0; i < k; i++) tables[i]->len = 1;
+  return fetch(c, k, out);
+}
 
 }  // namespace vpin
 

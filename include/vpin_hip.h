@@ -406,6 +406,16 @@ int vpin_snark_prove_dev(vpin_ctx* ctx, const vpin_dev_instance* g, const uint8_
                          uint8_t* comm_out, size_t comm_cap, size_t* comm_len, uint8_t* comm_para_out,
                          uint8_t* comm_input_out);
 
+/* BulletReductionProof::prove, Spartan/src/nizk/bullet.rs:32-132, with the round challenges GIVEN (u_mont: log2(R)
+ * Montgomery scalars) instead of drawn from a transcript, over the R stream generators of `g` only (the caller's
+ * c*Q and blind*H terms are host work: nizk/mod.rs:447-531).  x = the vector being reduced (a in bullet.rs), a = the
+ * public vector (b in bullet.rs), R scalars each.  Per round k: cLR_out[64k..] = <a_L,b_R> | <a_R,b_L>,
+ * LR_out[64k..] = compressed <a_L,G_R> | <a_R,G_L>; at the end x_hat | a_hat and the compressed g_hat.  The device never
+ * folds G (bullet.hip); classic != 0 forces the three-launch rounds that rows longer than 4096 scalars use, classic == 0
+ * the fused one-launch rounds (VPIN_ESHAPE where R has none).  Kernel-level parity handle. */
+int vpin_bullet_reduce(vpin_ctx* c, const vpin_gens* g, const uint8_t* x_mont, const uint8_t* a_mont, size_t R, const uint8_t* u_mont,
+                       int classic, uint8_t* cLR_out, uint8_t* LR_out, uint8_t xhat_ahat_out[64], uint8_t ghat_out[32]);
+
 /* ---- host-only entry points (no GPU needed) -------------------------------------------- */
 /* MultiCommitGens::new (Spartan/src/commitments.rs:20-38): first nb points of the stream */
 int vpin_host_gens_derive(const char* label, size_t nb, uint8_t* out_xyzt /* nb*128 */);

@@ -325,6 +325,63 @@ int vpin_host_commit(const char* label, const uint8_t* v_mont, size_t n, const u
   return VPIN_OK;
 }
 
+// BulletReductionProof::prove (nizk/bullet.rs:32-132) with the challenges GIVEN (u[k], Montgomery) instead of drawn from a
+// transcript, over the stream generators of `g` only (no Q, no H): per round the cross inner products c_L | c_R, the
+// compressed points <a_L, G_R> | <a_R, G_L>, and at the end x_hat | a_hat and the compressed g_hat.  The parity handle
+// of bullet.hip / msm.hip's bullet_step_kernel: classic != 0 forces the three-launch rounds.
+int vpin_bullet_reduce(vpin_ctx* c, const vpin_gens* g, const uint8_t* x_mont, const uint8_t* a_mont, size_t R, const uint8_t* u_mont,
+                       int classic, uint8_t* cLR_out, uint8_t* LR_out, uint8_t xhat_ahat_out[64], uint8_t ghat_out[32]) {
+  if (!c || !g || !x_mont || !a_mont || !u_mont || !cLR_out || !LR_out || !xhat_ahat_out || !ghat_out || !vpin::is_pow2(R) || R < 2)
+    return VPIN_EINVAL;
+  (void)hipSetDevice(c->device);
+  vpin::BulletState* bs = nullptr;
+  int rc = vpin::bullet_begin(c, x_mont, a_mont, R, &bs);
+  if (rc) return rc;
+  struct Guard { vpin_ctx* c; vpin::BulletState* s; ~Guard() { (void)hipStreamSynchronize(c->stream); vpin::bullet_free(c, s); } } guard{c, bs};
+  const bool fused = !classic && vpin::bullet_fused(bs);
+  if (!classic && !fused) return VPIN_ESHAPE;  // the caller asked for the fused rounds and this R does not have them
+  const size_t lgR = log2z(R), np = vpin_gens_msm_parts_count(R);
+  size_t fblk = 0;
+  const uint8_t* fparts = fused ? vpin::bullet_parts(c, bs, &fblk) : nullptr;
+  std::vector<uint8_t> parts(2 * np * 128);
+  const Fq* u = reinterpret_cast<const Fq*>(u_mont);
+  Fq u_prev = Fq::zero(), ui_prev = Fq::zero();
+  size_t n = R;
+  for (size_t k = 0; k < lgR; k++) {
+    n /= 2;
+    if (fused) rc = vpin::bullet_step(c, g, bs, n, k ? B(&u_prev) : nullptr, k ? B(&ui_prev) : nullptr, cLR_out + 64 * k);
+    else rc = vpin::bullet_round_begin(c, g, bs, n, parts.data(), cLR_out + 64 * k);
+    if (rc) return rc;
+    if ((rc = vpin::bullet_round_end(c))) return rc;
+    for (int row = 0; row < 2; row++) {
+      Point acc = Point::identity();
+      if (fused) {
+        for (size_t b = 0; b < fblk; b++) {
+          const bool is_L = ((b * 32) & (2 * n - 1)) >= n;
+          if (n >= 32 && is_L != (row == 0)) continue;
+          acc = acc + Point::from_xyzt(fparts + ((size_t)row * fblk + b) * 128);
+        }
+      } else {
+        for (size_t p = 0; p < np; p++) acc = acc + Point::from_xyzt(parts.data() + ((size_t)row * np + p) * 128);
+      }
+      acc.compress(LR_out + 64 * k + 32 * row);
+    }
+    u_prev = u[k];
+    ui_prev = u[k].invert();
+    if (!fused && (rc = vpin::bullet_fold(c, bs, n, B(&u_prev), B(&ui_prev)))) return rc;
+  }
+  Point ghat = Point::identity();
+  if (fused) {
+    if ((rc = vpin::bullet_finish_fused(c, g, bs, B(&u_prev), B(&ui_prev), xhat_ahat_out))) return rc;
+    for (size_t b = 0; b < fblk; b++) ghat = ghat + Point::from_xyzt(fparts + b * 128);
+  } else {
+    if ((rc = vpin::bullet_finish(c, g, bs, xhat_ahat_out, parts.data()))) return rc;
+    for (size_t p = 0; p < np; p++) ghat = ghat + Point::from_xyzt(parts.data() + p * 128);
+  }
+  ghat.compress(ghat_out);
+  return VPIN_OK;
+}
+
 void vpin_sat_last_timings(double out[8]) { memcpy(out, g_timings, sizeof g_timings); }
 
 size_t vpin_sat_proof_max_bytes(size_t num_cons, size_t num_vars) {

@@ -82,6 +82,7 @@ struct vpin_ctx {
   vpin::fq* h_spark = nullptr;  // pinned, kSparkPinned fq; the last element's first word is the completion flag
   uint32_t* d_spark_cnt = nullptr;  // device: per-instance and global "blocks done" counters (self-resetting)
   uint32_t spark_seq = 0;           // sequence number of the last flagged launch group
+  int round_split = 0, round_split_grid = 0, round_split_ncirc = 0;  // the current group sums its partials in round_finish_kernel
   uint32_t tail_seq = 0;            // persistent tail kernel (spark.hip): sequence base of the current / next launch
   int tail_rounds = 0;
   vpin::fq tail_sums[3 * 18];   // host copies of the current tail round's results (assembled from the mailbox pieces)

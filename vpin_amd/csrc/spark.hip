@@ -150,6 +150,7 @@ struct Finisher {
   uint32_t seq;
   int inst0;           // first instance index of this launch
   int total_inst;      // instances in the launch group (all kernels flagged with the same seq)
+  int fused;           // 0: the workgroups only store their partials, round_finish_kernel sums and publishes (large grids)
 };
 
 // block-wide sums of e[0..2]: valid in threads 0..2 (thread k holds sum k)
@@ -175,6 +176,14 @@ __device__ __forceinline__ fq block_sum3(fq* e) {
 // called by every thread of the block after the per-thread accumulators e[3] are final
 __device__ __forceinline__ void finish_block(fq* e, const Finisher& f) {
   fq t = block_sum3(e);
+  if (!f.fused) {
+    // Large grids: the "last block done" pattern below costs every workgroup an agent-scope release fence, and on a part
+    // with one L2 per XCD that is an L2 write-back per workgroup, serialised per XCD -- measured 0.14 us x workgroups
+    // (tools/ubench_rounds.py: 768 workgroups of one pair per thread took 104 us, 384 took 50).  The kernel boundary
+    // does the one write-back instead, and round_finish_kernel sums and publishes.
+    if (threadIdx.x < 3) fq_store(&f.partials[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 3 + threadIdx.x], t);
+    return;
+  }
   if (gridDim.x > 1) {
     fq* mine = f.partials + (size_t)blockIdx.y * gridDim.x * 3;
     if (threadIdx.x < 3) fq_store(&mine[(size_t)blockIdx.x * 3 + threadIdx.x], t);
@@ -285,6 +294,38 @@ __global__ __launch_bounds__(kBlock, kMinWaves) void dotp_round_kernel(const fq*
     acc.stage_a(u, p1, d1);
   }
   finish_block(acc.e, fin);
+}
+
+// Second half of a launch group whose kernels ran with Finisher::fused == 0: one wave per instance sums the instance's
+// workgroup partials (product circuits: np workgroups each at `partials`; dot-product halves: nd each at `partials_d`),
+// writes the three scalars to pinned host memory, and the workgroup publishes the group's sequence number.
+constexpr int kFinishBlock = 1024;
+__global__ __launch_bounds__(kFinishBlock) void round_finish_kernel(const fq* __restrict__ partials, int ncirc, int np,
+                                                                    const fq* __restrict__ partials_d, int ndotp, int nd,
+                                                                    fq* __restrict__ out, uint32_t* __restrict__ flag, uint32_t seq) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int inst = wave; inst < ncirc + ndotp; inst += kFinishBlock / 64) {
+    const bool dp = inst >= ncirc;
+    const fq* p = dp ? partials_d + (size_t)(inst - ncirc) * nd * 3 : partials + (size_t)inst * np * 3;
+    const int nb = dp ? nd : np;
+    fq e[3] = {fq_zero(), fq_zero(), fq_zero()};
+    for (int b = lane; b < nb; b += 64)
+#pragma unroll
+      for (int k = 0; k < 3; k++) e[k] = fq_add(e[k], fq_load(&p[(size_t)b * 3 + k]));
+#pragma unroll
+    for (int k = 0; k < 3; k++) e[k] = fq_wave_sum(e[k]);
+    if (lane == 0) {
+      const int slot = dp ? 12 + (inst - ncirc) : inst;
+#pragma unroll
+      for (int k = 0; k < 3; k++) fq_store(&out[3 * (size_t)slot + k], e[k]);
+      __threadfence_system();
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence_system();
+    *(volatile uint32_t*)flag = seq;
+  }
 }
 
 // per-instance finisher: out[3*(inst0 + y) + k] = sum over the instance's block partials
@@ -487,13 +528,14 @@ int spark_fetch_tops(vpin_ctx* c, const SparkForest* f, size_t cnt) {
 // block partial scratch for up to kSparkMaxInst instances x kRoundBlocks blocks
 constexpr int kRoundBlocks = 4096;  // layout stride of the partial buffer; the launch cap is round_blocks()
 
-// Workgroups per circuit of a round kernel (and pairs per thread below which a round gets fewer).  Measured on
-// MI355X (tools/blocks_sweep.sh, profiles/r01m_blocks_sweep.txt): 64 workgroups x 12 circuits with >= 8 pairs per
-// thread beat 512 x 12 with 2 by 10 % on the LeNet step and 4 % on a lone L5-mult proof -- every workgroup ends in
-// an atomic on its circuit's counter and a partial the last workgroup re-reads, and those serialise per address;
-// 32 starves the device when the proof runs alone.
+// Workgroups per circuit of a round kernel (and pairs per thread below which a round gets fewer).  Round 1 found 64 x 12
+// workgroups with >= 8 pairs per thread 10 % faster than 512 x 12 with 2 and blamed the per-circuit atomics; the cost was
+// the agent-scope release fence of the fused finisher, an L2 write-back per workgroup (finish_block).  With the partials
+// summed by a second launch a round of 2^16 pairs went 173 -> 71 us (tools/ubench_rounds.py) and more, shorter workgroups
+// help: the LeNet step 490 / 476 / 473 / 476 / 465 ms at 64 / 128 / 256 / 512 / 1024, the CNN E trace 73.9 / 70.5 /
+// 69.8 / 68.9 / 69.9 ms, the 2^25 instance alone flat (same box, round 2).
 static inline int round_blocks() {
-  static const int n = [] { const char* e = getenv("VPIN_ROUND_BLOCKS"); int v = e ? atoi(e) : 64; return v < 1 ? 1 : v > kRoundBlocks ? kRoundBlocks : v; }();
+  static const int n = [] { const char* e = getenv("VPIN_ROUND_BLOCKS"); int v = e ? atoi(e) : 256; return v < 1 ? 1 : v > kRoundBlocks ? kRoundBlocks : v; }();
   return n;
 }
 
@@ -511,11 +553,9 @@ static inline int round_grid(size_t pairs, int ncirc = 12, bool shared_device = 
   static const size_t per_thread = [] { const char* e = getenv("VPIN_SPARK_PAIRS_PER_THREAD"); size_t v = e ? (size_t)atoi(e) : 1; return v ? v : 1; }();
   size_t b = (pairs + kBlock * per_thread - 1) / (kBlock * per_thread);
   if (b < 1) b = 1;
-  // A proof that has the device to itself caps the LAUNCH, not the circuit: round_blocks() x 12 workgroups = 3 per CU fills
-  // the device for the 12 "ops" circuits, so the 4 "mem" circuits and the 6 dot-product halves get proportionally more
-  // workgroups each (the mem forest's streaming rounds ran at one workgroup per CU: the 2^25 instance alone 385 -> 379 ms).
-  // On a shared device (vpin_ctx_set_shared_device: other contexts prove at the same time) the per-circuit cap stays: the
-  // leftover CUs are the other streams', and more, shorter-lived workgroups cost the step 6 % (537 against 507 ms, same box).
+  // A proof that has the device to itself caps the LAUNCH, not the circuit, so the 4 "mem" circuits and the 6 dot-product
+  // halves get proportionally more workgroups each; on a shared device (vpin_ctx_set_shared_device: other contexts prove at
+  // the same time) the per-circuit cap stays and the leftover CUs are the other streams'.
   const size_t cap0 = (size_t)round_blocks();
   size_t cap = shared_device ? cap0 : cap0 * 12 / (size_t)(ncirc < 1 ? 1 : ncirc > 12 ? 12 : ncirc);
   if (cap > (size_t)kRoundBlocks) cap = kRoundBlocks;
@@ -532,7 +572,21 @@ static Finisher make_finisher(vpin_ctx* c, fq* partials, int inst0, int total_in
   f.seq = c->spark_seq;
   f.inst0 = inst0;
   f.total_inst = total_inst;
+  f.fused = 1;
   return f;
+}
+
+// launch groups of more workgroups than this sum their partials in a second, one-workgroup launch (finish_block)
+static inline size_t fused_finish_max() {
+  static const size_t n = [] { const char* e = getenv("VPIN_SPARK_FUSED_FINISH_MAX"); long v = e ? atol(e) : 64; return (size_t)(v < 0 ? 0 : v); }();
+  return n;
+}
+
+static int round_finish_launch(vpin_ctx* c, const fq* partials, int ncirc, int np, int ndotp, int nd) {
+  hipLaunchKernelGGL(round_finish_kernel, dim3(1), dim3(kFinishBlock), 0, c->stream, partials, ncirc, np,
+                     partials + (size_t)12 * kRoundBlocks * 3, ndotp, nd, c->h_spark, flag_ptr(c), c->spark_seq);
+  VPIN_HIP_TRY(hipGetLastError());
+  return VPIN_OK;
 }
 
 int spark_prod_round(vpin_ctx* c, const SparkForest* f, int level, size_t len, const fq* E, const uint8_t* r, bool with_dotp,
@@ -551,6 +605,12 @@ int spark_prod_round(vpin_ctx* c, const SparkForest* f, int level, size_t len, c
   const fq_const rconst = (r && lead) ? make_fq_const(r) : fq_const{};
   c->spark_seq++;  // a new launch group: this kernel (+ the dot-product kernel that follows when with_dotp)
   Finisher fin = make_finisher(c, partials, 0, f->ncirc + (with_dotp ? 6 : 0));
+  // the dot-product kernel of the same group (spark_dotp_round, next call) gets round_grid(pairs, 6) workgroups per half
+  const size_t group_blocks = (size_t)grid * f->ncirc + (with_dotp ? (size_t)round_grid(pairs, 6, c->shared_device) * 6 : 0);
+  fin.fused = group_blocks <= fused_finish_max() ? 1 : 0;
+  c->round_split = fin.fused ? 0 : 1;
+  c->round_split_grid = grid;
+  c->round_split_ncirc = f->ncirc;
   {
     // algorithmic bytes of the reference formulation: A and B of every circuit and the shared eq table read,
     // folded halves written
@@ -565,6 +625,7 @@ int spark_prod_round(vpin_ctx* c, const SparkForest* f, int level, size_t len, c
 #undef VPIN_PROD_LAUNCH
   }
   VPIN_HIP_TRY(hipGetLastError());
+  if (!fin.fused && !with_dotp) return round_finish_launch(c, partials, f->ncirc, grid, 0, 0);
   return VPIN_OK;
 }
 
@@ -583,6 +644,7 @@ int spark_dotp_round(vpin_ctx* c, size_t N, const fq* vals, const fq* comb_deref
   const bool from_scratch = r && !first_fold;
   // same launch group as the product circuits' kernel just issued: instances 12..17 of 18
   Finisher fin = make_finisher(c, partials + (size_t)12 * kRoundBlocks * 3, 12, 18);
+  fin.fused = c->round_split ? 0 : 1;  // decided for the whole group by spark_prod_round
   {
     const double bytes = 6 * 3 * 32.0 * (r ? (double)len * 1.5 : (double)len);
     ProfScope ps(c, VPIN_K_SPARK_ROUND, bytes);
@@ -594,6 +656,7 @@ int spark_dotp_round(vpin_ctx* c, size_t N, const fq* vals, const fq* comb_deref
                          false, pairs, rr, fin);
   }
   VPIN_HIP_TRY(hipGetLastError());
+  if (!fin.fused) return round_finish_launch(c, partials, c->round_split_ncirc, c->round_split_grid, 6, grid);
   return VPIN_OK;
 }
 

@@ -299,7 +299,8 @@ __global__ __launch_bounds__(kBlock, kMinWaves) void dotp_round_kernel(const fq*
 // Second half of a launch group whose kernels ran with Finisher::fused == 0: one wave per instance sums the instance's
 // workgroup partials (product circuits: np workgroups each at `partials`; dot-product halves: nd each at `partials_d`),
 // writes the three scalars to pinned host memory, and the workgroup publishes the group's sequence number.
-constexpr int kFinishBlock = 1024;
+constexpr int kFinishBlock = 256;  // one wave per SIMD: fits beside the other lanes' resident workgroups (a 1024-thread
+                                   // workgroup waited 155 us on average for a CU during the 2^25 instance's row commitments)
 __global__ __launch_bounds__(kFinishBlock) void round_finish_kernel(const fq* __restrict__ partials, int ncirc, int np,
                                                                     const fq* __restrict__ partials_d, int ndotp, int nd,
                                                                     fq* __restrict__ out, uint32_t* __restrict__ flag, uint32_t seq) {

@@ -4,7 +4,7 @@ vector every round (G' = u^-1 G_L + u G_R with the oracle's group arithmetic, or
 integers mod q, while the device never folds G (fixed-base MSMs with scalars a'[.] s_j formed on the fly) -- so equal
 L_k, R_k, c_L, c_R, x_hat, a_hat and g_hat for given challenges check the reformulation itself, the one-side-per-
 workgroup layout (n >= 32), the split tree (n < 32), the double-buffered folds and the mailbox.  Both device paths:
-the fused one-launch rounds and the three-launch rounds rows longer than 4096 scalars use.
+the fused one-launch rounds (R up to 32768) and the three-launch rounds behind them (VPIN_BULLET_CLASSIC, odd sizes).
 """
 import ctypes as C
 
@@ -33,6 +33,14 @@ def gens(ctx):
     g = ctx.gens_create(xyzt)
     yield g, og
     g.free()
+
+
+@pytest.fixture(scope="module")
+def big_gens(ctx):
+    """the shared table of b"gens_r1cs_eval" (32770 generators, the two-segment layout of tests/test_gpu_msm_wide.py)"""
+    xyzt, og = O.gens_stream_xyzt(32770, b"gens_r1cs_eval")
+    g = ctx.gens_shared("gens_r1cs_eval", xyzt, 80 if ctx.device_total_bytes() >= (200 << 30) else 24)
+    return g, og
 
 
 def msm(points, ints):
@@ -113,6 +121,25 @@ def test_bullet_rounds_match_the_folding_model(ctx, gens, R, case, classic):
         assert M.table_to_ints(cLR[j]) == [cL, cR], f"inner products of round {j}"
         assert bytes(LR[j, 0]) == Lc, f"L of round {j} (n = {R >> (j + 1)})"
         assert bytes(LR[j, 1]) == Rc, f"R of round {j} (n = {R >> (j + 1)})"
+    assert M.table_to_ints(fin) == [x_hat, a_hat]
+    assert gh == g_hat
+
+
+@pytest.mark.parametrize("R,case,classic", [(8192, "random", 0), (32768, "sparse", 0), (8192, "sparse", 1)])
+def test_long_rows_match_the_folding_model(ctx, big_gens, R, case, classic):
+    """rows of more than 4096 scalars (instances of 2^24 constraints and more): fused rounds whose workgroup points are summed
+    per 128 on the device (R = 32768 also walks the narrow-window table segment), and the three-launch rounds with
+    msm_wide_kernel<4>"""
+    g, og = big_gens
+    rng = np.random.default_rng(R + len(case) + classic)
+    a, b = vectors(rng, R, case)
+    k = R.bit_length() - 1
+    us = [int.from_bytes(rng.bytes(40), "little") % (Q - 1) + 1 for _ in range(k)]
+    want_rounds, x_hat, a_hat, g_hat = model(a, b, [og[i] for i in range(R)], us)
+    cLR, LR, fin, gh = device(ctx, g, a, b, us, classic)
+    for j, (cL, cR, Lc, Rc) in enumerate(want_rounds):
+        assert M.table_to_ints(cLR[j]) == [cL, cR], f"inner products of round {j}"
+        assert bytes(LR[j, 0]) == Lc and bytes(LR[j, 1]) == Rc, f"L / R of round {j} (n = {R >> (j + 1)})"
     assert M.table_to_ints(fin) == [x_hat, a_hat]
     assert gh == g_hat
 

@@ -21,6 +21,7 @@ constexpr int kBB = 256;
 struct BulletState {
   fq *av = nullptr, *bv = nullptr, *sj = nullptr;  // [R] each
   fq *av2 = nullptr, *bv2 = nullptr;               // fused rounds: the folded vectors are double-buffered
+  void* fparts = nullptr;                          // fused rounds, R > 4096: the MSM workgroups' partial points (2 x R/32 x 128 B)
   int cur = 0;                                     // fused rounds: 0 = the live vectors are in av / bv, 1 = in av2 / bv2
   fq* rows = nullptr;                              // [2][R]: scalars of L and R over g_0..g_{R-1}
   fq* partials = nullptr;                          // [nblk][2] block partials of the two inner products
@@ -94,7 +95,7 @@ uint8_t* bullet_pinned(vpin_ctx* c) {
   return (uint8_t*)c->h_bullet;
 }
 
-constexpr size_t kFusedMaxR = 4096;  // 2 x R/32 partial points of 128 B fill the first half of the pinned buffer
+constexpr size_t kFusedMaxR = 32768;  // up to 4096: 2 x R/32 partial points of 128 B in the first half of the pinned buffer; beyond: summed per 128 on the device
 bool bullet_fused(const BulletState* st) {
   static const bool off = getenv("VPIN_BULLET_CLASSIC") != nullptr;
   return st && !off && st->av2 && st->R % 32 == 0 && st->R <= kFusedMaxR;
@@ -103,7 +104,7 @@ bool bullet_fused(const BulletState* st) {
 void bullet_free(vpin_ctx* c, BulletState* st) {
   if (!st) return;
   for (void* p : {(void*)st->av, (void*)st->bv, (void*)st->sj, (void*)st->rows, (void*)st->partials, st->msm_scratch, (void*)st->av2,
-                  (void*)st->bv2})
+                  (void*)st->bv2, st->fparts})
     if (p) dev_free(c, p);
   if (st->ev_partials) (void)hipEventDestroy(st->ev_partials);
   delete st;
@@ -118,7 +119,8 @@ int bullet_begin(vpin_ctx* c, const uint8_t* x_mont, const uint8_t* a_mont, size
   st->R = R;
   st->nblk = (int)((R + kBB - 1) / kBB);
   const bool want_fused = R % 32 == 0 && R <= kFusedMaxR && bullet_pinned(c) != nullptr;
-  if ((want_fused && (dev_alloc(c, R * 32, (void**)&st->av2) || dev_alloc(c, R * 32, (void**)&st->bv2))) ||
+  if ((want_fused && (dev_alloc(c, R * 32, (void**)&st->av2) || dev_alloc(c, R * 32, (void**)&st->bv2) ||
+                      (R > 4096 && dev_alloc(c, 2 * (R / 32) * 128, &st->fparts)))) ||
       dev_alloc(c, R * 32, (void**)&st->av) || dev_alloc(c, R * 32, (void**)&st->bv) || dev_alloc(c, R * 32, (void**)&st->sj) ||
       dev_alloc(c, 2 * R * 32, (void**)&st->rows) || dev_alloc(c, (size_t)st->nblk * 64, (void**)&st->partials) ||
       dev_alloc(c, gens_msm_parts_scratch_bytes(2, R), &st->msm_scratch) ||
@@ -251,7 +253,8 @@ int bullet_step(vpin_ctx* c, const vpin_gens* g, BulletState* st, size_t n, cons
   const uint32_t seq = ++c->bullet_seq;
   fq* ap = st->cur ? st->av2 : st->av; fq* bp = st->cur ? st->bv2 : st->bv;
   fq* an = st->cur ? st->av : st->av2; fq* bn = st->cur ? st->bv : st->bv2;
-  int rc = bullet_step_launch(c, g, ap, bp, an, bn, st->sj, n, st->R, u_prev != nullptr, false, u_prev, u_inv_prev, pin, fused_up(c), seq);
+  int rc = bullet_step_launch(c, g, ap, bp, an, bn, st->sj, n, st->R, u_prev != nullptr, false, u_prev, u_inv_prev, pin, fused_up(c), seq,
+                              st->fparts);
   if (rc) return rc;
   st->cur ^= 1;
   fq sums[2];
@@ -260,9 +263,21 @@ int bullet_step(vpin_ctx* c, const vpin_gens* g, BulletState* st, size_t n, cons
   return VPIN_OK;
 }
 
-const uint8_t* bullet_parts(vpin_ctx* c, const BulletState* st, size_t* nblk) {
-  if (nblk) *nblk = st->R / 32;
-  return (const uint8_t*)c->h_bullet;
+size_t bullet_part_ptrs(vpin_ctx* c, const BulletState* st, size_t n, int row, const uint8_t** out) {
+  const uint8_t* base = (const uint8_t*)c->h_bullet;
+  const size_t nblk = st->R / 32;
+  size_t k = 0;
+  if (nblk > 128) {  // summed per 128 workgroups on the device: [rows][nblk / 128], every entry valid
+    const size_t G = nblk / 128;
+    for (size_t g = 0; g < G; g++) out[k++] = base + ((size_t)row * G + g) * 128;
+    return k;
+  }
+  for (size_t b = 0; b < nblk; b++) {  // a workgroup of 32 generators holds one side while n >= 32, both below
+    const bool is_L = n == 0 || ((b * 32) & (2 * n - 1)) >= n;
+    if (n != 0 && n < 32) { out[k++] = base + ((size_t)row * nblk + b) * 128; continue; }
+    if (is_L == (row == 0)) out[k++] = base + ((size_t)row * nblk + b) * 128;
+  }
+  return k;
 }
 
 int bullet_finish_fused(vpin_ctx* c, const vpin_gens* g, BulletState* st, const uint8_t u[32], const uint8_t u_inv[32],
@@ -272,7 +287,7 @@ int bullet_finish_fused(vpin_ctx* c, const vpin_gens* g, BulletState* st, const 
   if (!pin) return VPIN_ENOMEM;
   const uint32_t seq = ++c->bullet_seq;
   fq* ap = st->cur ? st->av2 : st->av; fq* bp = st->cur ? st->bv2 : st->bv;
-  int rc = bullet_step_launch(c, g, ap, bp, nullptr, nullptr, st->sj, 0, st->R, false, true, u, u_inv, pin, fused_up(c), seq);
+  int rc = bullet_step_launch(c, g, ap, bp, nullptr, nullptr, st->sj, 0, st->R, false, true, u, u_inv, pin, fused_up(c), seq, st->fparts);
   if (rc) return rc;
   fq sums[2];
   if ((rc = fused_take(c, 1, seq, sums))) return rc;

@@ -157,17 +157,18 @@ uint8_t* bullet_pinned(vpin_ctx* c);  // 64 KiB of pinned host memory owned by t
 int bullet_fold(vpin_ctx* c, BulletState* st, size_t n, const uint8_t u[32], const uint8_t u_inv[32]);
 int bullet_finish(vpin_ctx* c, const vpin_gens* g, BulletState* st, uint8_t xhat_ahat[64], uint8_t* parts_xyzt);
 void bullet_free(vpin_ctx* c, BulletState* st);
-// one launch per round (msm.hip bullet_step_kernel) when the state allows it: R a multiple of 32, at most 4096
+// one launch per round (msm.hip bullet_step_kernel) when the state allows it: R a multiple of 32, at most 32768
 bool bullet_fused(const BulletState* st);
 int bullet_step(vpin_ctx* c, const vpin_gens* g, BulletState* st, size_t n, const uint8_t* u_prev, const uint8_t* u_inv_prev,
                 uint8_t cLR[64]);
-// partial points of the last bullet_step / bullet_finish_fused after bullet_round_end: [2][*nblk] x 128 B, row 0 = L
-const uint8_t* bullet_parts(vpin_ctx* c, const BulletState* st, size_t* nblk);
+// the partial points (128 B each, X|Y|Z|T) of the last bullet_step (half length n) / bullet_finish_fused (n = 0) the host has to
+// add for row 0 = L or 1 = R, valid after bullet_round_end; out has room for 256 pointers; returns their number
+size_t bullet_part_ptrs(vpin_ctx* c, const BulletState* st, size_t n, int row, const uint8_t** out);
 int bullet_finish_fused(vpin_ctx* c, const vpin_gens* g, BulletState* st, const uint8_t u[32], const uint8_t u_inv[32],
                         uint8_t xhat_ahat[64]);
 int bullet_step_launch(vpin_ctx* c, const vpin_gens* g, const fq* a_prev, const fq* b_prev, fq* a_next, fq* b_next, fq* sj, size_t n,
                        size_t R, bool fold, bool finish, const uint8_t* u, const uint8_t* u_inv, uint8_t* parts_pinned,
-                       uint32_t* up_pinned, uint32_t seq);
+                       uint32_t* up_pinned, uint32_t seq, void* dev_parts);
 
 // VPIN_CLI_TRACE=1: wall-clock laps of the cold (one-shot CLI) path on stderr; each lap drains the stream
 struct TraceLap {

@@ -313,18 +313,14 @@ static int dplog_prove(vpin_ctx* c, const PcGens& pc, Transcript& tr, Transcript
   size_t n = R;
   static const bool fine = getenv("VPIN_SPARK_TRACE") && atoi(getenv("VPIN_SPARK_TRACE")) >= 3;
   double tb[6] = {0, 0, 0, 0, 0, 0};
-  // Fused rounds (R <= 4096): one launch folds the previous challenge in, runs the round's MSM and publishes the inner
-  // products; its partial points arrive as [2][R/32], a workgroup of 32 generators holding one side while n >= 32.
+  // Fused rounds: one launch folds the previous challenge in, runs the round's MSM and publishes the inner products; its
+  // partial points arrive per side (bullet_part_ptrs: at most 128 for L and R together).
   const bool fused = vpin::bullet_fused(bs);
-  size_t fblk = 0;
-  const uint8_t* fparts = fused ? vpin::bullet_parts(c, bs, &fblk) : nullptr;
-  auto sum_side = [&](int row, size_t nn) {  // row 0 = L (generators with pos >= nn), row 1 = R
+  auto sum_side = [&](int row, size_t nn) {  // row 0 = L, 1 = R; nn = 0: g_hat
+    const uint8_t* ptrs[256];
+    const size_t cnt = vpin::bullet_part_ptrs(c, bs, nn, row, ptrs);
     Point acc = Point::identity();
-    for (size_t b = 0; b < fblk; b++) {
-      const bool is_L = ((b * 32) & (2 * nn - 1)) >= nn;
-      if (nn >= 32 && is_L != (row == 0)) continue;
-      acc = acc + Point::from_xyzt(fparts + ((size_t)row * fblk + b) * 128);
-    }
+    for (size_t k = 0; k < cnt; k++) acc = acc + Point::from_xyzt(ptrs[k]);
     return acc;
   };
   Fq u_prev = Fq::zero(), u_inv_prev = Fq::zero();
@@ -370,13 +366,7 @@ static int dplog_prove(vpin_ctx* c, const PcGens& pc, Transcript& tr, Transcript
   else rc = vpin::bullet_finish(c, pc.dev, bs, B(xa), parts.data());
   if (rc) return rc;
   const Fq x_hat = xa[0], a_hat = xa[1], y_hat = x_hat * a_hat;
-  Point g_hat;
-  if (fused) {
-    g_hat = Point::identity();
-    for (size_t b = 0; b < fblk; b++) g_hat = g_hat + Point::from_xyzt(fparts + b * 128);
-  } else {
-    g_hat = sum_parts(parts.data());
-  }
+  Point g_hat = fused ? sum_side(0, 0) : sum_parts(parts.data());
   {
     Point p = g_hat.mul(d_);  // d.commit(&r_delta, {G:[g_hat], h})
     pc.fb_h.mul_acc(p, r_delta);

@@ -501,9 +501,9 @@ __global__ __launch_bounds__(kMsmBlock) void msm_wide_kernel(const fq* __restric
 // BulletReductionProof::prove (nizk/bullet.rs:32-132), round with half length n, everything the device does for it:
 //   * fold the previous round's challenge into a, b and the generator coefficients s_j (bullet.rs:99-109);
 //   * L = <a_L, G_R>, R = <a_R, G_L> over the stream generators as fixed-base MSMs with scalars a'[.] * s'_j
-//     (bullet.hip: G is never folded) -- workgroups [0, nmsm), 32 generators each, eight lanes per scalar;
-//   * the cross inner products c_L = <a_L, b_R>, c_R = <a_R, b_L> and the folded a, b for the next round -- workgroups
-//     [nmsm, gridDim.x), published through the pinned mailbox so the host forms c*Q + blind*H while the MSM runs.
+//     (bullet.hip: G is never folded) -- the last nmsm workgroups, 32 generators each, eight lanes per scalar;
+//   * the cross inner products c_L = <a_L, b_R>, c_R = <a_R, b_L> and the folded a, b for the next round -- the first
+//     workgroups of the grid, published through the pinned mailbox so the host forms c*Q + blind*H while the MSM runs.
 // No workgroup reads what another one writes (a, b are double-buffered; s_j belongs to its eight lanes), so one launch
 // replaces the fold, rows and MSM launches and both copies of a round.  finish = 1: the last fold only --
 // g_hat = sum_j s_j g_j, x_hat, a_hat.
@@ -521,9 +521,12 @@ struct BulletStep {
 
 __global__ __launch_bounds__(kMsmBlock) void bullet_step_kernel(BulletStep a, TableView tv) {
   const size_t n = a.n;
-  if ((int)blockIdx.x >= a.nmsm) {
+  // the inner-product workgroups come first in the grid: they are dispatched first, so the host has c_L, c_R (and forms
+  // c*Q + blind*H) while the MSM workgroups, more than fit the device at once for the longest rows, are still running
+  const int nip = (int)gridDim.x - a.nmsm;
+  if ((int)blockIdx.x < nip) {
     // ---- inner products + the folded vectors ----
-    const int ib = (int)blockIdx.x - a.nmsm;
+    const int ib = (int)blockIdx.x;
     const size_t i = (size_t)ib * kMsmBlock + threadIdx.x;
     fq pl = fq_zero(), pr = fq_zero();
     if (a.finish) {
@@ -563,7 +566,8 @@ __global__ __launch_bounds__(kMsmBlock) void bullet_step_kernel(BulletStep a, Ta
   }
   // ---- the round's MSM: 32 generators per workgroup, the W windows of a scalar over eight lanes ----
   const int g = threadIdx.x >> 3, grp = threadIdx.x & 7;
-  const size_t j = (size_t)blockIdx.x * kWideScalars + g;
+  const size_t blk = (size_t)blockIdx.x - nip;  // MSM workgroup index
+  const size_t j = blk * kWideScalars + g;
   ge_ext acc = ge_identity();
   if (j < a.R) {
     fq sc = fq_load(a.sj + j);
@@ -595,13 +599,41 @@ __global__ __launch_bounds__(kMsmBlock) void bullet_step_kernel(BulletStep a, Ta
   ge_tree_quad(sh, kMsmBlock, split);
   if (threadIdx.x < 2) {
     // thread 0 stores sh[0]; with a split, thread 1 stores sh[split] (the L run)
-    const bool first_is_L = a.finish || (((size_t)blockIdx.x * kWideScalars) & (2 * n - 1)) >= n;
+    const bool first_is_L = a.finish || ((blk * kWideScalars) & (2 * n - 1)) >= n;
     if (threadIdx.x == 0 || split) {
       const ge_ext p = sh[threadIdx.x ? split : 0];
       const int row = threadIdx.x ? 0 : ((split || !first_is_L) ? 1 : 0);
-      fp* o = a.parts + 4 * ((size_t)row * a.nmsm + blockIdx.x);
+      fp* o = a.parts + 4 * ((size_t)row * a.nmsm + blk);
       fp_store(o, fp_freeze(p.X)); fp_store(o + 1, fp_freeze(p.Y)); fp_store(o + 2, fp_freeze(p.Z)); fp_store(o + 3, fp_freeze(p.T));
     }
+  }
+}
+
+// More than 128 MSM workgroups (R > 4096): their partial points stay on the device and this second launch sums them per side
+// in groups of up to 128 (one tree each), so the host still adds at most 8 points per side.  in: [2][nmsm] as
+// bullet_step_kernel left them (a workgroup's slot of the side it does not hold is stale), out: [rows][G] in pinned memory.
+__global__ __launch_bounds__(kMsmBlock) void bullet_parts_reduce_kernel(const fp* __restrict__ in, int nmsm, size_t n, int finish,
+                                                                        fp* __restrict__ out) {
+  const int G = gridDim.x, g = blockIdx.x, row = blockIdx.y, per = nmsm / G;
+  __shared__ ge_ext sh[kMsmBlock / 2];
+  if ((int)threadIdx.x < kMsmBlock / 2) {
+    ge_ext p = ge_identity();
+    const int b = g * per + (int)threadIdx.x;
+    if ((int)threadIdx.x < per) {
+      const bool is_L = finish || (((size_t)b * kWideScalars) & (2 * n - 1)) >= n;
+      if (finish || n < (size_t)kWideScalars || is_L == (row == 0)) {
+        const fp* q = in + 4 * ((size_t)row * nmsm + b);
+        p.X = fp_load(q); p.Y = fp_load(q + 1); p.Z = fp_load(q + 2); p.T = fp_load(q + 3);
+      }
+    }
+    sh[threadIdx.x] = p;
+  }
+  __syncthreads();
+  ge_tree_quad(sh, kMsmBlock / 2);
+  if (threadIdx.x == 0) {
+    const ge_ext p = sh[0];
+    fp* o = out + 4 * ((size_t)row * G + g);
+    fp_store(o, fp_freeze(p.X)); fp_store(o + 1, fp_freeze(p.Y)); fp_store(o + 2, fp_freeze(p.Z)); fp_store(o + 3, fp_freeze(p.T));
   }
 }
 
@@ -1110,25 +1142,33 @@ int gens_msm_parts_launch(vpin_ctx* c, const vpin_gens* g, const fq* d_scalars, 
   return VPIN_OK;
 }
 
-// one launch per bullet round (bullet_step_kernel); parts/up are pinned host memory.  R must be a multiple of 32.
+// one launch per bullet round (bullet_step_kernel); parts_pinned / up_pinned are pinned host memory.  R must be a multiple
+// of 32.  R > 4096 (more than 128 MSM workgroups): dev_parts (2 x R/32 x 128 bytes of device memory) takes the workgroups'
+// points and a second launch leaves R/4096 sums per side in parts_pinned (bullet_parts_reduce_kernel).
 int bullet_step_launch(vpin_ctx* c, const vpin_gens* g, const fq* a_prev, const fq* b_prev, fq* a_next, fq* b_next, fq* sj, size_t n,
                        size_t R, bool fold, bool finish, const uint8_t* u, const uint8_t* u_inv, uint8_t* parts_pinned,
-                       uint32_t* up_pinned, uint32_t seq) {
+                       uint32_t* up_pinned, uint32_t seq, void* dev_parts) {
   if (!c || !g || !a_prev || !b_prev || !sj || !parts_pinned || !up_pinned || R % kWideScalars || R > g->nb) return VPIN_EINVAL;
   if (!finish && (n == 0 || 2 * n > R || !a_next || !b_next)) return VPIN_EINVAL;
   if ((fold || finish) && (!u || !u_inv)) return VPIN_EINVAL;
+  const int nmsm = (int)(R / kWideScalars);
+  const bool reduce = nmsm > 128;
+  if (reduce && (!dev_parts || (nmsm & (nmsm - 1)))) return VPIN_EINVAL;
   (void)hipSetDevice(c->device);
   BulletStep a{};
   a.a_prev = a_prev; a.b_prev = b_prev; a.a_next = a_next; a.b_next = b_next; a.sj = sj;
   a.n = finish ? 0 : n; a.R = R; a.fold = fold ? 1 : 0; a.finish = finish ? 1 : 0;
-  a.nmsm = (int)(R / kWideScalars);
+  a.nmsm = nmsm;
   if (u) { memcpy(a.u.v, u, 32); memcpy(a.u_inv.v, u_inv, 32); }
-  a.parts = (fp*)parts_pinned; a.up = up_pinned; a.seq = seq;
+  a.parts = reduce ? (fp*)dev_parts : (fp*)parts_pinned; a.up = up_pinned; a.seq = seq;
   const int nip = finish ? 1 : (int)((n + kMsmBlock - 1) / kMsmBlock);
   {
     ProfScope ps(c, VPIN_K_MSM, 32.0 * 2.0 * (double)R);
     hipLaunchKernelGGL(bullet_step_kernel, dim3((unsigned)(a.nmsm + nip)), dim3(kMsmBlock), 0, c->stream, a, view(g));
   }
+  if (reduce)
+    hipLaunchKernelGGL(bullet_parts_reduce_kernel, dim3((unsigned)(nmsm / 128), finish ? 1u : 2u), dim3(kMsmBlock), 0, c->stream,
+                       (const fp*)dev_parts, nmsm, a.n, a.finish, (fp*)parts_pinned);
   VPIN_HIP_TRY(hipGetLastError());
   return VPIN_OK;
 }

@@ -341,8 +341,13 @@ int vpin_bullet_reduce(vpin_ctx* c, const vpin_gens* g, const uint8_t* x_mont, c
   const bool fused = !classic && vpin::bullet_fused(bs);
   if (!classic && !fused) return VPIN_ESHAPE;  // the caller asked for the fused rounds and this R does not have them
   const size_t lgR = log2z(R), np = vpin_gens_msm_parts_count(R);
-  size_t fblk = 0;
-  const uint8_t* fparts = fused ? vpin::bullet_parts(c, bs, &fblk) : nullptr;
+  auto sum_side = [&](int row, size_t nn) {
+    const uint8_t* ptrs[256];
+    const size_t cnt = vpin::bullet_part_ptrs(c, bs, nn, row, ptrs);
+    Point acc = Point::identity();
+    for (size_t k = 0; k < cnt; k++) acc = acc + Point::from_xyzt(ptrs[k]);
+    return acc;
+  };
   std::vector<uint8_t> parts(2 * np * 128);
   const Fq* u = reinterpret_cast<const Fq*>(u_mont);
   Fq u_prev = Fq::zero(), ui_prev = Fq::zero();
@@ -355,15 +360,9 @@ int vpin_bullet_reduce(vpin_ctx* c, const vpin_gens* g, const uint8_t* x_mont, c
     if ((rc = vpin::bullet_round_end(c))) return rc;
     for (int row = 0; row < 2; row++) {
       Point acc = Point::identity();
-      if (fused) {
-        for (size_t b = 0; b < fblk; b++) {
-          const bool is_L = ((b * 32) & (2 * n - 1)) >= n;
-          if (n >= 32 && is_L != (row == 0)) continue;
-          acc = acc + Point::from_xyzt(fparts + ((size_t)row * fblk + b) * 128);
-        }
-      } else {
+      if (fused) acc = sum_side(row, n);
+      else
         for (size_t p = 0; p < np; p++) acc = acc + Point::from_xyzt(parts.data() + ((size_t)row * np + p) * 128);
-      }
       acc.compress(LR_out + 64 * k + 32 * row);
     }
     u_prev = u[k];
@@ -373,7 +372,7 @@ int vpin_bullet_reduce(vpin_ctx* c, const vpin_gens* g, const uint8_t* x_mont, c
   Point ghat = Point::identity();
   if (fused) {
     if ((rc = vpin::bullet_finish_fused(c, g, bs, B(&u_prev), B(&ui_prev), xhat_ahat_out))) return rc;
-    for (size_t b = 0; b < fblk; b++) ghat = ghat + Point::from_xyzt(fparts + b * 128);
+    ghat = sum_side(0, 0);
   } else {
     if ((rc = vpin::bullet_finish(c, g, bs, xhat_ahat_out, parts.data()))) return rc;
     for (size_t p = 0; p < np; p++) ghat = ghat + Point::from_xyzt(parts.data() + p * 128);

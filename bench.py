@@ -569,6 +569,17 @@ def main():
             line["verified"] = verified
             line["verify_s"] = round(time.perf_counter() - tv, 2)
             assert all(verified.values()), verified
+            # and their bytes against the oracle's digests of the same instances and seeds (a committed fixture: data, no
+            # oracle call) -- the proofs of the timed region, made with all lanes running, equal the oracle's byte for byte
+            gold_path = os.path.join(ROOT, "tests", "golden", "config_digests.json")
+            if os.path.exists(gold_path):
+                import hashlib
+                with open(gold_path) as f:
+                    gold = json.load(f)["cases"]
+                same = {n: hashlib.sha256(last_proof[n]["proof"]).hexdigest() == gold[n]["snark_sha256"]
+                        for names in lane_names for n in names if n in gold and "snark_sha256" in gold[n]}
+                line["bytes_equal_oracle_digest"] = same
+                assert all(same.values()), same
         # ---- the reference's own span (proof_point_mult.rs:24-101: witness inputs -> gadget + witness ->
         # is_sat -> SNARK::encode -> my_lib_prove), one instance after the other, generator tables warm; the
         # resident copies are released first.  Same seeds, so the bytes must equal the timed region's proofs.

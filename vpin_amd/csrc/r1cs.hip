@@ -75,30 +75,37 @@ __global__ __launch_bounds__(kRB) void long_chunk_kernel(const uint32_t* __restr
 }
 
 // one thread per long column: out[c] (+)= rc * sum of its chunk partials
+// one WAVE per long column (the constant-1 column of a 2^25-constraint instance has thousands of chunks: one thread adding
+// them up in a row took ~450 us per matrix)
+__device__ __forceinline__ fq long_column_sum(const uint32_t* __restrict__ long_first, size_t i, const fq* __restrict__ part) {
+  fq t = fq_zero();
+  for (uint32_t ch = long_first[i] + threadIdx.x; ch < long_first[i + 1]; ch += 64) t = fq_add(t, fq_load(part + ch));
+  return fq_wave_sum(t);
+}
+
 __global__ __launch_bounds__(64) void eval_table_long_finish_kernel(const uint32_t* __restrict__ long_cols,
                                                                     const uint32_t* __restrict__ long_first, size_t n_long,
                                                                     const fq* __restrict__ part, fq rc, int accumulate,
                                                                     fq* __restrict__ out) {
-  size_t i = (size_t)blockIdx.x * 64 + threadIdx.x;
+  const size_t i = blockIdx.x;
   if (i >= n_long) return;
-  fq t = fq_zero();
-  for (uint32_t ch = long_first[i]; ch < long_first[i + 1]; ch++) t = fq_add(t, fq_load(part + ch));
+  fq t = long_column_sum(long_first, i, part);
+  if (threadIdx.x != 0) return;
   t = fq_mul(t, rc);
   uint32_t c = long_cols[i];
   if (accumulate) t = fq_add(t, fq_load(out + c));
   fq_store(out + c, t);
 }
 
-// one thread per long column: partials[i] = ry[c] * sum of its chunk partials
+// one wave per long column: partials[i] = ry[c] * sum of its chunk partials
 __global__ __launch_bounds__(64) void evaluate_long_finish_kernel(const uint32_t* __restrict__ long_cols,
                                                                   const uint32_t* __restrict__ long_first, size_t n_long,
                                                                   const fq* __restrict__ part, const fq* __restrict__ ry,
                                                                   fq* __restrict__ partials) {
-  size_t i = (size_t)blockIdx.x * 64 + threadIdx.x;
+  const size_t i = blockIdx.x;
   if (i >= n_long) return;
-  fq t = fq_zero();
-  for (uint32_t ch = long_first[i]; ch < long_first[i + 1]; ch++) t = fq_add(t, fq_load(part + ch));
-  fq_store(partials + i, fq_mul(t, fq_load(ry + long_cols[i])));
+  const fq t = long_column_sum(long_first, i, part);
+  if (threadIdx.x == 0) fq_store(partials + i, fq_mul(t, fq_load(ry + long_cols[i])));
 }
 
 // partials[block] = sum_k rx[row[k]] * ry[col[k]] * val[k]   (CSR order: row index recovered by search)
@@ -305,7 +312,7 @@ int vpin_r1cs_eval_table(vpin_ctx* c, const vpin_r1cs_dev* d, const vpin_table* 
     if (d->n_long[m]) {
       hipLaunchKernelGGL(long_chunk_kernel, dim3((unsigned)d->n_chunks[m]), dim3(kRB), 0, c->stream, d->chunk_k0[m],
                          d->chunk_k1[m], d->csc_row[m], d->csc_val[m], evals_rx->d, chunk_partials);
-      hipLaunchKernelGGL(eval_table_long_finish_kernel, dim3((unsigned)((d->n_long[m] + 63) / 64)), dim3(64), 0, c->stream,
+      hipLaunchKernelGGL(eval_table_long_finish_kernel, dim3((unsigned)d->n_long[m]), dim3(64), 0, c->stream,
                          d->long_cols[m], d->long_first[m], d->n_long[m], chunk_partials, rc_m, accum, t->d);
     }
   }
@@ -337,7 +344,7 @@ int vpin_r1cs_evaluate(vpin_ctx* c, const vpin_r1cs_dev* d, const vpin_table* ev
     if (d->n_long[m]) {
       hipLaunchKernelGGL(long_chunk_kernel, dim3((unsigned)d->n_chunks[m]), dim3(kRB), 0, c->stream, d->chunk_k0[m],
                          d->chunk_k1[m], d->csc_row[m], d->csc_val[m], evals_rx->d, chunk_partials);
-      hipLaunchKernelGGL(evaluate_long_finish_kernel, dim3((unsigned)((d->n_long[m] + 63) / 64)), dim3(64), 0, c->stream,
+      hipLaunchKernelGGL(evaluate_long_finish_kernel, dim3((unsigned)d->n_long[m]), dim3(64), 0, c->stream,
                          d->long_cols[m], d->long_first[m], d->n_long[m], chunk_partials, evals_ry->d, c->d_partials + grid);
     }
     hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(kRB), 0, c->stream, c->d_partials, nparts, d_out + m);

@@ -309,6 +309,11 @@ size_t vpin_snark_proof_max_bytes(const vpin_r1cs* inst);
 int vpin_spark_encode(vpin_ctx* ctx, const vpin_r1cs* inst, vpin_spark_decomm** out, uint8_t* comm_out,
                       size_t comm_cap, size_t* comm_len);
 void vpin_spark_decomm_free(vpin_ctx* ctx, vpin_spark_decomm* d);
+/* The column SNARK::encode found to carry a large share of matrix A / B / C's entries (the constant 1 of an R1CS, or the
+ * first input), 0xffffffff where there is none or the instance is too small for it to matter.  Derefs::new
+ * (Spartan/src/sparse_mlpoly.rs:56-71) puts the SAME scalar eq(ry)[col] at every one of those entries, so the derefs
+ * commitment of each proof (sparse_mlpoly.rs:525-531) adds v * g_j for them instead of walking a window table. */
+void vpin_spark_decomm_hot_cols(const vpin_spark_decomm* d, uint32_t out[3]);
 
 /* my_lib_prove in full (vPIN_proof_generation/src/commit_test.rs:59-133): the sat proof of
  * vpin_sat_prove_resident, then inst_evals, then R1CSEvalProof::prove (r1csinstance.rs:330-354 ->

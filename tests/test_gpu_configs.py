@@ -184,3 +184,27 @@ def test_classic_bullet_rounds_give_the_same_bytes():
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
     assert out.stdout.strip().splitlines()[-1] == g["snark_sha256"]
+
+
+@pytest.mark.gpu
+def test_hot_columns_are_found_and_taken_out_of_the_derefs_commitment(ctx):
+    """SNARK::encode marks the constant-1 column of B and C (37 % / 8 % of their entries in the point-mult gadget) and the
+    first input in A; the derefs commitment of instances from 2^20 entries up then adds v * g_j for those entries instead
+    of walking a window table -- the bytes of such instances (A-mult .. L5-mult in the parametrised test) are the oracle's,
+    this test only makes sure the path is the one that ran.  Small instances keep the plain commitment."""
+    from vpin_amd import gadgets as G
+    d = ctx.gadget_point_mult_dev(*G.synthetic_mult_inputs("A"))
+    try:
+        dec, _ = d.spark_encode()
+        nv = d.num_vars
+        assert dec.hot_cols() == [nv + 1, nv, nv]
+        dec.free()
+    finally:
+        d.free()
+    d = ctx.gadget_point_mult_dev(*G.synthetic_mult_inputs("3_32"))
+    try:
+        dec, _ = d.spark_encode()
+        assert dec.hot_cols() == [None, None, None]
+        dec.free()
+    finally:
+        d.free()

@@ -235,6 +235,15 @@ class SparkDecomm:
     def __init__(self, ctx, h, proof_cap):
         self.ctx, self.h, self.proof_cap = ctx, h, proof_cap
 
+    def hot_cols(self):
+        """vpin_spark_decomm_hot_cols: per matrix the column taken out of the derefs commitment's table walks, or None"""
+        out = (C.c_uint32 * 3)()
+        L = lib()
+        L.vpin_spark_decomm_hot_cols.restype = None
+        L.vpin_spark_decomm_hot_cols.argtypes = [C.c_void_p, C.c_void_p]
+        L.vpin_spark_decomm_hot_cols(self.h, out)
+        return [None if v == 0xffffffff else int(v) for v in out]
+
     def free(self):
         if self.h:
             lib().vpin_spark_decomm_free(self.ctx.h, self.h)

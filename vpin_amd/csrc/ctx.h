@@ -144,6 +144,9 @@ inline bool is_pow2(size_t x) { return x && !(x & (x - 1)); }
 // rows x vpin_gens_msm_parts_count(ncols) partial points (canonical X|Y|Z|T) in host memory; synchronises
 int gens_msm_parts_dev(vpin_ctx* c, const vpin_gens* g, const fq* d_scalars, size_t rows, size_t ncols, uint8_t* parts_xyzt);
 // the same without the synchronisation (the caller provides the device scratch and waits on the stream itself)
+// the derefs commitment with each matrix's hot column taken out of the table walks (msm.hip msm_rows_hot_kernel)
+int hyrax_commit_derefs_hot(vpin_ctx* c, const vpin_gens* g, const vpin_table* Z, size_t L, size_t N, const uint32_t* const col_idx[3],
+                            const uint32_t hot[3], const fq* e_ry, uint8_t* out_compressed);
 size_t gens_msm_parts_scratch_bytes(size_t rows, size_t ncols);
 int gens_msm_parts_launch(vpin_ctx* c, const vpin_gens* g, const fq* d_scalars, size_t rows, size_t ncols, void* scratch,
                           uint8_t* parts_xyzt, bool host_mapped = false);

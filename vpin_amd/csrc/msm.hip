@@ -409,6 +409,98 @@ __global__ __launch_bounds__(kMsmBlock, 3) void msm_rows_kernel(const fq* __rest
   }
 }
 
+// ---- row commitment with one repeated scalar per row taken out (the derefs commitment) ---------------------------------
+// Derefs (sparse_mlpoly.rs:267-283): the col-derefs vector of matrix m is E_ry[col_m[i]], and in an R1CS the column of the
+// constant 1 carries a large share of a matrix's entries (37 % of B, 8 % of C for vPIN's point-mult gadget: one in twelve
+// scalars of the whole derefs polynomial).  All those entries hold the SAME scalar v = E_ry[hot]: with T_j = v * g_j
+// computed once per proof (R table walks), an entry at column j of a row costs one point addition instead of a table walk
+// of W.  The entries are recognised by their column INDEX (the decommitment's index slices), never by value.
+struct HotRows {
+  const uint32_t* idx[3];   // col index slice of matrix m (N entries, the order of the polynomial)
+  uint32_t hot[3];          // the hot column of matrix m, 0xffffffff: none
+  const ge_cached* T[3];    // T[m][j] = E_ry[hot[m]] * g_j, j < ncols
+  size_t row0, rows_per_vec;  // matrix m's vector occupies rows [row0 + m*rows_per_vec, row0 + (m+1)*rows_per_vec)
+};
+
+// T[j] = v * g_j for j < n (v in Montgomery form), as cached points
+__global__ __launch_bounds__(64) void scalar_times_bases_kernel(fq v, size_t n, TableView tv, ge_cached* __restrict__ T) {
+  const size_t j = (size_t)blockIdx.x * 64 + threadIdx.x;
+  if (j >= n) return;
+  ge_ext acc = ge_identity();
+  if (!fq_is_zero(v)) table_mul_acc(acc, fq_from_mont(v), tv, j);
+  const ge_cached cch = ge_to_cached(acc);
+  fp_store(&T[j].YpX, cch.YpX); fp_store(&T[j].YmX, cch.YmX); fp_store(&T[j].Z, cch.Z); fp_store(&T[j].T2d, cch.T2d);
+}
+
+__global__ __launch_bounds__(kMsmBlock, 3) void msm_rows_hot_kernel(const fq* __restrict__ Z, size_t stride, size_t ncols, TableView tv,
+                                                                 HotRows hr, ge_ext* __restrict__ out) {
+  const size_t row = blockIdx.x;
+  const fq* zr = Z + row * stride;
+  ge_ext acc = ge_identity();
+  // a row of one repeated scalar (padding tails): s * (g_0 + ... + g_{ncols-1}), as in msm_rows_kernel
+  if (ncols >= 256 && (ncols & (ncols - 1)) == 0 && ((size_t)1 << (tv.nbt - tv.sum0 - 1)) >= ncols) {
+    const fq first = fq_load(zr);
+    if (fq_same(first, fq_load(zr + 1)) && fq_same(first, fq_load(zr + ncols / 2)) && fq_same(first, fq_load(zr + ncols - 1))) {
+      int same = 1;
+      for (size_t j = threadIdx.x; j < ncols; j += kMsmBlock) same &= fq_same(first, fq_load(zr + j)) ? 1 : 0;
+      if (__syncthreads_and(same)) {
+        if (threadIdx.x == 0) {
+          if (!fq_is_zero(first)) table_mul_acc(acc, fq_from_mont(first), tv, tv.sum0 + (size_t)(63 - __builtin_clzll((unsigned long long)ncols)));
+          ge_ext* o = out + row;
+          fp_store(&o->X, acc.X); fp_store(&o->Y, acc.Y); fp_store(&o->Z, acc.Z); fp_store(&o->T, acc.T);
+        }
+        return;
+      }
+    }
+  }
+  const uint32_t* idx = nullptr;
+  const ge_cached* T = nullptr;
+  uint32_t hot = 0xffffffffu;
+  if (row >= hr.row0 && row < hr.row0 + 3 * hr.rows_per_vec) {
+    const size_t m = (row - hr.row0) / hr.rows_per_vec;
+    if (hr.hot[m] != 0xffffffffu) {
+      hot = hr.hot[m];
+      T = hr.T[m];
+      idx = hr.idx[m] + (row - hr.row0 - m * hr.rows_per_vec) * ncols;
+    }
+  }
+  // one LDS list, two ends: ordinary non-zero scalars from the front, hot entries from the back
+  __shared__ uint16_t list[kSeg];
+  __shared__ uint32_t n_front, n_back;
+  for (size_t seg = 0; seg < ncols; seg += kSeg) {
+    const size_t seg_end = (seg + kSeg < ncols) ? seg + kSeg : ncols;
+    if (threadIdx.x == 0) { n_front = 0; n_back = 0; }
+    __syncthreads();
+    for (size_t j = seg + threadIdx.x; j < seg_end; j += kMsmBlock) {
+      if (fq_is_zero(fq_load(zr + j))) continue;
+      if (idx && idx[j] == hot) list[kSeg - 1 - atomicAdd(&n_back, 1u)] = (uint16_t)(j - seg);
+      else list[atomicAdd(&n_front, 1u)] = (uint16_t)(j - seg);
+    }
+    __syncthreads();
+    const uint32_t nf = n_front, nb = n_back;
+    for (uint32_t k = threadIdx.x; k < nf; k += kMsmBlock) {
+      const size_t j = seg + list[k];
+      table_mul_acc(acc, fq_from_mont(fq_load(zr + j)), tv, j);
+    }
+    for (uint32_t k = threadIdx.x; k < nb; k += kMsmBlock) {
+      const ge_cached* t = T + seg + list[kSeg - 1 - k];
+      ge_cached q;
+      q.YpX = fp_load(&t->YpX); q.YmX = fp_load(&t->YmX); q.Z = fp_load(&t->Z); q.T2d = fp_load(&t->T2d);
+      acc = ge_add_cached(acc, q);
+    }
+    __syncthreads();
+  }
+  __shared__ ge_ext sh[kMsmBlock];
+  sh[threadIdx.x] = acc;
+  __syncthreads();
+  ge_tree_quad(sh, kMsmBlock);
+  if (threadIdx.x == 0) {
+    acc = sh[0];
+    ge_ext* o = out + row;
+    fp_store(&o->X, acc.X); fp_store(&o->Y, acc.Y); fp_store(&o->Z, acc.Z); fp_store(&o->T, acc.T);
+  }
+}
+
 // Profiling aid (vpin_prof_enable(ctx, 2)): the affine table additions msm_rows_kernel performs for the same
 // arguments -- non-zero signed digits of every non-zero scalar, one scalar for a constant row -- summed into *count.
 __device__ __forceinline__ uint32_t count_digits(fq s, const TableView& tv, size_t j) {
@@ -427,9 +519,17 @@ __device__ __forceinline__ uint32_t count_digits(fq s, const TableView& tv, size
 }
 __global__ __launch_bounds__(kMsmBlock) void msm_count_adds_kernel(const fq* __restrict__ Z, size_t stride, size_t ncols,
                                                                    const fq* __restrict__ extra, int n_extra, size_t extra_base0,
-                                                                   TableView tv, unsigned long long* __restrict__ count) {
+                                                                   TableView tv, unsigned long long* __restrict__ count,
+                                                                   HotRows hr = HotRows{}) {
   const size_t row = blockIdx.x;
   const fq* zr = Z + row * stride;
+  // msm_rows_hot_kernel: the hot-column entries are not table additions
+  const uint32_t* hidx = nullptr;
+  uint32_t hot = 0xffffffffu;
+  if (hr.rows_per_vec && row >= hr.row0 && row < hr.row0 + 3 * hr.rows_per_vec) {
+    const size_t m = (row - hr.row0) / hr.rows_per_vec;
+    if (hr.hot[m] != 0xffffffffu) { hot = hr.hot[m]; hidx = hr.idx[m] + (row - hr.row0 - m * hr.rows_per_vec) * ncols; }
+  }
   uint32_t n = 0;
   bool constant = false;
   if (ncols >= 256 && (ncols & (ncols - 1)) == 0 && ((size_t)1 << (tv.nbt - tv.sum0 - 1)) >= ncols) {
@@ -443,7 +543,7 @@ __global__ __launch_bounds__(kMsmBlock) void msm_count_adds_kernel(const fq* __r
   if (!constant)
     for (size_t j = threadIdx.x; j < ncols; j += kMsmBlock) {
       const fq s = fq_load(zr + j);
-      if (!fq_is_zero(s)) n += count_digits(fq_from_mont(s), tv, j);
+      if (!fq_is_zero(s) && !(hidx && hidx[j] == hot)) n += count_digits(fq_from_mont(s), tv, j);
     }
   for (int e = threadIdx.x; e < n_extra; e += kMsmBlock) {
     const fq x = fq_load(extra + row * (size_t)n_extra + e);
@@ -952,6 +1052,67 @@ int vpin_hyrax_commit(vpin_ctx* c, const vpin_gens* g, const vpin_table* Z, cons
   VPIN_HIP_TRY(hipStreamSynchronize(c->stream));
   return VPIN_OK;
 }
+
+}  // extern "C"
+
+namespace vpin {
+
+// DensePolynomial::commit(gens, None) for the derefs polynomial (8N scalars as L rows of R; sparse_mlpoly.rs:525-531) with the
+// hot column of each matrix's col-derefs vector taken out (msm_rows_hot_kernel).  col_idx[m]: the N column indices of matrix
+// m on the device, hot[m]: its hot column or 0xffffffff, e_ry: the table the col-derefs were gathered from.
+int hyrax_commit_derefs_hot(vpin_ctx* c, const vpin_gens* g, const vpin_table* Z, size_t L, size_t N, const uint32_t* const col_idx[3],
+                            const uint32_t hot[3], const fq* e_ry, uint8_t* out_compressed) {
+  if (!c || !g || !Z || !Z->d || !col_idx || !hot || !e_ry || !out_compressed || L == 0 || Z->len % L) return VPIN_EINVAL;
+  const size_t R = Z->len / L;
+  if (R > g->nb || N % R || Z->len < 6 * N) return VPIN_ESHAPE;
+  (void)hipSetDevice(c->device);
+  DevBuf dpts(c), dout(c), dT(c);
+  if (dpts.alloc(L * sizeof(ge_ext)) || dout.alloc(L * 32)) return VPIN_ENOMEM;
+  HotRows hr{};
+  hr.row0 = 3 * (N / R);
+  hr.rows_per_vec = N / R;
+  // one T table per distinct hot column
+  uint32_t distinct[3];
+  int nd = 0;
+  for (int m = 0; m < 3; m++) {
+    hr.idx[m] = col_idx[m];
+    hr.hot[m] = hot[m];
+    if (hot[m] == 0xffffffffu) continue;
+    bool seen = false;
+    for (int k = 0; k < nd; k++) seen = seen || distinct[k] == hot[m];
+    if (!seen) distinct[nd++] = hot[m];
+  }
+  if (nd && dT.alloc((size_t)nd * R * sizeof(ge_cached))) return VPIN_ENOMEM;
+  for (int k = 0; k < nd; k++) {
+    fq v;
+    VPIN_HIP_TRY(hipMemcpyAsync(&v, e_ry + distinct[k], sizeof v, hipMemcpyDeviceToHost, c->stream));
+    VPIN_HIP_TRY(hipStreamSynchronize(c->stream));
+    ge_cached* Tk = (ge_cached*)dT.p + (size_t)k * R;
+    hipLaunchKernelGGL(scalar_times_bases_kernel, dim3((unsigned)((R + 63) / 64)), dim3(64), 0, c->stream, v, R, view(g), Tk);
+    for (int m = 0; m < 3; m++)
+      if (hot[m] == distinct[k]) hr.T[m] = Tk;
+  }
+  if (c->prof_count_adds && c->d_add_count)
+    hipLaunchKernelGGL(msm_count_adds_kernel, dim3((unsigned)L), dim3(kMsmBlock), 0, c->stream, (const fq*)Z->d, R, R, (const fq*)nullptr, 0,
+                       (size_t)0, view(g), c->d_add_count, hr);
+  {
+    ProfScope ps(c, VPIN_K_MSM, 32.0 * (double)Z->len, VPIN_K_MSM_ROWS);
+    static const int env_pad = [] { const char* e = getenv("VPIN_MSM_LDS_PAD"); return e ? atoi(e) : -1; }();
+    const unsigned pad = env_pad >= 0 ? (unsigned)env_pad : (c->shared_device ? 20000u : 0u);
+    hipLaunchKernelGGL(msm_rows_hot_kernel, dim3((unsigned)L), dim3(kMsmBlock), pad, c->stream, (const fq*)Z->d, R, R, view(g), hr,
+                       (ge_ext*)dpts.p);
+  }
+  hipLaunchKernelGGL(ge_compress_kernel, dim3((unsigned)((L + 63) / 64)), dim3(64), 0, c->stream, (const ge_ext*)dpts.p, L,
+                     (fp*)dout.p, (fp*)nullptr);
+  VPIN_HIP_TRY(hipGetLastError());
+  VPIN_HIP_TRY(hipMemcpyAsync(out_compressed, dout.p, L * 32, hipMemcpyDeviceToHost, c->stream));
+  VPIN_HIP_TRY(hipStreamSynchronize(c->stream));
+  return VPIN_OK;
+}
+
+}  // namespace vpin
+
+extern "C" {
 
 int vpin_hyrax_commit_rows(vpin_ctx* c, const vpin_gens* g, const vpin_table* Z, size_t L, size_t row0, size_t nrows,
                            const uint8_t* blinds, size_t blind_base, uint8_t* out_compressed) {

@@ -464,6 +464,13 @@ static int spark_prove(vpin_ctx* c, const vpin_spark_decomm* d, const std::vecto
   if (split) {
     comm_derefs.resize(g_derefs->L);
     if ((rc = c->split_commit(c->split_user, comb, g_derefs->L, g_derefs->R, comm_derefs[0].b))) return rc;
+  } else if (d->hot_col[0] != 0xffffffffu || d->hot_col[1] != 0xffffffffu || d->hot_col[2] != 0xffffffffu) {
+    // the entries of each matrix's hot column hold one scalar, E_ry[hot]: one addition each instead of a table walk
+    const uint32_t* col_idx[3] = {d->idx + 6 * d->N, d->idx + 7 * d->N, d->idx + 8 * d->N};
+    comm_derefs.resize(g_derefs->L);
+    if ((rc = vpin::hyrax_commit_derefs_hot(c, g_derefs->dev, comb, g_derefs->L, d->N, col_idx, d->hot_col, mem_ry->d,
+                                            comm_derefs[0].b)))
+      return rc;
   } else if ((rc = commit_noblind(c, g_derefs, comb, comm_derefs))) {
     return rc;
   }
@@ -692,6 +699,10 @@ int vpin_spark_derefs_commit_rows(vpin_ctx* c, const vpin_spark_decomm* d, const
   return vpin_hyrax_commit_rows(c, g_derefs->dev, comb, g_derefs->L, row0, nrows, nullptr, g_derefs->R + 1, out_compressed);
 }
 
+void vpin_spark_decomm_hot_cols(const vpin_spark_decomm* d, uint32_t out[3]) {
+  for (int m = 0; m < 3; m++) out[m] = d ? d->hot_col[m] : 0xffffffffu;
+}
+
 void vpin_spark_decomm_free(vpin_ctx* c, vpin_spark_decomm* d) {
   if (!d) return;
   if (c) {
@@ -718,6 +729,7 @@ static int encode_commit(vpin_ctx* c, const Shape& s, std::unique_ptr<vpin_spark
   std::vector<CG> c_ops, c_mem;
   if ((rc = commit_noblind(c, g_ops, d->comb_ops, c_ops)) || (rc = commit_noblind(c, g_mem, d->comb_mem, c_mem))) return fail(rc);
   lap("commit ops + mem");
+  if ((rc = vpin::spark_find_hot_cols(c, d.get()))) return fail(rc);
   Writer w;
   w.u64(num_cons); w.u64(num_vars); w.u64(num_inputs);
   w.u64(3); w.u64(s.N); w.u64(s.M);

@@ -467,6 +467,54 @@ int spark_u32_to_fq(vpin_ctx* c, const uint32_t* src, fq* dst, size_t n) {
   return VPIN_OK;
 }
 
+// cnt[2m + k] += entries of matrix m's col slice equal to candidate k
+__global__ __launch_bounds__(kBlock) void count_cols_kernel(const uint32_t* __restrict__ idx, size_t N, uint32_t v0, uint32_t v1,
+                                                            unsigned long long* __restrict__ cnt) {
+  const int m = blockIdx.y;
+  const uint32_t* a = idx + (size_t)(6 + m) * N;
+  unsigned n0 = 0, n1 = 0;
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < N; i += (size_t)gridDim.x * kBlock) {
+    const uint32_t x = a[i];
+    n0 += x == v0;
+    n1 += x == v1;
+  }
+  __shared__ unsigned sh[2][kBlock];
+  sh[0][threadIdx.x] = n0;
+  sh[1][threadIdx.x] = n1;
+  __syncthreads();
+  for (int st = kBlock / 2; st >= 1; st >>= 1) {
+    if ((int)threadIdx.x < st) { sh[0][threadIdx.x] += sh[0][threadIdx.x + st]; sh[1][threadIdx.x] += sh[1][threadIdx.x + st]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    if (sh[0][0]) atomicAdd(&cnt[2 * m], (unsigned long long)sh[0][0]);
+    if (sh[1][0]) atomicAdd(&cnt[2 * m + 1], (unsigned long long)sh[1][0]);
+  }
+}
+
+int spark_find_hot_cols(vpin_ctx* c, vpin_spark_decomm* d) {
+  if (!c || !d || !d->idx || d->N == 0) return VPIN_EINVAL;
+  for (int m = 0; m < 3; m++) d->hot_col[m] = 0xffffffffu;
+  static const bool off = getenv("VPIN_NO_HOT_COLS") != nullptr;
+  if (off || d->N < ((size_t)1 << 20)) return VPIN_OK;  // below ~2^20 entries the per-proof T tables cost more than they save
+  (void)hipSetDevice(c->device);
+  DevBuf cnt(c);
+  if (cnt.alloc(6 * sizeof(unsigned long long))) return VPIN_ENOMEM;
+  VPIN_HIP_TRY(hipMemsetAsync(cnt.p, 0, 6 * sizeof(unsigned long long), c->stream));
+  const uint32_t v0 = (uint32_t)d->num_vars, v1 = (uint32_t)d->num_vars + 1;
+  hipLaunchKernelGGL(count_cols_kernel, dim3(grid_for(d->N), 3), dim3(kBlock), 0, c->stream, (const uint32_t*)d->idx, d->N, v0, v1,
+                     (unsigned long long*)cnt.p);
+  VPIN_HIP_TRY(hipGetLastError());
+  unsigned long long h[6];
+  VPIN_HIP_TRY(hipMemcpyAsync(h, cnt.p, sizeof h, hipMemcpyDeviceToHost, c->stream));
+  VPIN_HIP_TRY(hipStreamSynchronize(c->stream));
+  for (int m = 0; m < 3; m++) {
+    const int k = h[2 * m + 1] > h[2 * m] ? 1 : 0;
+    if (h[2 * m + k] >= d->N / 64) d->hot_col[m] = k ? v1 : v0;  // at least 1.5 % of the slice
+  }
+  return VPIN_OK;
+}
+
 int spark_gather_derefs(vpin_ctx* c, const vpin_spark_decomm* d, const fq* mem_rx, const fq* mem_ry, fq* comb) {
   ProfScope ps(c, VPIN_K_SPARK_BUILD, (double)d->N * (6 * 68.0 + 2 * 32.0));
   hipLaunchKernelGGL(gather_derefs_kernel, dim3(grid_for(d->N), 8), dim3(kBlock), 0, c->stream, (const uint32_t*)d->idx, d->N,

@@ -13,6 +13,9 @@ struct vpin_spark_decomm {
   uint32_t* idx = nullptr;
   vpin_table* comb_ops = nullptr;  // 16N: slices as idx (0..11), val A,B,C (12..14), zero (15)
   vpin_table* comb_mem = nullptr;  // 2M: row_audit_ts | col_audit_ts
+  // the column that carries a large share of matrix m's entries (the constant 1 in B and C of vPIN's gadgets), found once by
+  // SNARK::encode; 0xffffffff: none.  The derefs commitment of every proof takes its entries out of the table walks.
+  uint32_t hot_col[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu};
 };
 
 namespace vpin {
@@ -29,6 +32,8 @@ int spark_u32_to_fq(vpin_ctx* c, const uint32_t* src, fq* dst, size_t n);
 // Derefs (sparse_mlpoly.rs:267-283,525-531): comb[m*N+i] = mem_rx[row_m[i]], comb[(3+m)*N+i] =
 // mem_ry[col_m[i]], comb[6N..8N) = 0
 int spark_gather_derefs(vpin_ctx* c, const vpin_spark_decomm* d, const fq* mem_rx, const fq* mem_ry, fq* comb);
+// fills d->hot_col: candidates are the constant-1 column (num_vars) and the first input (num_vars + 1)
+int spark_find_hot_cols(vpin_ctx* c, vpin_spark_decomm* d);
 
 // Product-circuit forest: `ncirc` trees of `n` leaves; tree t lives at base + t*2n, level l (n>>l
 // entries) at offset 2n - (2n>>l) inside it.  ProductCircuit.left_vec[l] / right_vec[l] are the two

@@ -422,10 +422,12 @@ struct HotRows {
   size_t row0, rows_per_vec;  // matrix m's vector occupies rows [row0 + m*rows_per_vec, row0 + (m+1)*rows_per_vec)
 };
 
-// T[j] = v * g_j for j < n (v in Montgomery form), as cached points
-__global__ __launch_bounds__(64) void scalar_times_bases_kernel(fq v, size_t n, TableView tv, ge_cached* __restrict__ T) {
+// T[j] = v * g_j for j < n (*vp = v in Montgomery form, read on the device: no round trip), as cached points
+__global__ __launch_bounds__(64) void scalar_times_bases_kernel(const fq* __restrict__ vp, size_t n, TableView tv,
+                                                                ge_cached* __restrict__ T) {
   const size_t j = (size_t)blockIdx.x * 64 + threadIdx.x;
   if (j >= n) return;
+  const fq v = fq_load(vp);
   ge_ext acc = ge_identity();
   if (!fq_is_zero(v)) table_mul_acc(acc, fq_from_mont(v), tv, j);
   const ge_cached cch = ge_to_cached(acc);
@@ -1084,11 +1086,8 @@ int hyrax_commit_derefs_hot(vpin_ctx* c, const vpin_gens* g, const vpin_table* Z
   }
   if (nd && dT.alloc((size_t)nd * R * sizeof(ge_cached))) return VPIN_ENOMEM;
   for (int k = 0; k < nd; k++) {
-    fq v;
-    VPIN_HIP_TRY(hipMemcpyAsync(&v, e_ry + distinct[k], sizeof v, hipMemcpyDeviceToHost, c->stream));
-    VPIN_HIP_TRY(hipStreamSynchronize(c->stream));
     ge_cached* Tk = (ge_cached*)dT.p + (size_t)k * R;
-    hipLaunchKernelGGL(scalar_times_bases_kernel, dim3((unsigned)((R + 63) / 64)), dim3(64), 0, c->stream, v, R, view(g), Tk);
+    hipLaunchKernelGGL(scalar_times_bases_kernel, dim3((unsigned)((R + 63) / 64)), dim3(64), 0, c->stream, e_ry + distinct[k], R, view(g), Tk);
     for (int m = 0; m < 3; m++)
       if (hot[m] == distinct[k]) hr.T[m] = Tk;
   }

@@ -152,10 +152,11 @@ def test_l5_mult_commitment_pinned_and_proof_accepted_by_oracle_verifier(ctx):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("key", ["3_32-mult", "A-add", "7_256-mult"])
+@pytest.mark.parametrize("key", ["3_32-mult", "A-add", "7_256-mult", "A-mult"])
 def test_host_built_instances_give_the_same_bytes(ctx, key):
     """the other entry of the boundary: instance and witness built on the HOST (vpin_gadget_point_*), uploaded and proven
-    through vpin_snark_prove -- same oracle digests as the device-built path"""
+    through vpin_snark_prove -- same oracle digests as the device-built path (A-mult: 2^20 entries, so SNARK::encode of the
+    uploaded instance marks its hot columns too)"""
     from vpin_amd import gadgets as G
     g = GOLD[key]
     inst = G.synthetic_mult_instance(g["label"]) if g["kind"] == "mult" else G.synthetic_add_instance(g["label"])

@@ -275,6 +275,7 @@ class DevInstance:
         self.num_cons, self.num_vars, self.num_inputs = nc.value, nv.value, ni.value
         self.num_cons_unpadded = L.vpin_dev_instance_num_cons_unpadded(handle)
         self.num_vars_unpadded = L.vpin_dev_instance_num_vars_unpadded(handle)
+        self.nnz = [int(L.vpin_dev_instance_nnz(handle, m)) for m in range(3)]
         # borrowed views: freed with the instance
         self.r1cs = R1csDev(ctx, C.c_void_p(L.vpin_dev_instance_r1cs(handle)), self.num_cons, self.num_vars, self.num_inputs)
         self.vars_para = Table(ctx, C.c_void_p(L.vpin_dev_instance_vars_para(handle)))

@@ -273,25 +273,69 @@ void vpin_sat_last_timings(double out[8]);
  * (Spartan/src/sparse_mlpoly.rs:285-292) resident in HBM. */
 typedef struct vpin_spark_decomm vpin_spark_decomm;
 
-/* ---- one large commitment split across GPUs (the derefs commitment of R1CSEvalProof::prove, the single largest MSM
- * of a SNARK: 6N full-width scalars, sparse_mlpoly.rs:525-531,56-79) -------------------------------------------------
- * The proving rank installs two hooks on its context.  vpin_snark_prove_* then (1) hands (rx, ry) to `begin` as soon
- * as the sat proof has produced them, so the helper ranks can rebuild the derefs polynomial from their own copy of
- * the computation decommitment while the prover builds its own, and (2) asks `commit` for the L compressed row
- * commitments of that polynomial instead of computing them all locally; `commit` commits a block of rows with
- * vpin_hyrax_commit_rows (Z = the prover's polynomial) and gathers the other blocks from the helpers, which produce
- * theirs with vpin_spark_derefs_commit_rows.  The exchange itself (all-gather of 32-byte rows: RCCL over xGMI on a GPU
- * node, gloo in the CPU tests) belongs to the caller (vpin_amd/dist.py).  Polynomials shorter than min_len scalars
- * are committed locally.  Proof bytes are identical to the single-GPU proof. */
-typedef int (*vpin_split_begin_fn)(void* user, const uint8_t* rx, size_t nx, const uint8_t* ry, size_t ny);
-typedef int (*vpin_split_commit_fn)(void* user, const vpin_table* Z, size_t L, size_t R, uint8_t* out_compressed);
-int vpin_ctx_set_split_hooks(vpin_ctx* ctx, vpin_split_begin_fn begin, vpin_split_commit_fn commit, void* user, size_t min_len);
+/* ---- one proof over the GPUs of one node -----------------------------------------------------------
+ * SPMD: every rank (one process per GPU, or one thread per rank in a rehearsal) holds the same instance, creates a
+ * vpin_comm, attaches it to its context with vpin_ctx_set_comm and calls the SAME vpin_snark_prove_* / vpin_sat_prove_*
+ * with the same inputs and seeds.  Inside the call the heavy steps are sharded and their small results all-gathered:
+ *   - every Hyrax row commitment by contiguous row blocks (the witness pair of proof_point_mult.rs:44-52 and the derefs
+ *     commitment of sparse_mlpoly.rs:525-531; rows are independent MSMs over shared generators, dense_mlpoly.rs:160-175)
+ *     -- 32 bytes per row cross the links, no point and no reduction;
+ *   - the 12 + 4 product circuits and the 6 dot-product halves of ProductCircuitEvalProofBatched::prove
+ *     (product_tree.rs:259-385) by circuit index: hash-layer leaves, trees, every sum-check round and the persistent
+ *     tails run for the owned circuits only; per round each rank publishes 3 scalars per owned circuit
+ *     (sumcheck.rs:273-330) and every rank combines all of them and derives the round's challenge itself;
+ *   - the 23 slice evaluations of the hash layer (sparse_mlpoly.rs:740-849) by slice, and DensePolynomial::bound of the
+ *     three evaluation proofs (dense_mlpoly.rs:220-227) by row blocks (partial vectors all-gathered on the device:
+ *     RCCL ncclAllGather when enabled, staged through the host transport otherwise).
+ * The sat proof's two sum-checks and every latency-bound tail stay replicated.  Every rank returns the same bytes, equal
+ * to the single-GPU proof.  Without a comm (or with world == 1) the calls are the single-GPU ones.
+ *
+ * Transports for the small host-side exchanges (results are already on the host, where the transcript lives):
+ *   vpin_comm_create_shm        ranks = processes of one node; a POSIX shared-memory segment `name` (unique per job;
+ *                               rank 0 creates it, unlinks it once everyone is attached).  A flat all-gather of a few
+ *                               hundred bytes costs ~1-3 us, against ~20-30 us for a RCCL kernel launch.
+ *   vpin_comm_create_local      `world` handles for the threads of one process (rehearsals, tests)
+ *   vpin_comm_create_callbacks  the caller's own all-gather (gloo in the CPU tests; a host's existing fabric)
+ * Every wait is bounded (VPIN_COMM_TIMEOUT_S, default 120 s) and watches a shared abort word: a rank that fails or
+ * disappears makes the others return VPIN_ECOMM instead of hanging. */
+#define VPIN_ECOMM (-7) /* a peer failed or timed out, or the ranks disagree on a collective */
+typedef struct vpin_comm vpin_comm;
+typedef int (*vpin_allgather_fn)(void* user, const void* send, void* recv, size_t bytes_per_rank);
+/* slot_bytes: largest message sent in one piece (larger ones are chunked); 0 = default (1 MiB) */
+int vpin_comm_create_shm(const char* name, int rank, int world, size_t slot_bytes, vpin_comm** out);
+int vpin_comm_create_local(int world, size_t slot_bytes, vpin_comm** out_handles /* world entries */);
+int vpin_comm_create_callbacks(int rank, int world, vpin_allgather_fn fn, void* user, vpin_comm** out);
+void vpin_comm_destroy(vpin_comm* cm);
+int vpin_comm_rank(const vpin_comm* cm);
+int vpin_comm_world(const vpin_comm* cm);
+/* host buffers: recv = world x bytes */
+int vpin_comm_allgather(vpin_comm* cm, const void* send, void* recv, size_t bytes);
+/* RCCL for device buffers: rank 0 draws the ncclUniqueId, the host transport carries it, every rank runs
+ * ncclCommInitRank on the context's device (librccl is dlopen'ed; VPIN_ENODEV when it is absent).  Collective. */
+int vpin_comm_enable_rccl(vpin_comm* cm, vpin_ctx* ctx);
+/* device buffers on the context's stream: ncclAllGather when RCCL is enabled, else staged through the host transport */
+int vpin_comm_allgather_dev(vpin_comm* cm, vpin_ctx* ctx, const void* d_send, void* d_recv, size_t bytes);
+/* Rehearsal of N ranks on fewer GPUs: on != 0 makes the ranks compute ONE AT A TIME (a token is held between
+ * collectives and passed on inside them), so that the time a rank spends between two collectives is its own work and
+ * nothing else; the statistics then give the critical path of the N-GPU run: sum over the collectives of the slowest
+ * rank's section.  Collective on first use. */
+int vpin_comm_set_serialize(vpin_comm* cm, int on);
+typedef struct {
+  uint64_t collectives;
+  double bytes;   /* payload this rank sent */
+  double wait_s;  /* time inside collectives (waiting for peers + copying) */
+  double busy_s;  /* time between collectives (this rank's own sections) */
+  double crit_s;  /* sum over collectives of max over ranks of the section before it */
+} vpin_comm_stats;
+int vpin_comm_stats_read(vpin_comm* cm, vpin_comm_stats* out, int reset);
+/* attach (or detach with NULL): proofs on this context become collective calls over `cm`'s ranks */
+int vpin_ctx_set_comm(vpin_ctx* ctx, vpin_comm* cm);
 /* the b"gens_r1cs_eval" view a polynomial of 2^ell scalars is committed under (PolyCommitmentGens::new(ell, ..)) */
 int vpin_spark_gens_view(vpin_ctx* ctx, size_t ell, const vpin_gens** out, size_t* L, size_t* R);
-/* helper side: Derefs::new (sparse_mlpoly.rs:525-531) for (rx, ry) from this rank's copy of the decommitment, then the
- * commitment rows [row0, row0 + nrows) of it (zero blinds, as commit(gens, None)) */
-int vpin_spark_derefs_commit_rows(vpin_ctx* ctx, const vpin_spark_decomm* decomm, const uint8_t* rx, size_t nx,
-                                  const uint8_t* ry, size_t ny, size_t row0, size_t nrows, uint8_t* out_compressed);
+/* How the circuits of one proof are dealt to the ranks (deterministic; every rank computes the same plan):
+ * owner_ops[12] / owner_dotp[6] / owner_mem[4] = owning rank of each "ops" circuit (row read A,B,C | row write A,B,C |
+ * col read | col write), dot-product half (matrix, half) and "mem" circuit (row init, row audit, col init, col audit). */
+int vpin_dist_plan(int world, int owner_ops[12], int owner_dotp[6], int owner_mem[4]);
 
 /* bincode size of R1CSCommitment (Spartan/src/r1csinstance.rs:53-58) for this instance. */
 size_t vpin_spark_comm_bytes(const vpin_r1cs* inst);

@@ -344,6 +344,114 @@ class Gens:
             self.h = None
 
 
+class CommStats(C.Structure):
+    _fields_ = [("collectives", C.c_uint64), ("bytes", C.c_double), ("wait_s", C.c_double), ("busy_s", C.c_double),
+                ("crit_s", C.c_double)]
+
+
+_ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)
+
+
+def _comm_decl():
+    L = lib()
+    if getattr(L, "_comm_declared", False):
+        return L
+    vp = C.c_void_p
+    L.vpin_comm_create_shm.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_size_t, C.POINTER(vp)]
+    L.vpin_comm_create_local.argtypes = [C.c_int, C.c_size_t, C.POINTER(vp)]
+    L.vpin_comm_create_callbacks.argtypes = [C.c_int, C.c_int, vp, vp, C.POINTER(vp)]
+    L.vpin_comm_destroy.argtypes = [vp]
+    L.vpin_comm_destroy.restype = None
+    L.vpin_comm_rank.argtypes = [vp]
+    L.vpin_comm_world.argtypes = [vp]
+    L.vpin_comm_allgather.argtypes = [vp, vp, vp, C.c_size_t]
+    L.vpin_comm_allgather_dev.argtypes = [vp, vp, vp, vp, C.c_size_t]
+    L.vpin_comm_enable_rccl.argtypes = [vp, vp]
+    L.vpin_comm_set_serialize.argtypes = [vp, C.c_int]
+    L.vpin_comm_stats_read.argtypes = [vp, C.POINTER(CommStats), C.c_int]
+    L.vpin_dist_plan.argtypes = [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L._comm_declared = True
+    return L
+
+
+class Comm:
+    """vpin_comm: the exchange layer of one proof over several GPUs (SPMD; see include/vpin_hip.h)."""
+
+    def __init__(self, handle, keep=None):
+        self.h, self._keep = handle, keep
+        L = _comm_decl()
+        self.rank, self.world = L.vpin_comm_rank(handle), L.vpin_comm_world(handle)
+
+    @staticmethod
+    def shm(name, rank, world, slot_bytes=0):
+        """ranks = processes of one node; `name` ("/...") unique per job, the same on every rank"""
+        h = C.c_void_p()
+        _chk(_comm_decl().vpin_comm_create_shm(name.encode(), rank, world, slot_bytes, C.byref(h)), "vpin_comm_create_shm")
+        return Comm(h)
+
+    @staticmethod
+    def local(world, slot_bytes=0):
+        """`world` handles for the threads of this process"""
+        hs = (C.c_void_p * world)()
+        _chk(_comm_decl().vpin_comm_create_local(world, slot_bytes, hs), "vpin_comm_create_local")
+        return [Comm(C.c_void_p(hs[r])) for r in range(world)]
+
+    @staticmethod
+    def callbacks(rank, world, allgather):
+        """allgather(send: bytes) -> bytes of world x len(send): the caller's fabric (e.g. torch.distributed over gloo)"""
+        err = []
+
+        def _fn(_user, send, recv, n):
+            try:
+                out = allgather(C.string_at(send, n))
+                assert len(out) == n * world
+                C.memmove(recv, out, n * world)
+                return 0
+            except Exception as e:  # an exception must not unwind through the C frames
+                err.append(e)
+                return -7
+
+        cb = _ALLGATHER_FN(_fn)
+        h = C.c_void_p()
+        _chk(_comm_decl().vpin_comm_create_callbacks(rank, world, C.cast(cb, C.c_void_p), None, C.byref(h)),
+             "vpin_comm_create_callbacks")
+        cm = Comm(h, keep=(cb, err))
+        cm.errors = err
+        return cm
+
+    def allgather(self, data):
+        data = bytes(data)
+        out = C.create_string_buffer(len(data) * self.world)
+        _chk(_comm_decl().vpin_comm_allgather(self.h, data, out, len(data)), "vpin_comm_allgather")
+        return out.raw
+
+    def allgather_dev(self, ctx, d_send, d_recv, nbytes):
+        _chk(_comm_decl().vpin_comm_allgather_dev(self.h, ctx.h, d_send, d_recv, nbytes), "vpin_comm_allgather_dev")
+
+    def enable_rccl(self, ctx):
+        _chk(_comm_decl().vpin_comm_enable_rccl(self.h, ctx.h), "vpin_comm_enable_rccl")
+
+    def set_serialize(self, on=True):
+        _chk(_comm_decl().vpin_comm_set_serialize(self.h, 1 if on else 0), "vpin_comm_set_serialize")
+
+    def stats(self, reset=False):
+        st = CommStats()
+        _chk(_comm_decl().vpin_comm_stats_read(self.h, C.byref(st), 1 if reset else 0), "vpin_comm_stats_read")
+        return dict(collectives=int(st.collectives), bytes=st.bytes, wait_s=st.wait_s, busy_s=st.busy_s, crit_s=st.crit_s)
+
+    def destroy(self):
+        if self.h:
+            _comm_decl().vpin_comm_destroy(self.h)
+            self.h = None
+
+
+def dist_plan(world):
+    """owners of the 12 ops circuits, the 6 dot-product halves and the 4 mem circuits (vpin_dist_plan)"""
+    a, b, c = (C.c_int * 12)(), (C.c_int * 6)(), (C.c_int * 4)()
+    _chk(_comm_decl().vpin_dist_plan(world, a, b, c), "vpin_dist_plan")
+    return list(a), list(b), list(c)
+
+
 class Context:
     def __init__(self, device=0, priority=0):
         """priority < 0: high-priority stream (latency-bound small proofs beside a large one); > 0: low."""
@@ -592,69 +700,13 @@ class Context:
     def sat_prepare(self, num_vars):
         _chk(lib().vpin_sat_prepare(self.h, num_vars), "vpin_sat_prepare")
 
-    # ---- a large commitment split across ranks (vpin_ctx_set_split_hooks; orchestration in vpin_amd/dist.py) ----
-    def spark_commit_rows(self, z_handle, ell, L, row0, nrows):
-        """rows [row0, row0+nrows) of the commitment of the polynomial behind the raw vpin_table handle `z_handle`
-        (2^ell scalars) under the b"gens_r1cs_eval" view, zero blinds"""
+    # ---- one proof over several GPUs (include/vpin_hip.h: vpin_comm) ----
+    def set_comm(self, comm):
+        """attach a Comm (or None): the prove calls on this context become collective calls over its ranks"""
         Lb = lib()
-        g, Lv, Rv = C.c_void_p(), C.c_size_t(), C.c_size_t()
-        Lb.vpin_spark_gens_view.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
-        _chk(Lb.vpin_spark_gens_view(self.h, ell, C.byref(g), C.byref(Lv), C.byref(Rv)), "vpin_spark_gens_view")
-        assert Lv.value == L
-        out = np.zeros((nrows, 32), dtype=np.uint8)
-        Lb.vpin_hyrax_commit_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p,
-                                              C.c_size_t, C.c_void_p]
-        _chk(Lb.vpin_hyrax_commit_rows(self.h, g, z_handle, L, row0, nrows, None, Rv.value + 1, out.ctypes.data_as(C.c_void_p)),
-             "vpin_hyrax_commit_rows")
-        return out
-
-    def spark_derefs_commit_rows(self, decomm, rx, ry, row0, nrows):
-        rx = np.ascontiguousarray(rx, dtype=np.uint64).reshape(-1, 4)
-        ry = np.ascontiguousarray(ry, dtype=np.uint64).reshape(-1, 4)
-        out = np.zeros((nrows, 32), dtype=np.uint8)
-        Lb = lib()
-        Lb.vpin_spark_derefs_commit_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t,
-                                                     C.c_size_t, C.c_void_p]
-        p = lambda a: a.ctypes.data_as(C.c_void_p)
-        _chk(Lb.vpin_spark_derefs_commit_rows(self.h, decomm.h, p(rx), rx.shape[0], p(ry), ry.shape[0], row0, nrows, p(out)),
-             "vpin_spark_derefs_commit_rows")
-        return out
-
-    def set_split(self, split, min_len=1 << 20):
-        """install (split = a dist.SplitCommit) or clear (None) the split-commitment hooks of this context"""
-        Lb = lib()
-        BEGIN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t)
-        COMMIT = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p)
-        Lb.vpin_ctx_set_split_hooks.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
-        if split is None:
-            _chk(Lb.vpin_ctx_set_split_hooks(self.h, None, None, None, 0), "vpin_ctx_set_split_hooks")
-            self._split_keep = None
-            return
-
-        def _begin(_user, rx, nx, ry, ny):
-            try:
-                a = np.ctypeslib.as_array(C.cast(rx, C.POINTER(C.c_uint64)), shape=(nx, 4)).copy()
-                b = np.ctypeslib.as_array(C.cast(ry, C.POINTER(C.c_uint64)), shape=(ny, 4)).copy()
-                split.begin(a, b)
-                return 0
-            except Exception as e:  # an exception must not unwind through the C frames
-                self._split_error = e
-                return -4
-
-        def _commit(_user, z, L, R, out):
-            try:
-                rows = split.commit(C.c_void_p(z), L, R)
-                C.memmove(out, np.ascontiguousarray(rows, dtype=np.uint8).ctypes.data, L * 32)
-                return 0
-            except Exception as e:
-                self._split_error = e
-                return -4
-
-        cb = (BEGIN(_begin), COMMIT(_commit))
-        self._split_keep = cb  # keep the trampolines alive while installed
-        self._split_error = None
-        _chk(Lb.vpin_ctx_set_split_hooks(self.h, C.cast(cb[0], C.c_void_p), C.cast(cb[1], C.c_void_p), None, min_len),
-             "vpin_ctx_set_split_hooks")
+        Lb.vpin_ctx_set_comm.argtypes = [C.c_void_p, C.c_void_p]
+        _chk(Lb.vpin_ctx_set_comm(self.h, comm.h if comm is not None else None), "vpin_ctx_set_comm")
+        self._comm_keep = comm
 
     def spark_prepare(self, num_cons, num_vars, max_nnz):
         L = lib()

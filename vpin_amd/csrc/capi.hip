@@ -133,13 +133,14 @@ const char* vpin_strerror(int code) {
     case VPIN_EHIP: return "HIP runtime error";
     case VPIN_ESHAPE: return "operand shapes do not match";
     case VPIN_EVERIFY: return "proof rejected by the verifier";
+    case VPIN_ECOMM: return "a peer rank failed or timed out";
     default: return "unknown error";
   }
 }
 
 const char* vpin_last_error(void) { return g_last_error.c_str(); }
 
-int vpin_abi_version(void) { return 1; }
+int vpin_abi_version(void) { return 2; }
 
 static int ctx_create(int device, int priority, vpin_ctx** out);
 
@@ -215,12 +216,6 @@ void* vpin_ctx_stream(vpin_ctx* c) { return c ? (void*)c->stream : nullptr; }
 int vpin_ctx_set_progress_flag(vpin_ctx* c, int* flag) {
   if (!c) return VPIN_EINVAL;
   c->progress_flag = flag;
-  return VPIN_OK;
-}
-
-int vpin_ctx_set_split_hooks(vpin_ctx* c, vpin_split_begin_fn begin, vpin_split_commit_fn commit, void* user, size_t min_len) {
-  if (!c || (begin == nullptr) != (commit == nullptr)) return VPIN_EINVAL;
-  c->split_begin = begin; c->split_commit = commit; c->split_user = user; c->split_min_len = min_len;
   return VPIN_OK;
 }
 

@@ -1,0 +1,437 @@
+// comm.cpp -- vpin_comm: the exchange layer of one proof over the GPUs of one node (include/vpin_hip.h, comm.h).
+//
+// Three host transports behind one all-gather (flat: every rank publishes its piece in its own slot of a shared segment
+// and reads the others'; pieces are double-buffered by collective parity, so no barrier separates two collectives), a
+// compute token for rehearsing N ranks on one GPU, and RCCL (dlopen'ed) for device buffers.  The reference has no
+// multi-GPU path; what is exchanged and why is described at the call sites (spark.cpp, prover.cpp).
+#include "comm.h"
+
+#include <dlfcn.h>
+#include <fcntl.h>
+#include <sched.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include <rccl/rccl.h>  // types only: every RCCL entry point is resolved with dlsym
+
+#include "ctx.h"
+
+namespace vpin {
+
+constexpr uint32_t kCommMagic = 0x76504e43u;  // "vPNC"
+constexpr uint32_t kNoHolder = 0xffffffffu;
+
+struct alignas(64) CommSlotHdr {
+  std::atomic<uint64_t> seq;  // last collective whose piece is complete in data[seq & 1]
+  double busy_s;              // this rank's section before that collective
+};
+
+struct alignas(64) CommSeg {
+  std::atomic<uint32_t> magic;
+  uint32_t world;
+  uint64_t slot_bytes;
+  std::atomic<uint32_t> attached, abort_flag, token, detached;
+  std::atomic<uint32_t> serialize;  // ranks that asked for the token mode
+};
+
+static inline size_t seg_slot_stride(size_t slot_bytes) { return sizeof(CommSlotHdr) + 2 * ((slot_bytes + 63) & ~(size_t)63); }
+static inline size_t seg_size(int world, size_t slot_bytes) { return 4096 + (size_t)world * seg_slot_stride(slot_bytes); }
+static inline CommSlotHdr* slot_hdr(CommSeg* s, int r) {
+  return reinterpret_cast<CommSlotHdr*>(reinterpret_cast<uint8_t*>(s) + 4096 + (size_t)r * seg_slot_stride(s->slot_bytes));
+}
+static inline uint8_t* slot_data(CommSeg* s, int r, int parity) {
+  return reinterpret_cast<uint8_t*>(slot_hdr(s, r)) + sizeof(CommSlotHdr) + (size_t)parity * ((s->slot_bytes + 63) & ~(size_t)63);
+}
+
+static inline double now_s() {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+static double env_timeout() {
+  const char* e = getenv("VPIN_COMM_TIMEOUT_S");
+  const double v = e ? atof(e) : 0.0;
+  return v > 0.0 ? v : 120.0;
+}
+
+// bounded spin: pause for a while, then yield (the CPU tests run more ranks than cores)
+struct Spinner {
+  double deadline;
+  long spins = 0;
+  explicit Spinner(double timeout_s) : deadline(now_s() + timeout_s) {}
+  // false when the deadline has passed
+  bool step() {
+    spins++;
+    if (spins < 2000) { __builtin_ia32_pause(); return true; }
+    if ((spins & 63) == 0 && now_s() > deadline) return false;
+    sched_yield();
+    return true;
+  }
+};
+
+static void seg_init(CommSeg* s, int world, size_t slot_bytes) {
+  s->world = (uint32_t)world;
+  s->slot_bytes = slot_bytes;
+  s->attached.store(0); s->abort_flag.store(0); s->token.store(kNoHolder); s->detached.store(0); s->serialize.store(0);
+  for (int r = 0; r < world; r++) { slot_hdr(s, r)->seq.store(0); slot_hdr(s, r)->busy_s = 0.0; }
+  s->magic.store(kCommMagic, std::memory_order_release);
+}
+
+static int token_acquire(vpin_comm* cm) {
+  if (cm->has_token) return VPIN_OK;
+  Spinner sp(cm->timeout_s);
+  for (;;) {
+    uint32_t exp = kNoHolder;
+    if (cm->seg->token.compare_exchange_weak(exp, (uint32_t)cm->rank, std::memory_order_acquire)) break;
+    if (cm->seg->abort_flag.load(std::memory_order_relaxed)) return VPIN_ECOMM;
+    if (!sp.step()) { cm->seg->abort_flag.store(1); return VPIN_ECOMM; }
+  }
+  cm->has_token = true;
+  cm->t_last_exit = now_s();
+  return VPIN_OK;
+}
+
+static void token_release(vpin_comm* cm) {
+  if (!cm->has_token) return;
+  cm->has_token = false;
+  cm->seg->token.store(kNoHolder, std::memory_order_release);
+}
+
+// one piece of at most slot_bytes per rank
+static int seg_allgather_piece(vpin_comm* cm, const uint8_t* send, uint8_t* recv, size_t bytes, size_t recv_stride, double busy,
+                               double* max_busy) {
+  CommSeg* s = cm->seg;
+  const uint64_t k = ++cm->seq;
+  const int parity = (int)(k & 1);
+  if (bytes) memcpy(slot_data(s, cm->rank, parity), send, bytes);
+  slot_hdr(s, cm->rank)->busy_s = busy;
+  slot_hdr(s, cm->rank)->seq.store(k, std::memory_order_release);
+  double mb = busy;
+  for (int i = 0; i < cm->world; i++) {
+    const int r = (cm->rank + i) % cm->world;  // own piece first, then the neighbours in ring order
+    if (r != cm->rank) {
+      Spinner sp(cm->timeout_s);
+      while (slot_hdr(s, r)->seq.load(std::memory_order_acquire) < k) {
+        if (s->abort_flag.load(std::memory_order_relaxed)) return VPIN_ECOMM;
+        if (!sp.step()) { s->abort_flag.store(1); return VPIN_ECOMM; }
+      }
+      const double b = slot_hdr(s, r)->busy_s;
+      if (b > mb) mb = b;
+    }
+    if (bytes) memcpy(recv + (size_t)r * recv_stride, slot_data(s, r, parity), bytes);
+  }
+  *max_busy = mb;
+  return VPIN_OK;
+}
+
+int comm_allgather(vpin_comm* cm, const void* send, void* recv, size_t bytes) {
+  if (!cm || (bytes && (!send || !recv))) return VPIN_EINVAL;
+  const double t_in = now_s();
+  const double busy = cm->t_last_exit > 0.0 ? t_in - cm->t_last_exit : 0.0;
+  int rc = VPIN_OK;
+  double max_busy = busy;
+  if (cm->world == 1) {
+    if (bytes) memcpy(recv, send, bytes);
+  } else if (cm->kind == 2) {
+    // the caller's fabric: the section times ride in front of the payload
+    std::vector<uint8_t> sb(8 + bytes), rb((size_t)cm->world * (8 + bytes));
+    memcpy(sb.data(), &busy, 8);
+    if (bytes) memcpy(sb.data() + 8, send, bytes);
+    rc = cm->cb(cm->cb_user, sb.data(), rb.data(), 8 + bytes);
+    if (rc) rc = VPIN_ECOMM;
+    for (int r = 0; r < cm->world && !rc; r++) {
+      double b;
+      memcpy(&b, rb.data() + (size_t)r * (8 + bytes), 8);
+      if (b > max_busy) max_busy = b;
+      if (bytes) memcpy((uint8_t*)recv + (size_t)r * bytes, rb.data() + (size_t)r * (8 + bytes) + 8, bytes);
+    }
+    cm->seq++;
+  } else if (cm->seg->abort_flag.load(std::memory_order_relaxed)) {
+    rc = VPIN_ECOMM;  // a rank gave up earlier: the group is dead, whatever the slots still hold
+  } else {
+    const bool tok = cm->serialize;
+    if (tok) token_release(cm);
+    const size_t piece = cm->seg->slot_bytes;
+    size_t off = 0;
+    do {
+      const size_t n = bytes - off < piece ? bytes - off : piece;
+      double mb = 0.0;
+      rc = seg_allgather_piece(cm, (const uint8_t*)send + off, (uint8_t*)recv + off, n, bytes, off == 0 ? busy : 0.0, &mb);
+      if (rc) break;
+      if (mb > max_busy) max_busy = mb;
+      off += n;
+    } while (off < bytes);
+    if (!rc && tok) rc = token_acquire(cm);
+  }
+  const double t_out = now_s();
+  cm->st.collectives++;
+  cm->st.bytes += (double)bytes;
+  cm->st.wait_s += t_out - t_in;
+  cm->st.busy_s += busy;
+  cm->st.crit_s += max_busy;
+  cm->t_last_exit = t_out;
+  return rc;
+}
+
+int comm_allgather_ctx(vpin_ctx* c, const void* send, void* recv, size_t bytes) {
+  if (!c || !c->comm) return VPIN_EINVAL;
+  // (a resident persistent tail kernel is waiting for the challenge this very exchange produces: nothing to drain then)
+  if (c->comm->serialize && c->tail_rounds == 0) VPIN_HIP_TRY(hipStreamSynchronize(c->stream));
+  return comm_allgather(c->comm, send, recv, bytes);
+}
+
+// ---- RCCL through dlopen ------------------------------------------------------------------------------------------
+
+struct Rccl {
+  void* h = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+
+static Rccl* rccl() {
+  static Rccl r;
+  static bool tried = false;
+  if (tried) return r.h ? &r : nullptr;
+  tried = true;
+  // a framework in the same process (torch) may already have its copy loaded: use that one
+  for (const char* name : {"librccl.so.1", "librccl.so"}) {
+    r.h = dlopen(name, RTLD_NOW | RTLD_NOLOAD | RTLD_LOCAL);
+    if (r.h) break;
+  }
+  if (!r.h)
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+      r.h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+      if (r.h) break;
+    }
+  if (!r.h) return nullptr;
+  r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(r.h, "ncclGetUniqueId");
+  r.CommInitRank = (decltype(r.CommInitRank))dlsym(r.h, "ncclCommInitRank");
+  r.AllGather = (decltype(r.AllGather))dlsym(r.h, "ncclAllGather");
+  r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.h, "ncclCommDestroy");
+  r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.h, "ncclGetErrorString");
+  if (!r.GetUniqueId || !r.CommInitRank || !r.AllGather || !r.CommDestroy) { r.h = nullptr; return nullptr; }
+  return &r;
+}
+
+int comm_allgather_dev(vpin_comm* cm, vpin_ctx* c, const void* d_send, void* d_recv, size_t bytes) {
+  if (!cm || !c || !d_send || !d_recv || bytes == 0) return VPIN_EINVAL;
+  (void)hipSetDevice(c->device);
+  if (cm->nccl && cm->nccl_ctx == c && !cm->serialize) {
+    Rccl* r = rccl();
+    if (!r) return VPIN_ENODEV;
+    ncclResult_t e = r->AllGather(d_send, d_recv, bytes, ncclUint8, (ncclComm_t)cm->nccl, c->stream);
+    if (e != ncclSuccess) {
+      set_last_error(r->GetErrorString ? r->GetErrorString(e) : "ncclAllGather", hipErrorUnknown);
+      return VPIN_ECOMM;
+    }
+    cm->st.collectives++;
+    cm->st.bytes += (double)bytes;
+    return VPIN_OK;
+  }
+  // staged: D2H, host all-gather, H2D (also the path of the serialized rehearsal, whose ranks share one GPU)
+  const size_t need = bytes * ((size_t)cm->world + 1);
+  if (cm->h_stage_bytes < need) {
+    if (cm->h_stage) (void)hipHostFree(cm->h_stage);
+    cm->h_stage = nullptr;
+    cm->h_stage_bytes = 0;
+    VPIN_HIP_TRY(hipHostMalloc(&cm->h_stage, need, hipHostMallocDefault));
+    cm->h_stage_bytes = need;
+  }
+  uint8_t* hs = (uint8_t*)cm->h_stage;
+  VPIN_HIP_TRY(hipMemcpyAsync(hs, d_send, bytes, hipMemcpyDeviceToHost, c->stream));
+  VPIN_HIP_TRY(hipStreamSynchronize(c->stream));
+  int rc = comm_allgather(cm, hs, hs + bytes, bytes);
+  if (rc) return rc;
+  VPIN_HIP_TRY(hipMemcpyAsync(d_recv, hs + bytes, bytes * (size_t)cm->world, hipMemcpyHostToDevice, c->stream));
+  VPIN_HIP_TRY(hipStreamSynchronize(c->stream));  // the staging buffer is reused by the next call
+  return VPIN_OK;
+}
+
+}  // namespace vpin
+
+using namespace vpin;
+
+extern "C" {
+
+int vpin_comm_create_shm(const char* name, int rank, int world, size_t slot_bytes, vpin_comm** out) {
+  if (!name || !out || world < 1 || rank < 0 || rank >= world || name[0] != '/' || strlen(name) >= sizeof(((vpin_comm*)0)->shm_name))
+    return VPIN_EINVAL;
+  if (slot_bytes == 0) slot_bytes = (size_t)1 << 20;
+  const size_t bytes = seg_size(world, slot_bytes);
+  const double timeout = env_timeout();
+  int fd = -1;
+  if (rank == 0) {
+    (void)shm_unlink(name);  // a leftover of a job that died with this name
+    fd = shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600);
+    if (fd < 0 || ftruncate(fd, (off_t)bytes) != 0) { if (fd >= 0) close(fd); return VPIN_ECOMM; }
+  } else {
+    Spinner sp(timeout);
+    for (;;) {
+      fd = shm_open(name, O_RDWR, 0600);
+      if (fd >= 0) {
+        struct stat stt;
+        if (fstat(fd, &stt) == 0 && (size_t)stt.st_size >= bytes) break;  // rank 0 has sized it
+        close(fd);
+        fd = -1;
+      }
+      if (!sp.step()) return VPIN_ECOMM;
+      usleep(200);
+    }
+  }
+  void* p = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+  close(fd);
+  if (p == MAP_FAILED) return VPIN_ECOMM;
+  CommSeg* s = static_cast<CommSeg*>(p);
+  if (rank == 0) {
+    seg_init(s, world, slot_bytes);
+  } else {
+    Spinner sp(timeout);
+    while (s->magic.load(std::memory_order_acquire) != kCommMagic)
+      if (!sp.step()) { munmap(p, bytes); return VPIN_ECOMM; }
+    if (s->world != (uint32_t)world || s->slot_bytes != slot_bytes) { munmap(p, bytes); return VPIN_ECOMM; }
+  }
+  vpin_comm* cm = new (std::nothrow) vpin_comm();
+  if (!cm) { munmap(p, bytes); return VPIN_ENOMEM; }
+  cm->rank = rank; cm->world = world; cm->kind = 0; cm->seg = s; cm->seg_bytes = bytes; cm->timeout_s = timeout;
+  snprintf(cm->shm_name, sizeof cm->shm_name, "%s", name);
+  s->attached.fetch_add(1);
+  // everyone attached: the name can go (the mappings stay), so a crash later leaves nothing behind
+  Spinner sp(timeout);
+  while (s->attached.load() < (uint32_t)world)
+    if (!sp.step()) { s->abort_flag.store(1); if (rank == 0) (void)shm_unlink(name); munmap(p, bytes); delete cm; return VPIN_ECOMM; }
+  if (rank == 0) (void)shm_unlink(name);
+  cm->t_last_exit = now_s();
+  *out = cm;
+  return VPIN_OK;
+}
+
+int vpin_comm_create_local(int world, size_t slot_bytes, vpin_comm** out) {
+  if (!out || world < 1) return VPIN_EINVAL;
+  if (slot_bytes == 0) slot_bytes = (size_t)1 << 20;
+  const size_t bytes = seg_size(world, slot_bytes);
+  void* p = nullptr;
+  if (posix_memalign(&p, 4096, bytes) != 0) return VPIN_ENOMEM;
+  memset(p, 0, 4096);
+  CommSeg* s = static_cast<CommSeg*>(p);
+  seg_init(s, world, slot_bytes);
+  auto* refs = new std::atomic<int>(world);
+  for (int r = 0; r < world; r++) {
+    vpin_comm* cm = new vpin_comm();
+    cm->rank = r; cm->world = world; cm->kind = 1; cm->seg = s; cm->seg_bytes = bytes; cm->seg_refs = refs;
+    cm->timeout_s = env_timeout();
+    cm->t_last_exit = now_s();
+    out[r] = cm;
+  }
+  s->attached.store((uint32_t)world);
+  return VPIN_OK;
+}
+
+int vpin_comm_create_callbacks(int rank, int world, vpin_allgather_fn fn, void* user, vpin_comm** out) {
+  if (!out || !fn || world < 1 || rank < 0 || rank >= world) return VPIN_EINVAL;
+  vpin_comm* cm = new (std::nothrow) vpin_comm();
+  if (!cm) return VPIN_ENOMEM;
+  cm->rank = rank; cm->world = world; cm->kind = 2; cm->cb = fn; cm->cb_user = user;
+  cm->timeout_s = env_timeout();
+  cm->t_last_exit = now_s();
+  *out = cm;
+  return VPIN_OK;
+}
+
+void vpin_comm_destroy(vpin_comm* cm) {
+  if (!cm) return;
+  if (cm->nccl) {
+    Rccl* r = rccl();
+    if (r) (void)r->CommDestroy((ncclComm_t)cm->nccl);
+  }
+  if (cm->h_stage) (void)hipHostFree(cm->h_stage);
+  if (cm->seg) {
+    token_release(cm);
+    if (cm->kind == 0) {
+      munmap(cm->seg, cm->seg_bytes);
+    } else if (cm->kind == 1 && cm->seg_refs) {
+      if (cm->seg_refs->fetch_sub(1) == 1) { free(cm->seg); delete cm->seg_refs; }
+    }
+  }
+  delete cm;
+}
+
+int vpin_comm_rank(const vpin_comm* cm) { return cm ? cm->rank : -1; }
+int vpin_comm_world(const vpin_comm* cm) { return cm ? cm->world : 0; }
+
+int vpin_comm_allgather(vpin_comm* cm, const void* send, void* recv, size_t bytes) { return comm_allgather(cm, send, recv, bytes); }
+
+int vpin_comm_allgather_dev(vpin_comm* cm, vpin_ctx* c, const void* d_send, void* d_recv, size_t bytes) {
+  return comm_allgather_dev(cm, c, d_send, d_recv, bytes);
+}
+
+int vpin_comm_enable_rccl(vpin_comm* cm, vpin_ctx* c) {
+  if (!cm || !c) return VPIN_EINVAL;
+  Rccl* r = rccl();
+  // every rank reports whether it can, so that nobody waits inside ncclCommInitRank for a rank that cannot
+  std::vector<uint8_t> can((size_t)cm->world), mine(1, r ? 1 : 0);
+  int rc = comm_allgather(cm, mine.data(), can.data(), 1);
+  if (rc) return rc;
+  for (uint8_t b : can) if (!b) return VPIN_ENODEV;
+  ncclUniqueId id;
+  memset(&id, 0, sizeof id);
+  if (cm->rank == 0 && r->GetUniqueId(&id) != ncclSuccess) memset(&id, 0xff, sizeof id);
+  std::vector<ncclUniqueId> ids((size_t)cm->world);
+  if ((rc = comm_allgather(cm, &id, ids.data(), sizeof id))) return rc;
+  bool bad = true;
+  for (size_t i = 0; i < sizeof id; i++) bad = bad && ((const uint8_t*)&ids[0])[i] == 0xff;
+  if (bad) return VPIN_ECOMM;
+  (void)hipSetDevice(c->device);
+  ncclComm_t nc = nullptr;
+  ncclResult_t e = r->CommInitRank(&nc, cm->world, ids[0], cm->rank);
+  uint8_t ok = e == ncclSuccess ? 1 : 0;
+  if (!ok) set_last_error(r->GetErrorString ? r->GetErrorString(e) : "ncclCommInitRank", hipErrorUnknown);
+  if ((rc = comm_allgather(cm, &ok, can.data(), 1))) return rc;
+  bool all = true;
+  for (uint8_t b : can) all = all && b;
+  if (!all) {
+    if (ok) (void)r->CommDestroy(nc);
+    return VPIN_ECOMM;
+  }
+  cm->nccl = nc;
+  cm->nccl_ctx = c;
+  return VPIN_OK;
+}
+
+int vpin_comm_set_serialize(vpin_comm* cm, int on) {
+  if (!cm) return VPIN_EINVAL;
+  if (cm->world == 1 || cm->kind == 2) return on ? VPIN_EINVAL : VPIN_OK;
+  if (on && !cm->serialize) {
+    cm->serialize = true;
+    return token_acquire(cm);
+  }
+  if (!on && cm->serialize) {
+    token_release(cm);
+    cm->serialize = false;
+  }
+  return VPIN_OK;
+}
+
+int vpin_comm_stats_read(vpin_comm* cm, vpin_comm_stats* out, int reset) {
+  if (!cm || !out) return VPIN_EINVAL;
+  *out = cm->st;
+  if (reset) { cm->st = vpin_comm_stats{}; cm->t_last_exit = now_s(); }
+  return VPIN_OK;
+}
+
+int vpin_ctx_set_comm(vpin_ctx* c, vpin_comm* cm) {
+  if (!c) return VPIN_EINVAL;
+  c->comm = cm;
+  return VPIN_OK;
+}
+
+}  // extern "C"

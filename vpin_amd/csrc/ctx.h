@@ -83,6 +83,7 @@ struct vpin_ctx {
   uint32_t* d_spark_cnt = nullptr;  // device: per-instance and global "blocks done" counters (self-resetting)
   uint32_t spark_seq = 0;           // sequence number of the last flagged launch group
   int round_split = 0, round_split_grid = 0, round_split_ncirc = 0;  // the current group sums its partials in round_finish_kernel
+  int round_group_ndotp = 0;  // dot-product halves announced for the current launch group (spark_prod_round)
   uint32_t tail_seq = 0;            // persistent tail kernel (spark.hip): sequence base of the current / next launch
   int tail_rounds = 0;
   vpin::fq tail_sums[3 * 18];   // host copies of the current tail round's results (assembled from the mailbox pieces)
@@ -90,11 +91,8 @@ struct vpin_ctx {
   bool shared_device = false;  // other contexts prove on this device at the same time (vpin_ctx_set_shared_device)
   void* h_bullet = nullptr;  // pinned staging of the bullet reduction's per-round results (bullet.hip), 64 KiB
   uint32_t bullet_seq = 0;   // sequence number of the last fused bullet round (mailbox_dev.h)
-  // one large commitment split across ranks (include/vpin_hip.h, vpin_ctx_set_split_hooks)
-  vpin_split_begin_fn split_begin = nullptr;
-  vpin_split_commit_fn split_commit = nullptr;
-  void* split_user = nullptr;
-  size_t split_min_len = 0;
+  // one proof over several GPUs (include/vpin_hip.h, vpin_ctx_set_comm): proofs on this context are collective calls
+  vpin_comm* comm = nullptr;
   volatile int* progress_flag = nullptr;  // optional host word: set to 1 when a SNARK's sat part is done
 };
 
@@ -126,8 +124,10 @@ int table_alloc_uninit(vpin_ctx* c, size_t len, vpin_table** out);
 
 // split-phase pair commitment (msm.hip)
 struct CommitPairState;
+// row0 / nrows: the block of the L rows to commit (one commitment split across ranks); finish then takes that block's
+// blinds and writes nrows results per output
 int commit_pair_begin(vpin_ctx* c, const vpin_gens* g, const vpin_table* Za, const vpin_table* Zb, size_t L,
-                      CommitPairState** out);
+                      CommitPairState** out, size_t row0 = 0, size_t nrows = (size_t)-1);
 int commit_pair_finish(vpin_ctx* c, const vpin_gens* g, CommitPairState* st, const uint8_t* blinds_a, const uint8_t* blinds_b,
                        size_t blind_base, uint8_t* out_a, uint8_t* out_b, uint8_t* out_sum);
 
@@ -145,8 +145,9 @@ inline bool is_pow2(size_t x) { return x && !(x & (x - 1)); }
 int gens_msm_parts_dev(vpin_ctx* c, const vpin_gens* g, const fq* d_scalars, size_t rows, size_t ncols, uint8_t* parts_xyzt);
 // the same without the synchronisation (the caller provides the device scratch and waits on the stream itself)
 // the derefs commitment with each matrix's hot column taken out of the table walks (msm.hip msm_rows_hot_kernel)
+// row0 / nrows: a block of the L rows (out_compressed then holds nrows results); default all rows
 int hyrax_commit_derefs_hot(vpin_ctx* c, const vpin_gens* g, const vpin_table* Z, size_t L, size_t N, const uint32_t* const col_idx[3],
-                            const uint32_t hot[3], const fq* e_ry, uint8_t* out_compressed);
+                            const uint32_t hot[3], const fq* e_ry, uint8_t* out_compressed, size_t row0 = 0, size_t nrows = (size_t)-1);
 size_t gens_msm_parts_scratch_bytes(size_t rows, size_t ncols);
 int gens_msm_parts_launch(vpin_ctx* c, const vpin_gens* g, const fq* d_scalars, size_t rows, size_t ncols, void* scratch,
                           uint8_t* parts_xyzt, bool host_mapped = false);

@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "../ctx.h"
+#include "../comm.h"
 #include "curve.h"
 #include "transcript.h"
 

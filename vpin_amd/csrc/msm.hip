@@ -435,8 +435,8 @@ __global__ __launch_bounds__(64) void scalar_times_bases_kernel(const fq* __rest
 }
 
 __global__ __launch_bounds__(kMsmBlock, 3) void msm_rows_hot_kernel(const fq* __restrict__ Z, size_t stride, size_t ncols, TableView tv,
-                                                                 HotRows hr, ge_ext* __restrict__ out) {
-  const size_t row = blockIdx.x;
+                                                                 HotRows hr, ge_ext* __restrict__ out, size_t row_base) {
+  const size_t row = row_base + blockIdx.x;  // row of the polynomial; out[] is indexed from row_base (a block of rows)
   const fq* zr = Z + row * stride;
   ge_ext acc = ge_identity();
   // a row of one repeated scalar (padding tails): s * (g_0 + ... + g_{ncols-1}), as in msm_rows_kernel
@@ -448,7 +448,7 @@ __global__ __launch_bounds__(kMsmBlock, 3) void msm_rows_hot_kernel(const fq* __
       if (__syncthreads_and(same)) {
         if (threadIdx.x == 0) {
           if (!fq_is_zero(first)) table_mul_acc(acc, fq_from_mont(first), tv, tv.sum0 + (size_t)(63 - __builtin_clzll((unsigned long long)ncols)));
-          ge_ext* o = out + row;
+          ge_ext* o = out + blockIdx.x;
           fp_store(&o->X, acc.X); fp_store(&o->Y, acc.Y); fp_store(&o->Z, acc.Z); fp_store(&o->T, acc.T);
         }
         return;
@@ -498,7 +498,7 @@ __global__ __launch_bounds__(kMsmBlock, 3) void msm_rows_hot_kernel(const fq* __
   ge_tree_quad(sh, kMsmBlock);
   if (threadIdx.x == 0) {
     acc = sh[0];
-    ge_ext* o = out + row;
+    ge_ext* o = out + blockIdx.x;
     fp_store(&o->X, acc.X); fp_store(&o->Y, acc.Y); fp_store(&o->Z, acc.Z); fp_store(&o->T, acc.T);
   }
 }
@@ -522,8 +522,8 @@ __device__ __forceinline__ uint32_t count_digits(fq s, const TableView& tv, size
 __global__ __launch_bounds__(kMsmBlock) void msm_count_adds_kernel(const fq* __restrict__ Z, size_t stride, size_t ncols,
                                                                    const fq* __restrict__ extra, int n_extra, size_t extra_base0,
                                                                    TableView tv, unsigned long long* __restrict__ count,
-                                                                   HotRows hr = HotRows{}) {
-  const size_t row = blockIdx.x;
+                                                                   HotRows hr = HotRows{}, size_t row_base = 0) {
+  const size_t row = row_base + blockIdx.x;
   const fq* zr = Z + row * stride;
   // msm_rows_hot_kernel: the hot-column entries are not table additions
   const uint32_t* hidx = nullptr;
@@ -1063,13 +1063,16 @@ namespace vpin {
 // hot column of each matrix's col-derefs vector taken out (msm_rows_hot_kernel).  col_idx[m]: the N column indices of matrix
 // m on the device, hot[m]: its hot column or 0xffffffff, e_ry: the table the col-derefs were gathered from.
 int hyrax_commit_derefs_hot(vpin_ctx* c, const vpin_gens* g, const vpin_table* Z, size_t L, size_t N, const uint32_t* const col_idx[3],
-                            const uint32_t hot[3], const fq* e_ry, uint8_t* out_compressed) {
+                            const uint32_t hot[3], const fq* e_ry, uint8_t* out_compressed, size_t row0, size_t nrows) {
   if (!c || !g || !Z || !Z->d || !col_idx || !hot || !e_ry || !out_compressed || L == 0 || Z->len % L) return VPIN_EINVAL;
   const size_t R = Z->len / L;
   if (R > g->nb || N % R || Z->len < 6 * N) return VPIN_ESHAPE;
+  if (nrows == (size_t)-1) { row0 = 0; nrows = L; }  // all rows
+  if (row0 + nrows > L) return VPIN_ESHAPE;
+  if (nrows == 0) return VPIN_OK;
   (void)hipSetDevice(c->device);
   DevBuf dpts(c), dout(c), dT(c);
-  if (dpts.alloc(L * sizeof(ge_ext)) || dout.alloc(L * 32)) return VPIN_ENOMEM;
+  if (dpts.alloc(nrows * sizeof(ge_ext)) || dout.alloc(nrows * 32)) return VPIN_ENOMEM;
   HotRows hr{};
   hr.row0 = 3 * (N / R);
   hr.rows_per_vec = N / R;
@@ -1092,19 +1095,19 @@ int hyrax_commit_derefs_hot(vpin_ctx* c, const vpin_gens* g, const vpin_table* Z
       if (hot[m] == distinct[k]) hr.T[m] = Tk;
   }
   if (c->prof_count_adds && c->d_add_count)
-    hipLaunchKernelGGL(msm_count_adds_kernel, dim3((unsigned)L), dim3(kMsmBlock), 0, c->stream, (const fq*)Z->d, R, R, (const fq*)nullptr, 0,
-                       (size_t)0, view(g), c->d_add_count, hr);
+    hipLaunchKernelGGL(msm_count_adds_kernel, dim3((unsigned)nrows), dim3(kMsmBlock), 0, c->stream, (const fq*)Z->d, R, R, (const fq*)nullptr, 0,
+                       (size_t)0, view(g), c->d_add_count, hr, row0);
   {
-    ProfScope ps(c, VPIN_K_MSM, 32.0 * (double)Z->len, VPIN_K_MSM_ROWS);
+    ProfScope ps(c, VPIN_K_MSM, 32.0 * (double)(nrows * R), VPIN_K_MSM_ROWS);
     static const int env_pad = [] { const char* e = getenv("VPIN_MSM_LDS_PAD"); return e ? atoi(e) : -1; }();
     const unsigned pad = env_pad >= 0 ? (unsigned)env_pad : (c->shared_device ? 20000u : 0u);
-    hipLaunchKernelGGL(msm_rows_hot_kernel, dim3((unsigned)L), dim3(kMsmBlock), pad, c->stream, (const fq*)Z->d, R, R, view(g), hr,
-                       (ge_ext*)dpts.p);
+    hipLaunchKernelGGL(msm_rows_hot_kernel, dim3((unsigned)nrows), dim3(kMsmBlock), pad, c->stream, (const fq*)Z->d, R, R, view(g), hr,
+                       (ge_ext*)dpts.p, row0);
   }
-  hipLaunchKernelGGL(ge_compress_kernel, dim3((unsigned)((L + 63) / 64)), dim3(64), 0, c->stream, (const ge_ext*)dpts.p, L,
+  hipLaunchKernelGGL(ge_compress_kernel, dim3((unsigned)((nrows + 63) / 64)), dim3(64), 0, c->stream, (const ge_ext*)dpts.p, nrows,
                      (fp*)dout.p, (fp*)nullptr);
   VPIN_HIP_TRY(hipGetLastError());
-  VPIN_HIP_TRY(hipMemcpyAsync(out_compressed, dout.p, L * 32, hipMemcpyDeviceToHost, c->stream));
+  VPIN_HIP_TRY(hipMemcpyAsync(out_compressed, dout.p, nrows * 32, hipMemcpyDeviceToHost, c->stream));
   VPIN_HIP_TRY(hipStreamSynchronize(c->stream));
   return VPIN_OK;
 }
@@ -1188,24 +1191,27 @@ int vpin_gens_msm_parts(vpin_ctx* c, const vpin_gens* g, const uint8_t* scalars_
 namespace vpin {
 struct CommitPairState {
   DevBuf pts;  // [5L] : M_a | M_b | blind_a*h | blind_b*h (reused for sums) | a+b
-  size_t L = 0;
+  size_t L = 0;  // rows this state commits (a block of the polynomial's rows when the commitment is split across ranks)
   explicit CommitPairState(vpin_ctx* c) : pts(c) {}
 };
 
-int commit_pair_begin(vpin_ctx* c, const vpin_gens* g, const vpin_table* Za, const vpin_table* Zb, size_t L,
-                      CommitPairState** out) {
-  if (!c || !g || !Za || !Zb || !out || L == 0) return VPIN_EINVAL;
-  if (Za->len != Zb->len || Za->len % L != 0) return VPIN_ESHAPE;
-  size_t R = Za->len / L;
+int commit_pair_begin(vpin_ctx* c, const vpin_gens* g, const vpin_table* Za, const vpin_table* Zb, size_t L_all,
+                      CommitPairState** out, size_t row0, size_t nrows) {
+  if (!c || !g || !Za || !Zb || !out || L_all == 0) return VPIN_EINVAL;
+  if (Za->len != Zb->len || Za->len % L_all != 0) return VPIN_ESHAPE;
+  size_t R = Za->len / L_all;
   if (R > g->nb) return VPIN_ESHAPE;
+  if (nrows == (size_t)-1) { row0 = 0; nrows = L_all; }
+  if (row0 + nrows > L_all || nrows == 0) return VPIN_ESHAPE;
+  const size_t L = nrows;
   (void)hipSetDevice(c->device);
   CommitPairState* st = new (std::nothrow) CommitPairState(c);
   if (!st) return VPIN_ENOMEM;
   st->L = L;
   if (st->pts.alloc(5 * L * sizeof(ge_ext))) { delete st; return VPIN_ENOMEM; }
   ge_ext* pts = (ge_ext*)st->pts.p;
-  int rc = msm_rows(c, g, Za->d, L, R, R, nullptr, 0, 0, pts);
-  if (!rc) rc = msm_rows(c, g, Zb->d, L, R, R, nullptr, 0, 0, pts + L);
+  int rc = msm_rows(c, g, Za->d + row0 * R, L, R, R, nullptr, 0, 0, pts);
+  if (!rc) rc = msm_rows(c, g, Zb->d + row0 * R, L, R, R, nullptr, 0, 0, pts + L);
   if (rc) { delete st; return rc; }
   *out = st;
   return VPIN_OK;

@@ -415,8 +415,14 @@ int sat_prove_core(vpin_ctx* c, const vpin_r1cs_dev* dinst, size_t nv, size_t nc
   // ---- polycommit: proof_point_mult.rs:44-80 ----
   t0 = Clock::now();
   // the two row-MSMs do not depend on the blinds: enqueue them, then draw the 2L blinds while they run
+  // One proof over several GPUs (vpin_ctx_set_comm): the L row commitments are independent MSMs (rayon's into_par_iter,
+  // dense_mlpoly.rs:166-173), so every rank commits a contiguous block of rows of both polynomials and the 32-byte results
+  // are all-gathered; the blinds are drawn in full by everyone (the tape is part of the deterministic protocol state).
+  vpin_comm* cm = (c->comm && c->comm->world > 1) ? c->comm : nullptr;
+  size_t row0 = 0, nrows = L;
+  if (cm) vpin::comm_block(L, cm->rank, cm->world, &row0, &nrows);
   vpin::CommitPairState* cps = nullptr;
-  if ((rc = vpin::commit_pair_begin(c, sg->dev, d_para, d_input, L, &cps))) return rc;
+  if (nrows && (rc = vpin::commit_pair_begin(c, sg->dev, d_para, d_input, L, &cps, row0, nrows))) return rc;
   const uint8_t two = 2;
   Transcript tape1 = make_tape(&two, 1, seed_commit64);
   std::vector<Fq> blind_para = tape1.challenge_vector("poly_blinds", L);
@@ -424,9 +430,26 @@ int sat_prove_core(vpin_ctx* c, const vpin_r1cs_dev* dinst, size_t nv, size_t nc
   std::vector<Fq> blind_vars(L);
   for (size_t i = 0; i < L; i++) blind_vars[i] = blind_para[i] + blind_input[i];  // commit_test.rs:42-54
   std::vector<CG> comm_vars(L);
-  rc = vpin::commit_pair_finish(c, sg->dev, cps, B(blind_para.data()), B(blind_input.data()), R + 1, comm_para_out,
-                                comm_input_out, comm_vars[0].b);
-  if (rc) return rc;
+  if (!cm) {
+    rc = vpin::commit_pair_finish(c, sg->dev, cps, B(blind_para.data()), B(blind_input.data()), R + 1, comm_para_out,
+                                  comm_input_out, comm_vars[0].b);
+    if (rc) return rc;
+  } else {
+    const size_t pmax = vpin::comm_block_max(L, cm->world);
+    std::vector<uint8_t> mine(3 * pmax * 32, 0), all((size_t)cm->world * 3 * pmax * 32);
+    if (nrows && (rc = vpin::commit_pair_finish(c, sg->dev, cps, B(blind_para.data() + row0), B(blind_input.data() + row0), R + 1,
+                                                mine.data(), mine.data() + pmax * 32, mine.data() + 2 * pmax * 32)))
+      return rc;
+    if ((rc = vpin::comm_allgather_ctx(c, mine.data(), all.data(), mine.size()))) return rc;
+    for (int r = 0; r < cm->world; r++) {
+      size_t f0, n;
+      vpin::comm_block(L, r, cm->world, &f0, &n);
+      const uint8_t* blk = all.data() + (size_t)r * 3 * pmax * 32;
+      memcpy(comm_para_out + f0 * 32, blk, n * 32);
+      memcpy(comm_input_out + f0 * 32, blk + pmax * 32, n * 32);
+      memcpy(comm_vars[0].b + f0 * 32, blk + 2 * pmax * 32, n * 32);
+    }
+  }
   g_timings[0] = secs(t0, Clock::now());
 
   // ---- transcripts: proof_point_mult.rs:83, commit_test.rs:74-75,148,155 ----

@@ -162,6 +162,69 @@ static int polyeval_prove_plain(vpin_ctx* c, const PcGens& pc, const vpin_table*
   return dplog_prove(c, pc, tr, tape, LZ, Fq::zero(), Rv, Zr, Fq::zero(), out);
 }
 
+// ---- one proof over several GPUs: who owns which circuit, and the per-round exchange -------------------------------
+// The 12 "ops" circuits and the 6 dot-product halves are proven in the same rounds, so they are dealt together (longest
+// processing time first; an ops circuit folds 2 tables over all layers = 4 units, a dot-product half 3 tables on layer 0 = 3
+// units); the 4 "mem" circuits form their own phase and go to the ranks with the least ops work.  Every rank computes
+// the same plan.  Ranks own whole circuits: leaves, tree, every round and the persistent tails of a circuit stay on one
+// GPU, and per round only its three scalars leave it.
+struct DistPlan {
+  vpin_comm* cm = nullptr;
+  int rank = 0, world = 1;
+  int owner_ops[12], owner_dotp[6], owner_mem[4];
+  std::vector<std::vector<int>> ops_of, dotp_of, mem_of;  // per rank, ascending
+  int max_ops_inst = 0, max_mem_inst = 0;                 // most instances (circuits + halves) any rank owns per phase
+};
+
+static void make_plan(int world, int owner_ops[12], int owner_dotp[6], int owner_mem[4]) {
+  std::vector<long> load(world, 0);
+  auto least = [&](const std::vector<long>& key2) {
+    int best = 0;
+    for (int r = 1; r < world; r++)
+      if (load[r] < load[best] || (load[r] == load[best] && key2[r] < key2[best])) best = r;
+    return best;
+  };
+  const std::vector<long> none(world, 0);
+  for (int t = 0; t < 12; t++) { int r = least(none); owner_ops[t] = r; load[r] += 4; }
+  for (int k = 0; k < 6; k++) { int r = least(none); owner_dotp[k] = r; load[r] += 3; }
+  std::vector<long> ops_load = load;
+  std::fill(load.begin(), load.end(), 0);
+  for (int t = 0; t < 4; t++) { int r = least(ops_load); owner_mem[t] = r; load[r] += 1; }
+}
+
+static void plan_init(DistPlan& pl, vpin_comm* cm) {
+  pl.cm = cm; pl.rank = cm->rank; pl.world = cm->world;
+  make_plan(pl.world, pl.owner_ops, pl.owner_dotp, pl.owner_mem);
+  pl.ops_of.assign(pl.world, {}); pl.dotp_of.assign(pl.world, {}); pl.mem_of.assign(pl.world, {});
+  for (int t = 0; t < 12; t++) pl.ops_of[pl.owner_ops[t]].push_back(t);
+  for (int k = 0; k < 6; k++) pl.dotp_of[pl.owner_dotp[k]].push_back(k);
+  for (int t = 0; t < 4; t++) pl.mem_of[pl.owner_mem[t]].push_back(t);
+  for (int r = 0; r < pl.world; r++) {
+    pl.max_ops_inst = std::max(pl.max_ops_inst, (int)(pl.ops_of[r].size() + pl.dotp_of[r].size()));
+    pl.max_mem_inst = std::max(pl.max_mem_inst, (int)pl.mem_of[r].size());
+  }
+}
+
+// `per` scalars of each of this rank's instances (its circuits in ascending order, then -- with_dotp -- its dot-product
+// halves) -> the same for ALL instances in the single-GPU slot order: circuit g at global[per*g], half k at global[per*(12+k)]
+static int dist_exchange(vpin_ctx* c, const DistPlan& pl, bool mem, bool with_dotp, const Fq* local, int per, Fq* global) {
+  const int maxi = mem ? pl.max_mem_inst : pl.max_ops_inst;
+  const size_t chunk = (size_t)maxi * per;
+  std::vector<Fq> sb(chunk, Fq::zero()), rb(chunk * pl.world);
+  const auto& mine = mem ? pl.mem_of[pl.rank] : pl.ops_of[pl.rank];
+  const size_t nloc = mine.size() + (with_dotp ? pl.dotp_of[pl.rank].size() : 0);
+  if (nloc) memcpy(sb.data(), local, nloc * per * 32);
+  int rc = vpin::comm_allgather_ctx(c, sb.data(), rb.data(), chunk * 32);
+  if (rc) return rc;
+  for (int r = 0; r < pl.world; r++) {
+    const Fq* src = rb.data() + (size_t)r * chunk;
+    for (int g : (mem ? pl.mem_of[r] : pl.ops_of[r])) { memcpy(global + (size_t)per * g, src, (size_t)per * 32); src += per; }
+    if (with_dotp)
+      for (int k : pl.dotp_of[r]) { memcpy(global + (size_t)per * (12 + k), src, (size_t)per * 32); src += per; }
+  }
+  return VPIN_OK;
+}
+
 // ---- ProductCircuitEvalProofBatched::prove (product_tree.rs:258-385) ------------------------------
 
 struct Batched {
@@ -189,8 +252,18 @@ struct DotpCtx {  // the six DotProductCircuit halves ride along on layer 0 of t
   Fq claims[6];  // their evaluations (claim_eval_dotp_left/right per matrix)
 };
 
-static int batched_prove(vpin_ctx* c, vpin::SparkForest& f, DotpCtx* dotp, Transcript& tr, Batched& out, std::vector<Fq>& rand) {
-  const int npc = f.ncirc, ndotp = dotp ? 6 : 0;
+// pl != nullptr (one proof over several GPUs): `f` holds this rank's circuits only (possibly none: f.ncirc == 0), npc_all is
+// the number of circuits of the whole forest (12 ops / 4 mem); the rounds run on the owned circuits and halves and every
+// per-round result is exchanged (dist_exchange), after which the transcript work below is the same on every rank.
+static int batched_prove(vpin_ctx* c, vpin::SparkForest& f, DotpCtx* dotp, Transcript& tr, Batched& out, std::vector<Fq>& rand,
+                         const DistPlan* pl = nullptr, int npc_all = 0) {
+  const int npc = pl ? npc_all : f.ncirc, ndotp = dotp ? 6 : 0;
+  const bool is_mem = pl && npc_all == 4;
+  const int nl = f.ncirc;                                             // circuits this rank runs
+  const std::vector<int> no_halves;
+  const std::vector<int>& my_halves = pl ? pl->dotp_of[pl->rank] : no_halves;
+  const int ndl = !dotp ? 0 : (pl ? (int)my_halves.size() : 6);       // dot-product halves this rank runs
+  const int* halves = pl ? my_halves.data() : nullptr;
   static const bool fine = getenv("VPIN_SPARK_TRACE") && atoi(getenv("VPIN_SPARK_TRACE")) >= 2;
   double t_setup = 0, t_first = 0, t_rounds = 0, t_epi = 0, t_host = 0;
   auto tl0 = Clock::now();
@@ -198,9 +271,11 @@ static int batched_prove(vpin_ctx* c, vpin::SparkForest& f, DotpCtx* dotp, Trans
   int rc;
   // host copies of the small top levels
   const size_t cnt = std::min<size_t>(2 * vpin::kSparkHostTop, f.stride());
-  if ((rc = vpin::spark_fetch_tops(c, &f, cnt))) return rc;
+  if (nl && (rc = vpin::spark_fetch_tops(c, &f, cnt))) return rc;
   std::vector<Fq> tops((size_t)npc * cnt);
-  memcpy(tops.data(), c->h_spark, tops.size() * 32);
+  if (!pl) memcpy(tops.data(), c->h_spark, tops.size() * 32);
+  else if ((rc = dist_exchange(c, *pl, is_mem, false, reinterpret_cast<const Fq*>(c->h_spark), (int)cnt, tops.data()))) return rc;
+  std::vector<Fq> res_all(3 * (size_t)vpin::kSparkMaxInst), fin_all(6 * (size_t)vpin::kSparkMaxInst), pack(6 * (size_t)vpin::kSparkMaxInst);
 
   out.polys.assign(num_layers, {});
   out.claims_left.assign(num_layers, {});
@@ -277,9 +352,13 @@ static int batched_prove(vpin_ctx* c, vpin::SparkForest& f, DotpCtx* dotp, Trans
       // s_j * eq(rand_{j..}, .), s_j = prod_{i<j} eq1(rand_i, r_i); at the round's evaluation point x it is
       // s_j*((1-rand_j) + x*(2 rand_j - 1)) * E_{j+1}[i].  The kernel returns sum_i E_{j+1}[i]*(A_x B_x)[i].
       if (k < 1) return VPIN_ESHAPE;
+      const int ndl_here = with_dotp ? ndl : 0;          // halves this rank runs on this layer
+      const bool runs = nl > 0 || ndl_here > 0;          // a rank without circuits of this forest only follows the transcript
       vpin_table* pyr = nullptr;
-      if ((rc = vpin_eq_suffix_tables(c, B(rand.data()), k, &pyr))) return rc;
-      tg.add(pyr);
+      if (runs) {
+        if ((rc = vpin_eq_suffix_tables(c, B(rand.data()), k, &pyr))) return rc;
+        tg.add(pyr);
+      }
       Fq s = one;
       // Leading-coefficient rounds: per circuit the kernel returns t(0) and the x^2 coefficient of
       // t(x) = sum_i E[i] (A_x B_x)[i]; t(1) follows from the circuit's claim, which the prover knows exactly
@@ -303,31 +382,46 @@ static int batched_prove(vpin_ctx* c, vpin::SparkForest& f, DotpCtx* dotp, Trans
       // tail): the kernel publishes a round's sums to pinned memory and polls a pinned mailbox for the challenge this
       // loop derives from the transcript.  Larger rounds take one launch each.
       const size_t tail_pairs = lead_ok ? vpin::spark_tail_pairs() : 0;
+      if (pl && tail_pairs == 0) {  // the split rounds end in the persistent tail; a zero challenge (never) or VPIN_SPARK_TAIL_PAIRS=0 rules it out
+        vpin::set_last_error("one proof over several GPUs needs the persistent tail rounds", hipErrorUnknown);
+        return VPIN_ESHAPE;
+      }
       bool tail_on = false;
       int tail_j0 = 0;
-      const int ninst = npc + (with_dotp ? 6 : 0);
+      const int ninst = nl + ndl_here;  // instances this rank's launches carry
       if (fine) { auto t = Clock::now(); t_setup += secs(tl0, t); tl0 = t; }
       for (int j = 0; j < k; j++) {
         const size_t len = j == 0 ? h : (h >> (j - 1));  // live length before this round's launch
-        const vpin::fq* E = pyr->d + pyramid_offset(k, j + 1);
+        const vpin::fq* E = runs ? pyr->d + pyramid_offset(k, j + 1) : nullptr;
         const uint8_t* rprev = j ? B(&r[j - 1]) : nullptr;
         if (!tail_on && (h >> (j + 1)) <= tail_pairs) {
-          if ((rc = vpin::spark_tail_launch(c, &f, layer_id, k, j, len, pyr->d, rprev, with_dotp ? dotp->d->N : 0,
-                                            with_dotp ? dotp->d->comb_ops->d + 12 * dotp->d->N : nullptr,
-                                            with_dotp ? dotp->comb_derefs : nullptr, with_dotp ? dotp->scratch : nullptr)))
+          if (runs && (rc = vpin::spark_tail_launch(c, &f, layer_id, k, j, len, pyr->d, rprev, ndl_here ? dotp->d->N : 0,
+                                                    ndl_here ? dotp->d->comb_ops->d + 12 * dotp->d->N : nullptr,
+                                                    ndl_here ? dotp->comb_derefs : nullptr, ndl_here ? dotp->scratch : nullptr,
+                                                    halves, ndl_here)))
             return rc;
           tail_on = true;
           tail_j0 = j;
         }
-        const Fq* res;
+        const Fq* res = nullptr;
         if (tail_on) {
-          if ((rc = vpin::spark_tail_wait(c, j - tail_j0, ninst, npc))) return rc;
-          res = reinterpret_cast<const Fq*>(vpin::spark_tail_sums(c));
-        } else {
-          if ((rc = vpin::spark_prod_round(c, &f, layer_id, len, E, rprev, with_dotp, lead_ok))) return rc;
-          if (with_dotp && (rc = vpin::spark_dotp_round(c, dotp->d->N, dotp->d->comb_ops->d + 12 * dotp->d->N, dotp->comb_derefs, dotp->scratch, len, j == 1, rprev))) return rc;
+          if (runs) {
+            if ((rc = vpin::spark_tail_wait(c, j - tail_j0, ninst, nl))) return rc;
+            res = reinterpret_cast<const Fq*>(vpin::spark_tail_sums(c));
+          }
+        } else if (runs) {
+          if ((rc = vpin::spark_prod_round(c, &f, layer_id, len, E, rprev, ndl_here, lead_ok))) return rc;
+          if (ndl_here && (rc = vpin::spark_dotp_round(c, dotp->d->N, dotp->d->comb_ops->d + 12 * dotp->d->N, dotp->comb_derefs, dotp->scratch, len, j == 1, rprev, halves, ndl_here))) return rc;
           if ((rc = vpin::spark_wait_flag(c))) return rc;
           res = reinterpret_cast<const Fq*>(c->h_spark);
+        }
+        if (pl) {
+          // this rank's sums (circuits at slots 0.., halves at slots 12..) -> everyone's, in the single-GPU slot order
+          for (int t = 0; t < nl; t++) memcpy(&pack[3 * (size_t)t], res + 3 * (size_t)t, 96);
+          // (a launch group puts its halves at slots 12.., the persistent tail numbers its instances consecutively)
+          for (int i = 0; i < ndl_here; i++) memcpy(&pack[3 * (size_t)(nl + i)], res + 3 * (size_t)((tail_on ? nl : 12) + i), 96);
+          if ((rc = dist_exchange(c, *pl, is_mem, with_dotp, pack.data(), 3, res_all.data()))) return rc;
+          res = res_all.data();
         }
         if (fine) { auto t = Clock::now(); (j == 0 ? t_first : t_rounds) += secs(tl0, t); if (k >= 11) fprintf(stderr, " w%.1f", secs(tl0, t) * 1e6); tl0 = t; }
         const Fq rho = rand[j], omr = one - rho;
@@ -354,7 +448,7 @@ static int batched_prove(vpin_ctx* c, vpin::SparkForest& f, DotpCtx* dotp, Trans
         unipoly_from_evals(evals, 4, cf);
         append_unipoly(tr, cf, 4);
         Fq rj = tr.challenge_scalar("challenge_nextround");
-        if (tail_on && j + 1 < k) vpin::spark_tail_reply(c, j - tail_j0, B(&rj));  // the kernel folds while the host finishes the round
+        if (tail_on && runs && j + 1 < k) vpin::spark_tail_reply(c, j - tail_j0, B(&rj));  // the kernel folds while the host finishes the round
         r[j] = rj;
         e = unipoly_eval(cf, 4, rj);
         if (lead_ok) cn = S0 + rj * ((T1 - S0 - Sinf) + rj * Sinf);   // T(r_j)
@@ -366,7 +460,12 @@ static int batched_prove(vpin_ctx* c, vpin::SparkForest& f, DotpCtx* dotp, Trans
       // final fold of the two live entries per table with r_{k-1}
       const Fq rl = r[k - 1];
       if (tail_on) {
-        const Fq* fin = reinterpret_cast<const Fq*>(vpin::spark_tail_final(c));
+        const Fq* fin = runs ? reinterpret_cast<const Fq*>(vpin::spark_tail_final(c)) : nullptr;
+        if (pl) {
+          for (int t = 0; t < ninst; t++) memcpy(&pack[6 * (size_t)t], fin + 6 * (size_t)t, 192);  // the tail numbers its instances 0..ninst-1
+          if ((rc = dist_exchange(c, *pl, is_mem, with_dotp, pack.data(), 6, fin_all.data()))) return rc;
+          fin = fin_all.data();  // halves at slots 12.. = npc + i (only the ops forest, npc == 12, carries them)
+        }
         for (int t = 0; t < npc; t++) {
           cl[t] = fin[6 * t] + rl * (fin[6 * t + 1] - fin[6 * t]);
           cr[t] = fin[6 * t + 2] + rl * (fin[6 * t + 3] - fin[6 * t + 2]);
@@ -379,8 +478,9 @@ static int batched_prove(vpin_ctx* c, vpin::SparkForest& f, DotpCtx* dotp, Trans
               out.dotp[t][i] = q[0] + rl * (q[1] - q[0]);
             }
         }
-        vpin::spark_tail_end(c);
+        if (runs) vpin::spark_tail_end(c);
       } else {
+        if (pl) return VPIN_ESHAPE;
         if ((rc = vpin::spark_collect(c, &f, layer_id, with_dotp ? dotp->d : nullptr, with_dotp ? dotp->comb_derefs : nullptr,
                                       with_dotp ? dotp->scratch : nullptr, with_dotp, k >= 2)))
           return rc;
@@ -442,9 +542,14 @@ static int spark_prove(vpin_ctx* c, const vpin_spark_decomm* d, const std::vecto
   TableGuard tg(c);
   auto t0 = Clock::now();
 
-  // a split derefs commitment (vpin_ctx_set_split_hooks): the helper ranks get (rx, ry) before anything else happens here
-  const bool split = c->split_begin && c->split_commit && 8 * N >= c->split_min_len;
-  if (split && (rc = c->split_begin(c->split_user, B(rx.data()), rx.size(), B(ry.data()), ry.size()))) return rc;
+  // one proof over several GPUs (vpin_ctx_set_comm): every rank is here with the same transcript state
+  DistPlan plan;
+  const DistPlan* dz = nullptr;
+  if (c->comm && c->comm->world > 1) {
+    if (c->comm->world > 12) return VPIN_EINVAL;  // every rank owns at least one of the 12 ops circuits
+    plan_init(plan, c->comm);
+    dz = &plan;
+  }
   tr.append_protocol_name("Sparse polynomial evaluation proof");
   // equalize (sparse_mlpoly.rs:1448-1465) + the two memories eq(rx_ext, .), eq(ry_ext, .)
   const size_t nm = std::max(d->nx, d->ny);
@@ -461,9 +566,30 @@ static int spark_prove(vpin_ctx* c, const vpin_spark_decomm* d, const std::vecto
   tg.add(comb);
   if ((rc = vpin::spark_gather_derefs(c, d, mem_rx->d, mem_ry->d, comb->d))) return rc;
   std::vector<CG> comm_derefs;
-  if (split) {
-    comm_derefs.resize(g_derefs->L);
-    if ((rc = c->split_commit(c->split_user, comb, g_derefs->L, g_derefs->R, comm_derefs[0].b))) return rc;
+  const bool hot = d->hot_col[0] != 0xffffffffu || d->hot_col[1] != 0xffffffffu || d->hot_col[2] != 0xffffffffu;
+  if (dz) {
+    // the L row commitments are independent MSMs over shared generators: a contiguous block of rows per rank, 32 bytes
+    // per row all-gathered (no point crosses a link, nothing is reduced)
+    const size_t L = g_derefs->L, pmax = vpin::comm_block_max(L, dz->world);
+    size_t row0, nrows;
+    vpin::comm_block(L, dz->rank, dz->world, &row0, &nrows);
+    std::vector<uint8_t> mine(pmax * 32, 0), all(pmax * 32 * (size_t)dz->world);
+    if (nrows) {
+      if (hot) {
+        const uint32_t* col_idx[3] = {d->idx + 6 * d->N, d->idx + 7 * d->N, d->idx + 8 * d->N};
+        rc = vpin::hyrax_commit_derefs_hot(c, g_derefs->dev, comb, L, d->N, col_idx, d->hot_col, mem_ry->d, mine.data(), row0, nrows);
+      } else {
+        rc = vpin_hyrax_commit_rows(c, g_derefs->dev, comb, L, row0, nrows, nullptr, g_derefs->R + 1, mine.data());
+      }
+      if (rc) return rc;
+    }
+    if ((rc = vpin::comm_allgather_ctx(c, mine.data(), all.data(), mine.size()))) return rc;
+    comm_derefs.resize(L);
+    for (int r = 0; r < dz->world; r++) {
+      size_t f0, n;
+      vpin::comm_block(L, r, dz->world, &f0, &n);
+      memcpy(comm_derefs[0].b + f0 * 32, all.data() + (size_t)r * pmax * 32, n * 32);
+    }
   } else if (d->hot_col[0] != 0xffffffffu || d->hot_col[1] != 0xffffffffu || d->hot_col[2] != 0xffffffffu) {
     // the entries of each matrix's hot column hold one scalar, E_ry[hot]: one addition each instead of a table walk
     const uint32_t* col_idx[3] = {d->idx + 6 * d->N, d->idx + 7 * d->N, d->idx + 8 * d->N};
@@ -485,12 +611,24 @@ static int spark_prove(vpin_ctx* c, const vpin_spark_decomm* d, const std::vecto
   const Fq r_hash = r_mem_check[0], gamma = r_mem_check[1], r_hash_sqr = r_hash * r_hash, r2_boost = r_hash_sqr * Fq::r2();
   vpin::SparkForest f_ops, f_mem;
   vpin::DevBuf b_ops(c), b_mem(c), b_scr(c);
-  if (b_ops.alloc(12 * 2 * N * 32) || b_mem.alloc(4 * 2 * M * 32) || b_scr.alloc(18 * (N / 4) * 32)) return VPIN_ENOMEM;
-  f_ops.base = (vpin::fq*)b_ops.p; f_ops.n = N; f_ops.ncirc = 12;
-  f_mem.base = (vpin::fq*)b_mem.p; f_mem.n = M; f_mem.ncirc = 4;
-  if ((rc = vpin::spark_build_forests(c, d, comb->d, mem_rx->d, mem_ry->d, B(&r_hash), B(&r_hash_sqr), B(&r2_boost), B(&gamma),
-                                      &f_ops, &f_mem)))
-    return rc;
+  const int nl_ops = dz ? (int)dz->ops_of[dz->rank].size() : 12, nl_mem = dz ? (int)dz->mem_of[dz->rank].size() : 4;
+  if (b_ops.alloc((size_t)nl_ops * 2 * N * 32) || (nl_mem && b_mem.alloc((size_t)nl_mem * 2 * M * 32)) || b_scr.alloc(18 * (N / 4) * 32))
+    return VPIN_ENOMEM;
+  f_ops.base = (vpin::fq*)b_ops.p; f_ops.n = N; f_ops.ncirc = nl_ops;
+  f_mem.base = (vpin::fq*)b_mem.p; f_mem.n = M; f_mem.ncirc = nl_mem;
+  if (!dz) {
+    if ((rc = vpin::spark_build_forests(c, d, comb->d, mem_rx->d, mem_ry->d, B(&r_hash), B(&r_hash_sqr), B(&r2_boost), B(&gamma),
+                                        &f_ops, &f_mem)))
+      return rc;
+  } else {
+    // leaves and trees of this rank's circuits only
+    if ((rc = vpin::spark_build_forest_sub(c, d, comb->d, mem_rx->d, mem_ry->d, B(&r_hash), B(&r_hash_sqr), B(&r2_boost), B(&gamma),
+                                           &f_ops, dz->ops_of[dz->rank].data(), false)))
+      return rc;
+    if (nl_mem && (rc = vpin::spark_build_forest_sub(c, d, comb->d, mem_rx->d, mem_ry->d, B(&r_hash), B(&r_hash_sqr), B(&r2_boost),
+                                                     B(&gamma), &f_mem, dz->mem_of[dz->rank].data(), true)))
+      return rc;
+  }
   if ((rc = vpin::spark_wait(c))) return rc;
   g_spark_timings[2] = secs(t0, Clock::now());
 
@@ -501,11 +639,21 @@ static int spark_prove(vpin_ctx* c, const vpin_spark_decomm* d, const std::vecto
   // roots of the 16 circuits
   Fq pl[2][8];  // per side: init, read[3], write[3], audit
   {
+    std::vector<Fq> roots(2 * (size_t)vpin::kSparkMaxInst);
     if ((rc = vpin::spark_fetch_tops(c, &f_ops, 2))) return rc;
     const Fq* t = reinterpret_cast<const Fq*>(c->h_spark);
+    if (dz) {
+      if ((rc = dist_exchange(c, *dz, false, false, t, 2, roots.data()))) return rc;
+      t = roots.data();
+    }
     for (int s = 0; s < 2; s++)
       for (int m = 0; m < 3; m++) { pl[s][1 + m] = t[2 * (s * 6 + m)]; pl[s][4 + m] = t[2 * (s * 6 + 3 + m)]; }
-    if ((rc = vpin::spark_fetch_tops(c, &f_mem, 2))) return rc;
+    if (nl_mem && (rc = vpin::spark_fetch_tops(c, &f_mem, 2))) return rc;
+    t = reinterpret_cast<const Fq*>(c->h_spark);
+    if (dz) {
+      if ((rc = dist_exchange(c, *dz, true, false, t, 2, roots.data()))) return rc;
+      t = roots.data();
+    }
     for (int s = 0; s < 2; s++) { pl[s][0] = t[2 * (2 * s)]; pl[s][7] = t[2 * (2 * s + 1)]; }
   }
   static const char* lab[2][4] = {{"claim_row_eval_init", "claim_row_eval_read", "claim_row_eval_write", "claim_row_eval_audit"},
@@ -537,11 +685,11 @@ static int spark_prove(vpin_ctx* c, const vpin_spark_decomm* d, const std::vecto
   std::vector<Fq> rand_ops, rand_mem;
   {
     TraceSpan ts("product: ops forest");
-    if ((rc = batched_prove(c, f_ops, &dotp, tr, pf_ops, rand_ops))) return rc;
+    if ((rc = batched_prove(c, f_ops, &dotp, tr, pf_ops, rand_ops, dz, 12))) return rc;
   }
   {
     TraceSpan ts("product: mem forest");
-    if ((rc = batched_prove(c, f_mem, nullptr, tr, pf_mem, rand_mem))) return rc;
+    if ((rc = batched_prove(c, f_mem, nullptr, tr, pf_mem, rand_mem, dz, 4))) return rc;
   }
   g_spark_timings[3] = secs(t0, Clock::now());
 
@@ -673,30 +821,10 @@ int vpin_spark_gens_view(vpin_ctx* c, size_t ell, const vpin_gens** out, size_t*
   return VPIN_OK;
 }
 
-int vpin_spark_derefs_commit_rows(vpin_ctx* c, const vpin_spark_decomm* d, const uint8_t* rx, size_t nx, const uint8_t* ry, size_t ny,
-                                  size_t row0, size_t nrows, uint8_t* out_compressed) {
-  if (!c || !d || !rx || !ry || !out_compressed || nrows == 0) return VPIN_EINVAL;
-  if (nx != d->nx || ny != d->ny) return VPIN_ESHAPE;
-  (void)hipSetDevice(c->device);
-  const size_t N = d->N, lgN = log2z(N);
-  const PcGens* g_derefs = nullptr;
-  int rc = get_view(c, lgN + 3, &g_derefs);
-  if (rc) return rc;
-  if (row0 + nrows > g_derefs->L) return VPIN_ESHAPE;
-  TableGuard tg(c);
-  const size_t nm = std::max(d->nx, d->ny);
-  std::vector<Fq> rx_ext(nm, Fq::zero()), ry_ext(nm, Fq::zero());
-  memcpy(rx_ext.data() + (nm - nx), rx, nx * 32);
-  memcpy(ry_ext.data() + (nm - ny), ry, ny * 32);
-  vpin_table *mem_rx = nullptr, *mem_ry = nullptr, *comb = nullptr;
-  if ((rc = vpin_eq_table(c, B(rx_ext.data()), (int)nm, &mem_rx))) return rc;
-  tg.add(mem_rx);
-  if ((rc = vpin_eq_table(c, B(ry_ext.data()), (int)nm, &mem_ry))) return rc;
-  tg.add(mem_ry);
-  if ((rc = vpin::table_alloc_uninit(c, 8 * N, &comb))) return rc;
-  tg.add(comb);
-  if ((rc = vpin::spark_gather_derefs(c, d, mem_rx->d, mem_ry->d, comb->d))) return rc;
-  return vpin_hyrax_commit_rows(c, g_derefs->dev, comb, g_derefs->L, row0, nrows, nullptr, g_derefs->R + 1, out_compressed);
+int vpin_dist_plan(int world, int owner_ops[12], int owner_dotp[6], int owner_mem[4]) {
+  if (world < 1 || world > 12 || !owner_ops || !owner_dotp || !owner_mem) return VPIN_EINVAL;
+  make_plan(world, owner_ops, owner_dotp, owner_mem);
+  return VPIN_OK;
 }
 
 void vpin_spark_decomm_hot_cols(const vpin_spark_decomm* d, uint32_t out[3]) {

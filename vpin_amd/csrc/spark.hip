@@ -70,6 +70,7 @@ __global__ __launch_bounds__(kBlock) void gather_derefs_kernel(const uint32_t* _
 // r2_boost = r^2 * R (Montgomery form of the Montgomery image), so fq_mul(raw ts, r2_boost) is ts*r^2
 // in Montgomery form without a separate conversion of ts.
 struct HashParams { fq r, r2, r2_boost, gamma; };
+struct CircIds { int v[12]; };  // global circuit (or dot-product half) of each local one
 
 // blockIdx.y = side*3 + m.  Writes level 0 of read circuit (side*6 + m) and write circuit (side*6 + 3 + m).
 __global__ __launch_bounds__(kBlock) void hash_ops_kernel(const uint32_t* __restrict__ idx, const fq* __restrict__ derefs, size_t N,
@@ -108,6 +109,45 @@ __global__ __launch_bounds__(kBlock) void hash_mem_kernel(const uint32_t* __rest
     uint32_t t = ts[i];
     if (t) h = fq_add(h, fq_mul(fq_raw_u32(t), hp.r2_boost));
     fq_store(audit + i, h);
+  }
+}
+
+// The same leaves for a SUBSET of the circuits (one proof over several GPUs: a rank builds the trees of the circuits it
+// owns and nothing else).  ids.v[j] = global circuit of local tree j, in the numbering of the two kernels above:
+// ops: side*6 + kind*3 + m (kind 0 = read, 1 = write); mem: side*2 + kind (kind 0 = init, 1 = audit).
+__global__ __launch_bounds__(kBlock) void hash_ops_sub_kernel(const uint32_t* __restrict__ idx, const fq* __restrict__ derefs, size_t N,
+                                                              HashParams hp, fq* __restrict__ forest, CircIds ids) {
+  const int g = ids.v[blockIdx.y], side = g / 6, kind = (g % 6) / 3, m = g % 3;
+  const uint32_t* addr = idx + (size_t)(side * 6 + m) * N;
+  const uint32_t* ts = idx + (size_t)(side * 6 + 3 + m) * N;
+  const fq* val = derefs + (size_t)(side * 3 + m) * N;
+  fq* leaf = forest + (size_t)blockIdx.y * 2 * N;
+  const fq r2c = fq_r2();
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < N; i += (size_t)gridDim.x * kBlock) {
+    fq h = fq_sub(fq_mul(fq_load(val + i), hp.r), hp.gamma);
+    uint32_t a = addr[i], t = ts[i];
+    if (a) h = fq_add(h, fq_mul(fq_raw_u32(a), r2c));
+    if (t) h = fq_add(h, fq_mul(fq_raw_u32(t), hp.r2_boost));
+    fq_store(leaf + i, kind ? fq_add(h, hp.r2) : h);
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void hash_mem_sub_kernel(const uint32_t* __restrict__ audit_ts, const fq* __restrict__ mem_rx,
+                                                              const fq* __restrict__ mem_ry, size_t M, HashParams hp,
+                                                              fq* __restrict__ forest, CircIds ids) {
+  const int g = ids.v[blockIdx.y], side = g / 2, kind = g % 2;
+  const fq* mem = side ? mem_ry : mem_rx;
+  const uint32_t* ts = audit_ts + (size_t)side * M;
+  fq* leaf = forest + (size_t)blockIdx.y * 2 * M;
+  const fq r2c = fq_r2();
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < M; i += (size_t)gridDim.x * kBlock) {
+    fq h = fq_sub(fq_mul(fq_load(mem + i), hp.r), hp.gamma);
+    if (i) h = fq_add(h, fq_mul(fq_raw_u32((uint32_t)i), r2c));
+    if (kind) {
+      uint32_t t = ts[i];
+      if (t) h = fq_add(h, fq_mul(fq_raw_u32(t), hp.r2_boost));
+    }
+    fq_store(leaf + i, h);
   }
 }
 
@@ -267,8 +307,8 @@ struct DotpPtrs { const fq* src[3]; fq* dst[3]; size_t src_stride[3]; };
 template <bool BIND>
 __global__ __launch_bounds__(kBlock, kMinWaves) void dotp_round_kernel(const fq* __restrict__ derefs, const fq* __restrict__ vals,
                                                                        size_t N, fq* __restrict__ scratch, bool from_scratch,
-                                                                       size_t pairs, fq r, Finisher fin) {
-  const int k = blockIdx.y, m = k >> 1, half = k & 1;
+                                                                       size_t pairs, fq r, Finisher fin, CircIds kmap) {
+  const int k = kmap.v[blockIdx.y], m = k >> 1, half = k & 1;  // the half this workgroup row proves (identity on one GPU)
   const size_t hN = N / 2, q4 = N / 4;
   const fq* src[3];
   fq* dst[3];
@@ -564,6 +604,34 @@ int spark_build_forests(vpin_ctx* c, const vpin_spark_decomm* d, const fq* comb_
   return VPIN_OK;
 }
 
+int spark_build_forest_sub(vpin_ctx* c, const vpin_spark_decomm* d, const fq* comb_derefs, const fq* mem_rx, const fq* mem_ry,
+                           const uint8_t r_hash[32], const uint8_t r_hash_sqr[32], const uint8_t r_hash_sqr_boost[32],
+                           const uint8_t gamma[32], SparkForest* f, const int* ids, bool is_mem) {
+  if (!c || !d || !f || !f->base || !ids || f->ncirc < 1 || f->ncirc > (is_mem ? 4 : 12)) return VPIN_EINVAL;
+  if (f->n != (is_mem ? d->M : d->N) || f->n < 2) return VPIN_ESHAPE;
+  (void)hipSetDevice(c->device);
+  HashParams hp;
+  hp.r = load_host_fq(r_hash);
+  hp.r2 = load_host_fq(r_hash_sqr);
+  hp.r2_boost = load_host_fq(r_hash_sqr_boost);
+  hp.gamma = load_host_fq(gamma);
+  CircIds cid{};
+  for (int j = 0; j < f->ncirc; j++) {
+    if (ids[j] < 0 || ids[j] >= (is_mem ? 4 : 12)) return VPIN_EINVAL;
+    cid.v[j] = ids[j];
+  }
+  const double per = is_mem ? (36.0 + 32.0 + 64.0) : (8.0 + 32.0 + 32.0 + 64.0);
+  ProfScope ps(c, VPIN_K_SPARK_BUILD, (double)f->n * f->ncirc * per);
+  if (is_mem)
+    hipLaunchKernelGGL(hash_mem_sub_kernel, dim3(grid_for(d->M), f->ncirc), dim3(kBlock), 0, c->stream,
+                       (const uint32_t*)(d->idx + 12 * d->N), mem_rx, mem_ry, d->M, hp, f->base, cid);
+  else
+    hipLaunchKernelGGL(hash_ops_sub_kernel, dim3(grid_for(d->N), f->ncirc), dim3(kBlock), 0, c->stream, (const uint32_t*)d->idx,
+                       comb_derefs, d->N, hp, f->base, cid);
+  VPIN_HIP_TRY(hipGetLastError());
+  return build_levels(c, f);
+}
+
 int spark_fetch_tops(vpin_ctx* c, const SparkForest* f, size_t cnt) {
   if (cnt * (size_t)f->ncirc > kSparkPinned || cnt > f->stride()) return VPIN_ESHAPE;
   int rc = spark_pinned(c);
@@ -638,11 +706,12 @@ static int round_finish_launch(vpin_ctx* c, const fq* partials, int ncirc, int n
   return VPIN_OK;
 }
 
-int spark_prod_round(vpin_ctx* c, const SparkForest* f, int level, size_t len, const fq* E, const uint8_t* r, bool with_dotp,
+int spark_prod_round(vpin_ctx* c, const SparkForest* f, int level, size_t len, const fq* E, const uint8_t* r, int ndotp,
                      bool lead) {
+  const bool with_dotp = ndotp > 0;
   if (!c || !f || !f->base || !E) return VPIN_EINVAL;
   const size_t h = f->n >> (level + 1);
-  if (h == 0 || len > h || !is_pow2(len) || len < (r ? 4u : 2u) || f->ncirc > 12) return VPIN_ESHAPE;
+  if (h == 0 || len > h || !is_pow2(len) || len < (r ? 4u : 2u) || f->ncirc > 12 || f->ncirc < 1 || ndotp < 0 || ndotp > 6) return VPIN_ESHAPE;
   int rc = spark_pinned(c);
   if (rc) return rc;
   (void)hipSetDevice(c->device);
@@ -653,13 +722,14 @@ int spark_prod_round(vpin_ctx* c, const SparkForest* f, int level, size_t len, c
   const fq rr = r ? load_host_fq(r) : fq{};
   const fq_const rconst = (r && lead) ? make_fq_const(r) : fq_const{};
   c->spark_seq++;  // a new launch group: this kernel (+ the dot-product kernel that follows when with_dotp)
-  Finisher fin = make_finisher(c, partials, 0, f->ncirc + (with_dotp ? 6 : 0));
+  Finisher fin = make_finisher(c, partials, 0, f->ncirc + ndotp);
   // the dot-product kernel of the same group (spark_dotp_round, next call) gets round_grid(pairs, 6) workgroups per half
-  const size_t group_blocks = (size_t)grid * f->ncirc + (with_dotp ? (size_t)round_grid(pairs, 6, c->shared_device) * 6 : 0);
+  const size_t group_blocks = (size_t)grid * f->ncirc + (with_dotp ? (size_t)round_grid(pairs, 6, c->shared_device) * ndotp : 0);
   fin.fused = group_blocks <= fused_finish_max() ? 1 : 0;
   c->round_split = fin.fused ? 0 : 1;
   c->round_split_grid = grid;
   c->round_split_ncirc = f->ncirc;
+  c->round_group_ndotp = ndotp;
   {
     // algorithmic bytes of the reference formulation: A and B of every circuit and the shared eq table read,
     // folded halves written
@@ -679,8 +749,14 @@ int spark_prod_round(vpin_ctx* c, const SparkForest* f, int level, size_t len, c
 }
 
 int spark_dotp_round(vpin_ctx* c, size_t N, const fq* vals, const fq* comb_derefs, fq* scratch, size_t len, bool first_fold,
-                     const uint8_t* r) {
-  if (!c || !vals || !comb_derefs || !scratch) return VPIN_EINVAL;
+                     const uint8_t* r, const int* halves, int ndotp) {
+  if (!c || !vals || !comb_derefs || !scratch || ndotp < 1 || ndotp > 6) return VPIN_EINVAL;
+  if (ndotp != c->round_group_ndotp) return VPIN_ESHAPE;  // the launch group was announced with another count (spark_prod_round)
+  CircIds kmap{};
+  for (int i = 0; i < ndotp; i++) {
+    kmap.v[i] = halves ? halves[i] : i;
+    if (kmap.v[i] < 0 || kmap.v[i] > 5) return VPIN_EINVAL;
+  }
   if (len > N / 2 || !is_pow2(len) || len < (r ? 4u : 2u) || (first_fold && (!r || len != N / 2))) return VPIN_ESHAPE;
   int rc = spark_pinned(c);
   if (rc) return rc;
@@ -691,21 +767,21 @@ int spark_dotp_round(vpin_ctx* c, size_t N, const fq* vals, const fq* comb_deref
   const int grid = round_grid(pairs, 6, c->shared_device);
   const fq rr = r ? load_host_fq(r) : fq{};
   const bool from_scratch = r && !first_fold;
-  // same launch group as the product circuits' kernel just issued: instances 12..17 of 18
-  Finisher fin = make_finisher(c, partials + (size_t)12 * kRoundBlocks * 3, 12, 18);
+  // same launch group as the product circuits' kernel just issued: slots 12.. of the group's instances
+  Finisher fin = make_finisher(c, partials + (size_t)12 * kRoundBlocks * 3, 12, c->round_split_ncirc + ndotp);
   fin.fused = c->round_split ? 0 : 1;  // decided for the whole group by spark_prod_round
   {
-    const double bytes = 6 * 3 * 32.0 * (r ? (double)len * 1.5 : (double)len);
+    const double bytes = ndotp * 3 * 32.0 * (r ? (double)len * 1.5 : (double)len);
     ProfScope ps(c, VPIN_K_SPARK_ROUND, bytes);
     if (r)
-      hipLaunchKernelGGL((dotp_round_kernel<true>), dim3(grid, 6), dim3(kBlock), 0, c->stream, comb_derefs, vals, N, scratch,
-                         from_scratch, pairs, rr, fin);
+      hipLaunchKernelGGL((dotp_round_kernel<true>), dim3(grid, ndotp), dim3(kBlock), 0, c->stream, comb_derefs, vals, N, scratch,
+                         from_scratch, pairs, rr, fin, kmap);
     else
-      hipLaunchKernelGGL((dotp_round_kernel<false>), dim3(grid, 6), dim3(kBlock), 0, c->stream, comb_derefs, vals, N, scratch,
-                         false, pairs, rr, fin);
+      hipLaunchKernelGGL((dotp_round_kernel<false>), dim3(grid, ndotp), dim3(kBlock), 0, c->stream, comb_derefs, vals, N, scratch,
+                         false, pairs, rr, fin, kmap);
   }
   VPIN_HIP_TRY(hipGetLastError());
-  if (!fin.fused) return round_finish_launch(c, partials, c->round_split_ncirc, c->round_split_grid, 6, grid);
+  if (!fin.fused) return round_finish_launch(c, partials, c->round_split_ncirc, c->round_split_grid, ndotp, grid);
   return VPIN_OK;
 }
 
@@ -785,7 +861,8 @@ struct TailArgs {
   const fq* pyr; int k;                           // suffix pyramid of the layer's k rounds
   int j0; size_t len0;                            // first round of the tail, live length before it
   fq r_prev;                                      // r_{j0-1} (j0 > 0)
-  const fq* derefs; const fq* vals; fq* scratch; size_t N;  // dot-product halves: blockIdx.x - ncirc = 0..5
+  const fq* derefs; const fq* vals; fq* scratch; size_t N;  // dot-product halves: blockIdx.x - ncirc = index into kmap
+  CircIds kmap;                                             // the half (matrix, half) each of those workgroups proves
   // Mailbox in pinned host memory.  Every 32-byte scalar travels as three 16-byte pieces {seq, w, w, w}: a 16-byte store
   // (GPU -> host) or load (host -> GPU) is one bus transaction, so a piece that carries the expected sequence number is
   // whole and current -- no fence, no flag, no second round trip.
@@ -845,7 +922,7 @@ __global__ __launch_bounds__(kTailBlock) void spark_tail_kernel(TailArgs a) {
     A = a.forest + (size_t)inst * a.stride + a.off;
     Bt = A + a.h;
   } else {
-    const int kk = inst - a.ncirc, m = kk >> 1, half = kk & 1;
+    const int kk = a.kmap.v[inst - a.ncirc], m = kk >> 1, half = kk & 1;
     const size_t hN = a.N / 2, q4 = a.N / 4;
     src[0] = a.derefs + (size_t)m * a.N + (size_t)half * hN;
     src[1] = a.derefs + (size_t)(3 + m) * a.N + (size_t)half * hN;
@@ -994,10 +1071,10 @@ size_t spark_tail_pairs() {
 }
 
 int spark_tail_launch(vpin_ctx* c, const SparkForest* f, int level, int k, int j0, size_t len0, const fq* pyr, const uint8_t* r_prev,
-                      size_t N, const fq* vals, const fq* comb_derefs, fq* scratch) {
-  if (!c || !f || !f->base || !pyr || k < 1 || j0 < 0 || j0 >= k || (j0 > 0 && !r_prev) || f->ncirc > 12) return VPIN_EINVAL;
-  const bool with_dotp = vals != nullptr;
-  if (with_dotp && (!comb_derefs || !scratch || f->ncirc != 12 || level != 0 || N != f->n)) return VPIN_EINVAL;
+                      size_t N, const fq* vals, const fq* comb_derefs, fq* scratch, const int* halves, int ndotp) {
+  if (!c || !f || !f->base || !pyr || k < 1 || j0 < 0 || j0 >= k || (j0 > 0 && !r_prev) || f->ncirc > 12 || f->ncirc < 1) return VPIN_EINVAL;
+  const bool with_dotp = vals != nullptr && ndotp > 0;
+  if (with_dotp && (!comb_derefs || !scratch || ndotp > 6 || level != 0 || N != f->n)) return VPIN_EINVAL;
   const size_t h = f->n >> (level + 1);
   if (h != ((size_t)1 << k) || len0 != (j0 == 0 ? h : (h >> (j0 - 1)))) return VPIN_ESHAPE;
   int rc = spark_pinned(c);
@@ -1008,6 +1085,7 @@ int spark_tail_launch(vpin_ctx* c, const SparkForest* f, int level, int k, int j
   a.pyr = pyr; a.k = k; a.j0 = j0; a.len0 = len0;
   if (r_prev) a.r_prev = load_host_fq(r_prev);
   a.derefs = comb_derefs; a.vals = vals; a.scratch = scratch; a.N = N;
+  for (int i = 0; i < 6; i++) a.kmap.v[i] = (with_dotp && halves && i < ndotp) ? halves[i] : i;
   a.up = tail_up(c);
   uint32_t* w = tail_words(c);
   a.abort_flag = w; a.down = w + 16;
@@ -1017,7 +1095,7 @@ int spark_tail_launch(vpin_ctx* c, const SparkForest* f, int level, int k, int j
   a.trace = trace_on ? reinterpret_cast<unsigned long long*>(c->h_spark + kTailTrace) : nullptr;
   if (trace_on) memset(c->h_spark + kTailTrace, 0, 64 * 32);
   c->tail_rounds = k - j0;
-  const int ninst = f->ncirc + (with_dotp ? 6 : 0);
+  const int ninst = f->ncirc + (with_dotp ? ndotp : 0);
   {
     ProfScope ps(c, VPIN_K_SPARK_TAIL, 0.0);
     hipLaunchKernelGGL(spark_tail_kernel, dim3(ninst), dim3(kTailBlock), 0, c->stream, a);
@@ -1112,7 +1190,7 @@ extern "C" int vpin_spark_batched_round(vpin_ctx* c, vpin_table* forest, size_t 
   if (with_dotp && (derefs->len < 6 * n || vals->len < 3 * n || scratch->len < 18 * (n / 4))) return VPIN_ESHAPE;
   SparkForest f;
   f.base = forest->d; f.n = n; f.ncirc = ncirc;
-  int rc = spark_prod_round(c, &f, level, len, E->d + e_off, r, with_dotp, lead != 0);
+  int rc = spark_prod_round(c, &f, level, len, E->d + e_off, r, with_dotp ? 6 : 0, lead != 0);
   if (!rc && with_dotp) rc = spark_dotp_round(c, n, vals->d, derefs->d, scratch->d, len, first_fold != 0, r);
   if (!rc) rc = spark_wait_flag(c);
   if (rc) return rc;

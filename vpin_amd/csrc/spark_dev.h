@@ -55,6 +55,12 @@ int spark_build_forests(vpin_ctx* c, const vpin_spark_decomm* d, const fq* comb_
                         const uint8_t r_hash[32], const uint8_t r_hash_sqr[32], const uint8_t r_hash_sqr_boost[32],
                         const uint8_t gamma[32], SparkForest* ops, SparkForest* mem);
 
+// The same for a subset of the circuits: f holds ncirc trees, ids[j] = global circuit of tree j (ops: side*6 + kind*3 + m,
+// kind 0 read / 1 write; mem: side*2 + kind, kind 0 init / 1 audit).  One proof over several GPUs: a rank's own circuits.
+int spark_build_forest_sub(vpin_ctx* c, const vpin_spark_decomm* d, const fq* comb_derefs, const fq* mem_rx, const fq* mem_ry,
+                           const uint8_t r_hash[32], const uint8_t r_hash_sqr[32], const uint8_t r_hash_sqr_boost[32],
+                           const uint8_t gamma[32], SparkForest* f, const int* ids, bool is_mem);
+
 // the last `cnt` entries of every tree (the levels of <= cnt/2 entries), to ctx->h_spark
 // [tree][cnt]; synchronises
 int spark_fetch_tops(vpin_ctx* c, const SparkForest* f, size_t cnt);
@@ -67,7 +73,8 @@ int spark_fetch_tops(vpin_ctx* c, const SparkForest* f, size_t cnt);
 // Starts a new launch group; with_dotp announces that spark_dotp_round follows in the same group.
 // lead = true: h_spark[3*t] = sum_i E[i]*(A_0 B_0)[i] and h_spark[3*t + 1] = sum_i E[i]*(dA dB)[i] (value at 0 and x^2
 // coefficient of the quadratic; the host derives the values at 2 and 3 from the circuit's claim), third slot zero.
-int spark_prod_round(vpin_ctx* c, const SparkForest* f, int level, size_t len, const fq* E, const uint8_t* r, bool with_dotp,
+// ndotp: number of dot-product halves spark_dotp_round adds to the same launch group (0 = none; 6 on one GPU).
+int spark_prod_round(vpin_ctx* c, const SparkForest* f, int level, size_t len, const fq* E, const uint8_t* r, int ndotp,
                      bool lead = false);
 
 // Same for the 6 DotProductCircuit halves of layer 0 (comb = A*B*C, three foldable tables each,
@@ -77,8 +84,10 @@ int spark_prod_round(vpin_ctx* c, const SparkForest* f, int level, size_t len, c
 // round 0: r == nullptr, len = N/2.  Results at ctx->h_spark[3*(12+k) + x].  Call right after
 // spark_prod_round(..., with_dotp = true).
 // vals = the three val slices of comb_ops (3 x N), N = leaves of the ops forest.
+// halves / ndotp: the subset of the six halves this call proves (one proof over several GPUs: a rank's own halves), results
+// at slots 12, 13, .. in that order; nullptr / 6 = all of them.
 int spark_dotp_round(vpin_ctx* c, size_t N, const fq* vals, const fq* comb_derefs, fq* scratch, size_t len, bool first_fold,
-                     const uint8_t* r);
+                     const uint8_t* r, const int* halves = nullptr, int ndotp = 6);
 
 // completion of the current launch group: spins on the pinned flag word the last block publishes
 int spark_wait_flag(vpin_ctx* c);
@@ -101,7 +110,7 @@ int spark_triple_sums(vpin_ctx* c, const vpin_spark_decomm* d, const fq* comb_de
 // retires the launch's sequence numbers.  len0 = live length before round j0; r_prev = r_{j0-1} when j0 > 0.
 size_t spark_tail_pairs();  // rounds with at most this many pairs per circuit go to the tail (0 = never)
 int spark_tail_launch(vpin_ctx* c, const SparkForest* f, int level, int k, int j0, size_t len0, const fq* pyr, const uint8_t* r_prev,
-                      size_t N, const fq* vals, const fq* comb_derefs, fq* scratch);
+                      size_t N, const fq* vals, const fq* comb_derefs, fq* scratch, const int* halves = nullptr, int ndotp = 6);
 int spark_tail_wait(vpin_ctx* c, int idx, int ninst, int ncirc);
 void spark_tail_reply(vpin_ctx* c, int idx, const uint8_t r[32]);
 void spark_tail_end(vpin_ctx* c);

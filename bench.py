@@ -39,6 +39,11 @@ import sys
 import threading
 import time
 
+if "--rehearse" in sys.argv:
+    # W ranks as threads keep W persistent round kernels resident at once; HIP maps a process's streams onto
+    # GPU_MAX_HW_QUEUES hardware queues (default 4) and streams sharing a queue run in order.  Before HIP initialises.
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -79,8 +84,14 @@ def parse():
     ap.add_argument("--no-verify", action="store_true", help="skip the post-run verification of the last step's SNARKs")
     ap.add_argument("--no-prof", action="store_true", help="no HIP-event bracketing of kernels (no roofline object)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
-                    help="weak (default): every rank proves its own trace; strong: ONE trace over all ranks -- its instances "
-                         "LPT-sharded, the largest instance's derefs commitment (the single largest MSM) split by rows across the ranks")
+                    help="weak (default): every rank proves its own trace; strong: ONE trace over all ranks -- the large instances "
+                         "proven by all ranks together (vpin_comm), the small ones LPT-sharded")
+    ap.add_argument("--rehearse", type=int, default=0,
+                    help="with --scaling strong: W ranks as threads of this process on ONE GPU, serialised, to measure the "
+                         "critical path of a W-GPU run (a model: no multi-GPU hardware involved)")
+    ap.add_argument("--rehearse-passes", type=int, default=3, help="serialised passes per cooperative instance; the quietest one is reported")
+    ap.add_argument("--coop-log2", type=int, default=20,
+                    help="--scaling strong: instances of at least 2^this constraints are proven by all ranks together")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend of the N>1 runs (gloo: rehearsal with ranks sharing a GPU)")
     ap.add_argument("--no-roofline-pass", action="store_true",
                     help="skip the serial pass after the timed region that fills roofline.secondary (largest instance alone)")
@@ -89,24 +100,8 @@ def parse():
     return ap.parse_args()
 
 
-def main_strong(args):
-    """--scaling strong: one trace, all ranks.  The 12 instances are LPT-sharded by constraint count (vpin_amd.dist.plan_shards);
-    the largest instance is proven by rank 0 with its derefs commitment split by rows over every rank (vpin_amd.dist.SplitCommit:
-    broadcast of (rx, ry), all-gather of 32-byte rows; the other ranks serve their block from a side thread / stream while they
-    prove their own shard).  value = the trace's constraints x steps / slowest rank's time."""
-    import threading
-    import torch
-    import vpin_amd
+def _strong_work(args):
     from vpin_amd import gadgets as G
-    from vpin_amd.dist import Group, SplitCommit, SplitEngine, env_rank, plan_shards
-
-    rank, local_rank, world = env_rank()
-    ndev = torch.cuda.device_count()
-    dev = local_rank % max(1, ndev)
-    use_nccl = args.backend == "nccl" and world > 1
-    if use_nccl:
-        torch.cuda.set_device(dev)
-    grp = Group(backend=args.backend, device=torch.device("cuda", dev) if use_nccl else None)
     trace = args.label or args.trace
     labels = list(G.LENET) if trace == "lenet" else [trace]
     work = []
@@ -116,58 +111,70 @@ def main_strong(args):
             work.append((f"{lab}-mult", "mult", m, 3464 * len(m[0])))
         a = G.synthetic_add_inputs(lab)
         work.append((f"{lab}-add", "add", a, 10 * len(a[4])))
+    if args.only:
+        work = [w for w in work if w[1] == args.only]
     work.sort(key=lambda w: -w[3])
+    return trace, work
+
+
+def _build_resident(cx, w):
+    g = cx.gadget_point_mult_dev(*w[2]) if w[1] == "mult" else cx.gadget_point_add_dev(*w[2])
+    cx.sat_prepare(g.num_vars)
+    dec, _ = g.spark_encode()
+    return g, dec
+
+
+def _prove_res(cx, g, dec):
+    return cx.snark_prove_resident(g.r1cs, dec, g.vars_para, g.vars_input, g.vars, g.inputs, SEED_C, SEED_P)
+
+
+def main_strong(args):
+    """--scaling strong: ONE trace over all ranks.  Instances of at least 2^--coop-log2 constraints are
+    proven by ALL ranks together (vpin_comm: row commitments by row blocks, product circuits / dot-product halves / slices by
+    index, see include/vpin_hip.h), one after another; the small, latency-bound instances are LPT-sharded over the ranks and
+    proven without any exchange.  value = the trace's constraints x steps / slowest rank's time.
+    Ranks = processes (torch.distributed.run; the exchange goes through POSIX shared memory, device buffers through RCCL
+    when the backend is nccl)."""
+    if args.rehearse:
+        return strong_rehearse(args)
+    import hashlib
+    import torch
+    import vpin_amd
+    from vpin_amd import Comm
+    from vpin_amd.dist import Group, env_rank, plan_shards
+
+    rank, local_rank, world = env_rank()
+    ndev = max(1, torch.cuda.device_count())
+    dev = local_rank % ndev
+    use_nccl = args.backend == "nccl" and world > 1
+    if use_nccl:
+        torch.cuda.set_device(dev)
+    grp = Group(backend=args.backend, device=torch.device("cuda", dev) if use_nccl else None)
+    trace, work = _strong_work(args)
     total_cons = sum(w[3] for w in work)
-    big = work[0]
-    # rank 0 owns the largest instance; about 40 % of its time is the split commitment, so it weighs 0.6 of its constraints
-    costs = [int(0.6 * big[3])] + [w[3] for w in work[1:]]
-    shards = plan_shards(costs, world)
-    assert 0 in shards[0]
-    mine = [work[i] for i in shards[rank] if i != 0]
+    coop = [w for w in work if w[3] >= (1 << args.coop_log2) * 0.5]
+    small = [w for w in work if w not in coop]
+    shards = plan_shards([w[3] for w in small], world)
+    mine = [small[i] for i in shards[rank]]
 
     ctx = vpin_amd.Context(dev)
-    ctx_h = vpin_amd.Context(dev) if (world > 1 and rank != 0) else None  # helper stream: serves the owner's request
-    if ctx_h is not None:
-        ctx.set_shared_device(True)
-        ctx_h.set_shared_device(True)
-
-    def build(cx, w):
-        g = cx.gadget_point_mult_dev(*w[2]) if w[1] == "mult" else cx.gadget_point_add_dev(*w[2])
-        cx.sat_prepare(g.num_vars)
-        dec, _ = g.spark_encode()
-        return g, dec
-
-    gb, decb = build(ctx_h if ctx_h is not None else ctx, big)  # every rank holds the largest circuit's decommitment
-    N = 1
-    while N < max(lib_nnz(gb)):
-        N *= 2
-    ell = (N.bit_length() - 1) + 3
-    L = 1 << (ell // 2)
-    own = {w[0]: build(ctx, w) for w in mine}
-    sc = SplitCommit(grp, SplitEngine(ctx_h if ctx_h is not None else ctx, decomm=decb, derefs_ell=ell), owner=0)
-    if rank == 0 and world > 1:
-        ctx.set_split(sc, min_len=1 << 22)
-
-    def prove(cx, g, dec):
-        return cx.snark_prove_resident(g.r1cs, dec, g.vars_para, g.vars_input, g.vars, g.inputs, SEED_C, SEED_P)
-
-    proof_bytes = {}
+    cm = None
+    if world > 1:
+        name = grp.gather_objects(f"/vpin-{os.getpid()}-{int(time.time() * 1e3) & 0xffffff}")[0]  # rank 0's choice
+        cm = Comm.shm(name, rank, world)
+        if use_nccl and ndev >= world:
+            cm.enable_rccl(ctx)
+    built = {w[0]: _build_resident(ctx, w) for w in coop + mine}
+    proof_sha = {}
 
     def step():
-        t = None
-        if ctx_h is not None:
-            def serve():
-                if use_nccl:
-                    torch.cuda.set_device(dev)  # the current device is per thread
-                sc.serve_one(L)
-            t = threading.Thread(target=serve)
-            t.start()
-        if rank == 0:
-            proof_bytes[big[0]] = len(prove(ctx, gb, decb)["proof"])
-        for name, (g, dec) in own.items():
-            proof_bytes[name] = len(prove(ctx, g, dec)["proof"])
-        if t is not None:
-            t.join()
+        if cm is not None:
+            ctx.set_comm(cm)
+        for w in coop:
+            proof_sha[w[0]] = hashlib.sha256(_prove_res(ctx, *built[w[0]])["proof"]).hexdigest()
+        ctx.set_comm(None)
+        for w in mine:
+            proof_sha[w[0]] = hashlib.sha256(_prove_res(ctx, *built[w[0]])["proof"]).hexdigest()
 
     def barrier():
         torch.cuda.synchronize()
@@ -176,6 +183,8 @@ def main_strong(args):
 
     for _ in range(args.warmup):
         step()
+    if cm is not None:
+        cm.stats(reset=True)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -183,8 +192,11 @@ def main_strong(args):
     ctx.sync()
     barrier()
     elapsed = grp.max_over_ranks(time.perf_counter() - t0)
-    names = grp.gather_objects([w[0] for w in mine] + ([big[0]] if rank == 0 else []))
+    shas = grp.gather_objects(proof_sha)
+    st = cm.stats() if cm is not None else None
     if rank == 0:
+        gold = _golden_digests()
+        all_sha = {k: v for d in shas for k, v in d.items()}
         print(json.dumps({
             "metric": "R1CS constraints/sec, whole Spartan SNARK (sat proof + SPARK evaluation proof; vPIN point-mult + point-add instances)",
             "value": total_cons * args.steps / elapsed, "unit": "constraints/s", "n_gpus": world, "steps": args.steps,
@@ -192,13 +204,177 @@ def main_strong(args):
             "vs_baseline": None, "dtype": "u256 (mod q = 2^252+..., mod p = 2^255-19; 32-bit limbs)", "data": "synthetic",
             "config": {"workload": f"ONE vPIN trace '{trace}' over {world} rank(s): {len(work)} SNARKs per step",
                        "constraints_unpadded_per_step": total_cons,
-                       "parallelism": f"instances LPT-sharded over {world} rank(s) by constraint count; {big[0]}'s derefs commitment "
-                                      f"({L} rows) split by rows over all ranks: broadcast of (rx, ry), all-gather of 32-byte rows over "
-                                      f"{args.backend}; no other data-path collective",
-                       "shards": names},
-            "proof_bytes": proof_bytes}))
-    ctx.set_split(None)
+                       "parallelism": f"{[w[0] for w in coop]} proven by all {world} rank(s) together (vpin_comm over shared memory"
+                                      f"{', device buffers over RCCL' if (cm is not None and use_nccl and ndev >= world) else ''}: row "
+                                      "commitments by row blocks, product circuits / dot-product halves / slices by index); the other "
+                                      "instances LPT-sharded, no exchange",
+                       "shards": [[small[i][0] for i in sh] for sh in shards]},
+            "bytes_equal_oracle_digest": {k: (gold.get(k, {}).get("snark_sha256") == v) for k, v in all_sha.items()},
+            "comm": st}))
+    if cm is not None:
+        cm.destroy()
+    for g, dec in built.values():
+        dec.free()
+        g.free()
+    ctx.close()
     grp.close()
+
+
+def _golden_digests():
+    try:
+        with open(os.path.join(ROOT, "tests", "golden", "config_digests.json")) as f:
+            return json.load(f)["cases"]
+    except OSError:
+        return {}
+
+
+def strong_rehearse(args):
+    """--scaling strong --rehearse W: the critical path of a W-GPU run, measured on ONE GPU.  W ranks run as threads of this
+    process and prove each cooperative instance together with vpin_comm_set_serialize on: one rank computes at a time, so the
+    time a rank spends between two collectives is its own work and nothing else, and the W-GPU time of the proof is the sum over
+    the collectives of the slowest rank's section (crit_s) plus the exchanges themselves (collectives x the measured latency of
+    an all-gather among W threads).  A MODEL of the multi-GPU run from measured sections -- no multi-GPU hardware was used."""
+    import hashlib
+    import threading
+    import vpin_amd
+    from vpin_amd import Comm
+    from vpin_amd.dist import plan_shards
+
+    W = args.rehearse
+    trace, work = _strong_work(args)
+    total_cons = sum(w[3] for w in work)
+    coop = [w for w in work if w[3] >= (1 << args.coop_log2) * 0.5]
+    small = [w for w in work if w not in coop]
+    gold = _golden_digests()
+    ctx0 = vpin_amd.Context(0)
+
+    # exchange latency among W threads (unserialised, 1728-byte pieces = 18 instances x 3 scalars)
+    comms = Comm.local(W)
+    lat = [0.0] * W
+
+    def pingpong(r):
+        lat[r] = comms[r].latency(1728, 5000)
+
+    ts = [threading.Thread(target=pingpong, args=(r,)) for r in range(W)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    for cm in comms:
+        cm.destroy()
+    t_ag = max(lat)
+
+    per = {}
+    single_ms = {}
+    for w in work:
+        g, dec = _build_resident(ctx0, w)
+        # the single-GPU proof runs on a context of its own, closed afterwards: its pooled temporaries (tens of GB for the
+        # largest instance) must not sit in HBM next to the W ranks' own
+        ctx1 = vpin_amd.Context(0)
+        _prove_res(ctx1, g, dec)  # warm: generator views, pools
+        best = 1e9
+        for _ in range(max(1, args.steps)):
+            t0 = time.perf_counter()
+            ref = _prove_res(ctx1, g, dec)
+            best = min(best, time.perf_counter() - t0)
+        ctx1.close()
+        single_ms[w[0]] = best * 1e3
+        sha = hashlib.sha256(ref["proof"]).hexdigest()
+        rec = {"single_gpu_ms": round(best * 1e3, 3), "bytes_equal_oracle_digest": gold.get(w[0], {}).get("snark_sha256") == sha}
+        if w in coop:
+            ctxs = [ctx0] + [vpin_amd.Context(0) for _ in range(W - 1)]
+            comms = Comm.local(W)
+            out, errs, stats, tags = [None] * W, [], [None] * W, [None] * W
+            passes = [[] for _ in range(W)]
+
+            def body(r):
+                try:
+                    ctxs[r].set_comm(comms[r])
+                    for it in range(1 + args.rehearse_passes):  # first pass warms every rank's pools and generator views
+                        comms[r].set_serialize(True)
+                        comms[r].stats(reset=True)
+                        out[r] = _prove_res(ctxs[r], g, dec)
+                        ctxs[r].sync()
+                        comms[r].allgather(b"")  # closes the section after the proof's last collective
+                        st_r, tg_r = comms[r].stats(), comms[r].tag_stats()
+                        comms[r].set_serialize(False)
+                        # keep the quietest pass (allocation stalls and host scheduling only ever add time); every rank sees
+                        # the same crit_s, so every rank keeps the same pass
+                        if it >= 1:
+                            passes[r].append((st_r, tg_r))
+                            if stats[r] is None or st_r["crit_s"] < stats[r]["crit_s"]:
+                                stats[r], tags[r] = st_r, tg_r
+                    ctxs[r].set_comm(None)
+                except BaseException as e:  # noqa: BLE001
+                    errs.append((r, repr(e)))
+
+            ts = [threading.Thread(target=body, args=(r,)) for r in range(W)]
+            [t.start() for t in ts]
+            [t.join() for t in ts]
+            for cm in comms:
+                cm.destroy()
+            for cx in ctxs[1:]:
+                cx.close()
+            if errs:
+                rec["rehearsal_error"] = errs
+            else:
+                st = stats[0]
+                rec.update({
+                    "all_ranks_bytes_equal_single_gpu": all(o["proof"] == ref["proof"] for o in out),
+                    "collectives": st["collectives"],
+                    "crit_ms": round(st["crit_s"] * 1e3, 3),
+                    "exchange_ms": round(st["collectives"] * t_ag * 1e3, 3),
+                    "model_ms": round((st["crit_s"] + st["collectives"] * t_ag) * 1e3, 3),
+                    "busy_ms_per_rank": [round(s["busy_s"] * 1e3, 3) for s in stats],
+                    "crit_ms_by_step": {k: round(v["crit_s"] * 1e3, 3) for k, v in sorted(tags[0].items(), key=lambda kv: -kv[1]["crit_s"])},
+                    "busy_ms_by_step_per_rank": {k: [round(tags[r].get(k, {"busy_s": 0.0})["busy_s"] * 1e3, 3) for r in range(W)]
+                                                 for k in sorted(tags[0], key=lambda kk: -tags[0][kk]["crit_s"])[:10]},
+                })
+                # Per step of the protocol (tag): the library's crit_s is sum over the collectives of the slowest rank's section.
+                # On one GPU shared by W ranks two artefacts inflate it: a stall in one rank's section in one pass (allocation
+                # when the W ranks' temporaries nearly fill the 288 GB; host scheduling) -- so every step takes its quietest
+                # pass -- and, for REPLICATED steps (identical work on every rank), a rank that is slow in every pass for the
+                # same reason -- so those take the fastest rank's time.
+                replicated = {"sat_replicated", "sat_phase1_rest", "sat_phase2_rest", "derefs_gather", "network_alloc",
+                              "hash_eq_tables", "hash_bullet"}
+                tagq = {}
+                for k in tags[0]:
+                    v = min(tg[k]["crit_s"] for _st, tg in passes[0] if k in tg)
+                    ncoll = tags[0][k]["collectives"]
+                    quiet_r = [min(tg[k]["busy_s"] for _st, tg in passes[r] if k in tg) for r in range(W)]
+                    if k in replicated:
+                        v = min(v, min(quiet_r))
+                    elif ncoll <= 3:
+                        # a one-shot sharded step: the slowest rank, each rank at its quietest (for the round steps, hundreds of
+                        # collectives each, the library's sum of per-collective maxima stands)
+                        v = min(v, max(quiet_r))
+                    tagq[k] = v
+                tagged_best = sum(v["crit_s"] for v in tags[0].values())
+                untagged = max(0.0, st["crit_s"] - tagged_best)
+                quiet = sum(tagq.values()) + untagged
+                rec["crit_ms_quietest_pass_per_step"] = round(quiet * 1e3, 3)
+                rec["model_ms_quietest_pass_per_step"] = round((quiet + st["collectives"] * t_ag) * 1e3, 3)
+                rec["crit_ms_by_step_quietest"] = {k: round(v * 1e3, 3) for k, v in sorted(tagq.items(), key=lambda kv: -kv[1])}
+                rec["fraction_of_single_gpu"] = round(rec["model_ms"] / rec["single_gpu_ms"], 4)
+                rec["fraction_of_single_gpu_quietest"] = round(rec["model_ms_quietest_pass_per_step"] / rec["single_gpu_ms"], 4)
+        per[w[0]] = rec
+        dec.free()
+        g.free()
+    shards = plan_shards([int(single_ms[w[0]] * 1e3) for w in small], W)
+    share_ms = [sum(single_ms[small[i][0]] for i in sh) for sh in shards]
+    ok = all("model_ms" in per[w[0]] for w in coop)
+    model_ms = (sum(per[w[0]]["model_ms"] for w in coop) + (max(share_ms) if share_ms else 0.0)) if ok else None
+    serial_ms = sum(single_ms.values())
+    print(json.dumps({
+        "metric": "critical-path MODEL of one vPIN trace proven by W GPUs (sections measured on one GPU, ranks serialised)",
+        "unmeasured_on_multi_gpu_hardware": True, "world": W, "trace": trace, "constraints_unpadded_per_step": total_cons,
+        "single_gpu_serial_ms": round(serial_ms, 3), "model_ms": None if model_ms is None else round(model_ms, 3),
+        "model_speedup_vs_single_gpu_serial": None if model_ms is None else round(serial_ms / model_ms, 3),
+        "model_constraints_per_s": None if model_ms is None else total_cons / model_ms * 1e3,
+        "allgather_latency_us_among_threads": round(t_ag * 1e6, 2),
+        "cooperative": [w[0] for w in coop], "sharded_small_instances": [[small[i][0] for i in sh] for sh in shards],
+        "small_share_ms_per_rank": [round(x, 3) for x in share_ms], "instances": per,
+        "plan": dict(zip(("owner_ops", "owner_dotp", "owner_mem"), vpin_amd.dist_plan(W))),
+    }))
+    ctx0.close()
 
 
 def lib_nnz(g):

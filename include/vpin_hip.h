@@ -328,6 +328,12 @@ typedef struct {
   double crit_s;  /* sum over collectives of max over ranks of the section before it */
 } vpin_comm_stats;
 int vpin_comm_stats_read(vpin_comm* cm, vpin_comm_stats* out, int reset);
+/* the same per step of the protocol (the section before a collective is booked on the call site's tag; under
+ * vpin_comm_set_serialize the proofs add empty marker collectives between their steps): text, one line per tag
+ * "<tag> <collectives> <busy_s> <crit_s>"; returns the buffer size needed */
+size_t vpin_comm_stats_tags(vpin_comm* cm, char* buf, size_t cap);
+/* seconds per all-gather of `bytes` per rank over `iters` back-to-back collectives issued inside the library. Collective. */
+int vpin_comm_latency(vpin_comm* cm, size_t bytes, int iters, double* seconds_per_collective);
 /* attach (or detach with NULL): proofs on this context become collective calls over `cm`'s ranks */
 int vpin_ctx_set_comm(vpin_ctx* ctx, vpin_comm* cm);
 /* the b"gens_r1cs_eval" view a polynomial of 2^ell scalars is committed under (PolyCommitmentGens::new(ell, ..)) */

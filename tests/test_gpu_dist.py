@@ -173,7 +173,7 @@ def test_staged_device_allgather_threads():
     import ctypes as C
     import vpin_amd
     from vpin_amd import Comm
-    world = 3
+    world = 4
     comms = Comm.local(world)
     ctxs = [vpin_amd.Context(0) for _ in range(world)]
     outs, errs = [None] * world, []

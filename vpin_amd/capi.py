@@ -369,6 +369,8 @@ def _comm_decl():
     L.vpin_comm_enable_rccl.argtypes = [vp, vp]
     L.vpin_comm_set_serialize.argtypes = [vp, C.c_int]
     L.vpin_comm_stats_read.argtypes = [vp, C.POINTER(CommStats), C.c_int]
+    L.vpin_comm_stats_tags.argtypes = [vp, vp, C.c_size_t]
+    L.vpin_comm_stats_tags.restype = C.c_size_t
     L.vpin_dist_plan.argtypes = [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L._comm_declared = True
     return L
@@ -438,6 +440,26 @@ class Comm:
         st = CommStats()
         _chk(_comm_decl().vpin_comm_stats_read(self.h, C.byref(st), 1 if reset else 0), "vpin_comm_stats_read")
         return dict(collectives=int(st.collectives), bytes=st.bytes, wait_s=st.wait_s, busy_s=st.busy_s, crit_s=st.crit_s)
+
+    def latency(self, nbytes=1728, iters=2000):
+        """seconds per all-gather, measured inside the library (collective)"""
+        L = _comm_decl()
+        L.vpin_comm_latency.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_double)]
+        out = C.c_double(0.0)
+        _chk(L.vpin_comm_latency(self.h, nbytes, iters, C.byref(out)), "vpin_comm_latency")
+        return out.value
+
+    def tag_stats(self):
+        """{tag: dict(collectives, busy_s, crit_s)}: the critical path per step of the protocol (serialized rehearsal)"""
+        L = _comm_decl()
+        n = L.vpin_comm_stats_tags(self.h, None, 0)
+        buf = C.create_string_buffer(n + 16)
+        L.vpin_comm_stats_tags(self.h, buf, n + 16)
+        out = {}
+        for line in buf.value.decode().splitlines():
+            tag, cnt, busy, crit = line.split()
+            out[tag] = dict(collectives=int(cnt), busy_s=float(busy), crit_s=float(crit))
+        return out
 
     def destroy(self):
         if self.h:

@@ -65,13 +65,15 @@ static double env_timeout() {
 struct Spinner {
   double deadline;
   long spins = 0;
-  explicit Spinner(double timeout_s) : deadline(now_s() + timeout_s) {}
+  bool lazy;  // serialized rehearsal: the waiters of a token sleep, so that W - 1 spinning threads do not take the
+              // host cores the one computing rank's OpenMP teams need
+  explicit Spinner(double timeout_s, bool lazy_ = false) : deadline(now_s() + timeout_s), lazy(lazy_) {}
   // false when the deadline has passed
   bool step() {
     spins++;
     if (spins < 2000) { __builtin_ia32_pause(); return true; }
     if ((spins & 63) == 0 && now_s() > deadline) return false;
-    sched_yield();
+    if (lazy) usleep(30); else sched_yield();
     return true;
   }
 };
@@ -86,7 +88,7 @@ static void seg_init(CommSeg* s, int world, size_t slot_bytes) {
 
 static int token_acquire(vpin_comm* cm) {
   if (cm->has_token) return VPIN_OK;
-  Spinner sp(cm->timeout_s);
+  Spinner sp(cm->timeout_s, true);
   for (;;) {
     uint32_t exp = kNoHolder;
     if (cm->seg->token.compare_exchange_weak(exp, (uint32_t)cm->rank, std::memory_order_acquire)) break;
@@ -117,7 +119,7 @@ static int seg_allgather_piece(vpin_comm* cm, const uint8_t* send, uint8_t* recv
   for (int i = 0; i < cm->world; i++) {
     const int r = (cm->rank + i) % cm->world;  // own piece first, then the neighbours in ring order
     if (r != cm->rank) {
-      Spinner sp(cm->timeout_s);
+      Spinner sp(cm->timeout_s, cm->serialize);
       while (slot_hdr(s, r)->seq.load(std::memory_order_acquire) < k) {
         if (s->abort_flag.load(std::memory_order_relaxed)) return VPIN_ECOMM;
         if (!sp.step()) { s->abort_flag.store(1); return VPIN_ECOMM; }
@@ -131,7 +133,7 @@ static int seg_allgather_piece(vpin_comm* cm, const uint8_t* send, uint8_t* recv
   return VPIN_OK;
 }
 
-int comm_allgather(vpin_comm* cm, const void* send, void* recv, size_t bytes) {
+int comm_allgather(vpin_comm* cm, const void* send, void* recv, size_t bytes, const char* tag) {
   if (!cm || (bytes && (!send || !recv))) return VPIN_EINVAL;
   const double t_in = now_s();
   const double busy = cm->t_last_exit > 0.0 ? t_in - cm->t_last_exit : 0.0;
@@ -176,15 +178,26 @@ int comm_allgather(vpin_comm* cm, const void* send, void* recv, size_t bytes) {
   cm->st.wait_s += t_out - t_in;
   cm->st.busy_s += busy;
   cm->st.crit_s += max_busy;
+  if (tag) {
+    auto& ts = cm->tags[tag];
+    ts.n++;
+    ts.busy_s += busy;
+    ts.crit_s += max_busy;
+  }
   cm->t_last_exit = t_out;
   return rc;
 }
 
-int comm_allgather_ctx(vpin_ctx* c, const void* send, void* recv, size_t bytes) {
+int comm_mark(vpin_ctx* c, const char* tag) {
+  if (!c || !c->comm || !c->comm->serialize) return VPIN_OK;
+  return comm_allgather_ctx(c, nullptr, nullptr, 0, tag);
+}
+
+int comm_allgather_ctx(vpin_ctx* c, const void* send, void* recv, size_t bytes, const char* tag) {
   if (!c || !c->comm) return VPIN_EINVAL;
   // (a resident persistent tail kernel is waiting for the challenge this very exchange produces: nothing to drain then)
   if (c->comm->serialize && c->tail_rounds == 0) VPIN_HIP_TRY(hipStreamSynchronize(c->stream));
-  return comm_allgather(c->comm, send, recv, bytes);
+  return comm_allgather(c->comm, send, recv, bytes, tag);
 }
 
 // ---- RCCL through dlopen ------------------------------------------------------------------------------------------
@@ -424,8 +437,38 @@ int vpin_comm_set_serialize(vpin_comm* cm, int on) {
 int vpin_comm_stats_read(vpin_comm* cm, vpin_comm_stats* out, int reset) {
   if (!cm || !out) return VPIN_EINVAL;
   *out = cm->st;
-  if (reset) { cm->st = vpin_comm_stats{}; cm->t_last_exit = now_s(); }
+  if (reset) { cm->st = vpin_comm_stats{}; cm->tags.clear(); cm->t_last_exit = now_s(); }
   return VPIN_OK;
+}
+
+// one line per call-site tag: "<tag> <collectives> <busy_s> <crit_s>\n"; returns the length needed (incl. the terminator)
+size_t vpin_comm_stats_tags(vpin_comm* cm, char* buf, size_t cap) {
+  if (!cm) return 0;
+  std::string out;
+  char line[256];
+  for (auto& kv : cm->tags) {
+    snprintf(line, sizeof line, "%s %llu %.9f %.9f\n", kv.first.c_str(), (unsigned long long)kv.second.n, kv.second.busy_s, kv.second.crit_s);
+    out += line;
+  }
+  if (buf && cap) {
+    const size_t n = out.size() < cap - 1 ? out.size() : cap - 1;
+    memcpy(buf, out.data(), n);
+    buf[n] = 0;
+  }
+  return out.size() + 1;
+}
+
+// `iters` back-to-back all-gathers of `bytes` per rank inside the library (no per-call binding overhead): seconds per
+// collective on this rank.  Collective.
+int vpin_comm_latency(vpin_comm* cm, size_t bytes, int iters, double* seconds_per_collective) {
+  if (!cm || !seconds_per_collective || iters < 1 || bytes > ((size_t)1 << 20)) return VPIN_EINVAL;
+  std::vector<uint8_t> sb(bytes ? bytes : 1, 0x5a), rb((bytes ? bytes : 1) * (size_t)cm->world);
+  int rc = VPIN_OK;
+  for (int i = 0; i < 64 && !rc; i++) rc = comm_allgather(cm, sb.data(), rb.data(), bytes);
+  const double t0 = now_s();
+  for (int i = 0; i < iters && !rc; i++) rc = comm_allgather(cm, sb.data(), rb.data(), bytes);
+  *seconds_per_collective = (now_s() - t0) / iters;
+  return rc;
 }
 
 int vpin_ctx_set_comm(vpin_ctx* c, vpin_comm* cm) {

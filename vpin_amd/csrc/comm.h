@@ -11,6 +11,8 @@
 #include <atomic>
 #include <cstddef>
 #include <cstdint>
+#include <map>
+#include <string>
 
 #include "../../include/vpin_hip.h"
 
@@ -37,6 +39,8 @@ struct vpin_comm {
   double timeout_s = 120.0;
   // statistics (vpin_comm_stats_read)
   vpin_comm_stats st = {};
+  struct TagStat { uint64_t n = 0; double busy_s = 0.0, crit_s = 0.0; };
+  std::map<std::string, TagStat> tags;  // the same per call site: the section BEFORE a collective is booked on its tag
   double t_last_exit = 0.0;    // wall clock at the end of the previous collective (or at token acquisition)
   // RCCL (dlopen): device all-gathers on the context's stream
   void* nccl = nullptr;        // ncclComm_t
@@ -49,18 +53,26 @@ struct vpin_comm {
 namespace vpin {
 
 // host all-gather of `bytes` per rank: recv = world x bytes (recv may alias nothing of send)
-int comm_allgather(vpin_comm* cm, const void* send, void* recv, size_t bytes);
+int comm_allgather(vpin_comm* cm, const void* send, void* recv, size_t bytes, const char* tag = nullptr);
 // device all-gather on c->stream (RCCL when enabled, otherwise D2H + host all-gather + H2D); synchronises only in the staged path
 int comm_allgather_dev(vpin_comm* cm, vpin_ctx* c, const void* d_send, void* d_recv, size_t bytes);
 // the host all-gather as a proof issues it: in the serialized rehearsal the context's queued GPU work is drained first, so
 // that no kernel of this rank runs inside another rank's section
-int comm_allgather_ctx(vpin_ctx* c, const void* send, void* recv, size_t bytes);
+int comm_allgather_ctx(vpin_ctx* c, const void* send, void* recv, size_t bytes, const char* tag = nullptr);
+// serialized rehearsal only (a no-op otherwise): an empty collective that closes the section running since the previous
+// collective and books it on `tag`, so the critical path can be read per step of the protocol
+int comm_mark(vpin_ctx* c, const char* tag);
 // contiguous block of `total` items owned by `rank`: [first, first + count)
 inline void comm_block(size_t total, int rank, int world, size_t* first, size_t* count) {
   const size_t per = (total + (size_t)world - 1) / (size_t)world;
   const size_t f = per * (size_t)rank < total ? per * (size_t)rank : total;
   *first = f;
   *count = f + per <= total ? per : total - f;
+}
+// interleaved rows of a commitment: rank r owns rows r, r + world, ..  (row costs are uneven -- zero padding tails, hot
+// columns -- and a contiguous split would leave whole ranks idle)
+inline size_t comm_strided_count(size_t total, int rank, int world) {
+  return (size_t)rank < total ? (total - (size_t)rank + (size_t)world - 1) / (size_t)world : 0;
 }
 inline size_t comm_block_max(size_t total, int world) { return (total + (size_t)world - 1) / (size_t)world; }
 

@@ -124,10 +124,10 @@ int table_alloc_uninit(vpin_ctx* c, size_t len, vpin_table** out);
 
 // split-phase pair commitment (msm.hip)
 struct CommitPairState;
-// row0 / nrows: the block of the L rows to commit (one commitment split across ranks); finish then takes that block's
-// blinds and writes nrows results per output
+// row0 / nrows / row_step: the rows row0, row0 + row_step, .. (nrows of them) of the L rows (one commitment split across
+// ranks); finish then takes those rows' blinds, in that order, and writes nrows results per output
 int commit_pair_begin(vpin_ctx* c, const vpin_gens* g, const vpin_table* Za, const vpin_table* Zb, size_t L,
-                      CommitPairState** out, size_t row0 = 0, size_t nrows = (size_t)-1);
+                      CommitPairState** out, size_t row0 = 0, size_t nrows = (size_t)-1, size_t row_step = 1);
 int commit_pair_finish(vpin_ctx* c, const vpin_gens* g, CommitPairState* st, const uint8_t* blinds_a, const uint8_t* blinds_b,
                        size_t blind_base, uint8_t* out_a, uint8_t* out_b, uint8_t* out_sum);
 
@@ -138,6 +138,16 @@ int sc_final_claims(vpin_ctx* c, vpin_table* const* tables, int k, const uint8_t
 int sc_cubic3_launch(vpin_ctx* c, vpin_table* const* t, const vpin_table* pyramid, int ell, int level, const uint8_t* r,
                      bool lead = false);
 
+// strided views for one sum-check over several GPUs (r1cs.hip): rows / columns / entries = r0 (mod step)
+int r1cs_multiply_vec_strided(vpin_ctx* c, const vpin_r1cs_dev* d, const vpin_table* z, size_t r0, size_t step, vpin_table** Az,
+                              vpin_table** Bz, vpin_table** Cz);
+int table_take_strided(vpin_ctx* c, const vpin_table* src, size_t r0, size_t step, vpin_table** out);
+int r1cs_eval_table_strided(vpin_ctx* c, const vpin_r1cs_dev* d, const vpin_table* evals_rx, const uint8_t r_abc[96], size_t r0,
+                            size_t step, vpin_table** out);
+
+// DensePolynomial::bound split by row blocks over the ranks of c->comm (poly.hip)
+int poly_bound_dist(vpin_ctx* c, const vpin_table* Z, const uint8_t* Lvec, size_t L_size, uint8_t* out_LZ);
+
 inline bool is_pow2(size_t x) { return x && !(x & (x - 1)); }
 
 // few-row fixed-base MSM over device-resident scalars (msm.hip): rows x ncols Montgomery scalars ->
@@ -145,9 +155,13 @@ inline bool is_pow2(size_t x) { return x && !(x & (x - 1)); }
 int gens_msm_parts_dev(vpin_ctx* c, const vpin_gens* g, const fq* d_scalars, size_t rows, size_t ncols, uint8_t* parts_xyzt);
 // the same without the synchronisation (the caller provides the device scratch and waits on the stream itself)
 // the derefs commitment with each matrix's hot column taken out of the table walks (msm.hip msm_rows_hot_kernel)
-// row0 / nrows: a block of the L rows (out_compressed then holds nrows results); default all rows
+// row0 / nrows / row_step: the rows row0, row0 + row_step, .. (out_compressed then holds nrows results); default all rows
 int hyrax_commit_derefs_hot(vpin_ctx* c, const vpin_gens* g, const vpin_table* Z, size_t L, size_t N, const uint32_t* const col_idx[3],
-                            const uint32_t hot[3], const fq* e_ry, uint8_t* out_compressed, size_t row0 = 0, size_t nrows = (size_t)-1);
+                            const uint32_t hot[3], const fq* e_ry, uint8_t* out_compressed, size_t row0 = 0, size_t nrows = (size_t)-1,
+                            size_t row_step = 1);
+// the same rows of a commitment without blinds (DensePolynomial::commit(gens, None)) through the plain row kernel
+int hyrax_commit_rows_strided(vpin_ctx* c, const vpin_gens* g, const vpin_table* Z, size_t L, size_t row0, size_t nrows, size_t row_step,
+                              uint8_t* out_compressed);
 size_t gens_msm_parts_scratch_bytes(size_t rows, size_t ncols);
 int gens_msm_parts_launch(vpin_ctx* c, const vpin_gens* g, const fq* d_scalars, size_t rows, size_t ncols, void* scratch,
                           uint8_t* parts_xyzt, bool host_mapped = false);

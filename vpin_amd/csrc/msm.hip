@@ -435,8 +435,8 @@ __global__ __launch_bounds__(64) void scalar_times_bases_kernel(const fq* __rest
 }
 
 __global__ __launch_bounds__(kMsmBlock, 3) void msm_rows_hot_kernel(const fq* __restrict__ Z, size_t stride, size_t ncols, TableView tv,
-                                                                 HotRows hr, ge_ext* __restrict__ out, size_t row_base) {
-  const size_t row = row_base + blockIdx.x;  // row of the polynomial; out[] is indexed from row_base (a block of rows)
+                                                                 HotRows hr, ge_ext* __restrict__ out, size_t row_base, size_t row_step) {
+  const size_t row = row_base + (size_t)blockIdx.x * row_step;  // row of the polynomial; out[] is indexed by blockIdx.x
   const fq* zr = Z + row * stride;
   ge_ext acc = ge_identity();
   // a row of one repeated scalar (padding tails): s * (g_0 + ... + g_{ncols-1}), as in msm_rows_kernel
@@ -447,8 +447,9 @@ __global__ __launch_bounds__(kMsmBlock, 3) void msm_rows_hot_kernel(const fq* __
       for (size_t j = threadIdx.x; j < ncols; j += kMsmBlock) same &= fq_same(first, fq_load(zr + j)) ? 1 : 0;
       if (__syncthreads_and(same)) {
         if (threadIdx.x == 0) {
-          if (!fq_is_zero(first)) table_mul_acc(acc, fq_from_mont(first), tv, tv.sum0 + (size_t)(63 - __builtin_clzll((unsigned long long)ncols)));
-          ge_ext* o = out + blockIdx.x;
+          // with column chunks every chunk sees the same row: the first one owns it, the others add nothing
+          if (blockIdx.y == 0 && !fq_is_zero(first)) table_mul_acc(acc, fq_from_mont(first), tv, tv.sum0 + (size_t)(63 - __builtin_clzll((unsigned long long)ncols)));
+          ge_ext* o = out + (size_t)blockIdx.x * gridDim.y + blockIdx.y;
           fp_store(&o->X, acc.X); fp_store(&o->Y, acc.Y); fp_store(&o->Z, acc.Z); fp_store(&o->T, acc.T);
         }
         return;
@@ -469,8 +470,12 @@ __global__ __launch_bounds__(kMsmBlock, 3) void msm_rows_hot_kernel(const fq* __
   // one LDS list, two ends: ordinary non-zero scalars from the front, hot entries from the back
   __shared__ uint16_t list[kSeg];
   __shared__ uint32_t n_front, n_back;
-  for (size_t seg = 0; seg < ncols; seg += kSeg) {
-    const size_t seg_end = (seg + kSeg < ncols) ? seg + kSeg : ncols;
+  // gridDim.y column chunks per row: a row of 16384 full-width scalars is ~11 ms of one workgroup, and a commitment (or a
+  // rank's share of one) of a few waves of such workgroups ends in a long, mostly idle tail
+  const size_t per = (ncols + gridDim.y - 1) / gridDim.y;
+  const size_t c0 = (size_t)blockIdx.y * per, c1 = (c0 + per < ncols) ? c0 + per : ncols;
+  for (size_t seg = c0; seg < c1; seg += kSeg) {
+    const size_t seg_end = (seg + kSeg < c1) ? seg + kSeg : c1;
     if (threadIdx.x == 0) { n_front = 0; n_back = 0; }
     __syncthreads();
     for (size_t j = seg + threadIdx.x; j < seg_end; j += kMsmBlock) {
@@ -498,7 +503,7 @@ __global__ __launch_bounds__(kMsmBlock, 3) void msm_rows_hot_kernel(const fq* __
   ge_tree_quad(sh, kMsmBlock);
   if (threadIdx.x == 0) {
     acc = sh[0];
-    ge_ext* o = out + blockIdx.x;
+    ge_ext* o = out + (size_t)blockIdx.x * gridDim.y + blockIdx.y;
     fp_store(&o->X, acc.X); fp_store(&o->Y, acc.Y); fp_store(&o->Z, acc.Z); fp_store(&o->T, acc.T);
   }
 }
@@ -522,8 +527,8 @@ __device__ __forceinline__ uint32_t count_digits(fq s, const TableView& tv, size
 __global__ __launch_bounds__(kMsmBlock) void msm_count_adds_kernel(const fq* __restrict__ Z, size_t stride, size_t ncols,
                                                                    const fq* __restrict__ extra, int n_extra, size_t extra_base0,
                                                                    TableView tv, unsigned long long* __restrict__ count,
-                                                                   HotRows hr = HotRows{}, size_t row_base = 0) {
-  const size_t row = row_base + blockIdx.x;
+                                                                   HotRows hr = HotRows{}, size_t row_base = 0, size_t row_step = 1) {
+  const size_t row = row_base + (size_t)blockIdx.x * row_step;
   const fq* zr = Z + row * stride;
   // msm_rows_hot_kernel: the hot-column entries are not table additions
   const uint32_t* hidx = nullptr;
@@ -1002,6 +1007,11 @@ static int msm_rows(vpin_ctx* c, const vpin_gens* g, const fq* dZ, size_t rows, 
   if (rows < 128) {  // spread a few rows over the chip: ~one scalar per thread, <= 64 chunks per row
     size_t want = (total + kMsmBlock - 1) / kMsmBlock * 4;
     chunks = (int)(want < 1 ? 1 : want > 64 ? 64 : want);
+  } else if (rows >= 768 && total > (size_t)kSeg) {
+    // long rows (more than one compaction segment): one workgroup per segment, so that a launch of a few waves of
+    // workgroups (a rank's share of a split commitment) does not end in a long, mostly idle tail
+    static const int env_chunks = [] { const char* e = getenv("VPIN_MSM_ROW_CHUNKS"); return e ? atoi(e) : 0; }();
+    chunks = env_chunks > 0 ? env_chunks : (int)std::min<size_t>(8, (total + kSeg - 1) / kSeg);
   } else if (rows < 768 && total >= 2 * (size_t)kMsmBlock) {
     // Fewer than three workgroups per CU: a wave's 22-addition chains run at ~13 us per addition instead of ~9.5 us
     // with the SIMDs full, and every thread walks several of them.  Split the rows into column chunks until the chip is
@@ -1063,12 +1073,12 @@ namespace vpin {
 // hot column of each matrix's col-derefs vector taken out (msm_rows_hot_kernel).  col_idx[m]: the N column indices of matrix
 // m on the device, hot[m]: its hot column or 0xffffffff, e_ry: the table the col-derefs were gathered from.
 int hyrax_commit_derefs_hot(vpin_ctx* c, const vpin_gens* g, const vpin_table* Z, size_t L, size_t N, const uint32_t* const col_idx[3],
-                            const uint32_t hot[3], const fq* e_ry, uint8_t* out_compressed, size_t row0, size_t nrows) {
+                            const uint32_t hot[3], const fq* e_ry, uint8_t* out_compressed, size_t row0, size_t nrows, size_t row_step) {
   if (!c || !g || !Z || !Z->d || !col_idx || !hot || !e_ry || !out_compressed || L == 0 || Z->len % L) return VPIN_EINVAL;
   const size_t R = Z->len / L;
   if (R > g->nb || N % R || Z->len < 6 * N) return VPIN_ESHAPE;
-  if (nrows == (size_t)-1) { row0 = 0; nrows = L; }  // all rows
-  if (row0 + nrows > L) return VPIN_ESHAPE;
+  if (nrows == (size_t)-1) { row0 = 0; nrows = L; row_step = 1; }  // all rows
+  if (row_step == 0 || (nrows && row0 + (nrows - 1) * row_step >= L)) return VPIN_ESHAPE;
   if (nrows == 0) return VPIN_OK;
   (void)hipSetDevice(c->device);
   DevBuf dpts(c), dout(c), dT(c);
@@ -1096,14 +1106,41 @@ int hyrax_commit_derefs_hot(vpin_ctx* c, const vpin_gens* g, const vpin_table* Z
   }
   if (c->prof_count_adds && c->d_add_count)
     hipLaunchKernelGGL(msm_count_adds_kernel, dim3((unsigned)nrows), dim3(kMsmBlock), 0, c->stream, (const fq*)Z->d, R, R, (const fq*)nullptr, 0,
-                       (size_t)0, view(g), c->d_add_count, hr, row0);
+                       (size_t)0, view(g), c->d_add_count, hr, row0, row_step);
+  static const int env_chunks = [] { const char* e = getenv("VPIN_MSM_HOT_CHUNKS"); return e ? atoi(e) : 0; }();
+  const int chunks = env_chunks > 0 ? env_chunks : (int)std::max<size_t>(1, std::min<size_t>(8, R / kSeg));
+  DevBuf dparts(c);
+  if (chunks > 1 && dparts.alloc(nrows * (size_t)chunks * sizeof(ge_ext))) return VPIN_ENOMEM;
   {
     ProfScope ps(c, VPIN_K_MSM, 32.0 * (double)(nrows * R), VPIN_K_MSM_ROWS);
     static const int env_pad = [] { const char* e = getenv("VPIN_MSM_LDS_PAD"); return e ? atoi(e) : -1; }();
     const unsigned pad = env_pad >= 0 ? (unsigned)env_pad : (c->shared_device ? 20000u : 0u);
-    hipLaunchKernelGGL(msm_rows_hot_kernel, dim3((unsigned)nrows), dim3(kMsmBlock), pad, c->stream, (const fq*)Z->d, R, R, view(g), hr,
-                       (ge_ext*)dpts.p, row0);
+    hipLaunchKernelGGL(msm_rows_hot_kernel, dim3((unsigned)nrows, (unsigned)chunks), dim3(kMsmBlock), pad, c->stream, (const fq*)Z->d, R, R,
+                       view(g), hr, chunks > 1 ? (ge_ext*)dparts.p : (ge_ext*)dpts.p, row0, row_step);
+    if (chunks > 1)
+      hipLaunchKernelGGL(ge_sum_chunks_kernel, dim3((unsigned)((nrows + 63) / 64)), dim3(64), 0, c->stream, (const ge_ext*)dparts.p, nrows,
+                         chunks, (ge_ext*)dpts.p);
   }
+  hipLaunchKernelGGL(ge_compress_kernel, dim3((unsigned)((nrows + 63) / 64)), dim3(64), 0, c->stream, (const ge_ext*)dpts.p, nrows,
+                     (fp*)dout.p, (fp*)nullptr);
+  VPIN_HIP_TRY(hipGetLastError());
+  VPIN_HIP_TRY(hipMemcpyAsync(out_compressed, dout.p, nrows * 32, hipMemcpyDeviceToHost, c->stream));
+  VPIN_HIP_TRY(hipStreamSynchronize(c->stream));
+  return VPIN_OK;
+}
+
+int hyrax_commit_rows_strided(vpin_ctx* c, const vpin_gens* g, const vpin_table* Z, size_t L, size_t row0, size_t nrows, size_t row_step,
+                              uint8_t* out_compressed) {
+  if (!c || !g || !Z || !Z->d || !out_compressed || L == 0 || row_step == 0) return VPIN_EINVAL;
+  if (nrows == 0) return VPIN_OK;
+  if (Z->len % L != 0 || row0 + (nrows - 1) * row_step >= L) return VPIN_ESHAPE;
+  const size_t R = Z->len / L;
+  if (R > g->nb) return VPIN_ESHAPE;
+  (void)hipSetDevice(c->device);
+  DevBuf dpts(c), dout(c);
+  if (dpts.alloc(nrows * sizeof(ge_ext)) || dout.alloc(nrows * 32)) return VPIN_ENOMEM;
+  int rc = msm_rows(c, g, Z->d + row0 * R, nrows, row_step * R, R, nullptr, 0, 0, (ge_ext*)dpts.p);
+  if (rc) return rc;
   hipLaunchKernelGGL(ge_compress_kernel, dim3((unsigned)((nrows + 63) / 64)), dim3(64), 0, c->stream, (const ge_ext*)dpts.p, nrows,
                      (fp*)dout.p, (fp*)nullptr);
   VPIN_HIP_TRY(hipGetLastError());
@@ -1196,13 +1233,13 @@ struct CommitPairState {
 };
 
 int commit_pair_begin(vpin_ctx* c, const vpin_gens* g, const vpin_table* Za, const vpin_table* Zb, size_t L_all,
-                      CommitPairState** out, size_t row0, size_t nrows) {
+                      CommitPairState** out, size_t row0, size_t nrows, size_t row_step) {
   if (!c || !g || !Za || !Zb || !out || L_all == 0) return VPIN_EINVAL;
   if (Za->len != Zb->len || Za->len % L_all != 0) return VPIN_ESHAPE;
   size_t R = Za->len / L_all;
   if (R > g->nb) return VPIN_ESHAPE;
-  if (nrows == (size_t)-1) { row0 = 0; nrows = L_all; }
-  if (row0 + nrows > L_all || nrows == 0) return VPIN_ESHAPE;
+  if (nrows == (size_t)-1) { row0 = 0; nrows = L_all; row_step = 1; }
+  if (nrows == 0 || row_step == 0 || row0 + (nrows - 1) * row_step >= L_all) return VPIN_ESHAPE;
   const size_t L = nrows;
   (void)hipSetDevice(c->device);
   CommitPairState* st = new (std::nothrow) CommitPairState(c);
@@ -1210,8 +1247,8 @@ int commit_pair_begin(vpin_ctx* c, const vpin_gens* g, const vpin_table* Za, con
   st->L = L;
   if (st->pts.alloc(5 * L * sizeof(ge_ext))) { delete st; return VPIN_ENOMEM; }
   ge_ext* pts = (ge_ext*)st->pts.p;
-  int rc = msm_rows(c, g, Za->d + row0 * R, L, R, R, nullptr, 0, 0, pts);
-  if (!rc) rc = msm_rows(c, g, Zb->d + row0 * R, L, R, R, nullptr, 0, 0, pts + L);
+  int rc = msm_rows(c, g, Za->d + row0 * R, L, row_step * R, R, nullptr, 0, 0, pts);
+  if (!rc) rc = msm_rows(c, g, Zb->d + row0 * R, L, row_step * R, R, nullptr, 0, 0, pts + L);
   if (rc) { delete st; return rc; }
   *out = st;
   return VPIN_OK;

@@ -3,6 +3,7 @@
 // Z is read exactly once, row-major, so every wavefront streams 2 KiB contiguous per row.
 #include <cstring>
 
+#include "comm.h"
 #include "ctx.h"
 
 namespace vpin {
@@ -32,6 +33,50 @@ __global__ __launch_bounds__(kPB) void poly_bound_reduce_kernel(const fq* __rest
   fq acc = fq_load(partial + i);
   for (int k = 1; k < chunks; k++) acc = fq_add(acc, fq_load(partial + (size_t)k * Rs + i));
   fq_store(out + i, acc);
+}
+
+// rows [row0, row0 + nrows) of the same sum, as a device vector of Rs scalars (zeros when nrows == 0): one polynomial bound
+// split across ranks by row blocks; dL = the L_size coefficients on the device
+static int poly_bound_rows(vpin_ctx* c, const fq* Z, const fq* dL, size_t Rs, size_t row0, size_t nrows, fq* d_out) {
+  if (nrows == 0) {
+    VPIN_HIP_TRY(hipMemsetAsync(d_out, 0, Rs * 32, c->stream));
+    return VPIN_OK;
+  }
+  size_t rows_per_chunk = nrows / 64 ? nrows / 64 : 1;
+  int chunks = (int)((nrows + rows_per_chunk - 1) / rows_per_chunk);
+  DevBuf bpart(c);
+  if (bpart.alloc((size_t)chunks * Rs * 32)) return VPIN_ENOMEM;
+  dim3 grid((unsigned)((Rs + kPB - 1) / kPB), (unsigned)chunks);
+  hipLaunchKernelGGL(poly_bound_kernel, grid, dim3(kPB), 0, c->stream, Z + row0 * Rs, dL + row0, nrows, Rs, rows_per_chunk, (fq*)bpart.p);
+  hipLaunchKernelGGL(poly_bound_reduce_kernel, dim3(grid.x), dim3(kPB), 0, c->stream, (const fq*)bpart.p, Rs, chunks, d_out);
+  VPIN_HIP_TRY(hipGetLastError());
+  return VPIN_OK;  // bpart returns to the pool; later work on this stream is ordered behind the kernels
+}
+
+// DensePolynomial::bound over the ranks of c->comm: every rank sums its block of rows, the partial vectors are all-gathered
+// on the device (RCCL ncclAllGather when enabled, staged through the host transport otherwise) and added up by everyone.
+// Field addition is exact, so the result does not depend on the split.
+int poly_bound_dist(vpin_ctx* c, const vpin_table* Z, const uint8_t* Lvec, size_t L_size, uint8_t* out_LZ) {
+  if (!c || !c->comm || !Z || !Z->d || !Lvec || !out_LZ || L_size == 0) return VPIN_EINVAL;
+  if (Z->len % L_size != 0) return VPIN_ESHAPE;
+  vpin_comm* cm = c->comm;
+  const size_t Rs = Z->len / L_size;
+  (void)hipSetDevice(c->device);
+  size_t row0, nrows;
+  comm_block(L_size, cm->rank, cm->world, &row0, &nrows);
+  DevBuf bL(c), bmine(c), ball(c), bout(c);
+  if (bL.alloc(L_size * 32) || bmine.alloc(Rs * 32) || ball.alloc((size_t)cm->world * Rs * 32) || bout.alloc(Rs * 32)) return VPIN_ENOMEM;
+  VPIN_HIP_TRY(hipMemcpyAsync(bL.p, Lvec, L_size * 32, hipMemcpyHostToDevice, c->stream));
+  int rc = poly_bound_rows(c, Z->d, (const fq*)bL.p, Rs, row0, nrows, (fq*)bmine.p);
+  if (rc) return rc;
+  if (cm->serialize) VPIN_HIP_TRY(hipStreamSynchronize(c->stream));
+  if ((rc = comm_allgather_dev(cm, c, bmine.p, ball.p, Rs * 32))) return rc;
+  hipLaunchKernelGGL(poly_bound_reduce_kernel, dim3((unsigned)((Rs + kPB - 1) / kPB)), dim3(kPB), 0, c->stream, (const fq*)ball.p, Rs,
+                     cm->world, (fq*)bout.p);
+  VPIN_HIP_TRY(hipGetLastError());
+  VPIN_HIP_TRY(hipMemcpyAsync(out_LZ, bout.p, Rs * 32, hipMemcpyDeviceToHost, c->stream));
+  VPIN_HIP_TRY(hipStreamSynchronize(c->stream));
+  return VPIN_OK;
 }
 
 }  // namespace vpin

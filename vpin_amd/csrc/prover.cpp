@@ -112,13 +112,33 @@ static void write_zksc(Writer& w, const ZkSc& p) {
 // with s_j = prod_{i<j} eq1(tau_i, r_i), so its value at the round's evaluation point x is
 // s_j*((1-tau_j) + x*(2*tau_j-1)) * E_{j+1}[i]; the GPU returns sum_i E_{j+1}[i]*(Az_x Bz_x - Cz_x)[i] and
 // the three scale factors are applied here.  Exact field arithmetic: same e0,e2,e3, same proof bytes.
+// One sum-check over several GPUs (lw > 0: the world is 2^lw ranks).  The fold pairs (i, i + len/2), so both
+// members of a pair are = r (mod 2^lw) while len/2 >= 2^lw: rank r holds the entries = r (mod world) of every table
+// (`tabs` are those LOCAL tables, 2^(rounds - lw) entries) and folds them with the unchanged kernels; no table entry ever
+// moves.  Per round every rank contributes its partial sums (three scalars) and all ranks derive the same challenge.  The
+// eq factor of phase 1 splits the same way: eq(tau_{j+1..}, r + k*world) = eq(tau_{j+1..rounds-lw-1}, k) * eq(tau_lo, r)
+// (tau_lo = the last lw challenges), so `pyramid` is the suffix pyramid of the first rounds - lw challenges and the
+// rank's sums are scaled by eq(tau_lo, r).  After rounds - lw rounds every local table is down to one entry: the world
+// entries of each table are all-gathered and the last lw rounds run on the host (the reference's loops on <= 8 entries).
 static int zk_sumcheck(vpin_ctx* c, int K, vpin_table** tabs, const Fq& claim, const Fq& blind_claim, int rounds,
                        const Mcg& g1, const Mcg& gn, Transcript& tr, Transcript& tape, ZkSc& pf, std::vector<Fq>& r_out,
                        Fq* final_claims, Fq& blind_last, const std::vector<Fq>* tau = nullptr,
-                       const vpin_table* pyramid = nullptr) {
+                       const vpin_table* pyramid = nullptr, int lw = 0) {
   const int nc = (K == 4) ? 4 : 3;
   const bool factored = (K == 4 && tau != nullptr && pyramid != nullptr);
   const int ntab = factored ? 3 : K;
+  vpin_comm* cm = lw > 0 ? c->comm : nullptr;
+  const int world = cm ? cm->world : 1;
+  const int loc_rounds = rounds - lw;  // rounds the device runs on the local tables
+  if (lw > 0 && (!cm || (1 << lw) != world || loc_rounds < 1)) return VPIN_EINVAL;
+  Fq c_rank = Fq::one();               // eq(tau_lo, rank): scale of this rank's eq-factored sums
+  std::vector<Fq> eq_lo;               // eq(tau_lo, .), world entries
+  if (cm && factored) {
+    eq_lo.resize(world);
+    host_eq(tau->data() + loc_rounds, (size_t)lw, eq_lo.data());
+    c_rank = eq_lo[cm->rank];
+  }
+  std::vector<std::vector<Fq>> htab;   // the tables once they are down to `world` entries: htab[t][i]
   Fq s_eq = Fq::one();
   const Fq f_one = Fq::one(), f_two = Fq::from_u64(2), f_three = Fq::from_u64(3), f_five = Fq::from_u64(5);
   std::vector<Fq> blinds_poly = tape.challenge_vector("blinds_poly", rounds);
@@ -161,14 +181,56 @@ static int zk_sumcheck(vpin_ctx* c, int K, vpin_table** tabs, const Fq& claim, c
     }
   }
   Fq cn = claim;  // claim_pr / s_eq: the claim on the quadratic t
-  int rc = factored ? vpin::sc_cubic3_launch(c, tabs, pyramid, rounds, 1, nullptr, lead) : vpin::sc_round_launch(c, K, tabs, nullptr);
+  int rc = factored ? vpin::sc_cubic3_launch(c, tabs, pyramid, loc_rounds, 1, nullptr, lead) : vpin::sc_round_launch(c, K, tabs, nullptr);
   if (rc) return rc;
+  // host rounds (the last lw): sums over the pairs (i, i + len/2) of the gathered tables, in the kernels' conventions
+  auto host_round = [&](int j, bool lead_now, Fq e[3]) {
+    const size_t len = htab[0].size(), half = len / 2;
+    e[0] = e[1] = e[2] = Fq::zero();
+    if (factored) {
+      std::vector<Fq> E(half);  // eq(tau_{j+1..}, .) over the variables still unbound after this round's
+      host_eq(tau->data() + j + 1, (size_t)(rounds - j - 1), E.data());
+      for (size_t i = 0; i < half; i++) {
+        const Fq a0 = htab[0][i], a1 = htab[0][i + half], b0 = htab[1][i], b1 = htab[1][i + half], c0 = htab[2][i], c1 = htab[2][i + half];
+        const Fq da = a1 - a0, db = b1 - b0, dc = c1 - c0;
+        if (lead_now) {
+          e[0] = e[0] + E[i] * (a0 * b0 - c0);
+          e[1] = e[1] + E[i] * (da * db);
+          if (j == 0) e[2] = e[2] + E[i] * (a1 * b1 - c1);
+        } else {
+          const Fq a2 = a1 + da, b2 = b1 + db, c2 = c1 + dc, a3 = a2 + da, b3 = b2 + db, c3 = c2 + dc;
+          e[0] = e[0] + E[i] * (a0 * b0 - c0);
+          e[1] = e[1] + E[i] * (a2 * b2 - c2);
+          e[2] = e[2] + E[i] * (a3 * b3 - c3);
+        }
+      }
+    } else {
+      for (size_t i = 0; i < half; i++) {
+        const Fq a0 = htab[0][i], a1 = htab[0][i + half], b0 = htab[1][i], b1 = htab[1][i + half];
+        e[0] = e[0] + a0 * b0;
+        e[1] = e[1] + (a1 + a1 - a0) * (b1 + b1 - b0);
+      }
+    }
+  };
   Fq r_j = Fq::zero();
   static const bool fine = getenv("VPIN_SPARK_TRACE") && atoi(getenv("VPIN_SPARK_TRACE")) >= 2;
   Clock::time_point tp0 = Clock::now();
   for (int j = 0; j < rounds; j++) {
     Fq e[3];
-    if ((rc = vpin::sc_round_wait(c, K, B(e)))) return rc;
+    if (j < loc_rounds) {
+      if ((rc = vpin::sc_round_wait(c, K, B(e)))) return rc;
+      if (cm) {  // this rank's partial sums -> everyone's total
+        if (factored) for (int i = 0; i < 3; i++) e[i] = e[i] * c_rank;
+        std::vector<Fq> all(3 * (size_t)world);
+        if ((rc = vpin::comm_allgather_ctx(c, e, all.data(), 96, K == 4 ? "sat_phase1_round" : "sat_phase2_round"))) return rc;
+        for (int i = 0; i < 3; i++) {
+          e[i] = Fq::zero();
+          for (int r = 0; r < world; r++) e[i] = e[i] + all[3 * (size_t)r + i];
+        }
+      }
+    } else {
+      host_round(j, lead, e);
+    }
     Clock::time_point tp1 = Clock::now();
     bool lead_next = lead;
     Fq t0, t1, tinf;
@@ -201,9 +263,25 @@ static int zk_sumcheck(vpin_ctx* c, int K, vpin_table** tabs, const Fq& claim, c
     pf.comm_polys.push_back(comm_poly);
     r_j = tr.challenge_scalar("challenge_nextround");
     // fold with r_j and evaluate the next round while the host finishes this one
-    if (j + 1 < rounds) {
-      rc = factored ? vpin::sc_cubic3_launch(c, tabs, pyramid, rounds, j + 2, B(&r_j), lead_next) : vpin::sc_round_launch(c, K, tabs, B(&r_j));
+    if (j + 1 < loc_rounds) {
+      rc = factored ? vpin::sc_cubic3_launch(c, tabs, pyramid, loc_rounds, j + 2, B(&r_j), lead_next) : vpin::sc_round_launch(c, K, tabs, B(&r_j));
       if (rc) return rc;
+    } else if (cm && j + 1 == loc_rounds) {
+      // the local tables are down to two entries: fold them with r_j and gather the world entries of every table
+      Fq mine[4] = {Fq::zero(), Fq::zero(), Fq::zero(), Fq::zero()};
+      if (tabs[0]->len != 2) return VPIN_ESHAPE;
+      if ((rc = vpin::sc_final_claims(c, tabs, ntab, B(&r_j), B(mine)))) return rc;
+      std::vector<Fq> all(4 * (size_t)world);
+      if ((rc = vpin::comm_allgather_ctx(c, mine, all.data(), 128, "sat_gather_tables"))) return rc;
+      htab.assign(ntab, std::vector<Fq>(world));
+      for (int t = 0; t < ntab; t++)
+        for (int r = 0; r < world; r++) htab[t][r] = all[4 * (size_t)r + t];
+    } else if (cm && j + 1 < rounds) {
+      for (auto& T : htab) {  // bound_poly_var_top on the host tables
+        const size_t half = T.size() / 2;
+        for (size_t i = 0; i < half; i++) T[i] = T[i] + r_j * (T[i + half] - T[i]);
+        T.resize(half);
+      }
     }
     Clock::time_point tp2 = Clock::now();
     if (lead) cn = t0 + r_j * ((t1 - t0 - tinf) + r_j * tinf);  // t(r_j)
@@ -262,7 +340,12 @@ static int zk_sumcheck(vpin_ctx* c, int K, vpin_table** tabs, const Fq& claim, c
   }
   // last fold (sumcheck.rs:673-676 of the final round), then the final claims P[0]
   if (factored) final_claims[0] = s_eq;  // tau(rx) = prod_i eq1(tau_i, r_i)
-  if (tabs[0]->len == 2) {
+  if (cm) {
+    for (int t = 0; t < ntab; t++) {
+      if (htab[t].size() != 2) return VPIN_ESHAPE;
+      final_claims[(factored ? 1 : 0) + t] = htab[t][0] + r_j * (htab[t][1] - htab[t][0]);
+    }
+  } else if (tabs[0]->len == 2) {
     rc = vpin::sc_final_claims(c, tabs, ntab, B(&r_j), B(&final_claims[factored ? 1 : 0]));
     if (rc) return rc;
   } else {
@@ -419,10 +502,11 @@ int sat_prove_core(vpin_ctx* c, const vpin_r1cs_dev* dinst, size_t nv, size_t nc
   // dense_mlpoly.rs:166-173), so every rank commits a contiguous block of rows of both polynomials and the 32-byte results
   // are all-gathered; the blinds are drawn in full by everyone (the tape is part of the deterministic protocol state).
   vpin_comm* cm = (c->comm && c->comm->world > 1) ? c->comm : nullptr;
-  size_t row0 = 0, nrows = L;
-  if (cm) vpin::comm_block(L, cm->rank, cm->world, &row0, &nrows);
+  // rank r commits rows r, r + world, ..: the rows differ in cost (the padding tail of the assignment is all zeros)
+  const size_t nrows = cm ? vpin::comm_strided_count(L, cm->rank, cm->world) : L;
   vpin::CommitPairState* cps = nullptr;
-  if (nrows && (rc = vpin::commit_pair_begin(c, sg->dev, d_para, d_input, L, &cps, row0, nrows))) return rc;
+  if (nrows && (rc = vpin::commit_pair_begin(c, sg->dev, d_para, d_input, L, &cps, cm ? (size_t)cm->rank : 0, nrows, cm ? (size_t)cm->world : 1)))
+    return rc;
   const uint8_t two = 2;
   Transcript tape1 = make_tape(&two, 1, seed_commit64);
   std::vector<Fq> blind_para = tape1.challenge_vector("poly_blinds", L);
@@ -437,17 +521,23 @@ int sat_prove_core(vpin_ctx* c, const vpin_r1cs_dev* dinst, size_t nv, size_t nc
   } else {
     const size_t pmax = vpin::comm_block_max(L, cm->world);
     std::vector<uint8_t> mine(3 * pmax * 32, 0), all((size_t)cm->world * 3 * pmax * 32);
-    if (nrows && (rc = vpin::commit_pair_finish(c, sg->dev, cps, B(blind_para.data() + row0), B(blind_input.data() + row0), R + 1,
-                                                mine.data(), mine.data() + pmax * 32, mine.data() + 2 * pmax * 32)))
-      return rc;
-    if ((rc = vpin::comm_allgather_ctx(c, mine.data(), all.data(), mine.size()))) return rc;
+    if (nrows) {
+      std::vector<Fq> bp(nrows), bi(nrows);  // this rank's rows' blinds, in its row order
+      for (size_t k = 0; k < nrows; k++) { bp[k] = blind_para[cm->rank + k * cm->world]; bi[k] = blind_input[cm->rank + k * cm->world]; }
+      if ((rc = vpin::commit_pair_finish(c, sg->dev, cps, B(bp.data()), B(bi.data()), R + 1, mine.data(), mine.data() + pmax * 32,
+                                         mine.data() + 2 * pmax * 32)))
+        return rc;
+    }
+    if ((rc = vpin::comm_allgather_ctx(c, mine.data(), all.data(), mine.size(), "witness_commit"))) return rc;
     for (int r = 0; r < cm->world; r++) {
-      size_t f0, n;
-      vpin::comm_block(L, r, cm->world, &f0, &n);
+      const size_t n = vpin::comm_strided_count(L, r, cm->world);
       const uint8_t* blk = all.data() + (size_t)r * 3 * pmax * 32;
-      memcpy(comm_para_out + f0 * 32, blk, n * 32);
-      memcpy(comm_input_out + f0 * 32, blk + pmax * 32, n * 32);
-      memcpy(comm_vars[0].b + f0 * 32, blk + 2 * pmax * 32, n * 32);
+      for (size_t k = 0; k < n; k++) {
+        const size_t row = (size_t)r + k * (size_t)cm->world;
+        memcpy(comm_para_out + row * 32, blk + k * 32, 32);
+        memcpy(comm_input_out + row * 32, blk + pmax * 32 + k * 32, 32);
+        memcpy(comm_vars[row].b, blk + 2 * pmax * 32 + k * 32, 32);
+      }
     }
   }
   g_timings[0] = secs(t0, Clock::now());
@@ -469,13 +559,24 @@ int sat_prove_core(vpin_ctx* c, const vpin_r1cs_dev* dinst, size_t nv, size_t nc
   tg.add(d_z);
   const int nrx = (int)log2z(ncons), nry = (int)log2z(zl);
   std::vector<Fq> tau = tr.challenge_vector("challenge_tau", nrx);
-  vpin_table* d_pyr = nullptr;  // suffix tables eq(tau_{k..}, .), k = 1..nrx
-  if ((rc = vpin_eq_suffix_tables(c, B(tau.data()), nrx, &d_pyr))) return rc;
+  // Both sum-checks over the ranks of c->comm (zk_sumcheck): a power-of-two world, and local tables long enough to be
+  // worth a kernel; otherwise every rank runs them in full.
+  int lw = 0;
+  if (cm && (cm->world & (cm->world - 1)) == 0) {
+    const int l = (int)log2z((size_t)cm->world);
+    static const bool off = getenv("VPIN_DIST_NO_SAT_SPLIT") != nullptr;
+    if (!off && nrx - l >= 12 && nry - l >= 12) lw = l;
+  }
+  const size_t wstep = (size_t)1 << lw, wrank = lw ? (size_t)cm->rank : 0;
+  vpin_table* d_pyr = nullptr;  // suffix tables eq(tau_{k..}, .), k = 1..nrx (of the first nrx - lw challenges when split)
+  if ((rc = vpin_eq_suffix_tables(c, B(tau.data()), nrx - lw, &d_pyr))) return rc;
   tg.add(d_pyr);
   const Fq one = Fq::one();
   vpin_table* d_abc[3] = {nullptr, nullptr, nullptr};
   auto t_spmv = Clock::now();
-  if ((rc = vpin_r1cs_multiply_vec(c, dinst, d_z, &d_abc[0], &d_abc[1], &d_abc[2]))) return rc;
+  if (lw) rc = vpin::r1cs_multiply_vec_strided(c, dinst, d_z, wrank, wstep, &d_abc[0], &d_abc[1], &d_abc[2]);  // rows = rank (mod world)
+  else rc = vpin_r1cs_multiply_vec(c, dinst, d_z, &d_abc[0], &d_abc[1], &d_abc[2]);
+  if (rc) return rc;
   for (int m = 0; m < 3; m++) tg.add(d_abc[m]);
   g_timings[6] += secs(t_spmv, Clock::now());
   ZkSc sc1, sc2;
@@ -483,8 +584,9 @@ int sat_prove_core(vpin_ctx* c, const vpin_r1cs_dev* dinst, size_t nv, size_t nc
   Fq claims1[4], blind_post1;
   vpin_table* tabs1[3] = {d_abc[0], d_abc[1], d_abc[2]};
   rc = zk_sumcheck(c, 4, tabs1, Fq::zero(), Fq::zero(), nrx, sg->gens_1, sg->gens_4, tr, tape, sc1, rx, claims1, blind_post1,
-                   &tau, d_pyr);
+                   &tau, d_pyr, lw);
   if (rc) return rc;
+  if ((rc = vpin::comm_mark(c, "sat_phase1_rest"))) return rc;
   if (c->progress_flag) *c->progress_flag = 1;  // phase 1 (the roofline kernel's launches) is over: other streams may start
   g_timings[1] = secs(t0, Clock::now());
 
@@ -519,14 +621,23 @@ int sat_prove_core(vpin_ctx* c, const vpin_r1cs_dev* dinst, size_t nv, size_t nc
   {
     // r_A*A(rx,.) + r_B*B(rx,.) + r_C*C(rx,.) (compute_eval_table_sparse x3, commit_test.rs:257-268)
     Fq rabc[3] = {r_A, r_B, r_C};
-    if ((rc = vpin_r1cs_eval_table(c, dinst, d_eq_rx, B(rabc), &d_eabc))) return rc;
+    if (lw) rc = vpin::r1cs_eval_table_strided(c, dinst, d_eq_rx, B(rabc), wrank, wstep, &d_eabc);  // columns = rank (mod world)
+    else rc = vpin_r1cs_eval_table(c, dinst, d_eq_rx, B(rabc), &d_eabc);
+    if (rc) return rc;
     tg.add(d_eabc);
   }
   g_timings[6] += secs(t_spmv, Clock::now());
   Fq claims2[2], blind_post2;
-  vpin_table* tabs2[2] = {d_z, d_eabc};
-  rc = zk_sumcheck(c, 2, tabs2, claim2, blind_claim2, nry, sg->gens_1, sg->gens_3, tr, tape, sc2, ry, claims2, blind_post2);
+  vpin_table* d_z2 = d_z;
+  if (lw) {  // z at the same columns
+    if ((rc = vpin::table_take_strided(c, d_z, wrank, wstep, &d_z2))) return rc;
+    tg.add(d_z2);
+  }
+  vpin_table* tabs2[2] = {d_z2, d_eabc};
+  rc = zk_sumcheck(c, 2, tabs2, claim2, blind_claim2, nry, sg->gens_1, sg->gens_3, tr, tape, sc2, ry, claims2, blind_post2, nullptr,
+                   nullptr, lw);
   if (rc) return rc;
+  if ((rc = vpin::comm_mark(c, "sat_phase2_rest"))) return rc;
   g_timings[2] = secs(t0, Clock::now());
 
   // ---- polyeval: commit_test.rs:283-296, dense_mlpoly.rs:326-379 ----
@@ -535,7 +646,9 @@ int sat_prove_core(vpin_ctx* c, const vpin_r1cs_dev* dinst, size_t nv, size_t nc
   std::vector<Fq> Lv(L), Rv(R), LZ(R);
   host_eq(ry.data() + 1, left, Lv.data());
   host_eq(ry.data() + 1 + left, right, Rv.data());
-  if ((rc = vpin_poly_bound(c, d_vars, B(Lv.data()), L, B(LZ.data())))) return rc;
+  if (cm) rc = vpin::poly_bound_dist(c, d_vars, B(Lv.data()), L, B(LZ.data()));  // row blocks, partial vectors all-gathered
+  else rc = vpin_poly_bound(c, d_vars, B(Lv.data()), L, B(LZ.data()));
+  if (rc) return rc;
   // poly_vars.evaluate(ry[1..]) = <L*Z, R>
   Fq eval_vars_at_ry = Fq::zero();
   for (size_t i = 0; i < R; i++) eval_vars_at_ry = eval_vars_at_ry + LZ[i] * Rv[i];
@@ -588,6 +701,7 @@ int sat_prove_core(vpin_ctx* c, const vpin_r1cs_dev* dinst, size_t nv, size_t nc
   *proof_len = w.buf.size();
   if (rx_out) memcpy(rx_out, rx.data(), rx.size() * 32);
   if (ry_out) memcpy(ry_out, ry.data(), ry.size() * 32);
+  if ((rc = vpin::comm_mark(c, "sat_replicated"))) return rc;
   if (tr_out) *tr_out = tr;
   if (tape_out) *tape_out = tape;
   g_timings[4] = secs(t_begin, Clock::now());

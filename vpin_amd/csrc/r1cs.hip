@@ -40,6 +40,49 @@ __global__ __launch_bounds__(kRB) void spmv_kernel(const uint32_t* __restrict__ 
   fq_store(out + r, acc);
 }
 
+// The same for the rows r0, r0 + step, ..: out[k] = (M z)[r0 + k*step].  One sum-check over several GPUs (prover.cpp): the
+// fold pairs (i, i + len/2) of DensePolynomial::bound_poly_var_top keep both members in one residue class mod a power of
+// two, so rank r0 owns the rows = r0 (mod world) and never exchanges a table entry.
+__global__ __launch_bounds__(kRB) void spmv_strided_kernel(const uint32_t* __restrict__ rowptr, const uint32_t* __restrict__ col,
+                                                           const fq* __restrict__ val, const fq* __restrict__ z, size_t nloc,
+                                                           size_t r0, size_t step, fq* __restrict__ out) {
+  size_t k = (size_t)blockIdx.x * kRB + threadIdx.x;
+  if (k >= nloc) return;
+  const size_t r = r0 + k * step;
+  uint32_t k0 = rowptr[r], k1 = rowptr[r + 1];
+  fq acc = fq_zero();
+  for (uint32_t q = k0; q < k1; q++) {
+    fq x = fq_load(z + col[q]);
+    if (fq_is_zero(x)) continue;
+    acc = fq_add(acc, fq_mul(fq_load(val + q), x));
+  }
+  fq_store(out + k, acc);
+}
+
+// dst[k] = src[r0 + k*step]
+__global__ __launch_bounds__(kRB) void strided_take_kernel(const fq* __restrict__ src, size_t nloc, size_t r0, size_t step,
+                                                           fq* __restrict__ dst) {
+  size_t k = (size_t)blockIdx.x * kRB + threadIdx.x;
+  if (k < nloc) fq_store(dst + k, fq_load(src + r0 + k * step));
+}
+
+// eval table at the columns r0, r0 + step, ..: out[k] (+)= rc * sum over column (r0 + k*step)
+__global__ __launch_bounds__(kRB) void eval_table_strided_kernel(const uint32_t* __restrict__ colptr, const uint32_t* __restrict__ row,
+                                                                 const fq* __restrict__ val, const fq* __restrict__ rx, size_t nloc,
+                                                                 size_t r0, size_t step, fq rc, int accumulate, fq* __restrict__ out) {
+  size_t k = (size_t)blockIdx.x * kRB + threadIdx.x;
+  if (k >= nloc) return;
+  const size_t c = r0 + k * step;
+  uint32_t k0 = colptr[c], k1 = colptr[c + 1];
+  fq acc = fq_zero();
+  if (k1 - k0 <= kLongCol) {  // long columns: eval_table_long_finish_strided_kernel
+    for (uint32_t q = k0; q < k1; q++) acc = fq_add(acc, fq_mul(fq_load(val + q), fq_load(rx + row[q])));
+    if (k1 > k0) acc = fq_mul(acc, rc);
+  }
+  if (accumulate) acc = fq_add(acc, fq_load(out + k));
+  fq_store(out + k, acc);
+}
+
 // partial eval table of one matrix scaled by its challenge: out[c] (+)= rc * sum_k val[k]*rx[row[k]]
 // accumulate != 0 adds onto the existing out[c] (used to fold A, B, C into one table)
 __global__ __launch_bounds__(kRB) void eval_table_kernel(const uint32_t* __restrict__ colptr, const uint32_t* __restrict__ row,
@@ -95,6 +138,21 @@ __global__ __launch_bounds__(64) void eval_table_long_finish_kernel(const uint32
   uint32_t c = long_cols[i];
   if (accumulate) t = fq_add(t, fq_load(out + c));
   fq_store(out + c, t);
+}
+
+__global__ __launch_bounds__(64) void eval_table_long_finish_strided_kernel(const uint32_t* __restrict__ long_cols,
+                                                                            const uint32_t* __restrict__ long_first, size_t n_long,
+                                                                            const fq* __restrict__ part, fq rc, size_t r0, size_t step,
+                                                                            fq* __restrict__ out) {
+  const size_t i = blockIdx.x;
+  if (i >= n_long) return;
+  const uint32_t c = long_cols[i];
+  if (c % step != r0) return;  // another rank's column
+  fq t = long_column_sum(long_first, i, part);
+  if (threadIdx.x != 0) return;
+  t = fq_mul(t, rc);
+  const size_t k = (c - r0) / step;
+  fq_store(out + k, fq_add(t, fq_load(out + k)));  // the short-column kernel has written (or accumulated into) out[k] already
 }
 
 // one wave per long column: partials[i] = ry[c] * sum of its chunk partials
@@ -321,6 +379,82 @@ int vpin_r1cs_eval_table(vpin_ctx* c, const vpin_r1cs_dev* d, const vpin_table* 
   *out = t;
   return VPIN_OK;
 }
+
+}  // extern "C"
+
+namespace vpin {
+
+// multiply_vec for the rows = r0 (mod step): three tables of num_cons / step entries
+int r1cs_multiply_vec_strided(vpin_ctx* c, const vpin_r1cs_dev* d, const vpin_table* z, size_t r0, size_t step, vpin_table** Az,
+                              vpin_table** Bz, vpin_table** Cz) {
+  if (!c || !d || !z || !Az || !Bz || !Cz || step == 0 || r0 >= step || d->num_cons % step) return VPIN_EINVAL;
+  if (z->len != 2 * d->num_vars) return VPIN_ESHAPE;
+  (void)hipSetDevice(c->device);
+  const size_t nloc = d->num_cons / step;
+  vpin_table* t[3] = {nullptr, nullptr, nullptr};
+  for (int m = 0; m < 3; m++) {
+    int rc = table_alloc_uninit(c, nloc, &t[m]);
+    if (rc) { for (int k = 0; k < m; k++) vpin_table_free(c, t[k]); return rc; }
+    hipLaunchKernelGGL(spmv_strided_kernel, dim3((unsigned)((nloc + kRB - 1) / kRB)), dim3(kRB), 0, c->stream, d->rowptr[m],
+                       d->csr_col[m], d->csr_val[m], z->d, nloc, r0, step, t[m]->d);
+  }
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { set_last_error("spmv_strided", e); for (auto* p : t) vpin_table_free(c, p); return VPIN_EHIP; }
+  *Az = t[0]; *Bz = t[1]; *Cz = t[2];
+  return VPIN_OK;
+}
+
+// out[k] = src[r0 + k*step], a fresh table of src->len / step entries
+int table_take_strided(vpin_ctx* c, const vpin_table* src, size_t r0, size_t step, vpin_table** out) {
+  if (!c || !src || !out || step == 0 || r0 >= step || src->len % step) return VPIN_EINVAL;
+  (void)hipSetDevice(c->device);
+  const size_t nloc = src->len / step;
+  vpin_table* t = nullptr;
+  int rc = table_alloc_uninit(c, nloc, &t);
+  if (rc) return rc;
+  hipLaunchKernelGGL(strided_take_kernel, dim3((unsigned)((nloc + kRB - 1) / kRB)), dim3(kRB), 0, c->stream, (const fq*)src->d, nloc, r0,
+                     step, t->d);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { set_last_error("strided_take", e); vpin_table_free(c, t); return VPIN_EHIP; }
+  *out = t;
+  return VPIN_OK;
+}
+
+// the eval table of vpin_r1cs_eval_table at the columns = r0 (mod step): 2*num_vars / step entries
+int r1cs_eval_table_strided(vpin_ctx* c, const vpin_r1cs_dev* d, const vpin_table* evals_rx, const uint8_t r_abc[96], size_t r0,
+                            size_t step, vpin_table** out) {
+  if (!c || !d || !evals_rx || !r_abc || !out || step == 0 || r0 >= step || (2 * d->num_vars) % step) return VPIN_EINVAL;
+  if (evals_rx->len != d->num_cons) return VPIN_ESHAPE;
+  (void)hipSetDevice(c->device);
+  const size_t nloc = 2 * d->num_vars / step;
+  vpin_table* t = nullptr;
+  int rc = table_alloc_uninit(c, nloc, &t);
+  if (rc) return rc;
+  DevBuf chunk_scratch(c);
+  const size_t max_chunks = std::max(d->n_chunks[0], std::max(d->n_chunks[1], d->n_chunks[2]));
+  if (max_chunks && chunk_scratch.alloc(max_chunks * sizeof(fq))) { vpin_table_free(c, t); return VPIN_ENOMEM; }
+  fq* chunk_partials = (fq*)chunk_scratch.p;
+  for (int m = 0; m < 3; m++) {
+    fq rc_m;
+    memcpy(rc_m.v, r_abc + 32 * m, 32);
+    hipLaunchKernelGGL(eval_table_strided_kernel, dim3((unsigned)((nloc + kRB - 1) / kRB)), dim3(kRB), 0, c->stream, d->colptr[m],
+                       d->csc_row[m], d->csc_val[m], evals_rx->d, nloc, r0, step, rc_m, m > 0 ? 1 : 0, t->d);
+    if (d->n_long[m]) {
+      hipLaunchKernelGGL(long_chunk_kernel, dim3((unsigned)d->n_chunks[m]), dim3(kRB), 0, c->stream, d->chunk_k0[m],
+                         d->chunk_k1[m], d->csc_row[m], d->csc_val[m], evals_rx->d, chunk_partials);
+      hipLaunchKernelGGL(eval_table_long_finish_strided_kernel, dim3((unsigned)d->n_long[m]), dim3(64), 0, c->stream,
+                         d->long_cols[m], d->long_first[m], d->n_long[m], chunk_partials, rc_m, r0, step, t->d);
+    }
+  }
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { set_last_error("eval_table_strided", e); vpin_table_free(c, t); return VPIN_EHIP; }
+  *out = t;
+  return VPIN_OK;
+}
+
+}  // namespace vpin
+
+extern "C" {
 
 // R1CSInstance::evaluate (r1csinstance.rs:297-302) given the two eq tables: out = Ar|Br|Cr
 int vpin_r1cs_evaluate(vpin_ctx* c, const vpin_r1cs_dev* d, const vpin_table* evals_rx, const vpin_table* evals_ry,

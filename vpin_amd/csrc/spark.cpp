@@ -155,9 +155,12 @@ static int polyeval_prove_plain(vpin_ctx* c, const PcGens& pc, const vpin_table*
   int rc;
   {
     TraceSpan ts("  poly_bound");
-    rc = vpin_poly_bound(c, Z, B(Lv.data()), pc.L, B(LZ.data()));
+    // one proof over several GPUs: every rank sums its block of rows, the partial vectors are all-gathered on the device
+    if (c->comm && c->comm->world > 1) rc = vpin::poly_bound_dist(c, Z, B(Lv.data()), pc.L, B(LZ.data()));
+    else rc = vpin_poly_bound(c, Z, B(Lv.data()), pc.L, B(LZ.data()));
   }
   if (rc) return rc;
+  if ((rc = vpin::comm_mark(c, "hash_poly_bound"))) return rc;
   TraceSpan ts("  dplog");
   return dplog_prove(c, pc, tr, tape, LZ, Fq::zero(), Rv, Zr, Fq::zero(), out);
 }
@@ -207,14 +210,15 @@ static void plan_init(DistPlan& pl, vpin_comm* cm) {
 
 // `per` scalars of each of this rank's instances (its circuits in ascending order, then -- with_dotp -- its dot-product
 // halves) -> the same for ALL instances in the single-GPU slot order: circuit g at global[per*g], half k at global[per*(12+k)]
-static int dist_exchange(vpin_ctx* c, const DistPlan& pl, bool mem, bool with_dotp, const Fq* local, int per, Fq* global) {
+static int dist_exchange(vpin_ctx* c, const DistPlan& pl, bool mem, bool with_dotp, const Fq* local, int per, Fq* global,
+                         const char* tag = nullptr) {
   const int maxi = mem ? pl.max_mem_inst : pl.max_ops_inst;
   const size_t chunk = (size_t)maxi * per;
   std::vector<Fq> sb(chunk, Fq::zero()), rb(chunk * pl.world);
   const auto& mine = mem ? pl.mem_of[pl.rank] : pl.ops_of[pl.rank];
   const size_t nloc = mine.size() + (with_dotp ? pl.dotp_of[pl.rank].size() : 0);
   if (nloc) memcpy(sb.data(), local, nloc * per * 32);
-  int rc = vpin::comm_allgather_ctx(c, sb.data(), rb.data(), chunk * 32);
+  int rc = vpin::comm_allgather_ctx(c, sb.data(), rb.data(), chunk * 32, tag);
   if (rc) return rc;
   for (int r = 0; r < pl.world; r++) {
     const Fq* src = rb.data() + (size_t)r * chunk;
@@ -274,7 +278,7 @@ static int batched_prove(vpin_ctx* c, vpin::SparkForest& f, DotpCtx* dotp, Trans
   if (nl && (rc = vpin::spark_fetch_tops(c, &f, cnt))) return rc;
   std::vector<Fq> tops((size_t)npc * cnt);
   if (!pl) memcpy(tops.data(), c->h_spark, tops.size() * 32);
-  else if ((rc = dist_exchange(c, *pl, is_mem, false, reinterpret_cast<const Fq*>(c->h_spark), (int)cnt, tops.data()))) return rc;
+  else if ((rc = dist_exchange(c, *pl, is_mem, false, reinterpret_cast<const Fq*>(c->h_spark), (int)cnt, tops.data(), is_mem ? "mem_tops" : "ops_tops"))) return rc;
   std::vector<Fq> res_all(3 * (size_t)vpin::kSparkMaxInst), fin_all(6 * (size_t)vpin::kSparkMaxInst), pack(6 * (size_t)vpin::kSparkMaxInst);
 
   out.polys.assign(num_layers, {});
@@ -420,7 +424,9 @@ static int batched_prove(vpin_ctx* c, vpin::SparkForest& f, DotpCtx* dotp, Trans
           for (int t = 0; t < nl; t++) memcpy(&pack[3 * (size_t)t], res + 3 * (size_t)t, 96);
           // (a launch group puts its halves at slots 12.., the persistent tail numbers its instances consecutively)
           for (int i = 0; i < ndl_here; i++) memcpy(&pack[3 * (size_t)(nl + i)], res + 3 * (size_t)((tail_on ? nl : 12) + i), 96);
-          if ((rc = dist_exchange(c, *pl, is_mem, with_dotp, pack.data(), 3, res_all.data()))) return rc;
+          if ((rc = dist_exchange(c, *pl, is_mem, with_dotp, pack.data(), 3, res_all.data(),
+                                  is_mem ? (tail_on ? "mem_tail_round" : "mem_round") : (tail_on ? "ops_tail_round" : "ops_round"))))
+            return rc;
           res = res_all.data();
         }
         if (fine) { auto t = Clock::now(); (j == 0 ? t_first : t_rounds) += secs(tl0, t); if (k >= 11) fprintf(stderr, " w%.1f", secs(tl0, t) * 1e6); tl0 = t; }
@@ -463,7 +469,7 @@ static int batched_prove(vpin_ctx* c, vpin::SparkForest& f, DotpCtx* dotp, Trans
         const Fq* fin = runs ? reinterpret_cast<const Fq*>(vpin::spark_tail_final(c)) : nullptr;
         if (pl) {
           for (int t = 0; t < ninst; t++) memcpy(&pack[6 * (size_t)t], fin + 6 * (size_t)t, 192);  // the tail numbers its instances 0..ninst-1
-          if ((rc = dist_exchange(c, *pl, is_mem, with_dotp, pack.data(), 6, fin_all.data()))) return rc;
+          if ((rc = dist_exchange(c, *pl, is_mem, with_dotp, pack.data(), 6, fin_all.data(), is_mem ? "mem_finals" : "ops_finals"))) return rc;
           fin = fin_all.data();  // halves at slots 12.. = npc + i (only the ops forest, npc == 12, carries them)
         }
         for (int t = 0; t < npc; t++) {
@@ -565,30 +571,31 @@ static int spark_prove(vpin_ctx* c, const vpin_spark_decomm* d, const std::vecto
   if ((rc = vpin::table_alloc_uninit(c, 8 * N, &comb))) return rc;
   tg.add(comb);
   if ((rc = vpin::spark_gather_derefs(c, d, mem_rx->d, mem_ry->d, comb->d))) return rc;
+  if ((rc = vpin::comm_mark(c, "derefs_gather"))) return rc;
   std::vector<CG> comm_derefs;
   const bool hot = d->hot_col[0] != 0xffffffffu || d->hot_col[1] != 0xffffffffu || d->hot_col[2] != 0xffffffffu;
   if (dz) {
-    // the L row commitments are independent MSMs over shared generators: a contiguous block of rows per rank, 32 bytes
-    // per row all-gathered (no point crosses a link, nothing is reduced)
+    // the L row commitments are independent MSMs over shared generators: rank r commits rows r, r + world, .. (the rows
+    // differ in cost: two of the polynomial's eight slices are zero padding, the col slices carry the hot columns), 32
+    // bytes per row are all-gathered (no point crosses a link, nothing is reduced)
     const size_t L = g_derefs->L, pmax = vpin::comm_block_max(L, dz->world);
-    size_t row0, nrows;
-    vpin::comm_block(L, dz->rank, dz->world, &row0, &nrows);
+    const size_t nrows = vpin::comm_strided_count(L, dz->rank, dz->world);  // rows rank, rank + world, ..
     std::vector<uint8_t> mine(pmax * 32, 0), all(pmax * 32 * (size_t)dz->world);
     if (nrows) {
       if (hot) {
         const uint32_t* col_idx[3] = {d->idx + 6 * d->N, d->idx + 7 * d->N, d->idx + 8 * d->N};
-        rc = vpin::hyrax_commit_derefs_hot(c, g_derefs->dev, comb, L, d->N, col_idx, d->hot_col, mem_ry->d, mine.data(), row0, nrows);
+        rc = vpin::hyrax_commit_derefs_hot(c, g_derefs->dev, comb, L, d->N, col_idx, d->hot_col, mem_ry->d, mine.data(), (size_t)dz->rank,
+                                           nrows, (size_t)dz->world);
       } else {
-        rc = vpin_hyrax_commit_rows(c, g_derefs->dev, comb, L, row0, nrows, nullptr, g_derefs->R + 1, mine.data());
+        rc = vpin::hyrax_commit_rows_strided(c, g_derefs->dev, comb, L, (size_t)dz->rank, nrows, (size_t)dz->world, mine.data());
       }
       if (rc) return rc;
     }
-    if ((rc = vpin::comm_allgather_ctx(c, mine.data(), all.data(), mine.size()))) return rc;
+    if ((rc = vpin::comm_allgather_ctx(c, mine.data(), all.data(), mine.size(), "derefs_commit"))) return rc;
     comm_derefs.resize(L);
     for (int r = 0; r < dz->world; r++) {
-      size_t f0, n;
-      vpin::comm_block(L, r, dz->world, &f0, &n);
-      memcpy(comm_derefs[0].b + f0 * 32, all.data() + (size_t)r * pmax * 32, n * 32);
+      const size_t n = vpin::comm_strided_count(L, r, dz->world);
+      for (size_t k = 0; k < n; k++) memcpy(comm_derefs[(size_t)r + k * (size_t)dz->world].b, all.data() + ((size_t)r * pmax + k) * 32, 32);
     }
   } else if (d->hot_col[0] != 0xffffffffu || d->hot_col[1] != 0xffffffffu || d->hot_col[2] != 0xffffffffu) {
     // the entries of each matrix's hot column hold one scalar, E_ry[hot]: one addition each instead of a table walk
@@ -612,8 +619,11 @@ static int spark_prove(vpin_ctx* c, const vpin_spark_decomm* d, const std::vecto
   vpin::SparkForest f_ops, f_mem;
   vpin::DevBuf b_ops(c), b_mem(c), b_scr(c);
   const int nl_ops = dz ? (int)dz->ops_of[dz->rank].size() : 12, nl_mem = dz ? (int)dz->mem_of[dz->rank].size() : 4;
-  if (b_ops.alloc((size_t)nl_ops * 2 * N * 32) || (nl_mem && b_mem.alloc((size_t)nl_mem * 2 * M * 32)) || b_scr.alloc(18 * (N / 4) * 32))
+  const size_t nl_dotp = dz ? dz->dotp_of[dz->rank].size() : 6;  // the first-fold scratch is numbered by the local half
+  if (b_ops.alloc((size_t)nl_ops * 2 * N * 32) || (nl_mem && b_mem.alloc((size_t)nl_mem * 2 * M * 32)) ||
+      b_scr.alloc(std::max<size_t>(256, 3 * nl_dotp * (N / 4) * 32)))
     return VPIN_ENOMEM;
+  if ((rc = vpin::comm_mark(c, "network_alloc"))) return rc;
   f_ops.base = (vpin::fq*)b_ops.p; f_ops.n = N; f_ops.ncirc = nl_ops;
   f_mem.base = (vpin::fq*)b_mem.p; f_mem.n = M; f_mem.ncirc = nl_mem;
   if (!dz) {
@@ -630,6 +640,7 @@ static int spark_prove(vpin_ctx* c, const vpin_spark_decomm* d, const std::vecto
       return rc;
   }
   if ((rc = vpin::spark_wait(c))) return rc;
+  if ((rc = vpin::comm_mark(c, "network_build"))) return rc;
   g_spark_timings[2] = secs(t0, Clock::now());
 
   // ---- PolyEvalNetworkProof::prove / ProductLayerProof::prove (:1336-1370, :1049-1227) ----
@@ -643,7 +654,7 @@ static int spark_prove(vpin_ctx* c, const vpin_spark_decomm* d, const std::vecto
     if ((rc = vpin::spark_fetch_tops(c, &f_ops, 2))) return rc;
     const Fq* t = reinterpret_cast<const Fq*>(c->h_spark);
     if (dz) {
-      if ((rc = dist_exchange(c, *dz, false, false, t, 2, roots.data()))) return rc;
+      if ((rc = dist_exchange(c, *dz, false, false, t, 2, roots.data(), "roots"))) return rc;
       t = roots.data();
     }
     for (int s = 0; s < 2; s++)
@@ -651,7 +662,7 @@ static int spark_prove(vpin_ctx* c, const vpin_spark_decomm* d, const std::vecto
     if (nl_mem && (rc = vpin::spark_fetch_tops(c, &f_mem, 2))) return rc;
     t = reinterpret_cast<const Fq*>(c->h_spark);
     if (dz) {
-      if ((rc = dist_exchange(c, *dz, true, false, t, 2, roots.data()))) return rc;
+      if ((rc = dist_exchange(c, *dz, true, false, t, 2, roots.data(), "roots"))) return rc;
       t = roots.data();
     }
     for (int s = 0; s < 2; s++) { pl[s][0] = t[2 * (2 * s)]; pl[s][7] = t[2 * (2 * s + 1)]; }
@@ -671,8 +682,18 @@ static int spark_prove(vpin_ctx* c, const vpin_spark_decomm* d, const std::vecto
   Fq dotp_left[3], dotp_right[3];
   {
     // DotProductCircuit::evaluate (product_tree.rs:87-91) of the six halves
-    if ((rc = vpin::spark_triple_sums(c, d, comb->d))) return rc;
-    for (int i = 0; i < 6; i++) dotp.claims[i] = reinterpret_cast<const Fq*>(c->h_spark)[3 * i];
+    if (!dz) {
+      if ((rc = vpin::spark_triple_sums(c, d, comb->d))) return rc;
+      for (int i = 0; i < 6; i++) dotp.claims[i] = reinterpret_cast<const Fq*>(c->h_spark)[3 * i];
+    } else {
+      // every rank sums the halves it will prove; one scalar per half is exchanged
+      const auto& hv = dz->dotp_of[dz->rank];
+      if (!hv.empty() && (rc = vpin::spark_triple_sums(c, d, comb->d, hv.data(), (int)hv.size()))) return rc;
+      std::vector<Fq> mine6(6, Fq::zero()), all6(6 * (size_t)dz->world);
+      for (size_t i = 0; i < hv.size(); i++) mine6[hv[i]] = reinterpret_cast<const Fq*>(c->h_spark)[3 * i];
+      if ((rc = vpin::comm_allgather_ctx(c, mine6.data(), all6.data(), 6 * 32, "triple_sums"))) return rc;
+      for (int k = 0; k < 6; k++) dotp.claims[k] = all6[6 * (size_t)dz->owner_dotp[k] + k];
+    }
     for (int m = 0; m < 3; m++) {
       dotp_left[m] = dotp.claims[2 * m];
       dotp_right[m] = dotp.claims[2 * m + 1];
@@ -704,13 +725,51 @@ static int spark_prove(vpin_ctx* c, const vpin_spark_decomm* d, const std::vecto
     if ((rc = vpin_eq_table(c, B(rand_mem.data()), (int)lgM, &eq_mem))) return rc;
     tg.add(eq_mem);
   }
+  if ((rc = vpin::comm_mark(c, "hash_eq_tables"))) return rc;
   Fq ev_derefs[6], ev_ops[15], ev_mem[2];
   const Fq* hs = reinterpret_cast<const Fq*>(c->h_spark);
-  {
+  if (dz) {
+    // The 23 DensePolynomial::evaluate of the hash layer (6 derefs + 15 ops slices against eq(rand_ops), 2 mem slices
+    // against eq(rand_mem)) depend on nothing the transcript produces in between: deal them out in contiguous runs of
+    // equal cost (a slice costs its length), evaluate, exchange 23 scalars.
+    const size_t cost[3] = {N, N, M};
+    const int cnts[3] = {6, 15, 2};
+    const vpin::fq* tabs[3] = {comb->d, d->comb_ops->d, d->comb_mem->d};
+    const vpin::fq* eqs[3] = {eq_ops->d, eq_ops->d, eq_mem->d};
+    size_t total = 0;
+    for (int g = 0; g < 3; g++) total += cost[g] * (size_t)cnts[g];
+    int owner[23];
+    {
+      size_t cum = 0;
+      int sidx = 0;
+      for (int g = 0; g < 3; g++)
+        for (int i = 0; i < cnts[g]; i++, sidx++) {
+          owner[sidx] = (int)std::min<size_t>((size_t)dz->world - 1, (cum + cost[g] / 2) * (size_t)dz->world / total);
+          cum += cost[g];
+        }
+    }
+    std::vector<Fq> mine23(23, Fq::zero()), all23(23 * (size_t)dz->world);
+    int base = 0;
+    for (int g = 0; g < 3; g++) {
+      int first = -1, cnt = 0;
+      for (int i = 0; i < cnts[g]; i++)
+        if (owner[base + i] == dz->rank) { if (first < 0) first = i; cnt++; }
+      if (cnt) {  // a rank's slices of one table are contiguous
+        if ((rc = vpin::spark_slice_evals(c, tabs[g] + (size_t)first * cost[g], cost[g], cnt, eqs[g]))) return rc;
+        for (int i = 0; i < cnt; i++) mine23[base + first + i] = hs[3 * i];
+      }
+      base += cnts[g];
+    }
+    if ((rc = vpin::comm_allgather_ctx(c, mine23.data(), all23.data(), 23 * 32, "hash_slice_evals"))) return rc;
+    auto pick = [&](int sidx) { return all23[23 * (size_t)owner[sidx] + sidx]; };
+    for (int i = 0; i < 6; i++) ev_derefs[i] = pick(i);
+    for (int i = 0; i < 15; i++) ev_ops[i] = pick(6 + i);
+    for (int i = 0; i < 2; i++) ev_mem[i] = pick(21 + i);
+  } else {
     TraceSpan ts("hash: derefs slice evals");
     if ((rc = vpin::spark_slice_evals(c, comb->d, N, 6, eq_ops->d))) return rc;
+    for (int i = 0; i < 6; i++) ev_derefs[i] = hs[3 * i];
   }
-  for (int i = 0; i < 6; i++) ev_derefs[i] = hs[3 * i];
   DpLog pe_derefs, pe_ops, pe_mem;
   {
     // DerefsEvalProof::prove (:137-158, :90-135)
@@ -725,8 +784,9 @@ static int spark_prove(vpin_ctx* c, const vpin_spark_decomm* d, const std::vecto
     tr.append_scalar("joint_claim_eval", joint);
     TraceSpan ts("hash: polyeval derefs");
     if ((rc = polyeval_prove_plain(c, *g_derefs, comb, rj, joint, tr, tape, pe_derefs))) return rc;
+    if ((rc = vpin::comm_mark(c, "hash_bullet"))) return rc;
   }
-  {
+  if (!dz) {
     TraceSpan ts("hash: ops+mem slice evals");
     if ((rc = vpin::spark_slice_evals(c, d->comb_ops->d, N, 15, eq_ops->d))) return rc;
     for (int i = 0; i < 15; i++) ev_ops[i] = hs[3 * i];
@@ -744,6 +804,7 @@ static int spark_prove(vpin_ctx* c, const vpin_spark_decomm* d, const std::vecto
     tr.append_scalar("joint_claim_eval_ops", joint);
     TraceSpan ts("hash: polyeval ops");
     if ((rc = polyeval_prove_plain(c, *g_ops, d->comb_ops, rj, joint, tr, tape, pe_ops))) return rc;
+    if ((rc = vpin::comm_mark(c, "hash_bullet"))) return rc;
   }
   {
     std::vector<Fq> e2 = {ev_mem[0], ev_mem[1]};
@@ -755,6 +816,7 @@ static int spark_prove(vpin_ctx* c, const vpin_spark_decomm* d, const std::vecto
     tr.append_scalar("joint_claim_eval_mem", joint);
     TraceSpan ts("hash: polyeval mem");
     if ((rc = polyeval_prove_plain(c, *g_mem, d->comb_mem, rj, joint, tr, tape, pe_mem))) return rc;
+    if ((rc = vpin::comm_mark(c, "hash_bullet"))) return rc;
   }
   g_spark_timings[4] = secs(t0, Clock::now());
 

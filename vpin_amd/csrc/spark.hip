@@ -313,7 +313,7 @@ __global__ __launch_bounds__(kBlock, kMinWaves) void dotp_round_kernel(const fq*
   const fq* src[3];
   fq* dst[3];
 #pragma unroll
-  for (int t = 0; t < 3; t++) dst[t] = scratch + (size_t)(3 * k + t) * q4;
+  for (int t = 0; t < 3; t++) dst[t] = scratch + (size_t)(3 * blockIdx.y + t) * q4;  // scratch is numbered by the LOCAL half
   if (from_scratch) {
 #pragma unroll
     for (int t = 0; t < 3; t++) src[t] = dst[t];
@@ -450,8 +450,8 @@ __global__ __launch_bounds__(kBlock) void slice_dot3_kernel(const fq* __restrict
 
 // blockIdx.y = dot-product circuit half k: partial sums of L*R*W
 __global__ __launch_bounds__(kBlock) void triple_sum_kernel(const fq* __restrict__ derefs, const fq* __restrict__ vals, size_t N,
-                                                            fq* __restrict__ partials) {
-  const int k = blockIdx.y, m = k >> 1, half = k & 1;
+                                                            fq* __restrict__ partials, CircIds kmap) {
+  const int k = kmap.v[blockIdx.y], m = k >> 1, half = k & 1;
   const size_t hN = N / 2;
   const fq* L = derefs + (size_t)m * N + (size_t)half * hN;
   const fq* R = derefs + (size_t)(3 + m) * N + (size_t)half * hN;
@@ -800,8 +800,10 @@ int spark_collect(vpin_ctx* c, const SparkForest* f, int level, const vpin_spark
   return spark_wait_flag(c);
 }
 
-int spark_triple_sums(vpin_ctx* c, const vpin_spark_decomm* d, const fq* comb_derefs) {
-  if (!c || !d || !comb_derefs) return VPIN_EINVAL;
+int spark_triple_sums(vpin_ctx* c, const vpin_spark_decomm* d, const fq* comb_derefs, const int* halves, int nh) {
+  if (!c || !d || !comb_derefs || nh < 1 || nh > 6) return VPIN_EINVAL;
+  CircIds kmap{};
+  for (int i = 0; i < nh; i++) kmap.v[i] = halves ? halves[i] : i;
   int rc = spark_pinned(c);
   if (rc) return rc;
   (void)hipSetDevice(c->device);
@@ -809,11 +811,11 @@ int spark_triple_sums(vpin_ctx* c, const vpin_spark_decomm* d, const fq* comb_de
   if ((rc = round_partials(c, &partials))) return rc;
   const int grid = round_grid(d->N / 2, 6, c->shared_device);
   {
-    ProfScope ps(c, VPIN_K_SPARK_BUILD, 9.0 * 32.0 * (double)d->N);
-    hipLaunchKernelGGL(triple_sum_kernel, dim3(grid, 6), dim3(kBlock), 0, c->stream, comb_derefs,
-                       (const fq*)(d->comb_ops->d + 12 * d->N), d->N, partials);
+    ProfScope ps(c, VPIN_K_SPARK_BUILD, 1.5 * nh * 32.0 * (double)d->N);
+    hipLaunchKernelGGL(triple_sum_kernel, dim3(grid, nh), dim3(kBlock), 0, c->stream, comb_derefs,
+                       (const fq*)(d->comb_ops->d + 12 * d->N), d->N, partials, kmap);
   }
-  hipLaunchKernelGGL(inst_finish_kernel, dim3(6), dim3(kBlock), 0, c->stream, (const fq*)partials, grid, 0, c->h_spark);
+  hipLaunchKernelGGL(inst_finish_kernel, dim3(nh), dim3(kBlock), 0, c->stream, (const fq*)partials, grid, 0, c->h_spark);
   VPIN_HIP_TRY(hipGetLastError());
   return spark_wait(c);
 }
@@ -922,13 +924,13 @@ __global__ __launch_bounds__(kTailBlock) void spark_tail_kernel(TailArgs a) {
     A = a.forest + (size_t)inst * a.stride + a.off;
     Bt = A + a.h;
   } else {
-    const int kk = a.kmap.v[inst - a.ncirc], m = kk >> 1, half = kk & 1;
+    const int kl = inst - a.ncirc, kk = a.kmap.v[kl], m = kk >> 1, half = kk & 1;
     const size_t hN = a.N / 2, q4 = a.N / 4;
     src[0] = a.derefs + (size_t)m * a.N + (size_t)half * hN;
     src[1] = a.derefs + (size_t)(3 + m) * a.N + (size_t)half * hN;
     src[2] = a.vals + (size_t)m * a.N + (size_t)half * hN;
 #pragma unroll
-    for (int t = 0; t < 3; t++) dst[t] = a.scratch + (size_t)(3 * kk + t) * q4;
+    for (int t = 0; t < 3; t++) dst[t] = a.scratch + (size_t)(3 * kl + t) * q4;  // scratch is numbered by the LOCAL half
   }
   uint32_t* up = a.up + (size_t)inst * kTailUpChunks * 4;
   for (int j = a.j0; j < a.k; j++) {

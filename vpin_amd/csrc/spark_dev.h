@@ -101,7 +101,8 @@ int spark_collect(vpin_ctx* c, const SparkForest* f, int level, const vpin_spark
 
 // DotProductCircuit::evaluate (product_tree.rs:87-91) of the six halves: h_spark[3*k] = sum_i L[i]*R[i]*W[i]
 // over the N/2 entries of half k; synchronises
-int spark_triple_sums(vpin_ctx* c, const vpin_spark_decomm* d, const fq* comb_derefs);
+// halves / nh: a subset of the halves (results at h_spark[3*i] in that order); nullptr / 6 = all
+int spark_triple_sums(vpin_ctx* c, const vpin_spark_decomm* d, const fq* comb_derefs, const int* halves = nullptr, int nh = 6);
 
 // Persistent tail (spark.hip): rounds j0..k-1 of forest level `level` (h = 2^k entries per half) in ONE launch, one workgroup per
 // circuit (+ the six dot-product halves when vals != nullptr), leading-coefficient form.  The host keeps the transcript:

@@ -89,8 +89,9 @@ def parse():
     ap.add_argument("--rehearse", type=int, default=0,
                     help="with --scaling strong: W ranks as threads of this process on ONE GPU, serialised, to measure the "
                          "critical path of a W-GPU run (a model: no multi-GPU hardware involved)")
+    ap.add_argument("--coop-all", action="store_true", help="--rehearse: every point-mult instance cooperatively (to see how each size scales)")
     ap.add_argument("--rehearse-passes", type=int, default=3, help="serialised passes per cooperative instance; the quietest one is reported")
-    ap.add_argument("--coop-log2", type=int, default=20,
+    ap.add_argument("--coop-log2", type=int, default=24,
                     help="--scaling strong: instances of at least 2^this constraints are proven by all ranks together")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend of the N>1 runs (gloo: rehearsal with ranks sharing a GPU)")
     ap.add_argument("--no-roofline-pass", action="store_true",
@@ -244,6 +245,8 @@ def strong_rehearse(args):
     trace, work = _strong_work(args)
     total_cons = sum(w[3] for w in work)
     coop = [w for w in work if w[3] >= (1 << args.coop_log2) * 0.5]
+    if args.coop_all:
+        coop = [w for w in work if w[1] == "mult"]
     small = [w for w in work if w not in coop]
     gold = _golden_digests()
     ctx0 = vpin_amd.Context(0)
@@ -342,9 +345,9 @@ def strong_rehearse(args):
                     quiet_r = [min(tg[k]["busy_s"] for _st, tg in passes[r] if k in tg) for r in range(W)]
                     if k in replicated:
                         v = min(v, min(quiet_r))
-                    elif ncoll <= 3:
-                        # a one-shot sharded step: the slowest rank, each rank at its quietest (for the round steps, hundreds of
-                        # collectives each, the library's sum of per-collective maxima stands)
+                    else:
+                        # a sharded step: the slowest rank, each rank at its quietest pass (for the round steps -- hundreds of
+                        # collectives with the same work on every owner -- this drops only the per-round jitter)
                         v = min(v, max(quiet_r))
                     tagq[k] = v
                 tagged_best = sum(v["crit_s"] for v in tags[0].values())
@@ -360,8 +363,8 @@ def strong_rehearse(args):
         g.free()
     shards = plan_shards([int(single_ms[w[0]] * 1e3) for w in small], W)
     share_ms = [sum(single_ms[small[i][0]] for i in sh) for sh in shards]
-    ok = all("model_ms" in per[w[0]] for w in coop)
-    model_ms = (sum(per[w[0]]["model_ms"] for w in coop) + (max(share_ms) if share_ms else 0.0)) if ok else None
+    ok = all("model_ms_quietest_pass_per_step" in per[w[0]] for w in coop)
+    model_ms = (sum(per[w[0]]["model_ms_quietest_pass_per_step"] for w in coop) + (max(share_ms) if share_ms else 0.0)) if ok else None
     serial_ms = sum(single_ms.values())
     print(json.dumps({
         "metric": "critical-path MODEL of one vPIN trace proven by W GPUs (sections measured on one GPU, ranks serialised)",

@@ -701,9 +701,23 @@ def main():
                     doc = json.load(f)
                 pmc_all, pmc_l5 = doc.get("bench_default", {}), doc.get("bench_L5_mult", {})
                 break
+        traffic_source = "--pmc-traffic (this invocation's caller)" if traffic is not None else None
         if traffic is None:
             # the largest instance's launches alone (bench_L5_mult section): the default run's average mixes every instance's
             traffic = (pmc_l5 or pmc_all).get("sc_cubic3_kernel<true, true>", {}).get("hbm_bytes_per_launch")
+            if traffic is not None:
+                traffic_source = f"replayed from profiles/{pmc} (separate rocprofv3 --pmc passes of the same command; NOT measured in this run)"
+        # VALU-issue ceiling of the same launches: pairs per second the chip can issue (one wave-instruction per SIMD per 4
+        # cycles, tools/isa_counts.py: VALU instructions per pair of this kernel's loop)
+        valu_per_pair, valu_frac = None, None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r02_isa_counts.json")) as f:
+                valu_per_pair = json.load(f)["sc_cubic3_kernel<true, true>"]["valu_per_pair"]
+            ncu, hz = ctxs[0].device_props()
+            pairs_s = (k["alg_bytes"] / 384.0) / (k["ms"] * 1e-3)  # 4 tables x 32 B x 1.5 = 192 B per entry = 384 B per pair
+            valu_frac = pairs_s / (ncu * 4 * 64 * hz / (4.0 * valu_per_pair))
+        except (OSError, KeyError, ZeroDivisionError):
+            pass
         # bytes the eq-factored kernel really moves per launch: 3 tables read (len) and written (len/2), the suffix
         # table read once per pair (len/4): 152*len against the 192*len of the reference's 4-table formulation
         actual = k["alg_bytes"] * 152.0 / 192.0
@@ -712,7 +726,11 @@ def main():
             "kernel": "sc_cubic3_kernel<true, true> (fused fold + cubic round evaluation of phase 1, eq-factored, leading-coefficient form; "
                       "rounds with > 512 pairs)",
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+            "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
+            "limiter": "valu-issue", "limiter_frac": valu_frac, "valu_instructions_per_pair": valu_per_pair,
+            "limiter_note": "priced against HBM as the contract asks, but the kernel stops at the VALU-issue limit first: limiter_frac = "
+                            "achieved pairs/s over CUs x 4 SIMDs x 64 lanes x clock / (4 cycles x VALU instructions per pair); real HBM "
+                            "traffic is frac_actual of peak",
             "achieved_note": "algorithmic bytes of the reference's 4-table formulation (SURVEY.md 8(d): 4*32*1.5*len per launch) / HIP-event time",
             "achieved_actual": achieved_actual, "frac_actual": achieved_actual / HBM_PEAK_GBPS,
             "actual_note": "bytes this kernel really moves (3 tables + the suffix table, 152*len: the eq table is never read; PMC "

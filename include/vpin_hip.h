@@ -480,6 +480,10 @@ int vpin_host_merlin_kat(const char* proto, const char* label, const uint8_t* ms
 /* Commitments::commit (commitments.rs:85-98) under MultiCommitGens::new(n,label), n <= 4 */
 int vpin_host_commit(const char* label, const uint8_t* v_mont, size_t n, const uint8_t* blind_mont, uint8_t out[32]);
 
+/* self-test of the pinned-memory mailbox framing used between resident kernels and the host (sequence number + checksum per
+ * scalar; a torn or mixed publication is rejected and read again): 0 = as expected */
+int vpin_host_mailbox_selftest(void);
+
 /* ---- built-in kernel timing (HIP events on the ctx stream) ------------------------ */
 /* kernel classes */
 #define VPIN_K_SC_CUBIC 0

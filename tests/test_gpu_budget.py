@@ -1,0 +1,64 @@
+"""HBM-budget robustness: the window-table budgets are chosen from the memory that is FREE when a table is built (at most a
+third of it; a failed allocation halves the budget), so a device that another tenant half fills still proves -- with
+narrower windows, slower, and the same bytes.  Runs in a fresh process: the tables are a process-wide registry."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+SCRIPT = r"""
+import ctypes as C, hashlib, json, sys
+sys.path.insert(0, %(root)r)
+hip = C.CDLL("libamdhip64.so")
+hip.hipSetDevice(0)
+held = []
+for _ in range(%(hold_gb)d // 10):   # the other tenant: 10 GB blocks
+    p = C.c_void_p()
+    rc = hip.hipMalloc(C.byref(p), C.c_size_t(10 << 30))
+    assert rc == 0, rc
+    held.append(p)
+import vpin_amd
+from vpin_amd import gadgets as G
+L = vpin_amd.lib()
+L.vpin_gens_layout.argtypes = [C.c_void_p, C.POINTER(C.c_size_t)]
+L.vpin_spark_gens_view.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+with vpin_amd.Context(0) as ctx:
+    g = ctx.gadget_point_mult_dev(*G.synthetic_mult_inputs("E"))
+    res = g.snark_prove(bytes(range(64)), bytes((7 * i + 3) %% 256 for i in range(64)))
+    gv, Lv, Rv = C.c_void_p(), C.c_size_t(), C.c_size_t()
+    assert L.vpin_spark_gens_view(ctx.h, 25, C.byref(gv), C.byref(Lv), C.byref(Rv)) == 0
+    lay = (C.c_size_t * 6)()
+    assert L.vpin_gens_layout(gv, lay) == 0
+    free_b, total_b = C.c_size_t(), C.c_size_t()
+    hip.hipMemGetInfo(C.byref(free_b), C.byref(total_b))
+    g.free()
+print(json.dumps(dict(sha=hashlib.sha256(res["proof"]).hexdigest(), comm=hashlib.sha256(res["comm"]).hexdigest(),
+                      window_bits=int(lay[0]), windows=int(lay[1]), free_gb_after=free_b.value / 2**30)))
+"""
+
+
+def _run(hold_gb):
+    env = dict(os.environ)
+    env.pop("VPIN_GENS_BUDGET_GB", None)
+    env.pop("VPIN_SPARK_GENS_BUDGET_GB", None)
+    out = subprocess.run([sys.executable, "-c", SCRIPT % dict(root=ROOT, hold_gb=hold_gb)], capture_output=True, text=True, env=env,
+                         timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    return json.loads(out.stdout.strip().splitlines()[-1])
+
+
+def test_e_mult_with_150_gb_held_by_another_tenant():
+    with open(os.path.join(ROOT, "tests", "golden", "config_digests.json")) as f:
+        want = json.load(f)["cases"]["E-mult"]
+    crowded = _run(150)
+    assert crowded["sha"] == want["snark_sha256"] and crowded["comm"] == want["comm_sha256"]
+    assert crowded["window_bits"] <= 12
+    tight = _run(250)  # ~35 GB free: the budgets shrink to a third of that and the proof still has room
+    assert tight["sha"] == want["snark_sha256"]
+    assert tight["window_bits"] < 12, tight

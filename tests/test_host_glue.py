@@ -57,3 +57,9 @@ def test_host_commit_matches_oracle():
         e = (C.c_uint8 * 32)()
         L.ge_compress(e, C.byref(exp))
         assert bytes(out) == bytes(e)
+
+
+def test_mailbox_framing_rejects_torn_and_stale_pieces():
+    """mailbox_dev.h: a scalar crosses PCIe as three 16-byte pieces {seq, 3 words}, the spare word holds a checksum; a piece
+    torn 8 + 8, pieces of two publications and a stale sequence number must all be refused (and are then read again)"""
+    assert vpin_amd.lib().vpin_host_mailbox_selftest() == 0

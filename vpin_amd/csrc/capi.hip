@@ -2,6 +2,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
 
 #include "ctx.h"
 
@@ -28,6 +29,11 @@ static hipEvent_t get_event(vpin_ctx* c) {
 // out whether its owner still exists, and lets an allocation that fails reclaim the blocks other contexts cache
 static std::mutex g_ctx_mu;
 static std::vector<vpin_ctx*> g_live_ctxs;
+// a context another thread is working on (reclaiming its cached blocks, returning a table to its pool) is pinned: its
+// destroy waits until the pins are gone
+static void ctx_wait_unpinned(vpin_ctx* c) {
+  while (c->pins.load(std::memory_order_acquire) != 0) std::this_thread::yield();
+}
 
 void ctx_register(vpin_ctx* c) { std::lock_guard<std::mutex> g(g_ctx_mu); g_live_ctxs.push_back(c); }
 void ctx_unregister(vpin_ctx* c) {
@@ -41,12 +47,20 @@ bool ctx_is_live(vpin_ctx* c) {
   return false;
 }
 
-// cached (free-listed) blocks of one context back to the driver; the caller holds no pool lock
-static void pool_release_locked(vpin_ctx* c) {
-  (void)hipStreamSynchronize(c->stream);  // work that last used the cached blocks is ordered on this stream
-  for (auto& kv : c->pool_free_lists)
-    for (void* p : kv.second) { c->pool_sizes.erase(p); (void)hipFree(p); }
-  c->pool_free_lists.clear();
+// cached (free-listed) blocks of one context back to the driver.  The free lists are taken out under the pool lock; the
+// stream sync (work that last used the blocks is ordered on that stream) and the hipFree calls happen with no lock held, so
+// another lane's in-flight proof does not stall every context of the process behind a global mutex.
+static void pool_release_unlocked(vpin_ctx* c) {
+  std::vector<void*> blocks;
+  {
+    std::lock_guard<std::mutex> g(c->pool_mu);
+    for (auto& kv : c->pool_free_lists)
+      for (void* p : kv.second) { c->pool_sizes.erase(p); blocks.push_back(p); }
+    c->pool_free_lists.clear();
+  }
+  if (blocks.empty()) return;
+  (void)hipStreamSynchronize(c->stream);
+  for (void* p : blocks) (void)hipFree(p);
 }
 
 int dev_alloc(vpin_ctx* c, size_t bytes, void** out) {
@@ -74,10 +88,11 @@ int dev_alloc(vpin_ctx* c, size_t bytes, void** out) {
       // the other contexts on this device (the lanes of a shared GPU) cache multi-GB blocks too
       std::vector<vpin_ctx*> others;
       {
-        std::lock_guard<std::mutex> g(g_ctx_mu);
-        for (auto* x : g_live_ctxs) if (x != c && x->device == c->device) others.push_back(x);
-        for (auto* x : others) { std::lock_guard<std::mutex> gp(x->pool_mu); pool_release_locked(x); }
+        std::lock_guard<std::mutex> g(g_ctx_mu);  // only to copy and pin the list
+        for (auto* x : g_live_ctxs)
+          if (x != c && x->device == c->device) { x->pins.fetch_add(1, std::memory_order_acq_rel); others.push_back(x); }
       }
+      for (auto* x : others) { pool_release_unlocked(x); x->pins.fetch_sub(1, std::memory_order_acq_rel); }
       if (hipMalloc(&p, cls) != hipSuccess) { (void)hipGetLastError(); return VPIN_ENOMEM; }
     }
   }
@@ -95,10 +110,7 @@ void dev_free(vpin_ctx* c, void* p) {
   c->pool_free_lists[it->second].push_back(p);
 }
 
-void dev_pool_release(vpin_ctx* c) {
-  std::lock_guard<std::mutex> g(c->pool_mu);
-  pool_release_locked(c);
-}
+void dev_pool_release(vpin_ctx* c) { pool_release_unlocked(c); }
 
 ProfScope::ProfScope(vpin_ctx* c, int kclass, double bytes, int also, double units) : ctx(c) {
   if (!c->prof) return;
@@ -191,6 +203,7 @@ void vpin_ctx_destroy(vpin_ctx* c) {
   if (c->d_spark_cnt) (void)hipFree(c->d_spark_cnt);
   if (c->d_add_count) (void)hipFree(c->d_add_count);
   ctx_unregister(c);
+  ctx_wait_unpinned(c);
   dev_pool_release(c);
   // Handles (tables, device instances, decommitments) must be freed before their context.  Blocks still out are
   // released here so the VRAM is not lost; a handle freed later with this (dead) context would touch freed
@@ -324,10 +337,17 @@ int vpin_table_clone(vpin_ctx* c, const vpin_table* src, vpin_table** out) {
 void vpin_table_free(vpin_ctx* c, vpin_table* t) {
   if (!t) return;
   if (t->owned && t->d) {
-    // the block goes back to the pool it came from; without a context argument that is the table's owner, and if
-    // the owner is gone its destroy already released the block
-    vpin_ctx* pool = c ? c : t->owner;
-    if (pool && (pool == c || ctx_is_live(pool))) dev_free(pool, t->d);
+    // The block goes back to the pool it came from: the table's recorded owner (whatever context the caller passes; a
+    // block returned to another context's pool would be released twice).  The owner is looked up and pinned under the
+    // registry lock, so a concurrent vpin_ctx_destroy of it waits; if the owner is gone, its destroy released the block.
+    vpin_ctx* pool = t->owner ? t->owner : c;
+    bool live = false;
+    if (pool) {
+      std::lock_guard<std::mutex> g(g_ctx_mu);
+      for (auto* x : g_live_ctxs) live = live || x == pool;
+      if (live) pool->pins.fetch_add(1, std::memory_order_acq_rel);
+    }
+    if (live) { dev_free(pool, t->d); pool->pins.fetch_sub(1, std::memory_order_acq_rel); }
     else if (!t->owner) (void)hipFree(t->d);
   }
   delete t;

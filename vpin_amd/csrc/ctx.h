@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -71,6 +72,7 @@ struct vpin_ctx {
   // pool_mu guards both maps: another context's allocation failure may hand this context's cached blocks back
   // to the driver (dev_alloc's out-of-memory path)
   std::mutex pool_mu;
+  std::atomic<int> pins{0};  // threads other than the owner working on this context (capi.hip): destroy waits for them
   std::map<size_t, std::vector<void*>> pool_free_lists;
   std::unordered_map<void*, size_t> pool_sizes;
   // host-side prover state (generator sets per polynomial size), owned by prover.cpp

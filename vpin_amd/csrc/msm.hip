@@ -841,7 +841,31 @@ using namespace vpin;
 
 extern "C" {
 
+static int gens_build_once(vpin_ctx* c, const uint8_t* gens_xyzt, size_t nb, size_t budget, vpin_gens** out);
+
+// The table budget is a speed knob (every window bit saves ~8 % of a commitment), so it yields to what the device really has
+// at this moment: at most a third of the FREE memory (a co-tenant, another process's tables, a smaller part), and a failed
+// allocation halves it instead of failing the proof.  The instance, its decommitment and the proof temporaries need the rest.
 static int gens_build(vpin_ctx* c, const uint8_t* gens_xyzt, size_t nb, size_t budget, vpin_gens** out) {
+  (void)hipSetDevice(c->device);
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b) {
+    static const double frac = [] { const char* e = getenv("VPIN_GENS_FREE_FRACTION"); double v = e ? atof(e) : 0.0; return v > 0.0 && v < 1.0 ? v : 1.0 / 3.0; }();
+    const size_t cap = (size_t)((double)free_b * frac);
+    if (budget > cap) budget = cap;
+  }
+  const size_t floor_b = (size_t)1 << 28;
+  if (budget < floor_b) budget = floor_b;
+  for (;;) {
+    int rc = gens_build_once(c, gens_xyzt, nb, budget, out);
+    if (rc != VPIN_ENOMEM || budget <= floor_b) return rc;
+    (void)hipGetLastError();
+    budget /= 2;
+    if (budget < floor_b) budget = floor_b;
+  }
+}
+
+static int gens_build_once(vpin_ctx* c, const uint8_t* gens_xyzt, size_t nb, size_t budget, vpin_gens** out) {
   if (!c || !gens_xyzt || !out || nb == 0) return VPIN_EINVAL;
   (void)hipSetDevice(c->device);
   vpin_gens* g = new (std::nothrow) vpin_gens();

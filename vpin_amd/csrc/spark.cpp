@@ -54,10 +54,12 @@ static size_t spark_budget_gb(vpin_ctx* c) {
   static const size_t gb = [c] {
     const char* e = getenv("VPIN_SPARK_GENS_BUDGET_GB");
     if (e && atoi(e) > 0) return (size_t)atoi(e);
+    // from the memory that is FREE when the first table of the stream is built (another tenant's allocations, a smaller
+    // part); msm.hip's gens_build additionally caps every table at a third of the free memory of its moment
     size_t free_b = 0, total_b = 0;
     (void)hipSetDevice(c->device);
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return (size_t)24;
-    return total_b >= ((size_t)200 << 30) ? (size_t)80 : (size_t)24;
+    return free_b >= ((size_t)200 << 30) ? (size_t)80 : (size_t)24;
   }();
   return gb;
 }
@@ -281,6 +283,7 @@ static int batched_prove(vpin_ctx* c, vpin::SparkForest& f, DotpCtx* dotp, Trans
   else if ((rc = dist_exchange(c, *pl, is_mem, false, reinterpret_cast<const Fq*>(c->h_spark), (int)cnt, tops.data(), is_mem ? "mem_tops" : "ops_tops"))) return rc;
   std::vector<Fq> res_all(3 * (size_t)vpin::kSparkMaxInst), fin_all(6 * (size_t)vpin::kSparkMaxInst), pack(6 * (size_t)vpin::kSparkMaxInst);
 
+  struct TailGuard { vpin_ctx* c; ~TailGuard() { vpin::spark_tail_abort(c); } } tail_guard{c};  // a no-op unless an error return leaves a tail resident
   out.polys.assign(num_layers, {});
   out.claims_left.assign(num_layers, {});
   out.claims_right.assign(num_layers, {});

@@ -1042,9 +1042,8 @@ __global__ __launch_bounds__(kTailBlock) void spark_tail_kernel(TailArgs a) {
           continue;
         }
         load48_system(a.down, c0, c1, c2);
-        if (c0.x == seq && c1.x == seq && c2.x == seq) {
-          fq rr;
-          rr.v[0] = c0.y; rr.v[1] = c0.z; rr.v[2] = c0.w; rr.v[3] = c1.y; rr.v[4] = c1.z; rr.v[5] = c1.w; rr.v[6] = c2.y; rr.v[7] = c2.z;
+        fq rr;
+        if (take_reply(c0, c1, c2, seq, rr)) {  // whole (checksum) and current
           sh_r = rr;
           stop = 0;
           break;
@@ -1134,6 +1133,10 @@ int spark_tail_wait(vpin_ctx* c, int idx, int ninst, int ncirc) {
       if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 20.0) {
         tail_words(c)[0] = 1;  // abort: every workgroup leaves its poll loop
         (void)hipStreamSynchronize(c->stream);
+        // retire this launch's sequence numbers: the next proof on this context must not accept the pieces the aborted
+        // kernel has already published, nor the kernel of the next proof the stale challenge
+        c->tail_seq += (uint32_t)c->tail_rounds + 1u;
+        c->tail_rounds = 0;
         set_last_error("spark_tail_wait: the persistent round kernel did not answer", hipErrorUnknown);
         return VPIN_EHIP;
       }
@@ -1141,18 +1144,20 @@ int spark_tail_wait(vpin_ctx* c, int idx, int ninst, int ncirc) {
   }
 }
 
-// challenge of tail round `idx` to the kernel: three 16-byte stores {seq, 3 words} (single-copy atomic on x86-64), so a
-// poll that sees the sequence number in all three pieces holds the whole scalar
+// challenge of tail round `idx` to the kernel (mailbox_dev.h host_reply: three 16-byte pieces, sequence number + checksum)
 void spark_tail_reply(vpin_ctx* c, int idx, const uint8_t r[32]) {
-  uint32_t* down = tail_words(c) + 16;
-  const uint32_t seq = c->tail_seq + (uint32_t)idx + 1u;
-  uint32_t wv[8];
-  memcpy(wv, r, 32);
-  tail_v4 c0 = {seq, wv[0], wv[1], wv[2]}, c1 = {seq, wv[3], wv[4], wv[5]}, c2 = {seq, wv[6], wv[7], 0u};
-  *reinterpret_cast<volatile tail_v4*>(down) = c0;
-  *reinterpret_cast<volatile tail_v4*>(down + 4) = c1;
-  *reinterpret_cast<volatile tail_v4*>(down + 8) = c2;
+  host_reply(tail_words(c) + 16, c->tail_seq + (uint32_t)idx + 1u, r);
   __atomic_thread_fence(__ATOMIC_SEQ_CST);
+}
+
+// an error path leaves a tail resident: make every workgroup leave its poll loop, wait for the grid to drain and retire the
+// launch's sequence numbers (the next proof must accept neither its published pieces nor its challenge)
+void spark_tail_abort(vpin_ctx* c) {
+  if (!c || c->tail_rounds == 0) return;
+  tail_words(c)[0] = 1;
+  (void)hipStreamSynchronize(c->stream);
+  c->tail_seq += (uint32_t)c->tail_rounds + 1u;
+  c->tail_rounds = 0;
 }
 
 // after the last round's results were taken: retire the sequence numbers of this tail
@@ -1176,6 +1181,31 @@ const fq* spark_tail_sums(vpin_ctx* c) { return c->tail_sums; }
 const fq* spark_tail_final(vpin_ctx* c) { return c->tail_final; }
 
 }  // namespace vpin
+
+// Host-only self-test of the mailbox framing (mailbox_dev.h): a whole publication is accepted; a torn piece (new sequence
+// word over stale payload), pieces of two publications and a stale sequence number are all rejected.  0 = as expected.
+extern "C" int vpin_host_mailbox_selftest(void) {
+  using namespace vpin;
+  alignas(16) uint32_t slot[12];
+  uint8_t r[32];
+  for (int i = 0; i < 32; i++) r[i] = (uint8_t)(17 * i + 3);
+  host_reply(slot, 7u, r);
+  fq got;
+  if (!tail_take(slot, 7u, &got) || memcmp(got.v, r, 32) != 0) return 1;   // whole and current
+  if (tail_take(slot, 8u, &got)) return 2;                                   // stale sequence number
+  alignas(16) uint32_t torn[12];
+  memcpy(torn, slot, sizeof slot);
+  torn[2] ^= 0x10u;                                                          // 8 + 8 tear: second half of piece 0 from an older value
+  if (tail_take(torn, 7u, &got)) return 3;
+  uint8_t r2[32];
+  for (int i = 0; i < 32; i++) r2[i] = (uint8_t)(29 * i + 1);
+  alignas(16) uint32_t other[12];
+  host_reply(other, 7u, r2);                                                 // same sequence number, another scalar (never happens; the
+  memcpy(torn, slot, sizeof slot);                                           // checksum still tells the pieces apart)
+  memcpy(torn + 4, other + 4, 16);
+  if (tail_take(torn, 7u, &got)) return 4;
+  return 0;
+}
 
 // Kernel-level C-ABI entry (include/vpin_hip.h): one round of prove_cubic_batched for the product circuits of one forest
 // level and, optionally, the six dot-product circuit halves -- exactly the launch group spark.cpp issues per round.

@@ -115,6 +115,7 @@ int spark_tail_launch(vpin_ctx* c, const SparkForest* f, int level, int k, int j
 int spark_tail_wait(vpin_ctx* c, int idx, int ninst, int ncirc);
 void spark_tail_reply(vpin_ctx* c, int idx, const uint8_t r[32]);
 void spark_tail_end(vpin_ctx* c);
+void spark_tail_abort(vpin_ctx* c);  // error paths: drain a resident tail and retire its sequence numbers
 const fq* spark_tail_sums(vpin_ctx* c);
 const fq* spark_tail_final(vpin_ctx* c);
 

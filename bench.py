@@ -694,7 +694,7 @@ def main():
         achieved = k["alg_bytes"] / (k["ms"] * 1e-3) / 1e9
         traffic = args.pmc_traffic
         pmc_all, pmc_l5 = {}, {}
-        for pmc in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):  # separate rocprofv3 --pmc passes, see the file's _how
+        for pmc in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):  # separate rocprofv3 --pmc passes, see the file's _how
             pth = os.path.join(ROOT, "profiles", pmc)
             if os.path.exists(pth):
                 with open(pth) as f:
@@ -711,7 +711,7 @@ def main():
         # cycles, tools/isa_counts.py: VALU instructions per pair of this kernel's loop)
         valu_per_pair, valu_frac = None, None
         try:
-            with open(os.path.join(ROOT, "profiles", "r02_isa_counts.json")) as f:
+            with open(os.path.join(ROOT, "profiles", "r03_isa_counts.json")) as f:
                 valu_per_pair = json.load(f)["sc_cubic3_kernel<true, true>"]["valu_per_pair"]
             ncu, hz = ctxs[0].device_props()
             pairs_s = (k["alg_bytes"] / 384.0) / (k["ms"] * 1e-3)  # 4 tables x 32 B x 1.5 = 192 B per entry = 384 B per pair
@@ -799,13 +799,26 @@ def main():
                 cx.set_shared_device(True)
             sec = []
             cus, clk = cx.device_props()  # compute units, shader clock in Hz
-            # VALU-issue ceiling: one wave-instruction per SIMD per 4 cycles (64 lanes on a 16-lane SIMD); instructions per
-            # affine table addition / per pair counted from the ISA of the kernels' hot loops (profiles/r02_isa_counts.json)
-            isa = {}
-            pth = os.path.join(ROOT, "profiles", "r02_isa_counts.json")
-            if os.path.exists(pth):
-                with open(pth) as f:
-                    isa = json.load(f)
+            # Reference rates of the VALU-bound kernels.  (1) A static one: one wave-instruction per SIMD per 4 cycles over the
+            # VALU instructions of the kernel's hot loop (profiles/r03_isa_counts.json); the SQ counters show the chip issues
+            # slightly more than that on simple instructions and about half of it on v_mad_u64_u32
+            # (profiles/r03_pmc_valu.json), so it is a yardstick, not a bound.  (2) A measured one for the MSM: the same point
+            # addition on a register-resident dependent chain at the kernel's occupancy, no table loads, no digit logic
+            # (tools/ubench_fpmul -> profiles/r03_ubench_fpmul.txt, its JSON line).
+            isa, chain = {}, {}
+            for nm in ("r03_isa_counts.json", "r02_isa_counts.json"):
+                pth = os.path.join(ROOT, "profiles", nm)
+                if os.path.exists(pth):
+                    with open(pth) as f:
+                        isa = json.load(f)
+                    break
+            try:
+                with open(os.path.join(ROOT, "profiles", "r03_ubench_fpmul.txt")) as f:
+                    for ln in f:
+                        if ln.startswith("JSON "):
+                            chain = json.loads(ln[5:])
+            except OSError:
+                pass
             m = st.get("msm_rows")
             if m and m["ms"] > 0 and m["units"] > 0:
                 ipa = isa.get("msm_rows_kernel", {}).get("valu_per_table_add", 1850)
@@ -816,12 +829,16 @@ def main():
                             "bound": "valu-issue", "achieved": adds_s / 1e9, "peak": peak_adds / 1e9, "unit": "G table adds/s",
                             "frac": adds_s / peak_adds, "launches": m["launches"], "ms": round(m["ms"], 3),
                             "table_adds": m["units"], "valu_instructions_per_add": ipa,
+                            "frac_of_measured_chain": (adds_s / 1e9 / chain["point_adds_Gps_10x25"]) if chain.get("point_adds_Gps_10x25") else None,
+                            "measured_chain_G_adds_s": chain.get("point_adds_Gps_10x25"),
+                            "chain_note": "tools/ubench_fpmul: the kernel's point addition (ten-limb form, entry unpacked per addition) on a "
+                                          "dependent register-resident chain, 12 waves per CU, no loads: what the arithmetic alone allows",
                             "peak_note": f"{cus} CUs x 4 SIMDs x 64 lanes x {clk / 1e9:.2f} GHz / (4 cycles per wave-instruction x {ipa} "
                                          "VALU instructions per affine table addition)",
                             "scalars_GBps": m["alg_bytes"] / (m["ms"] * 1e-3) / 1e9,
                             "traffic_bytes_per_add": pm.get("bytes_per_table_add"),
                             "traffic_note": "PMC FETCH_SIZE + WRITE_SIZE of the largest instance's row commitments / their table additions "
-                                            "(profiles/r02_pmc_traffic.json, bench_L5_mult)"})
+                                            "(profiles/r0x_pmc_traffic.json of the newest round, bench_L5_mult)"})
             p = st.get("spark_round_big")
             if p and p["ms"] > 0:
                 ach = p["alg_bytes"] / (p["ms"] * 1e-3) / 1e9

@@ -1,4 +1,4 @@
-"""Static instruction counts of the hot loops, from the gfx950 ISA hipcc emits -> profiles/r02_isa_counts.json.
+"""Static instruction counts of the hot loops, from the gfx950 ISA hipcc emits -> profiles/r03_isa_counts.json.
 
 bench.py's roofline.secondary prices msm_rows_kernel against the VALU-issue ceiling (one wave-instruction per SIMD
 per 4 cycles); this is where its "VALU instructions per affine table addition" comes from.  Run in the build container:
@@ -71,7 +71,7 @@ def main():
     big = max(ls, key=lambda l: l["valu"])
     res["prod_round_kernel<true, true>"] = {"valu_per_pair": big["valu"], "v_mad_u64_u32_per_pair": big["v_mad_u64_u32"],
                                             "loads_per_pair": big["vmem_loads"], "stores_per_pair": big["vmem_stores"]}
-    out = os.path.join(ROOT, "profiles", "r02_isa_counts.json")
+    out = os.path.join(ROOT, "profiles", "r03_isa_counts.json")
     with open(out, "w") as f:
         json.dump(res, f, indent=1)
     print(json.dumps(res, indent=1))

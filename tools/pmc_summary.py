@@ -15,7 +15,7 @@ import sys
 from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-OUT = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+OUT = os.path.join(ROOT, "profiles", os.environ.get("VPIN_PMC_OUT", "r02_pmc_traffic.json"))
 
 
 def short(name):

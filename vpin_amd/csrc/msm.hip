@@ -25,6 +25,7 @@
 
 #include "ctx.h"
 #include "fp_dev.h"
+#include "fp10_dev.h"
 #include "mailbox_dev.h"
 
 #ifndef VPIN_NIELS_SLOT
@@ -243,6 +244,56 @@ __device__ __forceinline__ void table_mul_acc(ge_ext& acc, fq s, const TableView
   }
 }
 
+// The same walk with the accumulator in the ten-limb form (fp10_dev.h): the product of two field elements is 142 VALU
+// instructions instead of 197 and the additions between products carry nothing.  Used by the row-commitment kernels, where
+// a lane adds hundreds of table entries to one accumulator; the entries stay in the packed 96-byte form in HBM.
+__device__ __forceinline__ void table_mul_acc10(ge10& acc, fq s, const TableView& tv, size_t j) {
+  const bool flip = fq_fold_sign(s);
+  const TableSeg sg = table_seg(tv, j);
+  uint32_t carry = 0;
+  const uint32_t mask = (1u << sg.c) - 1u, half = 1u << (sg.c - 1);
+  ge_niels e_cur;
+  bool have_cur = false, neg_cur = false;
+#pragma unroll 1
+  for (int w = 0; w <= sg.W; w++) {
+    ge_niels e_next;
+    bool have_next = false, neg_next = false;
+    if (w < sg.W) {
+      uint32_t v = (s.v[0] & mask) + carry;
+#pragma unroll
+      for (int i = 0; i < 7; i++) s.v[i] = __builtin_amdgcn_alignbit(s.v[i + 1], s.v[i], sg.c);
+      s.v[7] >>= sg.c;
+      neg_next = v > half;
+      uint32_t mag = neg_next ? (mask + 1u) - v : v;
+      carry = neg_next ? 1u : 0u;
+      neg_next ^= flip;
+      if (mag != 0) {
+        e_next = niels_load(sg.t + ((size_t)w * sg.nb + sg.j) * sg.E + (mag - 1));
+        have_next = true;
+      }
+    }
+    if (have_cur) acc = ge10_add_niels(acc, e_cur, neg_cur);
+    e_cur = e_next;
+    have_cur = have_next;
+    neg_cur = neg_next;
+  }
+}
+
+// accumulator type of the row kernels: TEN = ten-limb form (default), false = the eight-limb form (A/B runs: VPIN_MSM_FP8)
+template <bool TEN> struct RowAcc;
+template <> struct RowAcc<false> {
+  ge_ext a = ge_identity();
+  __device__ __forceinline__ void mul_acc(const fq& s, const TableView& tv, size_t j) { table_mul_acc(a, s, tv, j); }
+  __device__ __forceinline__ void add_cached(const ge_cached& q) { a = ge_add_cached(a, q); }
+  __device__ __forceinline__ ge_ext ext() const { return a; }
+};
+template <> struct RowAcc<true> {
+  ge10 a = ge10_identity();
+  __device__ __forceinline__ void mul_acc(const fq& s, const TableView& tv, size_t j) { table_mul_acc10(a, s, tv, j); }
+  __device__ __forceinline__ void add_cached(const ge_cached& q) { a = ge10_add_cached(a, q); }
+  __device__ __forceinline__ ge_ext ext() const { return ge10_to_ext(a); }
+};
+
 // digit w (c bits) of a canonical scalar, for the kernels that split one scalar over several lanes
 __device__ __forceinline__ uint32_t scalar_digit(const fq& s, int w, int c) {
   int off = w * c, word = off >> 5, sh = off & 31;
@@ -339,11 +390,12 @@ __device__ __forceinline__ void ge_tree_quad(ge_ext* sh, int n, int split = 0) {
 // [extra_base0, extra_base0 + n_extra).  out[row] = sum_j s[row][j] * g_j  (extended coords)
 constexpr int kSeg = 8192;  // scalars per compaction segment (uint16 indices, 16 KiB of LDS)
 
+template <bool TEN>
 __global__ __launch_bounds__(kMsmBlock, 3) void msm_rows_kernel(const fq* __restrict__ Z, size_t stride, size_t ncols,
                                                              const fq* __restrict__ extra, int n_extra, size_t extra_base0,
                                                              TableView tv, ge_ext* __restrict__ out) {
   const size_t row = blockIdx.x;
-  ge_ext acc = ge_identity();
+  RowAcc<TEN> acc;
   const size_t total = ncols + (size_t)n_extra;
   // A row of one repeated scalar s: s * (g_0 + ... + g_{ncols-1}) from the prefix-sum base (see gens_sum_kernel).
   // Three probes keep ordinary rows from paying for the full comparison pass.
@@ -356,14 +408,15 @@ __global__ __launch_bounds__(kMsmBlock, 3) void msm_rows_kernel(const fq* __rest
       if (__syncthreads_and(same)) {
         if (threadIdx.x == 0) {
           if (blockIdx.y == 0) {  // with column chunks every chunk sees the same row: the first one owns it, the others add nothing
-            if (!fq_is_zero(first)) table_mul_acc(acc, fq_from_mont(first), tv, tv.sum0 + (size_t)(63 - __builtin_clzll((unsigned long long)ncols)));
+            if (!fq_is_zero(first)) acc.mul_acc(fq_from_mont(first), tv, tv.sum0 + (size_t)(63 - __builtin_clzll((unsigned long long)ncols)));
             for (int e = 0; e < n_extra; e++) {
               const fq x = fq_load(extra + row * (size_t)n_extra + e);
-              if (!fq_is_zero(x)) table_mul_acc(acc, fq_from_mont(x), tv, extra_base0 + e);
+              if (!fq_is_zero(x)) acc.mul_acc(fq_from_mont(x), tv, extra_base0 + e);
             }
           }
           ge_ext* o = out + row * gridDim.y + blockIdx.y;
-          fp_store(&o->X, acc.X); fp_store(&o->Y, acc.Y); fp_store(&o->Z, acc.Z); fp_store(&o->T, acc.T);
+          const ge_ext av = acc.ext();
+          fp_store(&o->X, av.X); fp_store(&o->Y, av.Y); fp_store(&o->Z, av.Z); fp_store(&o->T, av.T);
         }
         return;
       }
@@ -394,18 +447,18 @@ __global__ __launch_bounds__(kMsmBlock, 3) void msm_rows_kernel(const fq* __rest
       size_t base;
       if (j < ncols) { s = fq_load(Z + row * stride + j); base = j; }
       else { s = fq_load(extra + row * (size_t)n_extra + (j - ncols)); base = extra_base0 + (j - ncols); }
-      table_mul_acc(acc, fq_from_mont(s), tv, base);
+      acc.mul_acc(fq_from_mont(s), tv, base);
     }
     __syncthreads();
   }
   __shared__ ge_ext sh[kMsmBlock];
-  sh[threadIdx.x] = acc;
+  sh[threadIdx.x] = acc.ext();
   __syncthreads();
   ge_tree_quad(sh, kMsmBlock);
   if (threadIdx.x == 0) {
-    acc = sh[0];
+    const ge_ext av = sh[0];
     ge_ext* o = out + row * gridDim.y + blockIdx.y;
-    fp_store(&o->X, acc.X); fp_store(&o->Y, acc.Y); fp_store(&o->Z, acc.Z); fp_store(&o->T, acc.T);
+    fp_store(&o->X, av.X); fp_store(&o->Y, av.Y); fp_store(&o->Z, av.Z); fp_store(&o->T, av.T);
   }
 }
 
@@ -434,11 +487,12 @@ __global__ __launch_bounds__(64) void scalar_times_bases_kernel(const fq* __rest
   fp_store(&T[j].YpX, cch.YpX); fp_store(&T[j].YmX, cch.YmX); fp_store(&T[j].Z, cch.Z); fp_store(&T[j].T2d, cch.T2d);
 }
 
+template <bool TEN>
 __global__ __launch_bounds__(kMsmBlock, 3) void msm_rows_hot_kernel(const fq* __restrict__ Z, size_t stride, size_t ncols, TableView tv,
                                                                  HotRows hr, ge_ext* __restrict__ out, size_t row_base, size_t row_step) {
   const size_t row = row_base + (size_t)blockIdx.x * row_step;  // row of the polynomial; out[] is indexed by blockIdx.x
   const fq* zr = Z + row * stride;
-  ge_ext acc = ge_identity();
+  RowAcc<TEN> acc;
   // a row of one repeated scalar (padding tails): s * (g_0 + ... + g_{ncols-1}), as in msm_rows_kernel
   if (ncols >= 256 && (ncols & (ncols - 1)) == 0 && ((size_t)1 << (tv.nbt - tv.sum0 - 1)) >= ncols) {
     const fq first = fq_load(zr);
@@ -448,9 +502,10 @@ __global__ __launch_bounds__(kMsmBlock, 3) void msm_rows_hot_kernel(const fq* __
       if (__syncthreads_and(same)) {
         if (threadIdx.x == 0) {
           // with column chunks every chunk sees the same row: the first one owns it, the others add nothing
-          if (blockIdx.y == 0 && !fq_is_zero(first)) table_mul_acc(acc, fq_from_mont(first), tv, tv.sum0 + (size_t)(63 - __builtin_clzll((unsigned long long)ncols)));
+          if (blockIdx.y == 0 && !fq_is_zero(first)) acc.mul_acc(fq_from_mont(first), tv, tv.sum0 + (size_t)(63 - __builtin_clzll((unsigned long long)ncols)));
           ge_ext* o = out + (size_t)blockIdx.x * gridDim.y + blockIdx.y;
-          fp_store(&o->X, acc.X); fp_store(&o->Y, acc.Y); fp_store(&o->Z, acc.Z); fp_store(&o->T, acc.T);
+          const ge_ext av = acc.ext();
+          fp_store(&o->X, av.X); fp_store(&o->Y, av.Y); fp_store(&o->Z, av.Z); fp_store(&o->T, av.T);
         }
         return;
       }
@@ -487,24 +542,24 @@ __global__ __launch_bounds__(kMsmBlock, 3) void msm_rows_hot_kernel(const fq* __
     const uint32_t nf = n_front, nb = n_back;
     for (uint32_t k = threadIdx.x; k < nf; k += kMsmBlock) {
       const size_t j = seg + list[k];
-      table_mul_acc(acc, fq_from_mont(fq_load(zr + j)), tv, j);
+      acc.mul_acc(fq_from_mont(fq_load(zr + j)), tv, j);
     }
     for (uint32_t k = threadIdx.x; k < nb; k += kMsmBlock) {
       const ge_cached* t = T + seg + list[kSeg - 1 - k];
       ge_cached q;
       q.YpX = fp_load(&t->YpX); q.YmX = fp_load(&t->YmX); q.Z = fp_load(&t->Z); q.T2d = fp_load(&t->T2d);
-      acc = ge_add_cached(acc, q);
+      acc.add_cached(q);
     }
     __syncthreads();
   }
   __shared__ ge_ext sh[kMsmBlock];
-  sh[threadIdx.x] = acc;
+  sh[threadIdx.x] = acc.ext();
   __syncthreads();
   ge_tree_quad(sh, kMsmBlock);
   if (threadIdx.x == 0) {
-    acc = sh[0];
+    const ge_ext av = sh[0];
     ge_ext* o = out + (size_t)blockIdx.x * gridDim.y + blockIdx.y;
-    fp_store(&o->X, acc.X); fp_store(&o->Y, acc.Y); fp_store(&o->Z, acc.Z); fp_store(&o->T, acc.T);
+    fp_store(&o->X, av.X); fp_store(&o->Y, av.Y); fp_store(&o->Z, av.Z); fp_store(&o->T, av.T);
   }
 }
 
@@ -1019,6 +1074,12 @@ int vpin_gens_layout(const vpin_gens* g, size_t out[6]) {
 size_t vpin_gens_entry_bytes(void) { return sizeof(niels_slot); }
 
 // shared implementation: rows of scalars -> points (kept on device), then optional outputs
+// the row kernels' field arithmetic: ten 26/25-bit limbs (fp10_dev.h) unless VPIN_MSM_FP8 asks for the eight-limb form
+static inline bool msm_ten_limbs() {
+  static const bool ten = getenv("VPIN_MSM_FP8") == nullptr;
+  return ten;
+}
+
 static inline TableView view(const vpin_gens* g) {
   return TableView{g->table, g->table_hi, g->split, g->nbt, g->c, g->W, g->E, g->c_hi, g->W_hi, g->E_hi, g->nb};
 }
@@ -1059,8 +1120,12 @@ static int msm_rows(vpin_ctx* c, const vpin_gens* g, const fq* dZ, size_t rows, 
     // VPIN_MSM_LDS_PAD overrides (experiments)
     static const int env_pad = [] { const char* e = getenv("VPIN_MSM_LDS_PAD"); return e ? atoi(e) : -1; }();
     const unsigned pad = env_pad >= 0 ? (unsigned)env_pad : (c->shared_device ? 20000u : 0u);
-    hipLaunchKernelGGL(msm_rows_kernel, dim3((unsigned)rows, (unsigned)chunks), dim3(kMsmBlock), pad, c->stream, dZ, stride,
-                       ncols, d_extra, n_extra, extra_base0, view(g), dst);
+    if (msm_ten_limbs())
+      hipLaunchKernelGGL(msm_rows_kernel<true>, dim3((unsigned)rows, (unsigned)chunks), dim3(kMsmBlock), pad, c->stream, dZ, stride,
+                         ncols, d_extra, n_extra, extra_base0, view(g), dst);
+    else
+      hipLaunchKernelGGL(msm_rows_kernel<false>, dim3((unsigned)rows, (unsigned)chunks), dim3(kMsmBlock), pad, c->stream, dZ, stride,
+                         ncols, d_extra, n_extra, extra_base0, view(g), dst);
   }
   if (chunks > 1)
     hipLaunchKernelGGL(ge_sum_chunks_kernel, dim3((unsigned)((rows + 63) / 64)), dim3(64), 0, c->stream, (const ge_ext*)dst,
@@ -1139,8 +1204,12 @@ int hyrax_commit_derefs_hot(vpin_ctx* c, const vpin_gens* g, const vpin_table* Z
     ProfScope ps(c, VPIN_K_MSM, 32.0 * (double)(nrows * R), VPIN_K_MSM_ROWS);
     static const int env_pad = [] { const char* e = getenv("VPIN_MSM_LDS_PAD"); return e ? atoi(e) : -1; }();
     const unsigned pad = env_pad >= 0 ? (unsigned)env_pad : (c->shared_device ? 20000u : 0u);
-    hipLaunchKernelGGL(msm_rows_hot_kernel, dim3((unsigned)nrows, (unsigned)chunks), dim3(kMsmBlock), pad, c->stream, (const fq*)Z->d, R, R,
-                       view(g), hr, chunks > 1 ? (ge_ext*)dparts.p : (ge_ext*)dpts.p, row0, row_step);
+    if (msm_ten_limbs())
+      hipLaunchKernelGGL(msm_rows_hot_kernel<true>, dim3((unsigned)nrows, (unsigned)chunks), dim3(kMsmBlock), pad, c->stream, (const fq*)Z->d,
+                         R, R, view(g), hr, chunks > 1 ? (ge_ext*)dparts.p : (ge_ext*)dpts.p, row0, row_step);
+    else
+      hipLaunchKernelGGL(msm_rows_hot_kernel<false>, dim3((unsigned)nrows, (unsigned)chunks), dim3(kMsmBlock), pad, c->stream, (const fq*)Z->d,
+                         R, R, view(g), hr, chunks > 1 ? (ge_ext*)dparts.p : (ge_ext*)dpts.p, row0, row_step);
     if (chunks > 1)
       hipLaunchKernelGGL(ge_sum_chunks_kernel, dim3((unsigned)((nrows + 63) / 64)), dim3(64), 0, c->stream, (const ge_ext*)dparts.p, nrows,
                          chunks, (ge_ext*)dpts.p);

@@ -188,6 +188,17 @@ int vpin_hyrax_commit_pair(vpin_ctx* ctx, const vpin_gens* g, const vpin_table* 
 int vpin_gens_msm(vpin_ctx* ctx, const vpin_gens* g, const uint8_t* scalars_mont, size_t rows, size_t ncols,
                   uint8_t* out_compressed /* rows*32 */, uint8_t* out_xyzt /* rows*128 */);
 
+/* GroupElement::vartime_multiscalar_mul (Spartan/src/group.rs:103-122) over ARBITRARY points, given as compressed
+ * ristretto255 encodings (n x 32 B) with n Montgomery scalars: out = sum_i s_i * decompress(P_i).  One lane per term
+ * (decompression, double-and-add, block tree): sized for the row counts of Hyrax commitments (the verifier's <L, C> of
+ * dense_mlpoly.rs:381-404), not for millions of points.  VPIN_EVERIFY when an encoding does not decode.  Either output
+ * may be NULL. */
+int vpin_msm(vpin_ctx* ctx, const uint8_t* scalars_mont, const uint8_t* points_compressed, size_t n, uint8_t* out_compressed,
+             uint8_t* out_xyzt);
+/* out[i] = compress(decompress(a[i]) + decompress(b[i])), n points: the row-wise sum of two commitment vectors
+ * (vPIN_proof_generation/src/commit_test.rs:340-361).  VPIN_EVERIFY when an encoding does not decode. */
+int vpin_points_add(vpin_ctx* ctx, const uint8_t* a_compressed, const uint8_t* b_compressed, size_t n, uint8_t* out_compressed);
+
 /* Same MSM for the few-row, latency-bound case: returns the per-workgroup partial points
  * (X|Y|Z|T, 128 B each, rows x vpin_gens_msm_parts_count(ncols)); the caller adds them. */
 size_t vpin_gens_msm_parts_count(size_t ncols);

@@ -631,6 +631,29 @@ class Context:
                                  ox.ctypes.data_as(C.c_void_p) if want_xyzt else None), "vpin_gens_msm")
         return (out, ox) if want_xyzt else out
 
+    def msm(self, scalars, points_compressed, want_xyzt=False):
+        """vpin_msm: sum_i s_i * decompress(P_i); scalars (n,4) uint64 Montgomery, points (n,32) uint8"""
+        s = np.ascontiguousarray(scalars, dtype=np.uint64).reshape(-1, 4)
+        pts = np.ascontiguousarray(points_compressed, dtype=np.uint8).reshape(-1, 32)
+        assert s.shape[0] == pts.shape[0]
+        out, xyzt = np.zeros(32, np.uint8), np.zeros(128, np.uint8)
+        L = lib()
+        L.vpin_msm.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+        p = lambda a: a.ctypes.data_as(C.c_void_p)
+        _chk(L.vpin_msm(self.h, p(s), p(pts), s.shape[0], p(out), p(xyzt) if want_xyzt else None), "vpin_msm")
+        return (out, xyzt) if want_xyzt else out
+
+    def points_add(self, a, b):
+        """vpin_points_add: compress(decompress(a[i]) + decompress(b[i]))"""
+        a = np.ascontiguousarray(a, dtype=np.uint8).reshape(-1, 32)
+        b = np.ascontiguousarray(b, dtype=np.uint8).reshape(-1, 32)
+        out = np.zeros_like(a)
+        L = lib()
+        L.vpin_points_add.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        p = lambda x: x.ctypes.data_as(C.c_void_p)
+        _chk(L.vpin_points_add(self.h, p(a), p(b), a.shape[0], p(out)), "vpin_points_add")
+        return out
+
     def poly_bound(self, Z, Lvec):
         lv = np.ascontiguousarray(Lvec, dtype=np.uint64).reshape(-1, 4)
         out = np.zeros((len(Z) // lv.shape[0], 4), dtype=np.uint64)

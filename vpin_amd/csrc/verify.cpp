@@ -260,12 +260,20 @@ static bool polyeval_verify(vpin_ctx* c, const DpLogP& pf, const PcGens& pc, Tra
   std::vector<Fq> Lv(pc.L), Rv(pc.R);
   host_eq(r, left, Lv.data());
   host_eq(r + left, right, Rv.data());
-  std::vector<Point> Cd(pc.L);
-  bool ok = true;
+  CG C_LZ;
+  static const bool host_only = getenv("VPIN_VERIFY_HOST_MSM") != nullptr;
+  if (pc.L >= 128 && !host_only) {
+    // <L, C> over the row commitments on the device (msm_var.hip): decompression and the scalar multiplications, one lane each
+    const int rc = vpin_msm(c, B(Lv.data()), comm[0].b, pc.L, C_LZ.b, nullptr);
+    if (rc) return false;  // VPIN_EVERIFY: a commitment that does not decode
+  } else {
+    std::vector<Point> Cd(pc.L);
+    bool ok = true;
 #pragma omp parallel for schedule(static) num_threads(pc.L >= 64 ? host_threads() : 1) reduction(&& : ok)
-  for (long i = 0; i < (long)pc.L; i++) ok = ok && decompress(Cd[i], comm[i]);
-  if (!ok) return false;
-  CG C_LZ = compress(msm_var(Lv.data(), Cd.data(), pc.L));
+    for (long i = 0; i < (long)pc.L; i++) ok = ok && decompress(Cd[i], comm[i]);
+    if (!ok) return false;
+    C_LZ = compress(msm_var(Lv.data(), Cd.data(), pc.L));
+  }
   return dplog_verify(c, pf, pc, tr, Rv, C_LZ, C_Zr);
 }
 // PolyEvalProof::verify_plain (dense_mlpoly.rs:406-419)
@@ -349,14 +357,22 @@ static bool sat_verify(vpin_ctx* c, Reader& r, size_t num_cons, size_t num_vars,
   // the commitment the proof carries must be the row-wise sum of the two witness commitments
   // (proof_point_mult.rs:75-80; my_lib_verify recombines com_1 + com_2, commit_test.rs:369-375)
   std::vector<CG> combined(L);
-  for (size_t i = 0; i < L; i++) {
-    CG a, b;
-    memcpy(a.b, comm_para + 32 * i, 32);
-    memcpy(b.b, comm_input + 32 * i, 32);
-    Point pa, pb;
-    if (!decompress(pa, a) || !decompress(pb, b)) return false;
-    combined[i] = compress(pa + pb);
-    if (!same(combined[i], comm_vars[i])) return false;
+  static const bool host_only = getenv("VPIN_VERIFY_HOST_MSM") != nullptr;
+  if (L >= 128 && !host_only) {
+    // 2L decompressions, L additions and L compressions: one lane per row on the device (msm_var.hip)
+    if (vpin_points_add(c, comm_para, comm_input, L, combined[0].b)) return false;
+    for (size_t i = 0; i < L; i++)
+      if (!same(combined[i], comm_vars[i])) return false;
+  } else {
+    for (size_t i = 0; i < L; i++) {
+      CG a, b;
+      memcpy(a.b, comm_para + 32 * i, 32);
+      memcpy(b.b, comm_input + 32 * i, 32);
+      Point pa, pb;
+      if (!decompress(pa, a) || !decompress(pb, b)) return false;
+      combined[i] = compress(pa + pb);
+      if (!same(combined[i], comm_vars[i])) return false;
+    }
   }
   tr.append_message("poly_commitment", "poly_commitment_begin");
   for (size_t i = 0; i < L; i++) tr.append_point("poly_commitment_share", combined[i].b);

@@ -764,7 +764,13 @@ def main():
                     comm, meta = verify_meta[name]
                     verified[name] = bool(ctxs[li].snark_verify(meta, dict(last_proof[name], comm=comm)))
             line["verified"] = verified
-            line["verify_s"] = round(time.perf_counter() - tv, 2)
+            line["verify_s_first"] = round(time.perf_counter() - tv, 2)  # includes deriving the verifier's generator sets (once per context)
+            tv = time.perf_counter()
+            for li, names in enumerate(lane_names):
+                for name in names:
+                    comm, meta = verify_meta[name]
+                    verified[name] = verified[name] and bool(ctxs[li].snark_verify(meta, dict(last_proof[name], comm=comm)))
+            line["verify_s"] = round(time.perf_counter() - tv, 2)        # the same 12 verifications again: the steady state
             assert all(verified.values()), verified
             # and their bytes against the oracle's digests of the same instances and seeds (a committed fixture: data, no
             # oracle call) -- the proofs of the timed region, made with all lanes running, equal the oracle's byte for byte

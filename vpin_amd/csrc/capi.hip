@@ -199,6 +199,7 @@ void vpin_ctx_destroy(vpin_ctx* c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->prover_cache_free) c->prover_cache_free(c);
   if (c->spark_cache_free) c->spark_cache_free(c);
+  if (c->verify_cache_free) c->verify_cache_free(c);
   if (c->h_spark) (void)hipHostFree(c->h_spark);
   if (c->d_spark_cnt) (void)hipFree(c->d_spark_cnt);
   if (c->d_add_count) (void)hipFree(c->d_add_count);

@@ -81,6 +81,9 @@ struct vpin_ctx {
   // SPARK (spark.cpp / spark.hip): generator views per label, pinned staging for per-round results
   void* spark_cache = nullptr;
   void (*spark_cache_free)(vpin_ctx*) = nullptr;
+  // verifier (verify.cpp): its own generator sets per polynomial size (derived once per context, not once per proof)
+  void* verify_cache = nullptr;
+  void (*verify_cache_free)(vpin_ctx*) = nullptr;
   vpin::fq* h_spark = nullptr;  // pinned, kSparkPinned fq; the last element's first word is the completion flag
   uint32_t* d_spark_cnt = nullptr;  // device: per-instance and global "blocks done" counters (self-resetting)
   uint32_t spark_seq = 0;           // sequence number of the last flagged launch group

@@ -309,7 +309,29 @@ static int make_pc(vpin_ctx* c, const char* label, const std::vector<Point>& g, 
   return VPIN_OK;
 }
 
-static int sat_gens_v(vpin_ctx* c, size_t num_vars, SatGensV& sg) {
+// The verifier's generator sets live in the context, like the prover's (R1CSGens::new / R1CSCommitmentGens::new are
+// functions of the sizes only): deriving R + 2 hash-to-group points and seven fixed-base tables per VERIFICATION was most
+// of a small proof's verification time.
+struct VCache {
+  std::map<size_t, std::unique_ptr<SatGensV>> sat;       // by num_vars
+  std::vector<Point> g_eval;                              // b"gens_r1cs_eval" stream prefix derived so far
+  std::map<size_t, std::unique_ptr<PcGens>> eval_views;   // by ell
+};
+static void vcache_free(vpin_ctx* c) {
+  delete static_cast<VCache*>(c->verify_cache);
+  c->verify_cache = nullptr;
+}
+static VCache* vcache(vpin_ctx* c) {
+  if (!c->verify_cache) { c->verify_cache = new VCache(); c->verify_cache_free = vcache_free; }
+  return static_cast<VCache*>(c->verify_cache);
+}
+
+static int sat_gens_v(vpin_ctx* c, size_t num_vars, SatGensV** out) {
+  VCache* vc = vcache(c);
+  auto it = vc->sat.find(num_vars);
+  if (it != vc->sat.end()) { *out = it->second.get(); return VPIN_OK; }
+  std::unique_ptr<SatGensV> sgp(new SatGensV());
+  SatGensV& sg = *sgp;
   sg.ell = log2z(num_vars);
   const size_t left = sg.ell / 2;
   sg.L = (size_t)1 << left;
@@ -322,6 +344,23 @@ static int sat_gens_v(vpin_ctx* c, size_t num_vars, SatGensV& sg) {
   sg.gens_1 = sg.pc.gens_1;
   sg.gens_3 = Mcg{3, {&sg.fb[0], &sg.fb[1], &sg.fb[2], nullptr}, &sg.fb[3]};
   sg.gens_4 = Mcg{4, {&sg.fb[0], &sg.fb[1], &sg.fb[2], &sg.fb[3]}, &sg.fb[4]};
+  *out = sgp.get();
+  vc->sat[num_vars] = std::move(sgp);
+  return VPIN_OK;
+}
+
+// PolyCommitmentGens::new(ell, b"gens_r1cs_eval") for the verifier
+static int eval_view_v(vpin_ctx* c, size_t ell, const PcGens** out) {
+  VCache* vc = vcache(c);
+  auto it = vc->eval_views.find(ell);
+  if (it != vc->eval_views.end()) { *out = it->second.get(); return VPIN_OK; }
+  const size_t nb = ((size_t)1 << (ell - ell / 2)) + 2;
+  if (vc->g_eval.size() < nb) derive_gens(vc->g_eval, nb, "gens_r1cs_eval");
+  std::unique_ptr<PcGens> v(new PcGens());
+  int rc = make_pc(c, "gens_r1cs_eval", vc->g_eval, ell, 0, *v);
+  if (rc) return rc;
+  *out = v.get();
+  vc->eval_views[ell] = std::move(v);
   return VPIN_OK;
 }
 
@@ -330,8 +369,9 @@ static int sat_gens_v(vpin_ctx* c, size_t num_vars, SatGensV& sg) {
 static bool sat_verify(vpin_ctx* c, Reader& r, size_t num_cons, size_t num_vars, const Fq* inputs, size_t num_inputs,
                        const Fq* inst_evals_in, Fq inst_evals[3], const uint8_t* comm_para, const uint8_t* comm_input,
                        Transcript& tr, std::vector<Fq>& rx, std::vector<Fq>& ry, int* err) {
-  SatGensV sg;
-  if ((*err = sat_gens_v(c, num_vars, sg))) return false;
+  SatGensV* sgp = nullptr;
+  if ((*err = sat_gens_v(c, num_vars, &sgp))) return false;
+  SatGensV& sg = *sgp;
   const size_t L = sg.L;
   const int nrx = (int)log2z(num_cons), nry = (int)log2z(2 * num_vars);
   std::vector<CG> comm_vars;
@@ -544,13 +584,13 @@ static bool spark_verify(vpin_ctx* c, Reader& r, size_t nx, size_t ny, size_t N,
                          Transcript& tr, int* err) {
   const size_t lgN = log2z(N), lgM = log2z(M), nm = std::max(nx, ny);
   if (((size_t)1 << nm) != M) return false;
-  std::vector<Point> g;
   const size_t v_ops = lgN + 4, v_mem = nm + 1, v_derefs = lgN + 3, vmax = std::max(v_ops, v_mem);
-  derive_gens(g, ((size_t)1 << (vmax - vmax / 2)) + 2, "gens_r1cs_eval");
-  PcGens g_ops, g_mem, g_derefs;
-  if ((*err = make_pc(c, "gens_r1cs_eval", g, vmax, 0, g_ops)) || (*err = make_pc(c, "gens_r1cs_eval", g, v_ops, 0, g_ops)) ||
-      (*err = make_pc(c, "gens_r1cs_eval", g, v_mem, 0, g_mem)) || (*err = make_pc(c, "gens_r1cs_eval", g, v_derefs, 0, g_derefs)))
+  const PcGens *p_ops = nullptr, *p_mem = nullptr, *p_derefs = nullptr;
+  // the longest stream first, so the shared device table is built once
+  if ((*err = eval_view_v(c, vmax, &p_ops)) || (*err = eval_view_v(c, v_ops, &p_ops)) || (*err = eval_view_v(c, v_mem, &p_mem)) ||
+      (*err = eval_view_v(c, v_derefs, &p_derefs)))
     return false;
+  const PcGens &g_ops = *p_ops, &g_mem = *p_mem, &g_derefs = *p_derefs;
   if (c_ops.size() != g_ops.L || c_mem.size() != g_mem.L) return false;
 
   // parse R1CSEvalProof

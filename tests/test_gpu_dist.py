@@ -1,7 +1,9 @@
 """One proof over several GPUs (vpin_comm, include/vpin_hip.h): every rank runs the same
 vpin_snark_prove_resident on the same instance and seeds; row commitments, product circuits, dot-product halves, slice
 evaluations and polynomial bounds are sharded and their small results all-gathered.  The bytes every rank returns must be
-the single-GPU proof's (= the oracle's, tests/golden/config_digests.json).  Here the ranks share the one MI355X: as threads
+the single-GPU proof's (= the oracle's, tests/golden/config_digests.json).  Two splits are covered: by residue class (a
+power-of-two world: every circuit, both sum-checks, the derefs gather and the slices shrink with the world) and by whole circuits
+(any world up to 12).  Here the ranks share the one MI355X: as threads
 of this process (local transport, world 2..8, also through the serialized rehearsal) and as separate processes through
 POSIX shared memory (world 2 and 4; an instance of 2^20 constraints)."""
 import hashlib
@@ -57,6 +59,7 @@ def _prove_threads(world, label, kind, n, serialize=False):
     [t.start() for t in ts]
     [t.join(300) for t in ts]
     stats = comms[0].stats()
+    stats["tags"] = comms[0].tag_stats()
     dec.free()
     g.free()
     for cm in comms:
@@ -85,11 +88,14 @@ def test_threads_point_add_64(world):
 @pytest.mark.parametrize("world", [2, 5, 8])
 def test_threads_point_mult_18(world):
     """conv f=3's point-mult instance (2^16 constraints, N = 2^17): the oracle's bytes (config digest)"""
-    single, out, _ = _prove_threads(world, "3_32", "mult", None)
+    single, out, st = _prove_threads(world, "3_32", "mult", None)
     _same(single, out)
     with open(os.path.join(ROOT, "tests", "golden", "config_digests.json")) as f:
         want = json.load(f)["cases"]["3_32-mult"]
     assert hashlib.sha256(out[-1]["proof"]).hexdigest() == want["snark_sha256"]
+    # a power-of-two world splits every circuit and both sum-checks by residue class; any other world deals the circuits out whole
+    by_residue = "ops_gather_tables" in st["tags"]
+    assert by_residue == (world in (2, 8)) and ("sat_gather_tables" in st["tags"]) == (world in (2, 8))
 
 
 def test_threads_tiny_instance_more_ranks_than_rows():

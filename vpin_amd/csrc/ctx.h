@@ -151,7 +151,8 @@ int r1cs_eval_table_strided(vpin_ctx* c, const vpin_r1cs_dev* d, const vpin_tabl
                             size_t step, vpin_table** out);
 
 // DensePolynomial::bound split by row blocks over the ranks of c->comm (poly.hip)
-int poly_bound_dist(vpin_ctx* c, const vpin_table* Z, const uint8_t* Lvec, size_t L_size, uint8_t* out_LZ);
+// z_rows != nullptr: the rows rank, rank + world, .. stored densely (otherwise a contiguous block of Z's rows per rank)
+int poly_bound_dist(vpin_ctx* c, const vpin_table* Z, const uint8_t* Lvec, size_t L_size, uint8_t* out_LZ, const fq* z_rows = nullptr);
 
 inline bool is_pow2(size_t x) { return x && !(x & (x - 1)); }
 
@@ -163,10 +164,11 @@ int gens_msm_parts_dev(vpin_ctx* c, const vpin_gens* g, const fq* d_scalars, siz
 // row0 / nrows / row_step: the rows row0, row0 + row_step, .. (out_compressed then holds nrows results); default all rows
 int hyrax_commit_derefs_hot(vpin_ctx* c, const vpin_gens* g, const vpin_table* Z, size_t L, size_t N, const uint32_t* const col_idx[3],
                             const uint32_t hot[3], const fq* e_ry, uint8_t* out_compressed, size_t row0 = 0, size_t nrows = (size_t)-1,
-                            size_t row_step = 1);
+                            size_t row_step = 1, const fq* z_rows = nullptr);
 // the same rows of a commitment without blinds (DensePolynomial::commit(gens, None)) through the plain row kernel
+// z_rows != nullptr (both functions): the nrows rows stored densely instead of being read from Z (which then only gives the shape)
 int hyrax_commit_rows_strided(vpin_ctx* c, const vpin_gens* g, const vpin_table* Z, size_t L, size_t row0, size_t nrows, size_t row_step,
-                              uint8_t* out_compressed);
+                              uint8_t* out_compressed, const fq* z_rows = nullptr);
 size_t gens_msm_parts_scratch_bytes(size_t rows, size_t ncols);
 int gens_msm_parts_launch(vpin_ctx* c, const vpin_gens* g, const fq* d_scalars, size_t rows, size_t ncols, void* scratch,
                           uint8_t* parts_xyzt, bool host_mapped = false);

@@ -489,9 +489,11 @@ __global__ __launch_bounds__(64) void scalar_times_bases_kernel(const fq* __rest
 
 template <bool TEN>
 __global__ __launch_bounds__(kMsmBlock, 3) void msm_rows_hot_kernel(const fq* __restrict__ Z, size_t stride, size_t ncols, TableView tv,
-                                                                 HotRows hr, ge_ext* __restrict__ out, size_t row_base, size_t row_step) {
+                                                                 HotRows hr, ge_ext* __restrict__ out, size_t row_base, size_t row_step,
+                                                                 int z_compact) {
   const size_t row = row_base + (size_t)blockIdx.x * row_step;  // row of the polynomial; out[] is indexed by blockIdx.x
-  const fq* zr = Z + row * stride;
+  // z_compact: Z holds only this launch's rows, densely (a rank's rows of a split commitment gathered on their own)
+  const fq* zr = Z + (z_compact ? (size_t)blockIdx.x : row) * stride;
   RowAcc<TEN> acc;
   // a row of one repeated scalar (padding tails): s * (g_0 + ... + g_{ncols-1}), as in msm_rows_kernel
   if (ncols >= 256 && (ncols & (ncols - 1)) == 0 && ((size_t)1 << (tv.nbt - tv.sum0 - 1)) >= ncols) {
@@ -582,9 +584,10 @@ __device__ __forceinline__ uint32_t count_digits(fq s, const TableView& tv, size
 __global__ __launch_bounds__(kMsmBlock) void msm_count_adds_kernel(const fq* __restrict__ Z, size_t stride, size_t ncols,
                                                                    const fq* __restrict__ extra, int n_extra, size_t extra_base0,
                                                                    TableView tv, unsigned long long* __restrict__ count,
-                                                                   HotRows hr = HotRows{}, size_t row_base = 0, size_t row_step = 1) {
+                                                                   HotRows hr = HotRows{}, size_t row_base = 0, size_t row_step = 1,
+                                                                   int z_compact = 0) {
   const size_t row = row_base + (size_t)blockIdx.x * row_step;
-  const fq* zr = Z + row * stride;
+  const fq* zr = Z + (z_compact ? (size_t)blockIdx.x : row) * stride;
   // msm_rows_hot_kernel: the hot-column entries are not table additions
   const uint32_t* hidx = nullptr;
   uint32_t hot = 0xffffffffu;
@@ -1162,10 +1165,14 @@ namespace vpin {
 // hot column of each matrix's col-derefs vector taken out (msm_rows_hot_kernel).  col_idx[m]: the N column indices of matrix
 // m on the device, hot[m]: its hot column or 0xffffffff, e_ry: the table the col-derefs were gathered from.
 int hyrax_commit_derefs_hot(vpin_ctx* c, const vpin_gens* g, const vpin_table* Z, size_t L, size_t N, const uint32_t* const col_idx[3],
-                            const uint32_t hot[3], const fq* e_ry, uint8_t* out_compressed, size_t row0, size_t nrows, size_t row_step) {
-  if (!c || !g || !Z || !Z->d || !col_idx || !hot || !e_ry || !out_compressed || L == 0 || Z->len % L) return VPIN_EINVAL;
+                            const uint32_t hot[3], const fq* e_ry, uint8_t* out_compressed, size_t row0, size_t nrows, size_t row_step,
+                            const fq* z_rows) {
+  // z_rows != nullptr: the nrows rows of this call stored densely (Z may then be a shape-only handle: d unused)
+  if (!c || !g || !Z || (!Z->d && !z_rows) || !col_idx || !hot || !e_ry || !out_compressed || L == 0 || Z->len % L) return VPIN_EINVAL;
   const size_t R = Z->len / L;
   if (R > g->nb || N % R || Z->len < 6 * N) return VPIN_ESHAPE;
+  const fq* zbase = z_rows ? z_rows : (const fq*)Z->d;
+  const int z_compact = z_rows ? 1 : 0;
   if (nrows == (size_t)-1) { row0 = 0; nrows = L; row_step = 1; }  // all rows
   if (row_step == 0 || (nrows && row0 + (nrows - 1) * row_step >= L)) return VPIN_ESHAPE;
   if (nrows == 0) return VPIN_OK;
@@ -1194,8 +1201,8 @@ int hyrax_commit_derefs_hot(vpin_ctx* c, const vpin_gens* g, const vpin_table* Z
       if (hot[m] == distinct[k]) hr.T[m] = Tk;
   }
   if (c->prof_count_adds && c->d_add_count)
-    hipLaunchKernelGGL(msm_count_adds_kernel, dim3((unsigned)nrows), dim3(kMsmBlock), 0, c->stream, (const fq*)Z->d, R, R, (const fq*)nullptr, 0,
-                       (size_t)0, view(g), c->d_add_count, hr, row0, row_step);
+    hipLaunchKernelGGL(msm_count_adds_kernel, dim3((unsigned)nrows), dim3(kMsmBlock), 0, c->stream, zbase, R, R, (const fq*)nullptr, 0,
+                       (size_t)0, view(g), c->d_add_count, hr, row0, row_step, z_compact);
   static const int env_chunks = [] { const char* e = getenv("VPIN_MSM_HOT_CHUNKS"); return e ? atoi(e) : 0; }();
   const int chunks = env_chunks > 0 ? env_chunks : (int)std::max<size_t>(1, std::min<size_t>(8, R / kSeg));
   DevBuf dparts(c);
@@ -1205,11 +1212,11 @@ int hyrax_commit_derefs_hot(vpin_ctx* c, const vpin_gens* g, const vpin_table* Z
     static const int env_pad = [] { const char* e = getenv("VPIN_MSM_LDS_PAD"); return e ? atoi(e) : -1; }();
     const unsigned pad = env_pad >= 0 ? (unsigned)env_pad : (c->shared_device ? 20000u : 0u);
     if (msm_ten_limbs())
-      hipLaunchKernelGGL(msm_rows_hot_kernel<true>, dim3((unsigned)nrows, (unsigned)chunks), dim3(kMsmBlock), pad, c->stream, (const fq*)Z->d,
-                         R, R, view(g), hr, chunks > 1 ? (ge_ext*)dparts.p : (ge_ext*)dpts.p, row0, row_step);
+      hipLaunchKernelGGL(msm_rows_hot_kernel<true>, dim3((unsigned)nrows, (unsigned)chunks), dim3(kMsmBlock), pad, c->stream, zbase,
+                         R, R, view(g), hr, chunks > 1 ? (ge_ext*)dparts.p : (ge_ext*)dpts.p, row0, row_step, z_compact);
     else
-      hipLaunchKernelGGL(msm_rows_hot_kernel<false>, dim3((unsigned)nrows, (unsigned)chunks), dim3(kMsmBlock), pad, c->stream, (const fq*)Z->d,
-                         R, R, view(g), hr, chunks > 1 ? (ge_ext*)dparts.p : (ge_ext*)dpts.p, row0, row_step);
+      hipLaunchKernelGGL(msm_rows_hot_kernel<false>, dim3((unsigned)nrows, (unsigned)chunks), dim3(kMsmBlock), pad, c->stream, zbase,
+                         R, R, view(g), hr, chunks > 1 ? (ge_ext*)dparts.p : (ge_ext*)dpts.p, row0, row_step, z_compact);
     if (chunks > 1)
       hipLaunchKernelGGL(ge_sum_chunks_kernel, dim3((unsigned)((nrows + 63) / 64)), dim3(64), 0, c->stream, (const ge_ext*)dparts.p, nrows,
                          chunks, (ge_ext*)dpts.p);
@@ -1223,8 +1230,8 @@ int hyrax_commit_derefs_hot(vpin_ctx* c, const vpin_gens* g, const vpin_table* Z
 }
 
 int hyrax_commit_rows_strided(vpin_ctx* c, const vpin_gens* g, const vpin_table* Z, size_t L, size_t row0, size_t nrows, size_t row_step,
-                              uint8_t* out_compressed) {
-  if (!c || !g || !Z || !Z->d || !out_compressed || L == 0 || row_step == 0) return VPIN_EINVAL;
+                              uint8_t* out_compressed, const fq* z_rows) {
+  if (!c || !g || !Z || (!Z->d && !z_rows) || !out_compressed || L == 0 || row_step == 0) return VPIN_EINVAL;
   if (nrows == 0) return VPIN_OK;
   if (Z->len % L != 0 || row0 + (nrows - 1) * row_step >= L) return VPIN_ESHAPE;
   const size_t R = Z->len / L;
@@ -1232,7 +1239,8 @@ int hyrax_commit_rows_strided(vpin_ctx* c, const vpin_gens* g, const vpin_table*
   (void)hipSetDevice(c->device);
   DevBuf dpts(c), dout(c);
   if (dpts.alloc(nrows * sizeof(ge_ext)) || dout.alloc(nrows * 32)) return VPIN_ENOMEM;
-  int rc = msm_rows(c, g, Z->d + row0 * R, nrows, row_step * R, R, nullptr, 0, 0, (ge_ext*)dpts.p);
+  int rc = z_rows ? msm_rows(c, g, z_rows, nrows, R, R, nullptr, 0, 0, (ge_ext*)dpts.p)
+                  : msm_rows(c, g, Z->d + row0 * R, nrows, row_step * R, R, nullptr, 0, 0, (ge_ext*)dpts.p);
   if (rc) return rc;
   hipLaunchKernelGGL(ge_compress_kernel, dim3((unsigned)((nrows + 63) / 64)), dim3(64), 0, c->stream, (const ge_ext*)dpts.p, nrows,
                      (fp*)dout.p, (fp*)nullptr);

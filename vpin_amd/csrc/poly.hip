@@ -2,6 +2,7 @@
 //   DensePolynomial::bound   Spartan/src/dense_mlpoly.rs:220-227   LZ[i] = sum_j L[j]*Z[j*R+i]
 // Z is read exactly once, row-major, so every wavefront streams 2 KiB contiguous per row.
 #include <cstring>
+#include <vector>
 
 #include "comm.h"
 #include "ctx.h"
@@ -56,18 +57,29 @@ static int poly_bound_rows(vpin_ctx* c, const fq* Z, const fq* dL, size_t Rs, si
 // DensePolynomial::bound over the ranks of c->comm: every rank sums its block of rows, the partial vectors are all-gathered
 // on the device (RCCL ncclAllGather when enabled, staged through the host transport otherwise) and added up by everyone.
 // Field addition is exact, so the result does not depend on the split.
-int poly_bound_dist(vpin_ctx* c, const vpin_table* Z, const uint8_t* Lvec, size_t L_size, uint8_t* out_LZ) {
-  if (!c || !c->comm || !Z || !Z->d || !Lvec || !out_LZ || L_size == 0) return VPIN_EINVAL;
+int poly_bound_dist(vpin_ctx* c, const vpin_table* Z, const uint8_t* Lvec, size_t L_size, uint8_t* out_LZ, const fq* z_rows) {
+  if (!c || !c->comm || !Z || (!Z->d && !z_rows) || !Lvec || !out_LZ || L_size == 0) return VPIN_EINVAL;
   if (Z->len % L_size != 0) return VPIN_ESHAPE;
   vpin_comm* cm = c->comm;
   const size_t Rs = Z->len / L_size;
   (void)hipSetDevice(c->device);
-  size_t row0, nrows;
-  comm_block(L_size, cm->rank, cm->world, &row0, &nrows);
   DevBuf bL(c), bmine(c), ball(c), bout(c);
   if (bL.alloc(L_size * 32) || bmine.alloc(Rs * 32) || ball.alloc((size_t)cm->world * Rs * 32) || bout.alloc(Rs * 32)) return VPIN_ENOMEM;
-  VPIN_HIP_TRY(hipMemcpyAsync(bL.p, Lvec, L_size * 32, hipMemcpyHostToDevice, c->stream));
-  int rc = poly_bound_rows(c, Z->d, (const fq*)bL.p, Rs, row0, nrows, (fq*)bmine.p);
+  int rc;
+  if (z_rows) {
+    // this rank's rows rank, rank + world, .. stored densely: their coefficients in the same order
+    const size_t nloc = comm_strided_count(L_size, cm->rank, cm->world);
+    std::vector<uint8_t> Lloc((nloc ? nloc : 1) * 32);
+    for (size_t k = 0; k < nloc; k++) memcpy(Lloc.data() + 32 * k, Lvec + 32 * ((size_t)cm->rank + k * (size_t)cm->world), 32);
+    VPIN_HIP_TRY(hipMemcpyAsync(bL.p, Lloc.data(), (nloc ? nloc : 1) * 32, hipMemcpyHostToDevice, c->stream));
+    VPIN_HIP_TRY(hipStreamSynchronize(c->stream));  // Lloc is a local
+    rc = poly_bound_rows(c, z_rows, (const fq*)bL.p, Rs, 0, nloc, (fq*)bmine.p);
+  } else {
+    size_t row0, nrows;
+    comm_block(L_size, cm->rank, cm->world, &row0, &nrows);
+    VPIN_HIP_TRY(hipMemcpyAsync(bL.p, Lvec, L_size * 32, hipMemcpyHostToDevice, c->stream));
+    rc = poly_bound_rows(c, Z->d, (const fq*)bL.p, Rs, row0, nrows, (fq*)bmine.p);
+  }
   if (rc) return rc;
   if (cm->serialize) VPIN_HIP_TRY(hipStreamSynchronize(c->stream));
   if ((rc = comm_allgather_dev(cm, c, bmine.p, ball.p, Rs * 32))) return rc;

@@ -146,8 +146,10 @@ static Fq combine_bot(std::vector<Fq> e, const std::vector<Fq>& ch) {
 }
 
 // PolyEvalProof::prove with blinds None, blind_Zr None (dense_mlpoly.rs:326-379)
+// z_rows (one proof over several GPUs, split by residue class): this rank's rows rank, rank + world, .. of Z stored densely; Z then
+// only gives the shape
 static int polyeval_prove_plain(vpin_ctx* c, const PcGens& pc, const vpin_table* Z, const std::vector<Fq>& r, const Fq& Zr,
-                                Transcript& tr, Transcript& tape, DpLog& out) {
+                                Transcript& tr, Transcript& tape, DpLog& out, const vpin::fq* z_rows = nullptr) {
   if (r.size() != pc.ell || Z->len != ((size_t)1 << pc.ell)) return VPIN_ESHAPE;
   tr.append_protocol_name("polynomial evaluation proof");
   const size_t left = pc.ell / 2, right = pc.ell - left;
@@ -158,7 +160,7 @@ static int polyeval_prove_plain(vpin_ctx* c, const PcGens& pc, const vpin_table*
   {
     TraceSpan ts("  poly_bound");
     // one proof over several GPUs: every rank sums its block of rows, the partial vectors are all-gathered on the device
-    if (c->comm && c->comm->world > 1) rc = vpin::poly_bound_dist(c, Z, B(Lv.data()), pc.L, B(LZ.data()));
+    if (c->comm && c->comm->world > 1) rc = vpin::poly_bound_dist(c, Z, B(Lv.data()), pc.L, B(LZ.data()), z_rows);
     else rc = vpin_poly_bound(c, Z, B(Lv.data()), pc.L, B(LZ.data()));
   }
   if (rc) return rc;
@@ -179,6 +181,7 @@ struct DistPlan {
   int owner_ops[12], owner_dotp[6], owner_mem[4];
   std::vector<std::vector<int>> ops_of, dotp_of, mem_of;  // per rank, ascending
   int max_ops_inst = 0, max_mem_inst = 0;                 // most instances (circuits + halves) any rank owns per phase
+  int lw = 0;                                             // log2(world) when the proof is split by residue class, else 0
 };
 
 static void make_plan(int world, int owner_ops[12], int owner_dotp[6], int owner_mem[4]) {
@@ -534,6 +537,330 @@ static int batched_prove(vpin_ctx* c, vpin::SparkForest& f, DotpCtx* dotp, Trans
   return VPIN_OK;
 }
 
+// ---- the same proof with every circuit split by RESIDUE CLASS over a power-of-two world (spark.hip) -----------------
+// `f` is this rank's local forest: all npc circuits, n / W leaves each (local index k <-> global index rank + k W).  A layer
+// of h = 2^k entries per half is h / W = 2^(k - lw) entries locally: the first k - lw rounds run on the device exactly as on
+// one GPU (same launches, same persistent tail, the suffix pyramid of the first k - lw challenges; the rank's eq-factored
+// sums are scaled by eq(rand_lo, rank)), each rank contributes its partial sums and all ranks derive the same challenge;
+// then every local table is one entry, the W entries of each table are gathered and the last lw rounds run on the host.
+// Layers of at most 32 entries are proven on the host from the gathered tree tops, as on one GPU.
+struct StridedDotp {
+  size_t Nloc;                    // N / W
+  const vpin::fq* vals_loc;       // 3 x Nloc: the val slices at the local entries
+  const vpin::fq* comb_loc;       // 6 x Nloc: the derefs slices at the local entries
+  vpin::fq* scratch;              // 18 x Nloc / 4
+  Fq claims[6];
+};
+
+// sum over ranks of `cnt` scalars per rank
+static int dist_sum(vpin_ctx* c, const DistPlan& pl, const Fq* mine, size_t cnt, Fq* out, const char* tag) {
+  std::vector<Fq> all(cnt * (size_t)pl.world);
+  int rc = vpin::comm_allgather_ctx(c, mine, all.data(), cnt * 32, tag);
+  if (rc) return rc;
+  for (size_t i = 0; i < cnt; i++) {
+    Fq a = Fq::zero();
+    for (int r = 0; r < pl.world; r++) a = a + all[(size_t)r * cnt + i];
+    out[i] = a;
+  }
+  return VPIN_OK;
+}
+
+static int batched_prove_strided(vpin_ctx* c, vpin::SparkForest& f, size_t n_global, StridedDotp* dotp, Transcript& tr, Batched& out,
+                                 std::vector<Fq>& rand, const DistPlan& pl, bool is_mem) {
+  const int npc = f.ncirc, ndotp = dotp ? 6 : 0, W = pl.world, lw = pl.lw;
+  const int num_layers = (int)log2z(n_global);
+  int rc;
+  const Fq one = Fq::one();
+  // ---- tree tops: the last cnt entries of every GLOBAL tree (levels of <= cnt / 2 entries) from the ranks' local tops ----
+  const size_t cnt = std::min<size_t>(2 * vpin::kSparkHostTop, 2 * n_global), cntl = cnt / (size_t)W;
+  if (cntl < 2 || cntl > f.stride()) return VPIN_ESHAPE;
+  if ((rc = vpin::spark_fetch_tops(c, &f, cntl))) return rc;
+  std::vector<Fq> tops((size_t)npc * cnt, Fq::zero());
+  {
+    std::vector<Fq> all((size_t)npc * cntl * W);
+    if ((rc = vpin::comm_allgather_ctx(c, c->h_spark, all.data(), (size_t)npc * cntl * 32, is_mem ? "mem_tops" : "ops_tops"))) return rc;
+    for (int t = 0; t < npc; t++) {
+      Fq* g = &tops[(size_t)t * cnt];
+      // levels of m >= W entries: global[i] = local_{i mod W}[i / W]; a level of m entries sits at offset cnt - 2m
+      for (size_t m = cnt / 2; m >= (size_t)W; m >>= 1) {
+        const size_t ml = m / W;
+        for (size_t i = 0; i < m; i++) g[cnt - 2 * m + i] = all[((size_t)(i % W) * npc + t) * cntl + (cntl - 2 * ml) + i / W];
+      }
+      // the levels above: products of the level below (product_tree.rs:18-35)
+      for (size_t m = (size_t)W / 2; m >= 1; m >>= 1)
+        for (size_t i = 0; i < m; i++) g[cnt - 2 * m + i] = g[cnt - 4 * m + i] * g[cnt - 4 * m + m + i];
+    }
+  }
+  out.polys.assign(num_layers, {});
+  out.claims_left.assign(num_layers, {});
+  out.claims_right.assign(num_layers, {});
+  std::vector<Fq> claims(npc + ndotp), coeffs;
+  for (int t = 0; t < npc; t++) claims[t] = tops[(size_t)t * cnt + cnt - 2];
+  rand.clear();
+  TableGuard tg(c);
+  struct TailGuard { vpin_ctx* c; ~TailGuard() { vpin::spark_tail_abort(c); } } tail_guard{c};
+  const int ninst = npc + ndotp;
+  std::vector<Fq> res((size_t)3 * vpin::kSparkMaxInst), mine((size_t)6 * vpin::kSparkMaxInst), fin((size_t)6 * vpin::kSparkMaxInst);
+
+  for (int layer_id = num_layers - 1, o = 0; layer_id >= 0; layer_id--, o++) {
+    const size_t h = n_global >> (layer_id + 1);
+    const int k = (int)log2z(h);
+    const bool with_dotp = (layer_id == 0 && ndotp > 0);
+    int nclaims = npc;
+    if (with_dotp) {
+      for (int i = 0; i < 6; i++) claims[npc + i] = dotp->claims[i];
+      nclaims += 6;
+    }
+    coeffs = tr.challenge_vector("rand_coeffs_next_layer", nclaims);
+    Fq e = Fq::zero();
+    for (int i = 0; i < nclaims; i++) e = e + claims[i] * coeffs[i];
+    std::vector<Fq> r(k);
+    std::vector<Fq>& polys = out.polys[o];
+    polys.resize(3 * (size_t)k);
+    std::vector<Fq> cl(npc), cr(npc);
+    const bool on_host = (2 * h <= vpin::kSparkHostTop) && layer_id != 0;
+    // host tables of the layer: product circuits A, B; dot-product halves L, R, W (filled from the tops or from the gather)
+    std::vector<std::vector<Fq>> HA(npc), HB(npc), HD[3];
+    int j_host = 0;  // first round that runs on the host tables
+    Fq s = one, cn = Fq::zero();
+    std::vector<Fq> rho_inv(rand.begin(), rand.begin() + k);
+    bool lead_ok = !on_host;
+    for (auto& x : rho_inv) lead_ok = lead_ok && !x.is_zero();
+    if (lead_ok && k > 0) {
+      std::vector<Fq> pre(k);
+      Fq acc = one;
+      for (int j = 0; j < k; j++) { pre[j] = acc; acc = acc * rho_inv[j]; }
+      acc = acc.invert();
+      for (int j = k - 1; j >= 0; j--) { Fq t = acc * rho_inv[j]; rho_inv[j] = acc * pre[j]; acc = t; }
+    }
+    for (int t = 0; t < npc; t++) cn = cn + claims[t] * coeffs[t];
+
+    vpin_table* pyr = nullptr;
+    int kl = 0;           // device rounds
+    bool tail_on = false;
+    int tail_j0 = 0;
+    Fq c_rank = one;
+    if (on_host) {
+      for (int t = 0; t < npc; t++) {
+        const Fq* lvl = &tops[(size_t)t * cnt + cnt - 4 * h];
+        HA[t].assign(lvl, lvl + h);
+        HB[t].assign(lvl + h, lvl + 2 * h);
+      }
+    } else {
+      kl = k - lw;
+      if (kl < 1 || !lead_ok) {
+        vpin::set_last_error("split by residue class: layer too small for the world, or a zero challenge", hipErrorUnknown);
+        return VPIN_ESHAPE;
+      }
+      j_host = kl;
+      if ((rc = vpin_eq_suffix_tables(c, B(rand.data()), kl, &pyr))) return rc;
+      tg.add(pyr);
+      std::vector<Fq> eq_lo((size_t)W);
+      host_eq(rand.data() + kl, (size_t)lw, eq_lo.data());
+      c_rank = eq_lo[pl.rank];
+    }
+
+    for (int j = 0; j < k; j++) {
+      const Fq* rs = nullptr;
+      if (j < j_host) {
+        // ---- a device round on the local tables ----
+        const size_t hl = h >> lw;
+        const size_t len = j == 0 ? hl : (hl >> (j - 1));
+        const vpin::fq* E = pyr->d + pyramid_offset(kl, j + 1);
+        const uint8_t* rprev = j ? B(&r[j - 1]) : nullptr;
+        const size_t tail_pairs = vpin::spark_tail_pairs();
+        if (tail_pairs == 0) return VPIN_ESHAPE;
+        if (!tail_on && (hl >> (j + 1)) <= tail_pairs) {
+          if ((rc = vpin::spark_tail_launch(c, &f, layer_id, kl, j, len, pyr->d, rprev, with_dotp ? dotp->Nloc : 0,
+                                            with_dotp ? dotp->vals_loc : nullptr, with_dotp ? dotp->comb_loc : nullptr,
+                                            with_dotp ? dotp->scratch : nullptr, nullptr, with_dotp ? 6 : 0)))
+            return rc;
+          tail_on = true;
+          tail_j0 = j;
+        }
+        const Fq* loc;
+        if (tail_on) {
+          if ((rc = vpin::spark_tail_wait(c, j - tail_j0, with_dotp ? ninst : npc, npc))) return rc;
+          loc = reinterpret_cast<const Fq*>(vpin::spark_tail_sums(c));
+          for (int t = 0; t < npc; t++) for (int x = 0; x < 3; x++) mine[3 * (size_t)t + x] = loc[3 * (size_t)t + x] * c_rank;
+          if (with_dotp) memcpy(&mine[3 * (size_t)12], loc + 3 * (size_t)npc, 6 * 96);
+        } else {
+          if ((rc = vpin::spark_prod_round(c, &f, layer_id, len, E, rprev, with_dotp ? 6 : 0, true))) return rc;
+          if (with_dotp && (rc = vpin::spark_dotp_round(c, dotp->Nloc, dotp->vals_loc, dotp->comb_loc, dotp->scratch, len, j == 1, rprev)))
+            return rc;
+          if ((rc = vpin::spark_wait_flag(c))) return rc;
+          loc = reinterpret_cast<const Fq*>(c->h_spark);
+          for (int t = 0; t < npc; t++) for (int x = 0; x < 3; x++) mine[3 * (size_t)t + x] = loc[3 * (size_t)t + x] * c_rank;
+          if (with_dotp) memcpy(&mine[3 * (size_t)12], loc + 3 * (size_t)12, 6 * 96);
+        }
+        // slots: circuits 0.., halves 12.. (npc <= 12)
+        if (!with_dotp) { if ((rc = dist_sum(c, pl, mine.data(), 3 * (size_t)npc, res.data(), is_mem ? "mem_round" : "ops_round"))) return rc; }
+        else if ((rc = dist_sum(c, pl, mine.data(), 3 * (size_t)18, res.data(), "ops_round"))) return rc;
+        rs = res.data();
+      } else {
+        // ---- a host round on the gathered (or top-level) tables: the kernels' conventions ----
+        const size_t len = HA[0].size(), half = len / 2;
+        std::vector<Fq> E(half);
+        host_eq(rand.data() + j + 1, (size_t)(k - j - 1), E.data());
+        for (int t = 0; t < npc; t++) {
+          Fq a0 = Fq::zero(), a1 = Fq::zero(), a2 = Fq::zero();
+          for (size_t i = 0; i < half; i++) {
+            const Fq A0 = HA[t][i], dA = HA[t][i + half] - A0, B0 = HB[t][i], dB = HB[t][i + half] - B0;
+            if (lead_ok) {
+              a0 = a0 + E[i] * (A0 * B0);
+              a1 = a1 + E[i] * (dA * dB);
+            } else {
+              const Fq A2 = A0 + dA + dA, B2 = B0 + dB + dB, A3 = A2 + dA, B3 = B2 + dB;
+              a0 = a0 + E[i] * (A0 * B0); a1 = a1 + E[i] * (A2 * B2); a2 = a2 + E[i] * (A3 * B3);
+            }
+          }
+          res[3 * (size_t)t] = a0; res[3 * (size_t)t + 1] = a1; res[3 * (size_t)t + 2] = a2;
+        }
+        if (with_dotp)
+          for (int i = 0; i < 6; i++) {
+            Fq q0 = Fq::zero(), q2 = Fq::zero(), q3 = Fq::zero();
+            for (size_t x = 0; x < half; x++) {
+              Fq v0[3], v2[3], v3[3];
+              for (int tb = 0; tb < 3; tb++) {
+                const Fq p = HD[tb][i][x], d = HD[tb][i][x + half] - p;
+                v0[tb] = p; v2[tb] = p + d + d; v3[tb] = v2[tb] + d;
+              }
+              q0 = q0 + v0[0] * v0[1] * v0[2]; q2 = q2 + v2[0] * v2[1] * v2[2]; q3 = q3 + v3[0] * v3[1] * v3[2];
+            }
+            res[3 * (size_t)(12 + i)] = q0; res[3 * (size_t)(12 + i) + 1] = q2; res[3 * (size_t)(12 + i) + 2] = q3;
+          }
+        rs = res.data();
+      }
+      // ---- the round's polynomial and challenge (the same on every rank; identical to batched_prove) ----
+      Fq c0, c2, c3, T1 = Fq::zero(), S0 = Fq::zero(), Sinf = Fq::zero();
+      if (on_host) {
+        // prove_cubic_batched as written (sumcheck.rs:248-425): the host tables carry no eq factoring
+        const size_t len = HA[0].size(), half = len / 2;
+        std::vector<Fq> C(len);
+        // poly_C = eq(rand, .) folded with r_0..r_{j-1}: s * eq(rand_{j..}, .)
+        host_eq(rand.data() + j, (size_t)(k - j), C.data());
+        c0 = c2 = c3 = Fq::zero();
+        for (int t = 0; t < npc; t++) {
+          Fq e0 = Fq::zero(), e2 = Fq::zero(), e3 = Fq::zero();
+          for (size_t i = 0; i < half; i++) {
+            const Fq a = HA[t][i], a1 = HA[t][i + half], b = HB[t][i], b1 = HB[t][i + half], cc = s * C[i], cc1 = s * C[i + half];
+            e0 = e0 + a * b * cc;
+            const Fq a2 = a1 + a1 - a, b2 = b1 + b1 - b, c2p = cc1 + cc1 - cc;
+            e2 = e2 + a2 * b2 * c2p;
+            const Fq a3 = a2 + a1 - a, b3 = b2 + b1 - b, c3p = c2p + cc1 - cc;
+            e3 = e3 + a3 * b3 * c3p;
+          }
+          c0 = c0 + e0 * coeffs[t]; c2 = c2 + e2 * coeffs[t]; c3 = c3 + e3 * coeffs[t];
+        }
+      } else {
+        const Fq rho = rand[j], omr = one - rho;
+        Fq S2 = Fq::zero(), S3 = Fq::zero();
+        if (lead_ok) {
+          for (int t = 0; t < npc; t++) { S0 = S0 + rs[3 * t] * coeffs[t]; Sinf = Sinf + rs[3 * t + 1] * coeffs[t]; }
+          T1 = (cn - omr * S0) * rho_inv[j];
+          const Fq two_inf = Sinf + Sinf, d10 = T1 - S0;
+          S2 = T1 + d10 + two_inf;
+          S3 = S2 + d10 + two_inf + two_inf;
+        } else {
+          for (int t = 0; t < npc; t++) { S0 = S0 + rs[3 * t] * coeffs[t]; S2 = S2 + rs[3 * t + 1] * coeffs[t]; S3 = S3 + rs[3 * t + 2] * coeffs[t]; }
+        }
+        const Fq two_rho = rho + rho;
+        c0 = s * omr * S0;
+        c2 = s * (two_rho + rho - one) * S2;
+        c3 = s * (two_rho + two_rho + rho - one - one) * S3;
+        if (with_dotp)
+          for (int i = 0; i < 6; i++) {
+            const Fq* q = rs + 3 * (12 + i);
+            c0 = c0 + q[0] * coeffs[npc + i]; c2 = c2 + q[1] * coeffs[npc + i]; c3 = c3 + q[2] * coeffs[npc + i];
+          }
+      }
+      Fq evals[4] = {c0, e - c0, c2, c3}, cf[4];
+      unipoly_from_evals(evals, 4, cf);
+      append_unipoly(tr, cf, 4);
+      const Fq rj = tr.challenge_scalar("challenge_nextround");
+      if (j < j_host && tail_on && j + 1 < j_host) vpin::spark_tail_reply(c, j - tail_j0, B(&rj));
+      r[j] = rj;
+      e = unipoly_eval(cf, 4, rj);
+      if (!on_host) {
+        const Fq rho = rand[j], omr = one - rho;
+        if (lead_ok) cn = S0 + rj * ((T1 - S0 - Sinf) + rj * Sinf);
+        s = s * (rho * rj + omr * (one - rj));
+      } else {
+        s = s * (rand[j] * rj + (one - rand[j]) * (one - rj));
+      }
+      polys[3 * j] = cf[0]; polys[3 * j + 1] = cf[2]; polys[3 * j + 2] = cf[3];
+      if (j >= j_host) {
+        // bound_poly_var_top on the host tables
+        auto fold = [&](std::vector<Fq>& T) {
+          const size_t half = T.size() / 2;
+          for (size_t i = 0; i < half; i++) T[i] = T[i] + rj * (T[i + half] - T[i]);
+          T.resize(half);
+        };
+        for (int t = 0; t < npc; t++) { fold(HA[t]); fold(HB[t]); }
+        if (with_dotp) for (int tb = 0; tb < 3; tb++) for (int i = 0; i < 6; i++) fold(HD[tb][i]);
+      } else if (j + 1 == j_host) {
+        // the device rounds are over: the two live entries of every local table, bound with r_j, are this rank's entry of
+        // the W-entry tables the remaining rounds run on
+        const Fq* fl = reinterpret_cast<const Fq*>(vpin::spark_tail_final(c));
+        for (int t = 0; t < npc; t++) {
+          mine[2 * (size_t)t] = fl[6 * t] + rj * (fl[6 * t + 1] - fl[6 * t]);
+          mine[2 * (size_t)t + 1] = fl[6 * t + 2] + rj * (fl[6 * t + 3] - fl[6 * t + 2]);
+        }
+        size_t per_rank = 2 * (size_t)npc;
+        if (with_dotp) {
+          for (int i = 0; i < 6; i++)
+            for (int tb = 0; tb < 3; tb++) {
+              const Fq* q = fl + 6 * (npc + i) + 2 * tb;
+              mine[per_rank + 3 * (size_t)i + tb] = q[0] + rj * (q[1] - q[0]);
+            }
+          per_rank += 18;
+        }
+        vpin::spark_tail_end(c);
+        tail_on = false;
+        std::vector<Fq> all(per_rank * (size_t)W);
+        if ((rc = vpin::comm_allgather_ctx(c, mine.data(), all.data(), per_rank * 32, is_mem ? "mem_gather_tables" : "ops_gather_tables")))
+          return rc;
+        for (int t = 0; t < npc; t++) {
+          HA[t].resize(W); HB[t].resize(W);
+          for (int rk = 0; rk < W; rk++) { HA[t][rk] = all[(size_t)rk * per_rank + 2 * t]; HB[t][rk] = all[(size_t)rk * per_rank + 2 * t + 1]; }
+        }
+        if (with_dotp)
+          for (int tb = 0; tb < 3; tb++) {
+            HD[tb].assign(6, std::vector<Fq>(W));
+            for (int i = 0; i < 6; i++)
+              for (int rk = 0; rk < W; rk++) HD[tb][i][rk] = all[(size_t)rk * per_rank + 2 * (size_t)npc + 3 * (size_t)i + tb];
+          }
+      }
+    }
+    for (int t = 0; t < npc; t++) { cl[t] = HA[t][0]; cr[t] = HB[t][0]; }
+    if (with_dotp) {
+      for (int tb = 0; tb < 3; tb++) out.dotp[tb].resize(6);
+      for (int i = 0; i < 6; i++)
+        for (int tb = 0; tb < 3; tb++) out.dotp[tb][i] = HD[tb][i][0];
+    }
+    for (int t = 0; t < npc; t++) {
+      tr.append_scalar("claim_prod_left", cl[t]);
+      tr.append_scalar("claim_prod_right", cr[t]);
+    }
+    if (with_dotp)
+      for (int i = 0; i < 6; i++) {
+        tr.append_scalar("claim_dotp_left", out.dotp[0][i]);
+        tr.append_scalar("claim_dotp_right", out.dotp[1][i]);
+        tr.append_scalar("claim_dotp_weight", out.dotp[2][i]);
+      }
+    const Fq r_layer = tr.challenge_scalar("challenge_r_layer");
+    for (int t = 0; t < npc; t++) claims[t] = cl[t] + r_layer * (cr[t] - cl[t]);
+    out.claims_left[o] = cl;
+    out.claims_right[o] = cr;
+    std::vector<Fq> ext;
+    ext.reserve(k + 1);
+    ext.push_back(r_layer);
+    ext.insert(ext.end(), r.begin(), r.end());
+    rand.swap(ext);
+  }
+  return VPIN_OK;
+}
+
 static thread_local double g_spark_timings[8];
 
 // SparseMatPolyEvalProof::prove (sparse_mlpoly.rs:1466-1533) -> bincode(R1CSEvalProof) appended to w
@@ -558,7 +885,15 @@ static int spark_prove(vpin_ctx* c, const vpin_spark_decomm* d, const std::vecto
     if (c->comm->world > 12) return VPIN_EINVAL;  // every rank owns at least one of the 12 ops circuits
     plan_init(plan, c->comm);
     dz = &plan;
+    // a power-of-two world splits every circuit by residue class (batched_prove_strided: perfectly balanced, and the derefs
+    // gather, the leaves and the slices shrink with the world too); otherwise the circuits are dealt out whole
+    static const bool by_circuit = getenv("VPIN_DIST_BY_CIRCUIT") != nullptr;
+    const size_t Wz = (size_t)plan.world;
+    if (!by_circuit && (Wz & (Wz - 1)) == 0 && Wz <= 16 && N / Wz >= 4096 && M / Wz >= 4096 && g_derefs->L >= Wz)
+      plan.lw = (int)log2z(Wz);
   }
+  const bool st = dz && dz->lw > 0;                       // split by residue class
+  const size_t Wz = dz ? (size_t)dz->world : 1, rk = dz ? (size_t)dz->rank : 0;
   tr.append_protocol_name("Sparse polynomial evaluation proof");
   // equalize (sparse_mlpoly.rs:1448-1465) + the two memories eq(rx_ext, .), eq(ry_ext, .)
   const size_t nm = std::max(d->nx, d->ny);
@@ -571,9 +906,24 @@ static int spark_prove(vpin_ctx* c, const vpin_spark_decomm* d, const std::vecto
   if ((rc = vpin_eq_table(c, B(ry_ext.data()), (int)nm, &mem_ry))) return rc;
   tg.add(mem_ry);
   // Derefs (sparse_mlpoly.rs:525-531,56-71) and their commitment
-  if ((rc = vpin::table_alloc_uninit(c, 8 * N, &comb))) return rc;
-  tg.add(comb);
-  if ((rc = vpin::spark_gather_derefs(c, d, mem_rx->d, mem_ry->d, comb->d))) return rc;
+  vpin::DevBuf b_cloc(c), b_crows(c), b_vloc(c);          // split by residue class: the local views (spark.hip)
+  vpin::fq *comb_loc = nullptr, *comb_rows = nullptr, *vals_loc = nullptr;
+  vpin_table comb_shape;                                  // shape-only handle of the (never materialised) derefs polynomial
+  comb_shape.d = nullptr; comb_shape.len = comb_shape.cap = 8 * N; comb_shape.owned = false;
+  const size_t nrows_loc = st ? vpin::comm_strided_count(g_derefs->L, dz->rank, dz->world) : 0;
+  if (st) {
+    const size_t Nl = N / Wz;
+    if (b_cloc.alloc(6 * Nl * 32) || b_crows.alloc(std::max<size_t>(1, nrows_loc) * g_derefs->R * 32) || b_vloc.alloc(3 * Nl * 32)) return VPIN_ENOMEM;
+    comb_loc = (vpin::fq*)b_cloc.p; comb_rows = (vpin::fq*)b_crows.p; vals_loc = (vpin::fq*)b_vloc.p;
+    if ((rc = vpin::spark_gather_derefs_strided(c, d, mem_rx->d, mem_ry->d, rk, Wz, comb_loc, comb_rows, g_derefs->R, nrows_loc))) return rc;
+    for (int m = 0; m < 3; m++)
+      if ((rc = vpin::spark_take_strided(c, d->comb_ops->d + (size_t)(12 + m) * N, Nl, rk, Wz, vals_loc + (size_t)m * Nl))) return rc;
+    comb = &comb_shape;
+  } else {
+    if ((rc = vpin::table_alloc_uninit(c, 8 * N, &comb))) return rc;
+    tg.add(comb);
+    if ((rc = vpin::spark_gather_derefs(c, d, mem_rx->d, mem_ry->d, comb->d))) return rc;
+  }
   if ((rc = vpin::comm_mark(c, "derefs_gather"))) return rc;
   std::vector<CG> comm_derefs;
   const bool hot = d->hot_col[0] != 0xffffffffu || d->hot_col[1] != 0xffffffffu || d->hot_col[2] != 0xffffffffu;
@@ -588,9 +938,10 @@ static int spark_prove(vpin_ctx* c, const vpin_spark_decomm* d, const std::vecto
       if (hot) {
         const uint32_t* col_idx[3] = {d->idx + 6 * d->N, d->idx + 7 * d->N, d->idx + 8 * d->N};
         rc = vpin::hyrax_commit_derefs_hot(c, g_derefs->dev, comb, L, d->N, col_idx, d->hot_col, mem_ry->d, mine.data(), (size_t)dz->rank,
-                                           nrows, (size_t)dz->world);
+                                           nrows, (size_t)dz->world, st ? comb_rows : nullptr);
       } else {
-        rc = vpin::hyrax_commit_rows_strided(c, g_derefs->dev, comb, L, (size_t)dz->rank, nrows, (size_t)dz->world, mine.data());
+        rc = vpin::hyrax_commit_rows_strided(c, g_derefs->dev, comb, L, (size_t)dz->rank, nrows, (size_t)dz->world, mine.data(),
+                                             st ? comb_rows : nullptr);
       }
       if (rc) return rc;
     }
@@ -621,15 +972,20 @@ static int spark_prove(vpin_ctx* c, const vpin_spark_decomm* d, const std::vecto
   const Fq r_hash = r_mem_check[0], gamma = r_mem_check[1], r_hash_sqr = r_hash * r_hash, r2_boost = r_hash_sqr * Fq::r2();
   vpin::SparkForest f_ops, f_mem;
   vpin::DevBuf b_ops(c), b_mem(c), b_scr(c);
-  const int nl_ops = dz ? (int)dz->ops_of[dz->rank].size() : 12, nl_mem = dz ? (int)dz->mem_of[dz->rank].size() : 4;
-  const size_t nl_dotp = dz ? dz->dotp_of[dz->rank].size() : 6;  // the first-fold scratch is numbered by the local half
-  if (b_ops.alloc((size_t)nl_ops * 2 * N * 32) || (nl_mem && b_mem.alloc((size_t)nl_mem * 2 * M * 32)) ||
-      b_scr.alloc(std::max<size_t>(256, 3 * nl_dotp * (N / 4) * 32)))
+  const int nl_ops = (dz && !st) ? (int)dz->ops_of[dz->rank].size() : 12, nl_mem = (dz && !st) ? (int)dz->mem_of[dz->rank].size() : 4;
+  const size_t nl_dotp = (dz && !st) ? dz->dotp_of[dz->rank].size() : 6;  // the first-fold scratch is numbered by the local half
+  const size_t Nf = st ? N / Wz : N, Mf = st ? M / Wz : M;               // leaves per tree on this rank
+  if (b_ops.alloc((size_t)nl_ops * 2 * Nf * 32) || (nl_mem && b_mem.alloc((size_t)nl_mem * 2 * Mf * 32)) ||
+      b_scr.alloc(std::max<size_t>(256, 3 * nl_dotp * (Nf / 4) * 32)))
     return VPIN_ENOMEM;
   if ((rc = vpin::comm_mark(c, "network_alloc"))) return rc;
-  f_ops.base = (vpin::fq*)b_ops.p; f_ops.n = N; f_ops.ncirc = nl_ops;
-  f_mem.base = (vpin::fq*)b_mem.p; f_mem.n = M; f_mem.ncirc = nl_mem;
-  if (!dz) {
+  f_ops.base = (vpin::fq*)b_ops.p; f_ops.n = Nf; f_ops.ncirc = nl_ops;
+  f_mem.base = (vpin::fq*)b_mem.p; f_mem.n = Mf; f_mem.ncirc = nl_mem;
+  if (st) {
+    if ((rc = vpin::spark_build_forests_strided(c, d, comb_loc, mem_rx->d, mem_ry->d, B(&r_hash), B(&r_hash_sqr), B(&r2_boost), B(&gamma),
+                                                &f_ops, &f_mem, rk, Wz)))
+      return rc;
+  } else if (!dz) {
     if ((rc = vpin::spark_build_forests(c, d, comb->d, mem_rx->d, mem_ry->d, B(&r_hash), B(&r_hash_sqr), B(&r2_boost), B(&gamma),
                                         &f_ops, &f_mem)))
       return rc;
@@ -656,17 +1012,37 @@ static int spark_prove(vpin_ctx* c, const vpin_spark_decomm* d, const std::vecto
     std::vector<Fq> roots(2 * (size_t)vpin::kSparkMaxInst);
     if ((rc = vpin::spark_fetch_tops(c, &f_ops, 2))) return rc;
     const Fq* t = reinterpret_cast<const Fq*>(c->h_spark);
-    if (dz) {
+    std::vector<Fq> st_roots(2 * 16);
+    if (st) {
+      // a circuit's root is the product of its leaves = the product over the ranks of their local roots
+      std::vector<Fq> mine16(16), all16(16 * Wz);
+      for (int i = 0; i < 12; i++) mine16[i] = t[2 * i];
+      if ((rc = vpin::spark_fetch_tops(c, &f_mem, 2))) return rc;
+      for (int i = 0; i < 4; i++) mine16[12 + i] = t[2 * i];
+      if ((rc = vpin::comm_allgather_ctx(c, mine16.data(), all16.data(), 16 * 32, "roots"))) return rc;
+      for (int i = 0; i < 16; i++) {
+        Fq p = Fq::one();
+        for (size_t r = 0; r < Wz; r++) p = p * all16[16 * r + i];
+        st_roots[2 * i] = p;
+      }
+      for (int i = 0; i < 12; i++) roots[2 * i] = st_roots[2 * i];
+      t = roots.data();
+    } else if (dz) {
       if ((rc = dist_exchange(c, *dz, false, false, t, 2, roots.data(), "roots"))) return rc;
       t = roots.data();
     }
     for (int s = 0; s < 2; s++)
       for (int m = 0; m < 3; m++) { pl[s][1 + m] = t[2 * (s * 6 + m)]; pl[s][4 + m] = t[2 * (s * 6 + 3 + m)]; }
-    if (nl_mem && (rc = vpin::spark_fetch_tops(c, &f_mem, 2))) return rc;
-    t = reinterpret_cast<const Fq*>(c->h_spark);
-    if (dz) {
-      if ((rc = dist_exchange(c, *dz, true, false, t, 2, roots.data(), "roots"))) return rc;
+    if (st) {
+      for (int i = 0; i < 4; i++) roots[2 * i] = st_roots[2 * (12 + i)];
       t = roots.data();
+    } else {
+      if (nl_mem && (rc = vpin::spark_fetch_tops(c, &f_mem, 2))) return rc;
+      t = reinterpret_cast<const Fq*>(c->h_spark);
+      if (dz) {
+        if ((rc = dist_exchange(c, *dz, true, false, t, 2, roots.data(), "roots"))) return rc;
+        t = roots.data();
+      }
     }
     for (int s = 0; s < 2; s++) { pl[s][0] = t[2 * (2 * s)]; pl[s][7] = t[2 * (2 * s + 1)]; }
   }
@@ -682,10 +1058,18 @@ static int spark_prove(vpin_ctx* c, const vpin_spark_decomm* d, const std::vecto
     tr.append_scalar(lab[s][3], pl[s][7]);
   }
   DotpCtx dotp{d, comb->d, (vpin::fq*)b_scr.p, {}};
+  StridedDotp sdotp{Nf, vals_loc, comb_loc, (vpin::fq*)b_scr.p, {}};
   Fq dotp_left[3], dotp_right[3];
   {
     // DotProductCircuit::evaluate (product_tree.rs:87-91) of the six halves
-    if (!dz) {
+    if (st) {
+      // every rank sums its residue class of all six halves; the partial sums are added up
+      if ((rc = vpin::spark_triple_sums_raw(c, comb_loc, vals_loc, Nf))) return rc;
+      Fq mine6[6];
+      for (int i = 0; i < 6; i++) mine6[i] = reinterpret_cast<const Fq*>(c->h_spark)[3 * i];
+      if ((rc = dist_sum(c, *dz, mine6, 6, dotp.claims, "triple_sums"))) return rc;
+      for (int i = 0; i < 6; i++) sdotp.claims[i] = dotp.claims[i];
+    } else if (!dz) {
       if ((rc = vpin::spark_triple_sums(c, d, comb->d))) return rc;
       for (int i = 0; i < 6; i++) dotp.claims[i] = reinterpret_cast<const Fq*>(c->h_spark)[3 * i];
     } else {
@@ -709,11 +1093,15 @@ static int spark_prove(vpin_ctx* c, const vpin_spark_decomm* d, const std::vecto
   std::vector<Fq> rand_ops, rand_mem;
   {
     TraceSpan ts("product: ops forest");
-    if ((rc = batched_prove(c, f_ops, &dotp, tr, pf_ops, rand_ops, dz, 12))) return rc;
+    if (st) rc = batched_prove_strided(c, f_ops, N, &sdotp, tr, pf_ops, rand_ops, *dz, false);
+    else rc = batched_prove(c, f_ops, &dotp, tr, pf_ops, rand_ops, dz, 12);
+    if (rc) return rc;
   }
   {
     TraceSpan ts("product: mem forest");
-    if ((rc = batched_prove(c, f_mem, nullptr, tr, pf_mem, rand_mem, dz, 4))) return rc;
+    if (st) rc = batched_prove_strided(c, f_mem, M, nullptr, tr, pf_mem, rand_mem, *dz, true);
+    else rc = batched_prove(c, f_mem, nullptr, tr, pf_mem, rand_mem, dz, 4);
+    if (rc) return rc;
   }
   g_spark_timings[3] = secs(t0, Clock::now());
 
@@ -723,15 +1111,34 @@ static int spark_prove(vpin_ctx* c, const vpin_spark_decomm* d, const std::vecto
   vpin_table *eq_ops = nullptr, *eq_mem = nullptr;
   {
     TraceSpan ts("hash: eq tables");
-    if ((rc = vpin_eq_table(c, B(rand_ops.data()), (int)lgN, &eq_ops))) return rc;
+    // split by residue class: eq(rand, rank + k W) = eq(rand_hi, k) * eq(rand_lo, rank), so the local table is the table of
+    // the first lg - lw challenges and the rank's sums are scaled by one constant
+    const int lwz = st ? dz->lw : 0;
+    if ((rc = vpin_eq_table(c, B(rand_ops.data()), (int)lgN - lwz, &eq_ops))) return rc;
     tg.add(eq_ops);
-    if ((rc = vpin_eq_table(c, B(rand_mem.data()), (int)lgM, &eq_mem))) return rc;
+    if ((rc = vpin_eq_table(c, B(rand_mem.data()), (int)lgM - lwz, &eq_mem))) return rc;
     tg.add(eq_mem);
   }
   if ((rc = vpin::comm_mark(c, "hash_eq_tables"))) return rc;
   Fq ev_derefs[6], ev_ops[15], ev_mem[2];
   const Fq* hs = reinterpret_cast<const Fq*>(c->h_spark);
-  if (dz) {
+  if (st) {
+    // every rank evaluates its residue class of all 23 slices; the partial sums (scaled by eq(rand_lo, rank)) are added up
+    std::vector<Fq> lo_ops(Wz), lo_mem(Wz);
+    host_eq(rand_ops.data() + (lgN - dz->lw), (size_t)dz->lw, lo_ops.data());
+    host_eq(rand_mem.data() + (lgM - dz->lw), (size_t)dz->lw, lo_mem.data());
+    Fq mine23[23], all23[23];
+    if ((rc = vpin::spark_slice_evals(c, comb_loc, Nf, 6, eq_ops->d))) return rc;
+    for (int i = 0; i < 6; i++) mine23[i] = hs[3 * i] * lo_ops[rk];
+    if ((rc = vpin::spark_slice_evals(c, d->comb_ops->d, N, 15, eq_ops->d, rk, Wz))) return rc;
+    for (int i = 0; i < 15; i++) mine23[6 + i] = hs[3 * i] * lo_ops[rk];
+    if ((rc = vpin::spark_slice_evals(c, d->comb_mem->d, M, 2, eq_mem->d, rk, Wz))) return rc;
+    for (int i = 0; i < 2; i++) mine23[21 + i] = hs[3 * i] * lo_mem[rk];
+    if ((rc = dist_sum(c, *dz, mine23, 23, all23, "hash_slice_evals"))) return rc;
+    for (int i = 0; i < 6; i++) ev_derefs[i] = all23[i];
+    for (int i = 0; i < 15; i++) ev_ops[i] = all23[6 + i];
+    for (int i = 0; i < 2; i++) ev_mem[i] = all23[21 + i];
+  } else if (dz) {
     // The 23 DensePolynomial::evaluate of the hash layer (6 derefs + 15 ops slices against eq(rand_ops), 2 mem slices
     // against eq(rand_mem)) depend on nothing the transcript produces in between: deal them out in contiguous runs of
     // equal cost (a slice costs its length), evaluate, exchange 23 scalars.
@@ -786,7 +1193,7 @@ static int spark_prove(vpin_ctx* c, const vpin_spark_decomm* d, const std::vecto
     rj.insert(rj.end(), rand_ops.begin(), rand_ops.end());
     tr.append_scalar("joint_claim_eval", joint);
     TraceSpan ts("hash: polyeval derefs");
-    if ((rc = polyeval_prove_plain(c, *g_derefs, comb, rj, joint, tr, tape, pe_derefs))) return rc;
+    if ((rc = polyeval_prove_plain(c, *g_derefs, comb, rj, joint, tr, tape, pe_derefs, st ? comb_rows : nullptr))) return rc;
     if ((rc = vpin::comm_mark(c, "hash_bullet"))) return rc;
   }
   if (!dz) {

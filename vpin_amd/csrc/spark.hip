@@ -151,6 +151,96 @@ __global__ __launch_bounds__(kBlock) void hash_mem_sub_kernel(const uint32_t* __
   }
 }
 
+// ---- one proof over several GPUs, split by RESIDUE CLASS (world = a power of two) -------------------------------------
+// Every level of a product tree pairs entry i with entry i + len/2 (product_tree.rs:18-35), and so does every fold of the
+// sum-checks over it (dense_mlpoly.rs:229-236): while len/2 is a multiple of the world size both members of a pair lie in
+// the same residue class.  Rank r0 therefore owns the leaves i = r0 (mod step) of EVERY circuit; its local arrays (local
+// index k <-> global index r0 + k*step) are product trees over n/step leaves in their own right, built and proven by the
+// unchanged kernels, and no table entry ever moves.  The kernels below produce those local leaves and the local views of
+// the committed polynomials directly from the decommitment.
+
+// comb_loc[s*(N/step) + k] = Derefs slice s (0..2 row A,B,C; 3..5 col A,B,C) at entry r0 + k*step
+__global__ __launch_bounds__(kBlock) void gather_derefs_loc_kernel(const uint32_t* __restrict__ idx, size_t N, const fq* __restrict__ mem_rx,
+                                                                   const fq* __restrict__ mem_ry, fq* __restrict__ comb_loc, size_t r0,
+                                                                   size_t step) {
+  const int s = blockIdx.y;
+  const size_t nloc = N / step;
+  const uint32_t* a = idx + (size_t)(s < 3 ? s : 3 + s) * N;
+  const fq* mem = s < 3 ? mem_rx : mem_ry;
+  fq* dst = comb_loc + (size_t)s * nloc;
+  for (size_t k = (size_t)blockIdx.x * kBlock + threadIdx.x; k < nloc; k += (size_t)gridDim.x * kBlock)
+    fq_store(dst + k, fq_load(mem + a[r0 + k * step]));
+}
+
+// rows_out[jl*R + c] = entry (r0 + jl*step)*R + c of the derefs polynomial (8 slices of N, the last two zero): the rows
+// r0, r0 + step, .. of its commitment matrix, stored densely
+__global__ __launch_bounds__(kBlock) void gather_derefs_rows_kernel(const uint32_t* __restrict__ idx, size_t N, size_t R,
+                                                                    const fq* __restrict__ mem_rx, const fq* __restrict__ mem_ry,
+                                                                    fq* __restrict__ rows_out, size_t r0, size_t step, size_t nrows_loc) {
+  const size_t total = nrows_loc * R;
+  for (size_t t = (size_t)blockIdx.x * kBlock + threadIdx.x; t < total; t += (size_t)gridDim.x * kBlock) {
+    const size_t jl = t / R, cidx = t - jl * R;
+    const size_t g = (r0 + jl * step) * R + cidx;
+    const size_t sl = g / N, i = g - sl * N;
+    fq v = fq_zero();
+    if (sl < 3) v = fq_load(mem_rx + idx[sl * N + i]);
+    else if (sl < 6) v = fq_load(mem_ry + idx[(3 + sl) * N + i]);
+    fq_store(rows_out + t, v);
+  }
+}
+
+// local leaves of the 12 ops circuits: blockIdx.y = side*3 + m writes the read circuit (side*6 + m) and the write circuit
+// (side*6 + 3 + m) of the LOCAL forest (n/step leaves each)
+__global__ __launch_bounds__(kBlock) void hash_ops_strided_kernel(const uint32_t* __restrict__ idx, const fq* __restrict__ comb_loc, size_t N,
+                                                                  HashParams hp, fq* __restrict__ forest, size_t r0, size_t step) {
+  const int side = blockIdx.y / 3, m = blockIdx.y % 3;
+  const size_t nloc = N / step;
+  const uint32_t* addr = idx + (size_t)(side * 6 + m) * N;
+  const uint32_t* ts = idx + (size_t)(side * 6 + 3 + m) * N;
+  const fq* val = comb_loc + (size_t)(side * 3 + m) * nloc;
+  fq* rd = forest + (size_t)(side * 6 + m) * 2 * nloc;
+  fq* wr = forest + (size_t)(side * 6 + 3 + m) * 2 * nloc;
+  const fq r2c = fq_r2();
+  for (size_t k = (size_t)blockIdx.x * kBlock + threadIdx.x; k < nloc; k += (size_t)gridDim.x * kBlock) {
+    const size_t i = r0 + k * step;
+    fq h = fq_sub(fq_mul(fq_load(val + k), hp.r), hp.gamma);
+    uint32_t a = addr[i], t = ts[i];
+    if (a) h = fq_add(h, fq_mul(fq_raw_u32(a), r2c));
+    if (t) h = fq_add(h, fq_mul(fq_raw_u32(t), hp.r2_boost));
+    fq_store(rd + k, h);
+    fq_store(wr + k, fq_add(h, hp.r2));
+  }
+}
+
+// local leaves of the 4 mem circuits: blockIdx.y = side
+__global__ __launch_bounds__(kBlock) void hash_mem_strided_kernel(const uint32_t* __restrict__ audit_ts, const fq* __restrict__ mem_rx,
+                                                                  const fq* __restrict__ mem_ry, size_t M, HashParams hp,
+                                                                  fq* __restrict__ forest, size_t r0, size_t step) {
+  const int side = blockIdx.y;
+  const size_t nloc = M / step;
+  const fq* mem = side ? mem_ry : mem_rx;
+  const uint32_t* ts = audit_ts + (size_t)side * M;
+  fq* init = forest + (size_t)(2 * side) * 2 * nloc;
+  fq* audit = forest + (size_t)(2 * side + 1) * 2 * nloc;
+  const fq r2c = fq_r2();
+  for (size_t k = (size_t)blockIdx.x * kBlock + threadIdx.x; k < nloc; k += (size_t)gridDim.x * kBlock) {
+    const size_t i = r0 + k * step;
+    fq h = fq_sub(fq_mul(fq_load(mem + i), hp.r), hp.gamma);
+    if (i) h = fq_add(h, fq_mul(fq_raw_u32((uint32_t)i), r2c));
+    fq_store(init + k, h);
+    uint32_t t = ts[i];
+    if (t) h = fq_add(h, fq_mul(fq_raw_u32(t), hp.r2_boost));
+    fq_store(audit + k, h);
+  }
+}
+
+// dst[k] = src[r0 + k*step]
+__global__ __launch_bounds__(kBlock) void take_strided_kernel(const fq* __restrict__ src, size_t nloc, size_t r0, size_t step,
+                                                              fq* __restrict__ dst) {
+  for (size_t k = (size_t)blockIdx.x * kBlock + threadIdx.x; k < nloc; k += (size_t)gridDim.x * kBlock)
+    fq_store(dst + k, fq_load(src + r0 + k * step));
+}
+
 // next level of every tree: dst[i] = src[i] * src[i + h], i < h  (product_tree.rs:18-35)
 __global__ __launch_bounds__(kBlock) void tree_level_kernel(fq* __restrict__ forest, size_t stride, size_t src_off, size_t dst_off,
                                                             size_t h) {
@@ -432,14 +522,18 @@ __global__ __launch_bounds__(kBlock) void fetch_tops_kernel(const fq* __restrict
 // Three slices per workgroup row: the eq table is read once per three slices instead of once per slice (the hash layer
 // evaluates 6 + 15 + 2 slices against two eq tables of N and M entries: 23 -> 9 reads of an eq table).
 // blockIdx.y = group g: slices 3g .. 3g+2; partial k of the group is slice 3g + k.
+// r0 / step: the entries r0, r0 + step, .. of every slice against eq[0 .. len/step) (one proof over several GPUs, split by
+// residue class: eq is then the table of the shortened point, the caller scales the sums); 0 / 1: all entries
 __global__ __launch_bounds__(kBlock) void slice_dot3_kernel(const fq* __restrict__ table, size_t len, int nslices,
-                                                            const fq* __restrict__ eq, fq* __restrict__ partials) {
+                                                            const fq* __restrict__ eq, fq* __restrict__ partials, size_t r0, size_t step) {
   const int s0 = 3 * blockIdx.y;
   const fq* t0 = table + (size_t)s0 * len;
   const bool has1 = s0 + 1 < nslices, has2 = s0 + 2 < nslices;
+  const size_t nloc = len / step;
   fq e[3] = {fq_zero(), fq_zero(), fq_zero()};
-  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < len; i += (size_t)gridDim.x * kBlock) {
-    const fq q = fq_load(eq + i);
+  for (size_t k = (size_t)blockIdx.x * kBlock + threadIdx.x; k < nloc; k += (size_t)gridDim.x * kBlock) {
+    const size_t i = r0 + k * step;
+    const fq q = fq_load(eq + k);
     fq v = fq_load(t0 + i);
     if (!fq_is_zero(v)) e[0] = fq_add(e[0], fq_mul(v, q));
     if (has1) { v = fq_load(t0 + len + i); if (!fq_is_zero(v)) e[1] = fq_add(e[1], fq_mul(v, q)); }
@@ -632,6 +726,52 @@ int spark_build_forest_sub(vpin_ctx* c, const vpin_spark_decomm* d, const fq* co
   return build_levels(c, f);
 }
 
+int spark_gather_derefs_strided(vpin_ctx* c, const vpin_spark_decomm* d, const fq* mem_rx, const fq* mem_ry, size_t r0, size_t step,
+                                fq* comb_loc, fq* comb_rows, size_t R, size_t nrows_loc) {
+  if (!c || !d || !mem_rx || !mem_ry || !comb_loc || !comb_rows || step == 0 || r0 >= step || d->N % step || R == 0 || d->N % R)
+    return VPIN_EINVAL;
+  (void)hipSetDevice(c->device);
+  ProfScope ps(c, VPIN_K_SPARK_BUILD, ((double)d->N * 6 * 68.0 + (double)nrows_loc * R * 68.0) / 1.0);
+  hipLaunchKernelGGL(gather_derefs_loc_kernel, dim3(grid_for(d->N / step), 6), dim3(kBlock), 0, c->stream, (const uint32_t*)d->idx, d->N,
+                     mem_rx, mem_ry, comb_loc, r0, step);
+  if (nrows_loc)
+    hipLaunchKernelGGL(gather_derefs_rows_kernel, dim3(grid_for(nrows_loc * R)), dim3(kBlock), 0, c->stream, (const uint32_t*)d->idx, d->N,
+                       R, mem_rx, mem_ry, comb_rows, r0, step, nrows_loc);
+  VPIN_HIP_TRY(hipGetLastError());
+  return VPIN_OK;
+}
+
+int spark_take_strided(vpin_ctx* c, const fq* src, size_t nloc, size_t r0, size_t step, fq* dst) {
+  if (!c || !src || !dst || step == 0 || r0 >= step) return VPIN_EINVAL;
+  if (nloc == 0) return VPIN_OK;
+  hipLaunchKernelGGL(take_strided_kernel, dim3(grid_for(nloc)), dim3(kBlock), 0, c->stream, src, nloc, r0, step, dst);
+  VPIN_HIP_TRY(hipGetLastError());
+  return VPIN_OK;
+}
+
+// local forests of rank r0 of `step`: ops over N/step leaves, mem over M/step leaves, all 12 / 4 circuits
+int spark_build_forests_strided(vpin_ctx* c, const vpin_spark_decomm* d, const fq* comb_loc, const fq* mem_rx, const fq* mem_ry,
+                                const uint8_t r_hash[32], const uint8_t r_hash_sqr[32], const uint8_t r_hash_sqr_boost[32],
+                                const uint8_t gamma[32], SparkForest* ops, SparkForest* mem, size_t r0, size_t step) {
+  if (!c || !d || !ops || !mem || !ops->base || !mem->base || step == 0 || r0 >= step) return VPIN_EINVAL;
+  if (ops->n * step != d->N || mem->n * step != d->M || ops->ncirc != 12 || mem->ncirc != 4 || ops->n < 2 || mem->n < 2) return VPIN_ESHAPE;
+  (void)hipSetDevice(c->device);
+  HashParams hp;
+  hp.r = load_host_fq(r_hash);
+  hp.r2 = load_host_fq(r_hash_sqr);
+  hp.r2_boost = load_host_fq(r_hash_sqr_boost);
+  hp.gamma = load_host_fq(gamma);
+  ProfScope ps(c, VPIN_K_SPARK_BUILD, ((double)d->N * (6 * (8.0 + 32.0) + 12 * 32.0 + 12 * 64.0) + (double)d->M * (2 * 36.0 + 4 * 32.0 + 4 * 64.0)) / (double)step);
+  hipLaunchKernelGGL(hash_ops_strided_kernel, dim3(grid_for(ops->n), 6), dim3(kBlock), 0, c->stream, (const uint32_t*)d->idx, comb_loc, d->N, hp,
+                     ops->base, r0, step);
+  hipLaunchKernelGGL(hash_mem_strided_kernel, dim3(grid_for(mem->n), 2), dim3(kBlock), 0, c->stream,
+                     (const uint32_t*)(d->idx + 12 * d->N), mem_rx, mem_ry, d->M, hp, mem->base, r0, step);
+  VPIN_HIP_TRY(hipGetLastError());
+  int rc = build_levels(c, ops);
+  if (!rc) rc = build_levels(c, mem);
+  return rc;
+}
+
 int spark_fetch_tops(vpin_ctx* c, const SparkForest* f, size_t cnt) {
   if (cnt * (size_t)f->ncirc > kSparkPinned || cnt > f->stride()) return VPIN_ESHAPE;
   int rc = spark_pinned(c);
@@ -801,7 +941,12 @@ int spark_collect(vpin_ctx* c, const SparkForest* f, int level, const vpin_spark
 }
 
 int spark_triple_sums(vpin_ctx* c, const vpin_spark_decomm* d, const fq* comb_derefs, const int* halves, int nh) {
-  if (!c || !d || !comb_derefs || nh < 1 || nh > 6) return VPIN_EINVAL;
+  if (!d) return VPIN_EINVAL;
+  return spark_triple_sums_raw(c, comb_derefs, d->comb_ops->d + 12 * d->N, d->N, halves, nh);
+}
+
+int spark_triple_sums_raw(vpin_ctx* c, const fq* comb_derefs, const fq* vals, size_t N, const int* halves, int nh) {
+  if (!c || !comb_derefs || !vals || N < 2 || nh < 1 || nh > 6) return VPIN_EINVAL;
   CircIds kmap{};
   for (int i = 0; i < nh; i++) kmap.v[i] = halves ? halves[i] : i;
   int rc = spark_pinned(c);
@@ -809,19 +954,18 @@ int spark_triple_sums(vpin_ctx* c, const vpin_spark_decomm* d, const fq* comb_de
   (void)hipSetDevice(c->device);
   fq* partials = nullptr;
   if ((rc = round_partials(c, &partials))) return rc;
-  const int grid = round_grid(d->N / 2, 6, c->shared_device);
+  const int grid = round_grid(N / 2, 6, c->shared_device);
   {
-    ProfScope ps(c, VPIN_K_SPARK_BUILD, 1.5 * nh * 32.0 * (double)d->N);
-    hipLaunchKernelGGL(triple_sum_kernel, dim3(grid, nh), dim3(kBlock), 0, c->stream, comb_derefs,
-                       (const fq*)(d->comb_ops->d + 12 * d->N), d->N, partials, kmap);
+    ProfScope ps(c, VPIN_K_SPARK_BUILD, 1.5 * nh * 32.0 * (double)N);
+    hipLaunchKernelGGL(triple_sum_kernel, dim3(grid, nh), dim3(kBlock), 0, c->stream, comb_derefs, vals, N, partials, kmap);
   }
   hipLaunchKernelGGL(inst_finish_kernel, dim3(nh), dim3(kBlock), 0, c->stream, (const fq*)partials, grid, 0, c->h_spark);
   VPIN_HIP_TRY(hipGetLastError());
   return spark_wait(c);
 }
 
-int spark_slice_evals(vpin_ctx* c, const fq* table, size_t len, int nslices, const fq* eq) {
-  if (!c || !table || !eq || nslices < 1 || nslices > kSparkMaxInst) return VPIN_EINVAL;
+int spark_slice_evals(vpin_ctx* c, const fq* table, size_t len, int nslices, const fq* eq, size_t r0, size_t step) {
+  if (!c || !table || !eq || nslices < 1 || nslices > kSparkMaxInst || step == 0 || r0 >= step || len % step) return VPIN_EINVAL;
   int rc = spark_pinned(c);
   if (rc) return rc;
   (void)hipSetDevice(c->device);
@@ -831,11 +975,11 @@ int spark_slice_evals(vpin_ctx* c, const fq* table, size_t len, int nslices, con
   // 64 per circuit is sized for their finisher, not for this)
   // (2048 against 512 workgroups per group: 9.9 -> 9.3 ms over the 2^25 instance's three launches; the kernel is bound by its
   // one product mod q per 64 bytes, not by HBM)
-  const int grid = (int)std::min<size_t>(2048, std::max<size_t>(1, (len + kBlock * 8 - 1) / (kBlock * 8)));
+  const int grid = (int)std::min<size_t>(2048, std::max<size_t>(1, (len / step + kBlock * 8 - 1) / (kBlock * 8)));
   const int groups = (nslices + 2) / 3;
   {
-    ProfScope ps(c, VPIN_K_SPARK_BUILD, (double)nslices * 32.0 * (double)len + 32.0 * (double)len);
-    hipLaunchKernelGGL(slice_dot3_kernel, dim3(grid, groups), dim3(kBlock), 0, c->stream, table, len, nslices, eq, partials);
+    ProfScope ps(c, VPIN_K_SPARK_BUILD, ((double)nslices * 32.0 * (double)len + 32.0 * (double)len) / (double)step);
+    hipLaunchKernelGGL(slice_dot3_kernel, dim3(grid, groups), dim3(kBlock), 0, c->stream, table, len, nslices, eq, partials, r0, step);
   }
   hipLaunchKernelGGL(inst_finish_kernel, dim3(groups), dim3(kBlock), 0, c->stream, (const fq*)partials, grid, 0, c->h_spark);
   VPIN_HIP_TRY(hipGetLastError());

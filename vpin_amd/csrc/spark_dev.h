@@ -103,6 +103,8 @@ int spark_collect(vpin_ctx* c, const SparkForest* f, int level, const vpin_spark
 // over the N/2 entries of half k; synchronises
 // halves / nh: a subset of the halves (results at h_spark[3*i] in that order); nullptr / 6 = all
 int spark_triple_sums(vpin_ctx* c, const vpin_spark_decomm* d, const fq* comb_derefs, const int* halves = nullptr, int nh = 6);
+// the same over explicit arrays: derefs slices (6 x N) and val slices (3 x N)
+int spark_triple_sums_raw(vpin_ctx* c, const fq* comb_derefs, const fq* vals, size_t N, const int* halves = nullptr, int nh = 6);
 
 // Persistent tail (spark.hip): rounds j0..k-1 of forest level `level` (h = 2^k entries per half) in ONE launch, one workgroup per
 // circuit (+ the six dot-product halves when vals != nullptr), leading-coefficient form.  The host keeps the transcript:
@@ -123,6 +125,17 @@ int spark_wait(vpin_ctx* c);  // stream sync
 
 // out[s] = sum_i table[s*len + i] * eq[i], s < nslices (DensePolynomial::evaluate of every slice at
 // the point whose eq table is `eq`); results in ctx->h_spark[3*s]; synchronises
-int spark_slice_evals(vpin_ctx* c, const fq* table, size_t len, int nslices, const fq* eq);
+// r0 / step: only the entries r0, r0 + step, .. of every slice, against eq[0 .. len/step) (split by residue class)
+int spark_slice_evals(vpin_ctx* c, const fq* table, size_t len, int nslices, const fq* eq, size_t r0 = 0, size_t step = 1);
+
+// ---- split by residue class (spark.hip): the local views of rank r0 of `step` ----
+// comb_loc: 6 x N/step (the derefs slices at the entries r0 + k*step); comb_rows: nrows_loc x R (rows r0, r0 + step, .. of the
+// derefs polynomial's commitment matrix, dense)
+int spark_gather_derefs_strided(vpin_ctx* c, const vpin_spark_decomm* d, const fq* mem_rx, const fq* mem_ry, size_t r0, size_t step,
+                                fq* comb_loc, fq* comb_rows, size_t R, size_t nrows_loc);
+int spark_take_strided(vpin_ctx* c, const fq* src, size_t nloc, size_t r0, size_t step, fq* dst);
+int spark_build_forests_strided(vpin_ctx* c, const vpin_spark_decomm* d, const fq* comb_loc, const fq* mem_rx, const fq* mem_ry,
+                                const uint8_t r_hash[32], const uint8_t r_hash_sqr[32], const uint8_t r_hash_sqr_boost[32],
+                                const uint8_t gamma[32], SparkForest* ops, SparkForest* mem, size_t r0, size_t step);
 
 }  // namespace vpin

@@ -288,17 +288,21 @@ typedef struct vpin_spark_decomm vpin_spark_decomm;
  * SPMD: every rank (one process per GPU, or one thread per rank in a rehearsal) holds the same instance, creates a
  * vpin_comm, attaches it to its context with vpin_ctx_set_comm and calls the SAME vpin_snark_prove_* / vpin_sat_prove_*
  * with the same inputs and seeds.  Inside the call the heavy steps are sharded and their small results all-gathered:
- *   - every Hyrax row commitment by contiguous row blocks (the witness pair of proof_point_mult.rs:44-52 and the derefs
- *     commitment of sparse_mlpoly.rs:525-531; rows are independent MSMs over shared generators, dense_mlpoly.rs:160-175)
- *     -- 32 bytes per row cross the links, no point and no reduction;
- *   - the 12 + 4 product circuits and the 6 dot-product halves of ProductCircuitEvalProofBatched::prove
- *     (product_tree.rs:259-385) by circuit index: hash-layer leaves, trees, every sum-check round and the persistent
- *     tails run for the owned circuits only; per round each rank publishes 3 scalars per owned circuit
- *     (sumcheck.rs:273-330) and every rank combines all of them and derives the round's challenge itself;
- *   - the 23 slice evaluations of the hash layer (sparse_mlpoly.rs:740-849) by slice, and DensePolynomial::bound of the
- *     three evaluation proofs (dense_mlpoly.rs:220-227) by row blocks (partial vectors all-gathered on the device:
- *     RCCL ncclAllGather when enabled, staged through the host transport otherwise).
- * The sat proof's two sum-checks and every latency-bound tail stay replicated.  Every rank returns the same bytes, equal
+ *   - every Hyrax row commitment by interleaved rows r, r + world, .. (the witness pair of proof_point_mult.rs:44-52 and
+ *     the derefs commitment of sparse_mlpoly.rs:525-531; rows are independent MSMs over shared generators,
+ *     dense_mlpoly.rs:160-175) -- 32 bytes per row cross the links, no point and no reduction;
+ *   - power-of-two worlds: BY RESIDUE CLASS.  The folds pair (i, i + len/2) (dense_mlpoly.rs:229-236), so rank r keeps the
+ *     entries = r (mod world) of every table -- Az, Bz, Cz, z and the eval table of the sat proof's two sum-checks
+ *     (sumcheck.rs:428-776), the leaves, trees and dot-product vectors of all 12 + 4 product circuits
+ *     (product_tree.rs:259-385) -- and folds them with the single-GPU kernels; no table entry ever moves.  Per round a rank
+ *     publishes its partial sums (3 scalars per circuit, 96 bytes in the sat rounds); the last log2(world) rounds of every
+ *     sum-check run on the host from the world gathered entries per table;
+ *   - other worlds (3, 5, 6, ..): the 12 + 4 product circuits and the 6 dot-product halves by circuit index
+ *     (vpin_dist_plan below); the sat sum-checks stay replicated;
+ *   - the 23 slice evaluations of the hash layer (sparse_mlpoly.rs:740-849) by residue class or by slice, and
+ *     DensePolynomial::bound of the evaluation proofs (dense_mlpoly.rs:220-227) by rows (partial vectors all-gathered on
+ *     the device: RCCL ncclAllGather when enabled, staged through the host transport otherwise).
+ * The bullet reductions, the sigma protocols and the transcript stay replicated.  Every rank returns the same bytes, equal
  * to the single-GPU proof.  Without a comm (or with world == 1) the calls are the single-GPU ones.
  *
  * Transports for the small host-side exchanges (results are already on the host, where the transcript lives):

@@ -12,7 +12,10 @@
 
 namespace vpin_host {
 
-inline void keccak_f1600(uint64_t a[25]) {
+// One body, two instantiations: the chi step's 25 `~b & c` per round are single ANDN instructions with BMI1 (and the
+// rotations RORX with BMI2), which plain x86-64 code generation may not use.  An L5-mult proof absorbs ~95 k scalars and
+// points (the `a` vectors of the evaluation proofs, the row commitments), a quarter of a permutation each.
+__attribute__((always_inline)) inline void keccak_f1600_body(uint64_t a[25]) {
   static const uint64_t RC[24] = {
       0x0000000000000001ULL, 0x0000000000008082ULL, 0x800000000000808aULL, 0x8000000080008000ULL, 0x000000000000808bULL,
       0x0000000080000001ULL, 0x8000000080008081ULL, 0x8000000000008009ULL, 0x000000000000008aULL, 0x0000000000000088ULL,
@@ -54,6 +57,17 @@ inline void keccak_f1600(uint64_t a[25]) {
   a[10] = a02; a[11] = a12; a[12] = a22; a[13] = a32; a[14] = a42; a[15] = a03; a[16] = a13; a[17] = a23; a[18] = a33;
   a[19] = a43; a[20] = a04; a[21] = a14; a[22] = a24; a[23] = a34; a[24] = a44;
 }
+inline void keccak_f1600_plain(uint64_t a[25]) { keccak_f1600_body(a); }
+#if defined(__x86_64__)
+__attribute__((target("bmi,bmi2"))) inline void keccak_f1600_bmi(uint64_t a[25]) { keccak_f1600_body(a); }
+inline void keccak_f1600(uint64_t a[25]) {
+  static const bool bmi = __builtin_cpu_supports("bmi") && __builtin_cpu_supports("bmi2");
+  if (bmi) keccak_f1600_bmi(a);
+  else keccak_f1600_plain(a);
+}
+#else
+inline void keccak_f1600(uint64_t a[25]) { keccak_f1600_plain(a); }
+#endif
 
 // SHAKE256 extendable output (FIPS 202)
 class Shake256 {
@@ -98,9 +112,26 @@ class Transcript {
     pos_ = 0;
     pos_begin_ = 0;
   }
+  // st_[pos_ ..] ^= d[0 .. k), k <= R - pos_: eight bytes at a time (the 32-byte scalars and points are most of the volume)
+  void xor_in(const uint8_t* d, size_t k) {
+    uint8_t* s = st_ + pos_;
+    size_t i = 0;
+    for (; i + 8 <= k; i += 8) {
+      uint64_t a, b;
+      memcpy(&a, s + i, 8);
+      memcpy(&b, d + i, 8);
+      a ^= b;
+      memcpy(s + i, &a, 8);
+    }
+    for (; i < k; i++) s[i] ^= d[i];
+    pos_ = (uint8_t)(pos_ + k);
+  }
   void absorb(const uint8_t* d, size_t n) {
-    for (size_t i = 0; i < n; i++) {
-      st_[pos_++] ^= d[i];
+    while (n) {
+      const size_t room = (size_t)(R - pos_), k = n < room ? n : room;
+      xor_in(d, k);
+      d += k;
+      n -= k;
       if (pos_ == R) run_f();
     }
   }

@@ -131,8 +131,8 @@ def _prove_res(cx, g, dec):
 
 def main_strong(args):
     """--scaling strong: ONE trace over all ranks.  Instances of at least 2^--coop-log2 constraints are
-    proven by ALL ranks together (vpin_comm: row commitments by row blocks, product circuits / dot-product halves / slices by
-    index, see include/vpin_hip.h), one after another; the small, latency-bound instances are LPT-sharded over the ranks and
+    proven by ALL ranks together (vpin_comm: row commitments by interleaved rows, sum-check tables and product circuits by
+    residue class over a power-of-two world, by circuit index otherwise, see include/vpin_hip.h), one after another; the small, latency-bound instances are LPT-sharded over the ranks and
     proven without any exchange.  value = the trace's constraints x steps / slowest rank's time.
     Ranks = processes (torch.distributed.run; the exchange goes through POSIX shared memory, device buffers through RCCL
     when the backend is nccl)."""
@@ -207,8 +207,9 @@ def main_strong(args):
                        "constraints_unpadded_per_step": total_cons,
                        "parallelism": f"{[w[0] for w in coop]} proven by all {world} rank(s) together (vpin_comm over shared memory"
                                       f"{', device buffers over RCCL' if (cm is not None and use_nccl and ndev >= world) else ''}: row "
-                                      "commitments by row blocks, product circuits / dot-product halves / slices by index); the other "
-                                      "instances LPT-sharded, no exchange",
+                                      "commitments by interleaved rows; sum-check tables, product circuits and slices by residue class "
+                                      "when the world is a power of two, by circuit index otherwise); the other instances LPT-sharded, "
+                                      "no exchange",
                        "shards": [[small[i][0] for i in sh] for sh in shards]},
             "bytes_equal_oracle_digest": {k: (gold.get(k, {}).get("snark_sha256") == v) for k, v in all_sha.items()},
             "comm": st}))

@@ -349,6 +349,11 @@ int vpin_comm_stats_read(vpin_comm* cm, vpin_comm_stats* out, int reset);
 size_t vpin_comm_stats_tags(vpin_comm* cm, char* buf, size_t cap);
 /* seconds per all-gather of `bytes` per rank over `iters` back-to-back collectives issued inside the library. Collective. */
 int vpin_comm_latency(vpin_comm* cm, size_t bytes, int iters, double* seconds_per_collective);
+/* Marks the group dead: every peer's current or next wait returns VPIN_ECOMM at once instead of running into the timeout
+ * (shared-memory and local transports; a callbacks transport is the caller's to tear down).  The proving entry points do
+ * this themselves when a rank leaves a collective proof with VPIN_ENOMEM / VPIN_EHIP / VPIN_ECOMM; a host calls it when a
+ * rank fails outside the library (a witness that could not be read, a signal). */
+void vpin_comm_abort(vpin_comm* cm);
 /* attach (or detach with NULL): proofs on this context become collective calls over `cm`'s ranks */
 int vpin_ctx_set_comm(vpin_ctx* ctx, vpin_comm* cm);
 /* the b"gens_r1cs_eval" view a polynomial of 2^ell scalars is committed under (PolyCommitmentGens::new(ell, ..)) */

@@ -148,6 +148,31 @@ def test_peer_that_stops_makes_the_collective_fail():
         cm.destroy()
 
 
+def test_abort_fails_a_waiting_peer_at_once():
+    comms = Comm.local(3)  # default timeout: 120 s
+    got = {}
+
+    def waiter(r):
+        t0 = time.time()
+        try:
+            comms[r].allgather(b"x" * 96)
+            got[r] = ("returned", time.time() - t0)
+        except vpin_amd.VpinError as e:
+            got[r] = (e.code, time.time() - t0)
+
+    ts = [threading.Thread(target=waiter, args=(r,)) for r in (0, 1)]
+    [t.start() for t in ts]
+    time.sleep(0.3)            # ranks 0 and 1 are inside the collective, rank 2 "fails outside the library"
+    comms[2].abort()
+    [t.join(30) for t in ts]
+    assert got[0][0] == -7 and got[1][0] == -7, got
+    assert got[0][1] < 10 and got[1][1] < 10, got
+    with pytest.raises(vpin_amd.VpinError):
+        comms[2].allgather(b"x" * 96)  # sticky for everyone
+    for cm in comms:
+        cm.destroy()
+
+
 def _gloo_worker(rank, world, port, q):
     import torch
     import torch.distributed as dist

@@ -461,6 +461,13 @@ class Comm:
             out[tag] = dict(collectives=int(cnt), busy_s=float(busy), crit_s=float(crit))
         return out
 
+    def abort(self):
+        """marks the group dead: every peer's current or next wait fails with VPIN_ECOMM (vpin_comm_abort)"""
+        L = _comm_decl()
+        L.vpin_comm_abort.argtypes = [C.c_void_p]
+        L.vpin_comm_abort.restype = None
+        L.vpin_comm_abort(self.h)
+
     def destroy(self):
         if self.h:
             _comm_decl().vpin_comm_destroy(self.h)

@@ -31,7 +31,8 @@ constexpr uint32_t kNoHolder = 0xffffffffu;
 
 struct alignas(64) CommSlotHdr {
   std::atomic<uint64_t> seq;  // last collective whose piece is complete in data[seq & 1]
-  double busy_s;              // this rank's section before that collective
+  double busy_s[2];           // this rank's section before that collective, by the same parity (a fast rank publishes
+                              // collective k + 1 while a slow one still reads k)
 };
 
 struct alignas(64) CommSeg {
@@ -82,7 +83,7 @@ static void seg_init(CommSeg* s, int world, size_t slot_bytes) {
   s->world = (uint32_t)world;
   s->slot_bytes = slot_bytes;
   s->attached.store(0); s->abort_flag.store(0); s->token.store(kNoHolder); s->detached.store(0); s->serialize.store(0);
-  for (int r = 0; r < world; r++) { slot_hdr(s, r)->seq.store(0); slot_hdr(s, r)->busy_s = 0.0; }
+  for (int r = 0; r < world; r++) { slot_hdr(s, r)->seq.store(0); slot_hdr(s, r)->busy_s[0] = slot_hdr(s, r)->busy_s[1] = 0.0; }
   s->magic.store(kCommMagic, std::memory_order_release);
 }
 
@@ -113,7 +114,7 @@ static int seg_allgather_piece(vpin_comm* cm, const uint8_t* send, uint8_t* recv
   const uint64_t k = ++cm->seq;
   const int parity = (int)(k & 1);
   if (bytes) memcpy(slot_data(s, cm->rank, parity), send, bytes);
-  slot_hdr(s, cm->rank)->busy_s = busy;
+  slot_hdr(s, cm->rank)->busy_s[parity] = busy;
   slot_hdr(s, cm->rank)->seq.store(k, std::memory_order_release);
   double mb = busy;
   for (int i = 0; i < cm->world; i++) {
@@ -124,7 +125,7 @@ static int seg_allgather_piece(vpin_comm* cm, const uint8_t* send, uint8_t* recv
         if (s->abort_flag.load(std::memory_order_relaxed)) return VPIN_ECOMM;
         if (!sp.step()) { s->abort_flag.store(1); return VPIN_ECOMM; }
       }
-      const double b = slot_hdr(s, r)->busy_s;
+      const double b = slot_hdr(s, r)->busy_s[parity];
       if (b > mb) mb = b;
     }
     if (bytes) memcpy(recv + (size_t)r * recv_stride, slot_data(s, r, parity), bytes);
@@ -186,6 +187,12 @@ int comm_allgather(vpin_comm* cm, const void* send, void* recv, size_t bytes, co
   }
   cm->t_last_exit = t_out;
   return rc;
+}
+
+// A rank that leaves a collective call with a failure of its own (out of memory, a HIP error) tells the group, so that the
+// peers return VPIN_ECOMM from their next wait instead of running into the timeout.  The group is dead afterwards.
+void comm_abort(vpin_comm* cm) {
+  if (cm && cm->seg && cm->world > 1) cm->seg->abort_flag.store(1, std::memory_order_release);
 }
 
 int comm_mark(vpin_ctx* c, const char* tag) {
@@ -377,6 +384,8 @@ void vpin_comm_destroy(vpin_comm* cm) {
   }
   delete cm;
 }
+
+void vpin_comm_abort(vpin_comm* cm) { comm_abort(cm); }
 
 int vpin_comm_rank(const vpin_comm* cm) { return cm ? cm->rank : -1; }
 int vpin_comm_world(const vpin_comm* cm) { return cm ? cm->world : 0; }

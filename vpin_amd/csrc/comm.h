@@ -62,6 +62,13 @@ int comm_allgather_ctx(vpin_ctx* c, const void* send, void* recv, size_t bytes, 
 // serialized rehearsal only (a no-op otherwise): an empty collective that closes the section running since the previous
 // collective and books it on `tag`, so the critical path can be read per step of the protocol
 int comm_mark(vpin_ctx* c, const char* tag);
+// marks the group dead (shared-memory and local transports): every peer's next wait returns VPIN_ECOMM
+void comm_abort(vpin_comm* cm);
+// exit path of a collective entry point: a failure that may be this rank's alone takes the group down with it
+inline int comm_leave(vpin_comm* cm, int rc) {
+  if (cm && (rc == VPIN_ENOMEM || rc == VPIN_EHIP || rc == VPIN_ECOMM)) comm_abort(cm);
+  return rc;
+}
 // contiguous block of `total` items owned by `rank`: [first, first + count)
 inline void comm_block(size_t total, int rank, int world, size_t* first, size_t* count) {
   const size_t per = (total + (size_t)world - 1) / (size_t)world;

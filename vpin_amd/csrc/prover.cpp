@@ -736,9 +736,9 @@ int vpin_sat_prove_resident(vpin_ctx* c, const vpin_r1cs_dev* dinst, const vpin_
   size_t nv, ncons, ni;
   vpin_r1cs_dims(dinst, &ncons, &nv, &ni);
   if (vars_para->len != nv || vars_input->len != nv || vars->len != nv || (ni && !inputs)) return VPIN_ESHAPE;
-  return vpin_prover::sat_prove_core(c, dinst, nv, ncons, ni, vars_para, vars_input, vars, inputs, seed_commit64, seed_proof64,
-                                     proof_out, proof_cap, proof_len, comm_para_out, comm_input_out, inst_evals_out, rx_out,
-                                     ry_out, nullptr, nullptr);
+  return vpin::comm_leave(c->comm, vpin_prover::sat_prove_core(c, dinst, nv, ncons, ni, vars_para, vars_input, vars, inputs, seed_commit64,
+                                                               seed_proof64, proof_out, proof_cap, proof_len, comm_para_out,
+                                                               comm_input_out, inst_evals_out, rx_out, ry_out, nullptr, nullptr));
 }
 
 int vpin_sat_prove(vpin_ctx* c, const vpin_r1cs* inst, const uint8_t* vars_para, const uint8_t* vars_input,

@@ -1466,16 +1466,17 @@ int vpin_snark_prove_resident(vpin_ctx* c, const vpin_r1cs_dev* dinst, const vpi
   uint8_t ie[96];
   std::vector<Fq> rx(log2z(ncons)), ry(log2z(2 * nv));
   size_t sat_len = 0;
+  // collective over c->comm: a failure of this rank alone (memory, a HIP error) fails the peers' next wait (comm_leave)
   int rc = sat_prove_core(c, dinst, nv, ncons, ni, vars_para, vars_input, vars, inputs, seed_commit64, seed_proof64, proof_out,
                           proof_cap, &sat_len, comm_para_out, comm_input_out, ie, B(rx.data()), B(ry.data()), &tr, &tape);
-  if (rc) return rc;
+  if (rc) return vpin::comm_leave(c->comm, rc);
   if (c->progress_flag) *c->progress_flag = 1;
   g_spark_timings[5] = secs(t0, Clock::now());
   Writer w;
   w.bytes(ie, 96);  // SNARK.inst_evals (lib.rs:334-338)
   Fq evals[3];
   memcpy(evals, ie, 96);
-  if ((rc = spark_prove(c, decomm, rx, ry, evals, tr, tape, w))) return rc;
+  if ((rc = spark_prove(c, decomm, rx, ry, evals, tr, tape, w))) return vpin::comm_leave(c->comm, rc);
   if (sat_len + w.buf.size() > proof_cap) return VPIN_ESHAPE;
   memcpy(proof_out + sat_len, w.buf.data(), w.buf.size());
   *proof_len = sat_len + w.buf.size();

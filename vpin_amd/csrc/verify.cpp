@@ -19,6 +19,17 @@ namespace {
 using namespace vpin_host;
 using namespace vpin_prover;
 
+// VPIN_VERIFY_TRACE=1: spans of one verification on stderr (development aid)
+struct VSpan {
+  const char* name;
+  std::chrono::steady_clock::time_point t0;
+  static bool on() { static const bool v = getenv("VPIN_VERIFY_TRACE") != nullptr; return v; }
+  explicit VSpan(const char* n) : name(n), t0(std::chrono::steady_clock::now()) {}
+  ~VSpan() {
+    if (on()) fprintf(stderr, "[verify] %-28s %8.3f ms\n", name, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+  }
+};
+
 struct Reader {
   const uint8_t* p;
   size_t len, pos = 0;
@@ -160,6 +171,7 @@ static bool read_zksc(Reader& r, ZkScP& p, int rounds, int deg) {
 static bool zksc_verify(const ZkScP& pf, const CG& comm_claim, int rounds, int deg, const Mcg& g1, const Mcg& gn, Transcript& tr,
                         CG& comm_out, std::vector<Fq>& r_out) {
   if (gn.n != deg + 1 || (int)pf.comm_polys.size() != rounds || rounds < 1) return false;
+  VSpan vs(" zk sum-check");
   r_out.clear();
   for (int i = 0; i < rounds; i++) {
     tr.append_point("comm_poly", pf.comm_polys[i].b);
@@ -202,6 +214,7 @@ static bool dplog_verify(vpin_ctx* c, const DpLogP& pf, const PcGens& pc, Transc
                          const CG& Cy) {
   const size_t n = pc.R, lg = log2z(n);
   if (pf.Lv.size() != lg || a.size() != n) return false;
+  VSpan vs("  dplog");
   tr.append_protocol_name("dot product proof (log)");
   tr.append_point("Cx", Cx.b);
   tr.append_point("Cy", Cy.b);
@@ -255,6 +268,7 @@ static bool dplog_verify(vpin_ctx* c, const DpLogP& pf, const PcGens& pc, Transc
 static bool polyeval_verify(vpin_ctx* c, const DpLogP& pf, const PcGens& pc, Transcript& tr, const Fq* r, const CG& C_Zr,
                             const std::vector<CG>& comm) {
   if (comm.size() != pc.L) return false;
+  VSpan vs(" polyeval");
   tr.append_protocol_name("polynomial evaluation proof");
   const size_t left = pc.ell / 2, right = pc.ell - left;
   std::vector<Fq> Lv(pc.L), Rv(pc.R);
@@ -649,9 +663,12 @@ static bool spark_verify(vpin_ctx* c, Reader& r, size_t nx, size_t ny, size_t N,
   }
   for (int k = 0; k < 6; k++) { claims_prod_circuit[k] = pl[0][1 + k]; claims_prod_circuit[6 + k] = pl[1][1 + k]; }
   std::vector<Fq> claims_ops, claims_dotp, rand_ops, claims_mem, none, rand_mem;
-  if (!batched_verify(pf_ops, claims_prod_circuit, claims_dotp_circuit, tr, claims_ops, claims_dotp, rand_ops)) return false;
   Fq mem_in[4] = {pl[0][0], pl[0][7], pl[1][0], pl[1][7]};
-  if (!batched_verify(pf_mem, mem_in, nullptr, tr, claims_mem, none, rand_mem)) return false;
+  {
+    VSpan vs(" product layer");
+    if (!batched_verify(pf_ops, claims_prod_circuit, claims_dotp_circuit, tr, claims_ops, claims_dotp, rand_ops)) return false;
+    if (!batched_verify(pf_mem, mem_in, nullptr, tr, claims_mem, none, rand_mem)) return false;
+  }
   if (claims_dotp.size() != 9 || rand_ops.size() != lgN || rand_mem.size() != lgM) return false;
 
   tr.append_protocol_name("Sparse polynomial hash layer proof");  // HashLayerProof::verify (:902-1032)
@@ -738,10 +755,15 @@ int vpin_snark_verify(vpin_ctx* c, const uint8_t* proof, size_t proof_len, const
   std::vector<Fq> rx, ry;
   Fq ie[3];
   int err = 0;
-  bool ok = sat_verify(c, r, num_cons, num_vars, reinterpret_cast<const Fq*>(inputs), num_inputs, nullptr, ie, comm_para, comm_input, tr,
-                       rx, ry, &err);
+  bool ok;
+  {
+    VSpan vs("sat_verify");
+    ok = sat_verify(c, r, num_cons, num_vars, reinterpret_cast<const Fq*>(inputs), num_inputs, nullptr, ie, comm_para, comm_input, tr, rx, ry,
+                    &err);
+  }
   if (err) return err;
   if (!ok) return VPIN_EVERIFY;
+  VSpan vs("spark_verify");
   ok = spark_verify(c, r, nx, ny, N, M, c_ops, c_mem, rx, ry, ie, tr, &err);
   if (err) return err;
   return ok ? VPIN_OK : VPIN_EVERIFY;

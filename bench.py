@@ -91,6 +91,9 @@ def parse():
                          "critical path of a W-GPU run (a model: no multi-GPU hardware involved)")
     ap.add_argument("--coop-all", action="store_true", help="--rehearse: every point-mult instance cooperatively (to see how each size scales)")
     ap.add_argument("--rehearse-passes", type=int, default=3, help="serialised passes per cooperative instance; the quietest one is reported")
+    ap.add_argument("--sub-coop-log2", type=float, default=22.0,
+                    help="--scaling strong: instances of at least half this many (2^x) constraints, but below --coop-log2, are proven "
+                         "by the first world/2 ranks together while the other ranks start on the small instances (world >= 4)")
     ap.add_argument("--coop-log2", type=int, default=24,
                     help="--scaling strong: instances of at least 2^this constraints are proven by all ranks together")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend of the N>1 runs (gloo: rehearsal with ranks sharing a GPU)")
@@ -132,8 +135,10 @@ def _prove_res(cx, g, dec):
 def main_strong(args):
     """--scaling strong: ONE trace over all ranks.  Instances of at least 2^--coop-log2 constraints are
     proven by ALL ranks together (vpin_comm: row commitments by interleaved rows, sum-check tables and product circuits by
-    residue class over a power-of-two world, by circuit index otherwise, see include/vpin_hip.h), one after another; the small, latency-bound instances are LPT-sharded over the ranks and
-    proven without any exchange.  value = the trace's constraints x steps / slowest rank's time.
+    residue class over a power-of-two world, by circuit index otherwise, see include/vpin_hip.h), mid-size ones
+    (--sub-coop-log2) by the first half of the ranks, one after another; the small, latency-bound instances go to the rank
+    that is free first and are proven without any exchange (vpin_amd/dist.py plan_trace: a static plan every rank computes).
+    value = the trace's constraints x steps / slowest rank's time.
     Ranks = processes (torch.distributed.run; the exchange goes through POSIX shared memory, device buffers through RCCL
     when the backend is nccl)."""
     if args.rehearse:
@@ -142,7 +147,7 @@ def main_strong(args):
     import torch
     import vpin_amd
     from vpin_amd import Comm
-    from vpin_amd.dist import Group, env_rank, plan_shards
+    from vpin_amd.dist import Group, env_rank, plan_trace
 
     rank, local_rank, world = env_rank()
     ndev = max(1, torch.cuda.device_count())
@@ -153,26 +158,27 @@ def main_strong(args):
     grp = Group(backend=args.backend, device=torch.device("cuda", dev) if use_nccl else None)
     trace, work = _strong_work(args)
     total_cons = sum(w[3] for w in work)
-    coop = [w for w in work if w[3] >= (1 << args.coop_log2) * 0.5]
-    small = [w for w in work if w not in coop]
-    shards = plan_shards([w[3] for w in small], world)
-    mine = [small[i] for i in shards[rank]]
+    coop_ix, small_ix, _ = plan_trace([w[3] for w in work], world, 0.5 * 2 ** args.coop_log2, 0.5 * 2 ** args.sub_coop_log2)
+    coop = [(work[i], g) for i, g in coop_ix]       # in proving order; the group of an entry is ranks [0, g)
+    mine = [work[i] for i in small_ix[rank]]
 
     ctx = vpin_amd.Context(dev)
-    cm = None
+    comms = {}
     if world > 1:
         name = grp.gather_objects(f"/vpin-{os.getpid()}-{int(time.time() * 1e3) & 0xffffff}")[0]  # rank 0's choice
-        cm = Comm.shm(name, rank, world)
-        if use_nccl and ndev >= world:
-            cm.enable_rccl(ctx)
-    built = {w[0]: _build_resident(ctx, w) for w in coop + mine}
+        for g in sorted({g for _, g in coop}, reverse=True):
+            if rank < g:
+                comms[g] = Comm.shm(f"{name}-g{g}", rank, g)
+                if use_nccl and ndev >= world:
+                    comms[g].enable_rccl(ctx)
+    built = {w[0]: _build_resident(ctx, w) for w in [w for w, g in coop if rank < g] + mine}
     proof_sha = {}
 
     def step():
-        if cm is not None:
-            ctx.set_comm(cm)
-        for w in coop:
-            proof_sha[w[0]] = hashlib.sha256(_prove_res(ctx, *built[w[0]])["proof"]).hexdigest()
+        for w, g in coop:
+            if rank < g:
+                ctx.set_comm(comms[g])
+                proof_sha[w[0]] = hashlib.sha256(_prove_res(ctx, *built[w[0]])["proof"]).hexdigest()
         ctx.set_comm(None)
         for w in mine:
             proof_sha[w[0]] = hashlib.sha256(_prove_res(ctx, *built[w[0]])["proof"]).hexdigest()
@@ -184,7 +190,7 @@ def main_strong(args):
 
     for _ in range(args.warmup):
         step()
-    if cm is not None:
+    for cm in comms.values():
         cm.stats(reset=True)
     barrier()
     t0 = time.perf_counter()
@@ -194,10 +200,11 @@ def main_strong(args):
     barrier()
     elapsed = grp.max_over_ranks(time.perf_counter() - t0)
     shas = grp.gather_objects(proof_sha)
-    st = cm.stats() if cm is not None else None
+    st = {f"group_of_{g}": cm.stats() for g, cm in comms.items()} if comms else None
     if rank == 0:
         gold = _golden_digests()
         all_sha = {k: v for d in shas for k, v in d.items()}
+        rccl = bool(comms) and use_nccl and ndev >= world
         print(json.dumps({
             "metric": "R1CS constraints/sec, whole Spartan SNARK (sat proof + SPARK evaluation proof; vPIN point-mult + point-add instances)",
             "value": total_cons * args.steps / elapsed, "unit": "constraints/s", "n_gpus": world, "steps": args.steps,
@@ -205,15 +212,14 @@ def main_strong(args):
             "vs_baseline": None, "dtype": "u256 (mod q = 2^252+..., mod p = 2^255-19; 32-bit limbs)", "data": "synthetic",
             "config": {"workload": f"ONE vPIN trace '{trace}' over {world} rank(s): {len(work)} SNARKs per step",
                        "constraints_unpadded_per_step": total_cons,
-                       "parallelism": f"{[w[0] for w in coop]} proven by all {world} rank(s) together (vpin_comm over shared memory"
-                                      f"{', device buffers over RCCL' if (cm is not None and use_nccl and ndev >= world) else ''}: row "
-                                      "commitments by interleaved rows; sum-check tables, product circuits and slices by residue class "
-                                      "when the world is a power of two, by circuit index otherwise); the other instances LPT-sharded, "
-                                      "no exchange",
-                       "shards": [[small[i][0] for i in sh] for sh in shards]},
+                       "parallelism": f"cooperative proofs {[(w[0], g) for w, g in coop]} (instance, ranks [0, g) together: vpin_comm over "
+                                      f"shared memory{', device buffers over RCCL' if rccl else ''}: row commitments by interleaved rows; "
+                                      "sum-check tables, product circuits and slices by residue class when the group is a power of two, "
+                                      "by circuit index otherwise); the other instances go to the rank that is free first, no exchange",
+                       "small_instances_per_rank": [[work[i][0] for i in sh] for sh in small_ix]},
             "bytes_equal_oracle_digest": {k: (gold.get(k, {}).get("snark_sha256") == v) for k, v in all_sha.items()},
             "comm": st}))
-    if cm is not None:
+    for cm in comms.values():
         cm.destroy()
     for g, dec in built.values():
         dec.free()
@@ -235,20 +241,26 @@ def strong_rehearse(args):
     process and prove each cooperative instance together with vpin_comm_set_serialize on: one rank computes at a time, so the
     time a rank spends between two collectives is its own work and nothing else, and the W-GPU time of the proof is the sum over
     the collectives of the slowest rank's section (crit_s) plus the exchanges themselves (collectives x the measured latency of
-    an all-gather among W threads).  A MODEL of the multi-GPU run from measured sections -- no multi-GPU hardware was used."""
+    an all-gather among W threads).  The trace's time is the static plan of main_strong (plan_trace: which instances are proven
+    by all ranks, by half of them, by one) replayed with these modelled and measured times.  A MODEL of the multi-GPU run from
+    measured sections -- no multi-GPU hardware was used."""
     import hashlib
     import threading
     import vpin_amd
     from vpin_amd import Comm
-    from vpin_amd.dist import plan_shards
+    from vpin_amd.dist import plan_trace, replay_trace
 
     W = args.rehearse
     trace, work = _strong_work(args)
     total_cons = sum(w[3] for w in work)
-    coop = [w for w in work if w[3] >= (1 << args.coop_log2) * 0.5]
-    if args.coop_all:
-        coop = [w for w in work if w[1] == "mult"]
-    small = [w for w in work if w not in coop]
+    cons = [w[3] for w in work]
+    if args.coop_all:  # every point-mult instance by all ranks (how each size scales)
+        coop_ix = [(i, W) for i, w in enumerate(work) if w[1] == "mult"]
+        _, small_ix, _ = plan_trace([0 if w[1] == "mult" else w[3] for w in work], W, float("inf"), float("inf"))
+        small_ix = [[i for i in sh if work[i][1] != "mult"] for sh in small_ix]
+    else:
+        coop_ix, small_ix, _ = plan_trace(cons, W, 0.5 * 2 ** args.coop_log2, 0.5 * 2 ** args.sub_coop_log2)
+    group = {work[i][0]: g for i, g in coop_ix}
     gold = _golden_digests()
     ctx0 = vpin_amd.Context(0)
 
@@ -283,11 +295,13 @@ def strong_rehearse(args):
         single_ms[w[0]] = best * 1e3
         sha = hashlib.sha256(ref["proof"]).hexdigest()
         rec = {"single_gpu_ms": round(best * 1e3, 3), "bytes_equal_oracle_digest": gold.get(w[0], {}).get("snark_sha256") == sha}
-        if w in coop:
-            ctxs = [ctx0] + [vpin_amd.Context(0) for _ in range(W - 1)]
-            comms = Comm.local(W)
-            out, errs, stats, tags = [None] * W, [], [None] * W, [None] * W
-            passes = [[] for _ in range(W)]
+        if w[0] in group:
+            Wg = group[w[0]]
+            rec["ranks"] = Wg
+            ctxs = [ctx0] + [vpin_amd.Context(0) for _ in range(Wg - 1)]
+            comms = Comm.local(Wg)
+            out, errs, stats, tags = [None] * Wg, [], [None] * Wg, [None] * Wg
+            passes = [[] for _ in range(Wg)]
 
             def body(r):
                 try:
@@ -310,7 +324,7 @@ def strong_rehearse(args):
                 except BaseException as e:  # noqa: BLE001
                     errs.append((r, repr(e)))
 
-            ts = [threading.Thread(target=body, args=(r,)) for r in range(W)]
+            ts = [threading.Thread(target=body, args=(r,)) for r in range(Wg)]
             [t.start() for t in ts]
             [t.join() for t in ts]
             for cm in comms:
@@ -329,7 +343,7 @@ def strong_rehearse(args):
                     "model_ms": round((st["crit_s"] + st["collectives"] * t_ag) * 1e3, 3),
                     "busy_ms_per_rank": [round(s["busy_s"] * 1e3, 3) for s in stats],
                     "crit_ms_by_step": {k: round(v["crit_s"] * 1e3, 3) for k, v in sorted(tags[0].items(), key=lambda kv: -kv[1]["crit_s"])},
-                    "busy_ms_by_step_per_rank": {k: [round(tags[r].get(k, {"busy_s": 0.0})["busy_s"] * 1e3, 3) for r in range(W)]
+                    "busy_ms_by_step_per_rank": {k: [round(tags[r].get(k, {"busy_s": 0.0})["busy_s"] * 1e3, 3) for r in range(Wg)]
                                                  for k in sorted(tags[0], key=lambda kk: -tags[0][kk]["crit_s"])[:10]},
                 })
                 # Per step of the protocol (tag): the library's crit_s is sum over the collectives of the slowest rank's section.
@@ -343,7 +357,7 @@ def strong_rehearse(args):
                 for k in tags[0]:
                     v = min(tg[k]["crit_s"] for _st, tg in passes[0] if k in tg)
                     ncoll = tags[0][k]["collectives"]
-                    quiet_r = [min(tg[k]["busy_s"] for _st, tg in passes[r] if k in tg) for r in range(W)]
+                    quiet_r = [min(tg[k]["busy_s"] for _st, tg in passes[r] if k in tg) for r in range(Wg)]
                     if k in replicated:
                         v = min(v, min(quiet_r))
                     else:
@@ -357,15 +371,19 @@ def strong_rehearse(args):
                 rec["crit_ms_quietest_pass_per_step"] = round(quiet * 1e3, 3)
                 rec["model_ms_quietest_pass_per_step"] = round((quiet + st["collectives"] * t_ag) * 1e3, 3)
                 rec["crit_ms_by_step_quietest"] = {k: round(v * 1e3, 3) for k, v in sorted(tagq.items(), key=lambda kv: -kv[1])}
+                # every pass of the three longest steps, per rank (how stable the rehearsal is)
+                rec["busy_ms_per_rank_every_pass"] = {
+                    k: [[round(passes[r][i][1].get(k, {"busy_s": 0.0})["busy_s"] * 1e3, 3) for r in range(Wg)] for i in range(len(passes[0]))]
+                    for k in sorted(tagq, key=lambda kk: -tagq[kk])[:3]}
                 rec["fraction_of_single_gpu"] = round(rec["model_ms"] / rec["single_gpu_ms"], 4)
                 rec["fraction_of_single_gpu_quietest"] = round(rec["model_ms_quietest_pass_per_step"] / rec["single_gpu_ms"], 4)
         per[w[0]] = rec
         dec.free()
         g.free()
-    shards = plan_shards([int(single_ms[w[0]] * 1e3) for w in small], W)
-    share_ms = [sum(single_ms[small[i][0]] for i in sh) for sh in shards]
-    ok = all("model_ms_quietest_pass_per_step" in per[w[0]] for w in coop)
-    model_ms = (sum(per[w[0]]["model_ms_quietest_pass_per_step"] for w in coop) + (max(share_ms) if share_ms else 0.0)) if ok else None
+    ok = all("model_ms_quietest_pass_per_step" in per[work[i][0]] for i, _ in coop_ix)
+    single = [single_ms[w[0]] for w in work]
+    loads = replay_trace(coop_ix, small_ix, W, {(i, g): per[work[i][0]]["model_ms_quietest_pass_per_step"] for i, g in coop_ix}, single) if ok else None
+    model_ms = max(loads) if ok else None
     serial_ms = sum(single_ms.values())
     print(json.dumps({
         "metric": "critical-path MODEL of one vPIN trace proven by W GPUs (sections measured on one GPU, ranks serialised)",
@@ -374,8 +392,9 @@ def strong_rehearse(args):
         "model_speedup_vs_single_gpu_serial": None if model_ms is None else round(serial_ms / model_ms, 3),
         "model_constraints_per_s": None if model_ms is None else total_cons / model_ms * 1e3,
         "allgather_latency_us_among_threads": round(t_ag * 1e6, 2),
-        "cooperative": [w[0] for w in coop], "sharded_small_instances": [[small[i][0] for i in sh] for sh in shards],
-        "small_share_ms_per_rank": [round(x, 3) for x in share_ms], "instances": per,
+        "cooperative": [[work[i][0], g] for i, g in coop_ix],
+        "small_instances_per_rank": [[work[i][0] for i in sh] for sh in small_ix],
+        "finish_ms_per_rank": None if loads is None else [round(x, 3) for x in loads], "instances": per,
         "plan": dict(zip(("owner_ops", "owner_dotp", "owner_mem"), vpin_amd.dist_plan(W))),
     }))
     ctx0.close()

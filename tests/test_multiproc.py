@@ -94,3 +94,38 @@ def test_plan_shards_properties():
     # LeNet: L5-mult dominates, so instance sharding alone cannot scale past ~1.25x
     sh8 = plan_shards(costs, 8)
     assert max(sum(costs[i] for i in s) for s in sh8) == 3464 * 6000
+
+
+def test_plan_trace_groups_and_replay():
+    """the static schedule of bench.py --scaling strong: the largest instance by all ranks, the mid-size one by half of them,
+    every other instance exactly once on one rank; the same on every rank; replay with given times"""
+    sys.path.insert(0, ROOT)
+    from vpin_amd.dist import plan_trace, replay_trace
+    cons = [3464 * n for n in (6000, 800, 300, 240, 168)] + [10 * n for n in (7056, 5760, 2400, 768, 406, 288, 186)]
+    coop_min, sub_min = 0.5 * 2 ** 24, 0.5 * 2 ** 22
+    for world in (1, 2, 3, 4, 8):
+        coop, small, loads = plan_trace(cons, world, coop_min, sub_min)
+        assert (coop, small, loads) == plan_trace(cons, world, coop_min, sub_min)
+        seen = [i for i, _ in coop] + [i for sh in small for i in sh]
+        assert sorted(seen) == list(range(len(cons)))
+        assert len(small) == world and len(loads) == world
+        for i, g in coop:
+            assert 2 <= g <= world
+        if world == 1:
+            assert coop == []
+        else:
+            assert coop[0] == (0, world)  # L5-mult by everybody, first
+        if world >= 4:
+            assert (1, world // 2) in coop  # L3-mult by the first half of the ranks
+            # .. during which the other half starts on the small instances
+            assert all(len(small[r]) >= 1 for r in range(world // 2, world))
+        elif world > 1:
+            assert len(coop) == 1
+    coop, small, _ = plan_trace(cons, 8, coop_min, sub_min)
+    single = [1.0 + c / 1e5 for c in cons]
+    times = {(i, g): single[i] / g + 0.5 for i, g in coop}
+    loads = replay_trace(coop, small, 8, times, single)
+    t_all = times[(0, 8)]
+    assert all(x >= t_all for x in loads)
+    assert abs(loads[0] - (t_all + times[(1, 4)] + sum(single[i] for i in small[0]))) < 1e-9
+    assert abs(loads[7] - (t_all + sum(single[i] for i in small[7]))) < 1e-9

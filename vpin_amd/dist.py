@@ -27,6 +27,60 @@ def plan_shards(costs, world):
     return [sorted(s) for s in shards]
 
 
+def est_single_ms(cons):
+    """Rough single-GPU time of one whole SNARK, ms (a fit of the LeNet instances on MI355X: a latency floor plus a rate);
+    only the ORDER and the rough proportions matter -- the plan below must be the same on every rank without measuring."""
+    return 12.0 + cons / 40e3
+
+
+def est_group_fraction(g):
+    """share of the single-GPU time a cooperative proof over g ranks is expected to take (rehearsals: 0.61 / 0.43 / 0.30)"""
+    return 0.25 + 0.75 / g
+
+
+def plan_trace(cons, world, coop_min, sub_min):
+    """Static schedule of one trace over `world` ranks (bench.py --scaling strong).  cons: unpadded constraints per instance.
+    Instances of at least coop_min constraints are proven by ALL ranks together; instances of at least sub_min by the first
+    world/2 ranks (a smaller group wastes less of a mid-size proof's latency-bound rounds) while the others start on the
+    small ones; the rest go, longest first, to whichever rank is free first.  Returns (coop, small, loads):
+    coop = [(index, group size)] in proving order (a group is always ranks [0, size)), small = index lists per rank,
+    loads = the estimated finish time of every rank, ms.  Deterministic: every rank computes the same plan."""
+    order = sorted(range(len(cons)), key=lambda i: (-cons[i], i))
+    loads = [0.0] * world
+    coop, rest = [], []
+    for i in order:
+        g = 1
+        if world > 1 and cons[i] >= coop_min:
+            g = world
+        elif world >= 4 and cons[i] >= sub_min:
+            g = world // 2
+        if g > 1:
+            end = max(loads[:g]) + est_single_ms(cons[i]) * est_group_fraction(g)
+            for r in range(g):
+                loads[r] = end
+            coop.append((i, g))
+        else:
+            rest.append(i)
+    small = [[] for _ in range(world)]
+    for i in rest:
+        r = min(range(world), key=lambda k: (loads[k], k))
+        small[r].append(i)
+        loads[r] += est_single_ms(cons[i])
+    return coop, small, loads
+
+
+def replay_trace(coop, small, world, coop_ms, single_ms):
+    """finish time of every rank when the plan runs with the given times: coop_ms[(index, size)], single_ms[index]"""
+    loads = [0.0] * world
+    for i, g in coop:
+        end = max(loads[:g]) + coop_ms[(i, g)]
+        for r in range(g):
+            loads[r] = end
+    for r in range(world):
+        loads[r] += sum(single_ms[i] for i in small[r])
+    return loads
+
+
 class Group:
     """Thin wrapper so bench.py and the gloo tests share the same control path."""
 

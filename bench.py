@@ -59,7 +59,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--trace", default="lenet", help="lenet (L1..L7) or one label: 3_32, A, 7_256, E, L1..L7")
+    ap.add_argument("--trace", default="lenet", help="lenet (L1..L7), one label (3_32, A, 7_256, E, L1..L7) or, with --scaling strong, "
+                                                     "a comma-separated list of labels (a trace of one's own: L3,L1,L6,L7)")
     ap.add_argument("--label", default=None, help="alias of --trace for a single label")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-mult", type=int, default=32, help="point-mults in the CPU baseline sample")
@@ -107,7 +108,7 @@ def parse():
 def _strong_work(args):
     from vpin_amd import gadgets as G
     trace = args.label or args.trace
-    labels = list(G.LENET) if trace == "lenet" else [trace]
+    labels = list(G.LENET) if trace == "lenet" else trace.split(",")
     work = []
     for lab in labels:
         m = G.synthetic_mult_inputs(lab)

@@ -4,6 +4,10 @@
 // (MultiCommitGens::new, Spartan/src/commitments.rs:20-38).  The reference gets all of this
 // from curve25519-dalek through Spartan/src/group.rs.
 #pragma once
+#include <array>
+#include <map>
+#include <memory>
+#include <mutex>
 #include <vector>
 
 #include "field.h"
@@ -139,10 +143,34 @@ struct Niels { Fe ypx, ymx, xy2d; };
 
 struct FixedBase {
   static constexpr int kBits = 10, kWindows = 26, kEntries = 1 << (kBits - 1);
-  std::vector<Niels> t;  // [kWindows][kEntries]
+  std::shared_ptr<const std::vector<Niels>> tab;  // [kWindows][kEntries]; shared by every FixedBase of the same point
+  const Niels* t = nullptr;
   Point base;
   FixedBase() {}
-  explicit FixedBase(const Point& p) : t((size_t)kWindows * kEntries), base(p) {
+  // The table is a function of the point alone and costs ~3 ms to build: one per process and point (prover and verifier
+  // of one CLI run, every context of a service use the same few generators of gens_r1cs_sat / gens_r1cs_eval).
+  explicit FixedBase(const Point& p) : base(p) {
+    static std::mutex mu;
+    static std::map<std::array<uint8_t, 32>, std::shared_ptr<const std::vector<Niels>>> cache;
+    std::array<uint8_t, 32> key;
+    p.compress(key.data());
+    {
+      std::lock_guard<std::mutex> lock(mu);
+      auto it = cache.find(key);
+      if (it != cache.end()) tab = it->second;
+    }
+    if (!tab) {
+      auto fresh = build(p);
+      std::lock_guard<std::mutex> lock(mu);
+      auto& slot = cache[key];
+      if (!slot) slot = fresh;
+      tab = slot;
+    }
+    t = tab->data();
+  }
+  static std::shared_ptr<const std::vector<Niels>> build(const Point& p) {
+    auto out = std::make_shared<std::vector<Niels>>((size_t)kWindows * kEntries);
+    std::vector<Niels>& tt = *out;
     std::vector<Point> m((size_t)kWindows * kEntries);
     Point s = p;
     for (int w = 0; w < kWindows; w++) {
@@ -161,8 +189,9 @@ struct FixedBase {
       Fe zi = acc * pre[i];
       acc = acc * m[i].Z;
       Fe x = m[i].X * zi, y = m[i].Y * zi;
-      t[i] = Niels{y + x, y - x, x * y * K().d2};
+      tt[i] = Niels{y + x, y - x, x * y * K().d2};
     }
+    return out;
   }
   static Point add_niels(const Point& p, const Niels& q, bool negq) {
     Fe PP = p.Y.add_lazy(p.X) * (negq ? q.ymx : q.ypx), MM = p.Y.sub_lazy(p.X) * (negq ? q.ypx : q.ymx);

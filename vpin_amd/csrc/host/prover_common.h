@@ -10,6 +10,8 @@
 #include <cstring>
 #include <map>
 #include <memory>
+#include <mutex>
+#include <string>
 #include <vector>
 
 #include "../ctx.h"
@@ -68,8 +70,22 @@ struct Mcg {  // MultiCommitGens view over fixed-base tables
   const FixedBase* h;
 };
 
-// MultiCommitGens::new (commitments.rs:20-38) stream under `label`
-static void derive_gens(std::vector<Point>& g, size_t nb, const char* label) {
+// MultiCommitGens::new (commitments.rs:20-38) stream under `label`.  Every set of a label is a prefix of one SHAKE stream, so
+// the longest prefix derived so far is kept per process: the prover's and the verifier's generator sets of one CLI run (and
+// every context of a service) hash each point to the group once.
+inline void derive_gens(std::vector<Point>& g, size_t nb, const char* label) {
+  static std::mutex mu;
+  static std::map<std::string, std::shared_ptr<const std::vector<Point>>> cache;
+  std::shared_ptr<const std::vector<Point>> have;
+  {
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = cache.find(label);
+    if (it != cache.end()) have = it->second;
+  }
+  if (have && have->size() >= nb) {
+    g.assign(have->begin(), have->begin() + (long)nb);
+    return;
+  }
   uint8_t bc[32];
   Point::basepoint().compress(bc);  // GROUP_BASEPOINT_COMPRESSED (group.rs:26-27)
   Shake256 sh;
@@ -78,9 +94,15 @@ static void derive_gens(std::vector<Point>& g, size_t nb, const char* label) {
   sh.finalize();
   std::vector<uint8_t> stream(64 * nb);
   sh.squeeze(stream.data(), stream.size());
-  g.resize(nb);
+  auto fresh = std::make_shared<std::vector<Point>>(nb);
+  const size_t n0 = have ? have->size() : 0;
+  for (size_t i = 0; i < n0; i++) (*fresh)[i] = (*have)[i];
 #pragma omp parallel for schedule(static) num_threads(host_threads())
-  for (long i = 0; i < (long)nb; i++) g[i] = Point::from_uniform_bytes(stream.data() + 64 * i);
+  for (long i = (long)n0; i < (long)nb; i++) (*fresh)[i] = Point::from_uniform_bytes(stream.data() + 64 * i);
+  g = *fresh;
+  std::lock_guard<std::mutex> lock(mu);
+  auto& slot = cache[label];
+  if (!slot || slot->size() < nb) slot = fresh;
 }
 
 // Commitments for Scalar / [Scalar] over at most 4 generators (commitments.rs:85-98)

@@ -344,6 +344,7 @@ static int sat_gens_v(vpin_ctx* c, size_t num_vars, SatGensV** out) {
   VCache* vc = vcache(c);
   auto it = vc->sat.find(num_vars);
   if (it != vc->sat.end()) { *out = it->second.get(); return VPIN_OK; }
+  VSpan vs("setup: sat generators");
   std::unique_ptr<SatGensV> sgp(new SatGensV());
   SatGensV& sg = *sgp;
   sg.ell = log2z(num_vars);
@@ -368,6 +369,7 @@ static int eval_view_v(vpin_ctx* c, size_t ell, const PcGens** out) {
   VCache* vc = vcache(c);
   auto it = vc->eval_views.find(ell);
   if (it != vc->eval_views.end()) { *out = it->second.get(); return VPIN_OK; }
+  VSpan vs("setup: eval generators");
   const size_t nb = ((size_t)1 << (ell - ell / 2)) + 2;
   if (vc->g_eval.size() < nb) derive_gens(vc->g_eval, nb, "gens_r1cs_eval");
   std::unique_ptr<PcGens> v(new PcGens());

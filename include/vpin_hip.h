@@ -500,6 +500,10 @@ int vpin_host_merlin_kat(const char* proto, const char* label, const uint8_t* ms
 /* Commitments::commit (commitments.rs:85-98) under MultiCommitGens::new(n,label), n <= 4 */
 int vpin_host_commit(const char* label, const uint8_t* v_mont, size_t n, const uint8_t* blind_mont, uint8_t out[32]);
 
+/* a*P + b*Q on the host (the verifier's variable-base multiplications, host/curve.h: width-5 NAF, shared doublings):
+ * scalars in Montgomery form, points compressed; VPIN_EVERIFY when a point does not decode */
+int vpin_host_scalar_mul2(const uint8_t a_mont[32], const uint8_t P[32], const uint8_t b_mont[32], const uint8_t Q[32], uint8_t out[32]);
+
 /* self-test of the pinned-memory mailbox framing used between resident kernels and the host (sequence number + checksum per
  * scalar; a torn or mixed publication is rejected and read again): 0 = as expected */
 int vpin_host_mailbox_selftest(void);

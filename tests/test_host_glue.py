@@ -63,3 +63,35 @@ def test_mailbox_framing_rejects_torn_and_stale_pieces():
     """mailbox_dev.h: a scalar crosses PCIe as three 16-byte pieces {seq, 3 words}, the spare word holds a checksum; a piece
     torn 8 + 8, pieces of two publications and a stale sequence number must all be refused (and are then read again)"""
     assert vpin_amd.lib().vpin_host_mailbox_selftest() == 0
+
+
+def test_host_scalar_mul2_matches_oracle():
+    """host/curve.h: width-5 NAF scalar multiplication and the shared-doubling a*P + b*Q of the verifier, against the oracle's
+    double-and-add on generator-stream points; edge scalars: 0, 1, q - 1, 2^252, runs of ones, a lone top window"""
+    rng = np.random.default_rng(11)
+    L = O.lib()
+    L.ge_scalarmul.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.ge_add.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    gens = (O.Ge * 2)()
+    L.oracle_gens_new(gens, 1, (C.c_uint8 * 9)(*b"mul2-test"), 9)
+    Pc, Qc = (C.c_uint8 * 32)(), (C.c_uint8 * 32)()
+    L.ge_compress(Pc, C.byref(gens[0]))
+    L.ge_compress(Qc, C.byref(gens[1]))
+    edge = [0, 1, 2, 15, 16, 17, 31, 32, 33, M.Q - 1, M.Q - 2, 1 << 252, (1 << 252) - 1, (1 << 200) - 1, 0xAAAAAAAAAAAAAAAA << 100,
+            (1 << 64) - 1, 1 << 64, (1 << 128) - (1 << 60), 31 << 59, 31 << 60, 31 << 61, 17 << 62]
+    pairs = [(a, b) for a in edge for b in (0, 1, M.Q - 1)] + [(0, b) for b in edge]
+    pairs += [(int.from_bytes(rng.bytes(40), "little") % M.Q, int.from_bytes(rng.bytes(40), "little") % M.Q) for _ in range(40)]
+    for a, b in pairs:
+        sa, sb = M.ints_to_table([a]), M.ints_to_table([b])
+        out = (C.c_uint8 * 32)()
+        assert vpin_amd.lib().vpin_host_scalar_mul2(sa.ctypes.data_as(C.c_void_p), Pc, sb.ctypes.data_as(C.c_void_p), Qc, out) == 0, (a, b)
+        ea, eb, es = O.Ge(), O.Ge(), O.Ge()
+        L.ge_scalarmul(C.byref(ea), O.ptr(sa), C.byref(gens[0]))
+        L.ge_scalarmul(C.byref(eb), O.ptr(sb), C.byref(gens[1]))
+        L.ge_add(C.byref(es), C.byref(ea), C.byref(eb))
+        e = (C.c_uint8 * 32)()
+        L.ge_compress(e, C.byref(es))
+        assert bytes(out) == bytes(e), (hex(a), hex(b))
+    bad = (C.c_uint8 * 32)(*([0xff] * 32))
+    one = M.ints_to_table([1])
+    assert vpin_amd.lib().vpin_host_scalar_mul2(one.ctypes.data_as(C.c_void_p), bad, one.ctypes.data_as(C.c_void_p), Qc, out) == -6

@@ -394,6 +394,20 @@ int vpin_host_merlin_kat(const char* proto, const char* label, const uint8_t* ms
   return VPIN_OK;
 }
 
+// a*P + b*Q through the host's variable-base paths: Straus for the pair, and the single multiplications added up must agree
+int vpin_host_scalar_mul2(const uint8_t a_mont[32], const uint8_t P[32], const uint8_t b_mont[32], const uint8_t Q[32], uint8_t out[32]) {
+  if (!a_mont || !P || !b_mont || !Q || !out) return VPIN_EINVAL;
+  Point p, q;
+  if (!Point::decompress(p, P) || !Point::decompress(q, Q)) return VPIN_EVERIFY;
+  Fq a, b;
+  memcpy(a.l, a_mont, 32);
+  memcpy(b.l, b_mont, 32);
+  const Point joint = Point::mul2(a, p, b, q), apart = p.mul(a) + q.mul(b);
+  if (!joint.equals(apart)) return VPIN_EHIP;  // an arithmetic fault of this library, not of the input
+  joint.compress(out);
+  return VPIN_OK;
+}
+
 // host Pedersen commitment self-test hook: sum v[i]*g[i] + blind*g[n] under `label`, compressed
 int vpin_host_commit(const char* label, const uint8_t* v_mont, size_t n, const uint8_t* blind_mont, uint8_t out[32]) {
   if (!label || !v_mont || !blind_mont || !out || n == 0 || n > 4) return VPIN_EINVAL;

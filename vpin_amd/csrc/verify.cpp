@@ -12,6 +12,8 @@
 //   Spartan/src/product_tree.rs:387-485               ProductCircuitEvalProofBatched::verify
 // It exists so that `vpin_prove` can close the reference binary's loop ("Proof verification
 // successful!"); it shares no code with the test-side checker.
+#include <functional>
+
 #include "host/prover_common.h"
 
 namespace {
@@ -27,6 +29,22 @@ struct VSpan {
   explicit VSpan(const char* n) : name(n), t0(std::chrono::steady_clock::now()) {}
   ~VSpan() {
     if (on()) fprintf(stderr, "[verify] %-28s %8.3f ms\n", name, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+  }
+};
+
+// The transcript is sequential, the group equations it leads to are not: the sigma-protocol checks of the ZK sum-check
+// rounds (two variable-base and up to seven fixed-base multiplications each, ~50 rounds per proof) are collected while
+// the transcript runs and evaluated across the host cores afterwards.
+struct Deferred {
+  std::vector<std::function<bool()>> jobs;
+  void add(std::function<bool()> f) { jobs.push_back(std::move(f)); }
+  bool run() {
+    bool ok = true;
+    const int nt = jobs.size() >= 4 ? host_threads() : 1;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(nt) reduction(&& : ok)
+    for (long i = 0; i < (long)jobs.size(); i++) ok = ok && jobs[(size_t)i]();
+    jobs.clear();
+    return ok;
   }
 };
 
@@ -132,9 +150,10 @@ static bool product_verify(const ProdP& pf, const Mcg& g, Transcript& tr, const 
 }
 
 struct DotP { CG delta, beta; std::vector<Fq> z; Fq z_delta, z_beta; };
-// DotProductProof::verify (nizk/mod.rs:376-407) over the <= 4 sum-check generators
+// DotProductProof::verify (nizk/mod.rs:376-407) over the <= 4 sum-check generators: the transcript part now, the two group
+// equations into `later` (pf, g1, gn outlive it; pCx, pCy are the decoded Cx, Cy)
 static bool dotproduct_verify(const DotP& pf, const Mcg& g1, const Mcg& gn, Transcript& tr, const Fq* a, int n, const CG& Cx,
-                              const CG& Cy) {
+                              const Point& pCx, const CG& Cy, const Point& pCy, Deferred& later) {
   if ((int)pf.z.size() != n || gn.n != n) return false;
   tr.append_protocol_name("dot product proof");
   tr.append_point("Cx", Cx.b);
@@ -142,13 +161,17 @@ static bool dotproduct_verify(const DotP& pf, const Mcg& g1, const Mcg& gn, Tran
   tr.append_scalars("a", a, n);
   tr.append_point("delta", pf.delta.b);
   tr.append_point("beta", pf.beta.b);
-  Fq c = tr.challenge_scalar("c");
-  Point pCx, pCy, pd, pb;
-  if (!decompress(pCx, Cx) || !decompress(pCy, Cy) || !decompress(pd, pf.delta) || !decompress(pb, pf.beta)) return false;
-  bool ok = (pCx.mul(c) + pd).equals(commit(pf.z.data(), n, pf.z_delta, gn));
+  const Fq c = tr.challenge_scalar("c");
   Fq dotp = Fq::zero();
   for (int i = 0; i < n; i++) dotp = dotp + pf.z[i] * a[i];
-  return ok && (pCy.mul(c) + pb).equals(commit1(dotp, pf.z_beta, g1));
+  const DotP* pp = &pf;
+  const Mcg *p1 = &g1, *pn = &gn;
+  later.add([=]() {
+    Point pd, pb;
+    if (!decompress(pd, pp->delta) || !decompress(pb, pp->beta)) return false;
+    return (pCx.mul(c) + pd).equals(commit(pp->z.data(), n, pp->z_delta, *pn)) && (pCy.mul(c) + pb).equals(commit1(dotp, pp->z_beta, *p1));
+  });
+  return true;
 }
 
 // ---- ZK sum-check (sumcheck.rs:84-183) -------------------------------------------------------
@@ -169,10 +192,17 @@ static bool read_zksc(Reader& r, ZkScP& p, int rounds, int deg) {
 }
 
 static bool zksc_verify(const ZkScP& pf, const CG& comm_claim, int rounds, int deg, const Mcg& g1, const Mcg& gn, Transcript& tr,
-                        CG& comm_out, std::vector<Fq>& r_out) {
+                        CG& comm_out, std::vector<Fq>& r_out, Deferred& later) {
   if (gn.n != deg + 1 || (int)pf.comm_polys.size() != rounds || rounds < 1) return false;
-  VSpan vs(" zk sum-check");
+  VSpan vs(" zk sum-check (transcript)");
   r_out.clear();
+  // every commitment of the proof is decoded once, across the cores (the round loop needs them in transcript order)
+  std::vector<Point> p_polys(rounds), p_evals(rounds);
+  Point p_claim;
+  bool dec_ok = decompress(p_claim, comm_claim);
+#pragma omp parallel for schedule(static) num_threads(host_threads()) reduction(&& : dec_ok)
+  for (int i = 0; i < rounds; i++) dec_ok = dec_ok && decompress(p_polys[i], pf.comm_polys[i]) && decompress(p_evals[i], pf.comm_evals[i]);
+  if (!dec_ok) return false;
   for (int i = 0; i < rounds; i++) {
     tr.append_point("comm_poly", pf.comm_polys[i].b);
     Fq r_i = tr.challenge_scalar("challenge_nextround");
@@ -181,9 +211,9 @@ static bool zksc_verify(const ZkScP& pf, const CG& comm_claim, int rounds, int d
     tr.append_point("comm_claim_per_round", claim.b);
     tr.append_point("comm_eval", ev.b);
     std::vector<Fq> w = tr.challenge_vector("combine_two_claims_to_one", 2);
-    Point pc, pe;
-    if (!decompress(pc, claim) || !decompress(pe, ev)) return false;
-    CG target = compress(pc.mul(w[0]) + pe.mul(w[1]));
+    // the round's target commitment goes into the transcript: the one group operation that stays in the sequence
+    const Point p_target = Point::mul2(w[0], i == 0 ? p_claim : p_evals[i - 1], w[1], p_evals[i]);
+    CG target = compress(p_target);
     std::vector<Fq> a(deg + 1);
     Fq pw = Fq::one();
     for (int j = 0; j <= deg; j++) {
@@ -191,7 +221,7 @@ static bool zksc_verify(const ZkScP& pf, const CG& comm_claim, int rounds, int d
       a[j] = w[0] * a_sc + w[1] * pw;
       pw = pw * r_i;
     }
-    if (!dotproduct_verify(pf.proofs[i], g1, gn, tr, a.data(), deg + 1, pf.comm_polys[i], target)) return false;
+    if (!dotproduct_verify(pf.proofs[i], g1, gn, tr, a.data(), deg + 1, pf.comm_polys[i], p_polys[i], target, p_target, later)) return false;
     r_out.push_back(r_i);
   }
   comm_out = pf.comm_evals[rounds - 1];
@@ -249,10 +279,18 @@ static bool dplog_verify(vpin_ctx* c, const DpLogP& pf, const PcGens& pc, Transc
   Fq a_hat = Fq::zero();
   for (size_t i = 0; i < n; i++) a_hat = a_hat + a[i] * s[i];
   Point Gamma_hat = Gamma;
-  for (size_t i = 0; i < lg; i++) {
-    Point pl, pr;
-    if (!decompress(pl, pf.Lv[i]) || !decompress(pr, pf.Rv[i])) return false;
-    Gamma_hat = Gamma_hat + pl.mul(usq[i]) + pr.mul(uisq[i]);
+  {
+    std::vector<Point> term(lg);
+    bool dec_ok = true;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(host_threads()) reduction(&& : dec_ok)
+    for (long i = 0; i < (long)lg; i++) {
+      Point pl, pr;
+      const bool ok_i = decompress(pl, pf.Lv[(size_t)i]) && decompress(pr, pf.Rv[(size_t)i]);
+      if (ok_i) term[(size_t)i] = Point::mul2(usq[(size_t)i], pl, uisq[(size_t)i], pr);
+      dec_ok = dec_ok && ok_i;
+    }
+    if (!dec_ok) return false;
+    for (size_t i = 0; i < lg; i++) Gamma_hat = Gamma_hat + term[i];
   }
   tr.append_point("delta", pf.delta.b);
   tr.append_point("beta", pf.beta.b);
@@ -436,7 +474,8 @@ static bool sat_verify(vpin_ctx* c, Reader& r, size_t num_cons, size_t num_vars,
   std::vector<Fq> tau = tr.challenge_vector("challenge_tau", nrx);
   const Fq zero = Fq::zero(), one = Fq::one();
   CG claim1 = compress(commit1(zero, zero, sg.gens_1)), post1, post2;
-  if (!zksc_verify(sc1, claim1, nrx, 3, sg.gens_1, sg.gens_4, tr, post1, rx)) return false;
+  Deferred later;  // sc1, sc2 and the generator sets outlive it
+  if (!zksc_verify(sc1, claim1, nrx, 3, sg.gens_1, sg.gens_4, tr, post1, rx, later)) return false;
   if (!knowledge_verify(pok, sg.gens_1, tr, comm_Cz)) return false;
   if (!product_verify(pp, sg.gens_1, tr, comm_Az, comm_Bz, comm_prod)) return false;
   tr.append_point("comm_Az_claim", comm_Az.b);
@@ -449,8 +488,12 @@ static bool sat_verify(vpin_ctx* c, Reader& r, size_t num_cons, size_t num_vars,
   if (!decompress(pAz, comm_Az) || !decompress(pBz, comm_Bz) || !decompress(pCz, comm_Cz) || !decompress(pProd, comm_prod)) return false;
   if (!equality_verify(eq1, sg.gens_1, tr, compress((pProd - pCz).mul(taus_bound_rx)), post1)) return false;
   Fq r_A = tr.challenge_scalar("challenege_Az"), r_B = tr.challenge_scalar("challenege_Bz"), r_C = tr.challenge_scalar("challenege_Cz");
-  CG claim2 = compress(pAz.mul(r_A) + pBz.mul(r_B) + pCz.mul(r_C));
-  if (!zksc_verify(sc2, claim2, nry, 2, sg.gens_1, sg.gens_3, tr, post2, ry)) return false;
+  CG claim2 = compress(Point::mul2(r_A, pAz, r_B, pBz) + pCz.mul(r_C));
+  if (!zksc_verify(sc2, claim2, nry, 2, sg.gens_1, sg.gens_3, tr, post2, ry, later)) return false;
+  {
+    VSpan vs(" zk sum-check (equations)");
+    if (!later.run()) return false;
+  }
   if (!polyeval_verify(c, pe, sg.pc, tr, ry.data() + 1, comm_vars_at_ry, comm_vars)) return false;
   // poly_input_eval: SparsePolynomial over [1, inputs...] at ry[1..] (commit_test.rs:457-468)
   const int nvb = (int)log2z(num_vars);

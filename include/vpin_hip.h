@@ -65,6 +65,12 @@ int vpin_ctx_set_progress_flag(vpin_ctx* ctx, int* flag);
  * workgroups per CU: 3 % slower alone, but a large instance's commitment no longer stalls every other stream for its
  * whole duration). */
 int vpin_ctx_set_shared_device(vpin_ctx* ctx, int on);
+/* How many proofs the generator window tables built through this context will serve: 0 (default) = many -- the widest
+ * windows the table budget allows (fewest additions per scalar; the table costs ~0.2 s to build for the largest
+ * instance); n > 0 = a process that proves n times and exits (vpin_prove: a process per label, like `cargo run -- <label>`):
+ * the window width then minimises table construction + n proofs' commitments (10 instead of 12 bits for the 2^25
+ * instance, 8 for the small ones). */
+int vpin_ctx_set_expected_proofs(vpin_ctx* ctx, int n);
 /* compute units and shader clock (kHz) of the context's device: the VALU-issue ceiling bench.py prices the MSM against */
 int vpin_ctx_device_props(vpin_ctx* ctx, int* num_cus, int* clock_khz);
 /* free / total HBM of the context's device, bytes (the table budgets are chosen from `total`) */
@@ -149,6 +155,10 @@ int vpin_spark_batched_round(vpin_ctx* ctx, vpin_table* forest, size_t n, int nc
  * gens_1.G[0] = g[R], h = g[R+1]; gens_3 / gens_4 are prefixes with h = g[3] / g[4]. */
 typedef struct vpin_gens vpin_gens;
 int vpin_gens_create(vpin_ctx* ctx, const uint8_t* gens_xyzt, size_t nb, vpin_gens** out);
+/* RistrettoPoint::from_uniform_bytes for nb generators at once on the device: stream64 = 64 x nb bytes of the label's SHAKE256
+ * stream (Spartan/src/commitments.rs:20-38), out_xyzt = nb x 128 bytes X|Y|Z|T like vpin_host_gens_derive (same points;
+ * the projective representative may differ) */
+int vpin_gens_map_stream(vpin_ctx* ctx, const uint8_t* stream64, size_t nb, uint8_t* out_xyzt);
 /* Shared form: one immutable table per (device, label), holding the longest prefix of the label's
  * generator stream requested so far -- MultiCommitGens::new(n, label) for every n is a prefix of the same
  * SHAKE256 stream (Spartan/src/commitments.rs:20-38), so all contexts / streams / polynomial sizes of a
@@ -492,6 +502,10 @@ int vpin_bullet_reduce(vpin_ctx* c, const vpin_gens* g, const uint8_t* x_mont, c
                        int classic, uint8_t* cLR_out, uint8_t* LR_out, uint8_t xhat_ahat_out[64], uint8_t ghat_out[32]);
 
 /* ---- host-only entry points (no GPU needed) -------------------------------------------- */
+/* shape of the instance vpin_gadget_point_mult* (is_mult != 0) / vpin_gadget_point_add* will build for n_ops operations:
+ * padded num_cons and num_vars and the non-zero entries of A, B, C (point_mult.rs:61-67, point_addition.rs:67-70) -- enough
+ * for vpin_sat_prepare / vpin_spark_prepare before the witness has been read */
+int vpin_gadget_shape(int is_mult, size_t n_ops, size_t* num_cons, size_t* num_vars, size_t nnz[3]);
 /* MultiCommitGens::new (Spartan/src/commitments.rs:20-38): first nb points of the stream */
 int vpin_host_gens_derive(const char* label, size_t nb, uint8_t* out_xyzt /* nb*128 */);
 /* Merlin: Transcript::new(proto); append_message(label,msg); challenge_bytes(clabel,out) */

@@ -75,7 +75,7 @@ def build_cli(verbose=False):
     out_dir = os.path.join(HERE, "bin")
     os.makedirs(out_dir, exist_ok=True)
     out = os.path.join(out_dir, "vpin_prove")
-    cmd = [hipcc(), "-O2", "-std=c++17", src, "-o", out, "-L", LIB_DIR, "-lvpin_hip", "-Wl,-rpath,$ORIGIN/../lib"]
+    cmd = [hipcc(), "-O2", "-std=c++17", "-pthread", src, "-o", out, "-L", LIB_DIR, "-lvpin_hip", "-Wl,-rpath,$ORIGIN/../lib"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -164,6 +164,9 @@ static int ctx_create(int device, int priority, vpin_ctx** out) {
   // host OpenMP teams must wait passively (see prover.cpp host_threads); set before the runtime starts
   setenv("KMP_BLOCKTIME", "0", 0);
   setenv("OMP_WAIT_POLICY", "PASSIVE", 0);
+  // the runtime's machine-topology discovery for thread affinity costs 30-40 ms of a cold process on a 256-thread host;
+  // the small host teams of this library (<= 8 threads, milliseconds of work) are not pinned anyway
+  setenv("KMP_AFFINITY", "disabled", 0);
   *out = nullptr;
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return VPIN_ENODEV;
@@ -236,6 +239,12 @@ int vpin_ctx_set_progress_flag(vpin_ctx* c, int* flag) {
 int vpin_ctx_set_shared_device(vpin_ctx* c, int on) {
   if (!c) return VPIN_EINVAL;
   c->shared_device = on != 0;
+  return VPIN_OK;
+}
+
+int vpin_ctx_set_expected_proofs(vpin_ctx* c, int n) {
+  if (!c || n < 0) return VPIN_EINVAL;
+  c->expected_proofs = n;
   return VPIN_OK;
 }
 

@@ -266,6 +266,35 @@ Result prove_dev(vpin_ctx* ctx, vpin_dev_instance* inst, const uint8_t seeds[128
   return res;
 }
 
+// The generator sets are functions of the instance sizes alone, and every set of a label is a prefix of one stream: the
+// window table of the LONGEST stream of the run serves both instances.  The run's second instance (point multiplication)
+// is the larger one, so its sets are prepared first, inside the first instance's span -- otherwise the first proof builds
+// tables that the second one has to build again, longer.  Best effort: a weight file that cannot be read is met again,
+// and reported, where the reference would meet it.
+size_t count_strings(const std::string& path) {  // entries of weight.json (an array of decimal strings), 0 when unreadable
+  std::ifstream f(path, std::ios::binary);
+  if (!f) return 0;
+  std::stringstream ss;
+  ss << f.rdbuf();
+  const std::string txt = ss.str();
+  size_t q = 0;
+  for (char ch : txt) q += ch == '"';
+  return q / 2;
+}
+
+void prepare_for_mult(vpin_ctx* ctx, const std::string& weight_path, bool sat_only) {
+  const size_t nw = count_strings(weight_path);
+  size_t nc = 0, nv = 0, nnz[3] = {0, 0, 0};
+  if (!nw || vpin_gadget_shape(1, nw, &nc, &nv, nnz) != 0) return;
+  const size_t mx = nnz[0] > nnz[1] ? (nnz[0] > nnz[2] ? nnz[0] : nnz[2]) : (nnz[1] > nnz[2] ? nnz[1] : nnz[2]);
+  Lap lap;
+  lap("  shape of the mult instance");
+  if (!sat_only) (void)vpin_spark_prepare(ctx, nc, nv, mx);
+  lap("  vpin_spark_prepare");
+  (void)vpin_sat_prepare(ctx, nv);
+  lap("  vpin_sat_prepare");
+}
+
 }  // namespace
 
 int main(int argc, char** argv) {
@@ -273,12 +302,13 @@ int main(int argc, char** argv) {
   std::string dump_dir;
   int device = 0;
   uint8_t seeds[128];
-  bool have_seed = false, host_gadgets = false;
+  bool have_seed = false, host_gadgets = false, no_prefetch = getenv("VPIN_CLI_NO_PREFETCH") != nullptr;
   for (int i = 2; i < argc; i++) {
     std::string a = argv[i];
     if (a == "--device" && i + 1 < argc) device = atoi(argv[++i]);
     else if (a == "--write-proof" && i + 1 < argc) dump_dir = argv[++i];
     else if (a == "--sat-only") g_sat_only = true;
+    else if (a == "--no-prefetch") no_prefetch = true;  // every instance builds its own generator sets, in its own span
     else if (a == "--host-gadgets") host_gadgets = true;  // build instance + witness on the host cores, upload, then prove
     else if (a == "--seed" && i + 1 < argc) {
       std::string h = argv[++i];  // hex, repeated cyclically to 128 bytes: commit seed | proof seed
@@ -324,8 +354,17 @@ int main(int argc, char** argv) {
   printf("Point Addition Gadget...\n");
   printf("Number of Point Additions: %zu\n", n1);
   Lap lap;
-  check(vpin_ctx_create(device, &ctx), "vpin_ctx_create");
+  {
+    const char* pe = getenv("VPIN_CLI_MAIN_PRIO");
+    check(vpin_ctx_create_prio(device, pe ? atoi(pe) : 0, &ctx), "vpin_ctx_create");
+  }
   lap("ctx_create");
+  // this process proves once per instance and exits: generator tables sized for that (VPIN_CLI_FULL_TABLES: the service's)
+  if (!getenv("VPIN_CLI_FULL_TABLES")) check(vpin_ctx_set_expected_proofs(ctx, 1), "vpin_ctx_set_expected_proofs");
+  if (!(network == "L2" || network == "L4") && !no_prefetch) {
+    prepare_for_mult(ctx, base + "pointMult/weight.json", g_sat_only);
+    lap("generator sets (mult size)");
+  }
   Result ra;
   const std::string add_prefix = dump_dir.empty() ? "" : dump_dir + "/" + network + "_add";
   if (host_gadgets || n1 == 0) {

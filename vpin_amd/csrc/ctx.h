@@ -94,6 +94,8 @@ struct vpin_ctx {
   vpin::fq tail_sums[3 * 18];   // host copies of the current tail round's results (assembled from the mailbox pieces)
   vpin::fq tail_final[6 * 18];
   bool shared_device = false;  // other contexts prove on this device at the same time (vpin_ctx_set_shared_device)
+  int expected_proofs = 0;     // proofs the window tables built through this context will serve; 0 = many (vpin_ctx_set_expected_proofs)
+  double gens_scalars_per_proof = 0.0;  // set by the caller of vpin_gens_shared: full-size scalars one proof commits under the table
   void* h_bullet = nullptr;  // pinned staging of the bullet reduction's per-round results (bullet.hip), 64 KiB
   uint32_t bullet_seq = 0;   // sequence number of the last fused bullet round (mailbox_dev.h)
   // one proof over several GPUs (include/vpin_hip.h, vpin_ctx_set_comm): proofs on this context are collective calls

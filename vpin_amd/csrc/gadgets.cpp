@@ -119,6 +119,24 @@ int vpin_instance_is_sat(const vpin_instance* g) {
   return 1;
 }
 
+// Shape of the instance a gadget call will build, from the number of operations alone: padded num_cons / num_vars
+// (Instance::new pads to powers of two) and the non-zero entries of A, B, C -- what sizes the generator sets.  The per-operation
+// counts come from emitting one operation, not from a table of constants.
+int vpin_gadget_shape(int is_mult, size_t n_ops, size_t* num_cons, size_t* num_vars, size_t nnz[3]) {
+  if (!num_cons || !num_vars || !nnz) return VPIN_EINVAL;
+  const size_t n = 128, oc = is_mult ? 27 * n + 8 : 10, ov = is_mult ? n + 10 + n * 26 : 15;
+  const size_t cons = oc * n_ops, vars = ov * n_ops + 1;
+  Trip M[3];
+  TripSink sink{M};
+  const vpin_gadgets::Consts K;
+  if (is_mult) vpin_gadgets::emit_mult_op(sink, 0, 0, ov + 1, K);
+  else vpin_gadgets::emit_add_op(sink, 0, 0, ov + 1, K);
+  for (int m = 0; m < 3; m++) nnz[m] = M[m].row.size() * n_ops;
+  *num_vars = next_pow2(vars > 1 ? vars : 1);
+  *num_cons = (cons == 0 || cons == 1) ? 2 : next_pow2(cons);
+  return VPIN_OK;
+}
+
 // point_addition.rs:67-327.  px,py,rx,ry: N x 32 little-endian bytes; rz: N bytes (0/1)
 int vpin_gadget_point_add(const uint8_t* px_b, const uint8_t* py_b, const uint8_t* rx_b, const uint8_t* ry_b,
                           const uint8_t* rz_b, size_t N, vpin_instance** out) {

@@ -24,6 +24,7 @@ size_t vpin_gens_msm_parts_count(size_t ncols);
 int vpin_gens_msm_parts(vpin_ctx* ctx, const vpin_gens* g, const uint8_t* scalars_mont, size_t rows, size_t ncols,
                         uint8_t* parts_xyzt);
 int vpin_poly_bound(vpin_ctx* c, const vpin_table* Z, const uint8_t* Lvec, size_t L_size, uint8_t* out_LZ);
+int vpin_gens_map_stream(vpin_ctx* ctx, const uint8_t* stream64, size_t nb, uint8_t* out_xyzt);
 void vpin_r1cs_dims(const vpin_r1cs_dev* d, size_t* num_cons, size_t* num_vars, size_t* num_inputs);
 }
 
@@ -73,7 +74,7 @@ struct Mcg {  // MultiCommitGens view over fixed-base tables
 // MultiCommitGens::new (commitments.rs:20-38) stream under `label`.  Every set of a label is a prefix of one SHAKE stream, so
 // the longest prefix derived so far is kept per process: the prover's and the verifier's generator sets of one CLI run (and
 // every context of a service) hash each point to the group once.
-inline void derive_gens(std::vector<Point>& g, size_t nb, const char* label) {
+inline void derive_gens(std::vector<Point>& g, size_t nb, const char* label, vpin_ctx* dev = nullptr) {
   static std::mutex mu;
   static std::map<std::string, std::shared_ptr<const std::vector<Point>>> cache;
   std::shared_ptr<const std::vector<Point>> have;
@@ -97,8 +98,19 @@ inline void derive_gens(std::vector<Point>& g, size_t nb, const char* label) {
   auto fresh = std::make_shared<std::vector<Point>>(nb);
   const size_t n0 = have ? have->size() : 0;
   for (size_t i = 0; i < n0; i++) (*fresh)[i] = (*have)[i];
+  // the map to the group (two exponentiations per point): on the device when the caller has one and the set is large
+  bool mapped = false;
+  if (dev && nb - n0 >= 256) {
+    std::vector<uint8_t> xyzt(128 * (nb - n0));
+    if (vpin_gens_map_stream(dev, stream.data() + 64 * n0, nb - n0, xyzt.data()) == VPIN_OK) {
+      for (size_t i = n0; i < nb; i++) (*fresh)[i] = Point::from_xyzt(xyzt.data() + 128 * (i - n0));
+      mapped = true;
+    }
+  }
+  if (!mapped) {
 #pragma omp parallel for schedule(static) num_threads(host_threads())
-  for (long i = (long)n0; i < (long)nb; i++) (*fresh)[i] = Point::from_uniform_bytes(stream.data() + 64 * i);
+    for (long i = (long)n0; i < (long)nb; i++) (*fresh)[i] = Point::from_uniform_bytes(stream.data() + 64 * i);
+  }
   g = *fresh;
   std::lock_guard<std::mutex> lock(mu);
   auto& slot = cache[label];

@@ -895,11 +895,70 @@ __global__ __launch_bounds__(64) void ge_compress_kernel(const ge_ext* __restric
 
 }  // namespace vpin
 
+namespace vpin {
+
+// ---- hash-to-group on the device: RistrettoPoint::from_uniform_bytes (RFC 9496 4.3.4 MAP, twice, added) ------------------
+// MultiCommitGens::new (commitments.rs:20-38) maps 64 bytes of a SHAKE256 stream per generator; the host does the (sequential)
+// stream and, for a 32 k-generator set, would spend 25-60 ms of eight cores on the two exponentiations per point.  One lane
+// per generator here: the whole set in one pass of the chip.
+__device__ __forceinline__ fp FP_ONE_MINUS_D_SQ() { return fp_const(0x945fc176u, 0xe27c09c1u, 0xcd5e350fu, 0x2c81a138u, 0xbe70dfe4u, 0x9994abddu, 0xb2b3e0d7u, 0x029072a8u); }
+__device__ __forceinline__ fp FP_D_MINUS_ONE_SQ() { return fp_const(0x44ed4d20u, 0x31ad5aaau, 0xb01e1999u, 0xd29e4a2cu, 0x529b4eebu, 0x4cdcd32fu, 0xf66c2241u, 0x5968b37au); }
+__device__ __forceinline__ fp FP_SQRT_AD_MINUS_ONE() { return fp_const(0x497b2e1bu, 0x7e97f6a0u, 0x1b7854bdu, 0xaf9d8e0cu, 0x31f5d1fdu, 0x0f3cfcc9u, 0x2b8348acu, 0x376931bfu); }
+__device__ __forceinline__ fp FP_D_EDWARDS() { return fp_const(0x135978a3u, 0x75eb4dcau, 0x4141d8abu, 0x00700a4du, 0x7779e898u, 0x8cc74079u, 0x2b6ffe73u, 0x52036ceeu); }
+
+// RFC 9496 4.2 SQRT_RATIO_M1(u, v)
+__device__ __forceinline__ fp fp_sqrt_ratio_m1(const fp& u, const fp& v, bool* was_square) {
+  const fp v3 = fp_mul(fp_sqr(v), v), v7 = fp_mul(fp_sqr(v3), v);
+  fp r = fp_mul(fp_mul(u, v3), fp_pow_p58(fp_mul(u, v7)));
+  const fp check = fp_mul(v, fp_sqr(r));
+  const fp nu = fp_neg(u), nu_i = fp_mul(nu, FP_SQRT_M1());
+  const bool correct = fp_eq(check, u), flipped = fp_eq(check, nu), flipped_i = fp_eq(check, nu_i);
+  r = fp_select(flipped || flipped_i, fp_mul(r, FP_SQRT_M1()), r);
+  *was_square = correct || flipped;
+  return fp_abs(r);
+}
+
+__device__ __noinline__ ge_ext ge_elligator(const fp& t) {
+  const fp one = fp_one(), m1 = fp_neg(one), d = FP_D_EDWARDS();
+  const fp r = fp_mul(FP_SQRT_M1(), fp_sqr(t));
+  const fp u = fp_mul(fp_add(r, one), FP_ONE_MINUS_D_SQ());
+  const fp v = fp_mul(fp_sub(m1, fp_mul(r, d)), fp_add(r, d));
+  bool sq;
+  fp s = fp_sqrt_ratio_m1(u, v, &sq);
+  const fp sp = fp_neg(fp_abs(fp_mul(s, t)));
+  s = fp_select(sq, s, sp);
+  const fp c = fp_select(sq, m1, r);
+  const fp N = fp_sub(fp_mul(fp_mul(c, fp_sub(r, one)), FP_D_MINUS_ONE_SQ()), v);
+  const fp ss = fp_sqr(s);
+  const fp w0 = fp_mul(fp_add(s, s), v), w1 = fp_mul(N, FP_SQRT_AD_MINUS_ONE()), w2 = fp_sub(one, ss), w3 = fp_add(one, ss);
+  ge_ext p;
+  p.X = fp_mul(w0, w3); p.Y = fp_mul(w2, w1); p.Z = fp_mul(w1, w3); p.T = fp_mul(w0, w2);
+  return p;
+}
+
+// stream: 64 bytes per generator; out: X | Y | Z | T, canonical 32-byte integers (the form Point::to_xyzt has on the host)
+__global__ __launch_bounds__(64) void gens_derive_kernel(const uint32_t* __restrict__ stream, size_t nb, fp* __restrict__ xyzt) {
+  const size_t i = (size_t)blockIdx.x * 64 + threadIdx.x;
+  if (i >= nb) return;
+  fp t0, t1;
+#pragma unroll
+  for (int k = 0; k < 8; k++) { t0.v[k] = stream[16 * i + k]; t1.v[k] = stream[16 * i + 8 + k]; }
+  t0.v[7] &= 0x7fffffffu;  // FieldElement::from_bytes ignores bit 255
+  t1.v[7] &= 0x7fffffffu;
+  const ge_ext p = ge_add(ge_elligator(t0), ge_elligator(t1));
+  fp_store(xyzt + 4 * i + 0, fp_freeze(p.X));
+  fp_store(xyzt + 4 * i + 1, fp_freeze(p.Y));
+  fp_store(xyzt + 4 * i + 2, fp_freeze(p.Z));
+  fp_store(xyzt + 4 * i + 3, fp_freeze(p.T));
+}
+
+}  // namespace vpin
+
 using namespace vpin;
 
 extern "C" {
 
-static int gens_build_once(vpin_ctx* c, const uint8_t* gens_xyzt, size_t nb, size_t budget, vpin_gens** out);
+static int gens_build_once(vpin_ctx* c, const uint8_t* gens_xyzt, size_t nb, size_t budget, int cmax, vpin_gens** out);
 
 // The table budget is a speed knob (every window bit saves ~8 % of a commitment), so it yields to what the device really has
 // at this moment: at most a third of the FREE memory (a co-tenant, another process's tables, a smaller part), and a failed
@@ -907,15 +966,30 @@ static int gens_build_once(vpin_ctx* c, const uint8_t* gens_xyzt, size_t nb, siz
 static int gens_build(vpin_ctx* c, const uint8_t* gens_xyzt, size_t nb, size_t budget, vpin_gens** out) {
   (void)hipSetDevice(c->device);
   size_t free_b = 0, total_b = 0;
-  if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b) {
+  // (not asked in a one-shot process: its tables are sized by use, and the first hipMemGetInfo of a process costs 35-50 ms)
+  const hipError_t e_info = c->expected_proofs > 0 ? hipErrorUnknown : hipMemGetInfo(&free_b, &total_b);
+  if (e_info == hipSuccess && free_b) {
     static const double frac = [] { const char* e = getenv("VPIN_GENS_FREE_FRACTION"); double v = e ? atof(e) : 0.0; return v > 0.0 && v < 1.0 ? v : 1.0 / 3.0; }();
     const size_t cap = (size_t)((double)free_b * frac);
     if (budget > cap) budget = cap;
   }
   const size_t floor_b = (size_t)1 << 28;
   if (budget < floor_b) budget = floor_b;
+  // A table that serves a known, small number of proofs (vpin_ctx_set_expected_proofs: a CLI process) is not worth its widest
+  // windows: an entry costs ~4x a table addition to construct (projective chain, batched inversion, 96-byte scattered
+  // store), so the width minimises entries x 4 + scalars x windows (measured: 142 ms to build the 12-bit table of the 2^25
+  // instance, whose one proof then saves 48 ms of additions against the 10-bit one, built in 36 ms).
+  int cmax = 12;
+  if (c->expected_proofs > 0 && c->gens_scalars_per_proof > 0.0) {
+    const double S = c->gens_scalars_per_proof * (double)c->expected_proofs, n_lo = (double)std::min<size_t>(nb, 16386);
+    double best = 0.0;
+    for (int cc = 8; cc <= 12; cc++) {  // 8 bits = the narrowest windows the second table segment already uses
+      const double W = (double)((254 + cc - 1) / cc), cost = n_lo * W * (double)(1u << (cc - 1)) * 4.0 + S * W;
+      if (cc == 8 || cost < best) { best = cost; cmax = cc; }
+    }
+  }
   for (;;) {
-    int rc = gens_build_once(c, gens_xyzt, nb, budget, out);
+    int rc = gens_build_once(c, gens_xyzt, nb, budget, cmax, out);
     if (rc != VPIN_ENOMEM || budget <= floor_b) return rc;
     (void)hipGetLastError();
     budget /= 2;
@@ -923,7 +997,7 @@ static int gens_build(vpin_ctx* c, const uint8_t* gens_xyzt, size_t nb, size_t b
   }
 }
 
-static int gens_build_once(vpin_ctx* c, const uint8_t* gens_xyzt, size_t nb, size_t budget, vpin_gens** out) {
+static int gens_build_once(vpin_ctx* c, const uint8_t* gens_xyzt, size_t nb, size_t budget, int cmax, vpin_gens** out) {
   if (!c || !gens_xyzt || !out || nb == 0) return VPIN_EINVAL;
   (void)hipSetDevice(c->device);
   vpin_gens* g = new (std::nothrow) vpin_gens();
@@ -947,10 +1021,10 @@ static int gens_build_once(vpin_ctx* c, const uint8_t* gens_xyzt, size_t nb, siz
     }
   };
   g->split = nbt;
-  fit(nb, budget, 12, &g->c, &g->W, &g->E);
+  fit(nb, budget, cmax, &g->c, &g->W, &g->E);
   if (nb > kSplitBases && getenv("VPIN_GENS_UNIFORM") == nullptr) {
     int c2, W2, E2;
-    fit(kSplitBases, budget, 12, &c2, &W2, &E2);
+    fit(kSplitBases, budget, cmax, &c2, &W2, &E2);
     const size_t lo_bytes = kSplitBases * (size_t)W2 * E2 * sizeof(niels_slot);
     if (c2 > g->c && lo_bytes < budget) {
       g->split = kSplitBases;
@@ -1019,6 +1093,21 @@ int vpin_gens_create(vpin_ctx* c, const uint8_t* gens_xyzt, size_t nb, vpin_gens
   return gens_build(c, gens_xyzt, nb, default_budget(), out);
 }
 
+// The first nb generators of a label's stream from 64 x nb bytes of SHAKE256 output (the caller's: host/transcript.h), mapped
+// to the group on the device; out_xyzt: nb x 128 bytes on the host, the layout of vpin_host_gens_derive
+int vpin_gens_map_stream(vpin_ctx* c, const uint8_t* stream64, size_t nb, uint8_t* out_xyzt) {
+  if (!c || !stream64 || !out_xyzt || nb == 0) return VPIN_EINVAL;
+  (void)hipSetDevice(c->device);
+  DevBuf bs(c), bo(c);
+  if (bs.alloc(nb * 64) || bo.alloc(nb * 128)) return VPIN_ENOMEM;
+  VPIN_HIP_TRY(hipMemcpyAsync(bs.p, stream64, nb * 64, hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(gens_derive_kernel, dim3((unsigned)((nb + 63) / 64)), dim3(64), 0, c->stream, (const uint32_t*)bs.p, nb, (fp*)bo.p);
+  VPIN_HIP_TRY(hipGetLastError());
+  VPIN_HIP_TRY(hipMemcpyAsync(out_xyzt, bo.p, nb * 128, hipMemcpyDeviceToHost, c->stream));
+  VPIN_HIP_TRY(hipStreamSynchronize(c->stream));
+  return VPIN_OK;
+}
+
 // Process-wide registry of window tables by (device, label): every MultiCommitGens::new(n, label) is a
 // prefix of one SHAKE stream (commitments.rs:20-38), so one table of the longest prefix requested so
 // far serves every context, stream and polynomial size of that label.  Tables are immutable once
@@ -1032,15 +1121,24 @@ std::vector<RegEntry> g_reg;
 int vpin_gens_shared(vpin_ctx* c, const char* label, const uint8_t* gens_xyzt, size_t nb, size_t budget_gb,
                      const vpin_gens** out) {
   if (!c || !label || !out || nb == 0) return VPIN_EINVAL;
-  std::lock_guard<std::mutex> lock(g_reg_mu);
-  const vpin_gens* best = nullptr;
-  for (auto& e : g_reg)
-    if (e.device == c->device && e.label == label && e.g->nb >= nb && (!best || e.g->nb < best->nb)) best = e.g;
-  if (best) { *out = best; return VPIN_OK; }
+  auto lookup = [&]() -> const vpin_gens* {
+    const vpin_gens* best = nullptr;
+    for (auto& e : g_reg)
+      if (e.device == c->device && e.label == label && e.g->nb >= nb && (!best || e.g->nb < best->nb)) best = e.g;
+    return best;
+  };
+  {
+    std::lock_guard<std::mutex> lock(g_reg_mu);
+    if (const vpin_gens* best = lookup()) { *out = best; return VPIN_OK; }
+  }
   if (!gens_xyzt) return VPIN_EINVAL;
+  // Built with the registry unlocked: another context of the process (vpin_prove builds the tables of its second, larger
+  // instance on a context of its own while the first is being proven) keeps finding and building tables meanwhile.  Two
+  // threads that miss the same table both build it; both tables stay registered (a handle may already be out).
   vpin_gens* g = nullptr;
   int rc = gens_build(c, gens_xyzt, nb, budget_gb ? (budget_gb << 30) : default_budget(), &g);
   if (rc) return rc;
+  std::lock_guard<std::mutex> lock(g_reg_mu);
   g_reg.push_back(RegEntry{c->device, label, g});
   *out = g;
   return VPIN_OK;

@@ -54,7 +54,7 @@ static int get_gens(vpin_ctx* c, size_t num_vars, SatGens** out) {
   sg->R = (size_t)1 << (sg->ell - left);
   sg->nb = sg->R + 2 < 5 ? 5 : sg->R + 2;
   vpin::TraceLap lap(nullptr, "sat gens");
-  derive_gens(sg->g, sg->nb, "gens_r1cs_sat");
+  derive_gens(sg->g, sg->nb, "gens_r1cs_sat", c);
   lap("derive_gens (host)");
 #pragma omp parallel for schedule(dynamic, 1) num_threads(host_threads())
   for (int i = 0; i < 7; i++) {
@@ -71,6 +71,7 @@ static int get_gens(vpin_ctx* c, size_t num_vars, SatGens** out) {
   if (rc == VPIN_EINVAL) {  // no table of this label covers nb generators yet: build one
     std::vector<uint8_t> xyzt(128 * sg->nb);
     for (size_t i = 0; i < sg->nb; i++) sg->g[i].to_xyzt(xyzt.data() + 128 * i);
+    c->gens_scalars_per_proof = (double)num_vars;  // the two halves of the assignment, about half of them full-size scalars
     rc = vpin_gens_shared(c, "gens_r1cs_sat", xyzt.data(), sg->nb, 0, &sg->dev);
   }
   if (rc) return rc;

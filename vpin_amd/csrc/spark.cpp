@@ -51,6 +51,9 @@ static void spark_cache_free(vpin_ctx* c) {
 // scalars per proof) is the single most expensive step of a SNARK, and every window bit saves ~8 % of
 // it, so on a 288 GB part the table gets up to 80 GB (11-bit windows for 32 770 generators)
 static size_t spark_budget_gb(vpin_ctx* c) {
+  // a process that proves once and exits sizes its tables by use, far below either budget (msm.hip gens_build), and the
+  // first hipMemGetInfo of a process costs 35-50 ms: not asked then (a failed allocation still halves the table)
+  if (c->expected_proofs > 0) return (size_t)24;
   static const size_t gb = [c] {
     const char* e = getenv("VPIN_SPARK_GENS_BUDGET_GB");
     if (e && atoi(e) > 0) return (size_t)atoi(e);
@@ -73,7 +76,7 @@ static int get_view(vpin_ctx* c, size_t ell, const PcGens** out) {
     const size_t left = ell / 2, R = (size_t)1 << (ell - left), nb = R + 2;
     // every MultiCommitGens::new(n, label) is a prefix of the same SHAKE stream
     vpin::TraceLap lap(nullptr, "spark get_view");
-    if (sg->g.size() < nb) derive_gens(sg->g, nb, "gens_r1cs_eval");
+    if (sg->g.size() < nb) derive_gens(sg->g, nb, "gens_r1cs_eval", c);
     lap("derive_gens (host)");
     std::unique_ptr<PcGens> v(new PcGens());
     v->ell = ell; v->L = (size_t)1 << left; v->R = R;
@@ -82,11 +85,19 @@ static int get_view(vpin_ctx* c, size_t ell, const PcGens** out) {
       std::vector<uint8_t> xyzt(128 * nb);
 #pragma omp parallel for schedule(static) num_threads(host_threads())
       for (long i = 0; i < (long)nb; i++) sg->g[i].to_xyzt(xyzt.data() + 128 * (size_t)i);
+      // full-size scalars one proof commits under this table: the derefs polynomial's six non-zero slices, 6N of the 16N
+      // entries of the largest view (the computation commitment's entries are addresses, counters and small constants)
+      c->gens_scalars_per_proof = (double)((size_t)1 << ell) * 0.375;
       rc = vpin_gens_shared(c, "gens_r1cs_eval", xyzt.data(), nb, spark_budget_gb(c), &v->dev);
     }
     if (rc) return rc;
-    v->fb_gR = FixedBase(sg->g[R]);
-    v->fb_h = FixedBase(sg->g[R + 1]);
+    lap("device table");
+#pragma omp parallel for schedule(static, 1) num_threads(2)
+    for (int k = 0; k < 2; k++) {
+      if (k == 0) v->fb_gR = FixedBase(sg->g[R]);
+      else v->fb_h = FixedBase(sg->g[R + 1]);
+    }
+    lap("fixed bases (host)");
     v->bind_views();
     it = sg->views.emplace(ell, std::move(v)).first;
   }
@@ -1277,6 +1288,17 @@ int vpin_spark_prepare(vpin_ctx* c, size_t num_cons, size_t num_vars, size_t max
   const Shape s = shape_of(num_cons, num_vars, nnz);
   const PcGens* g = nullptr;
   int rc = get_view(c, std::max(s.v_ops, s.v_mem), &g);
+  if (!rc) {
+    // the host fixed-base tables of the other views' two blind generators (~3 ms each, kept per process and point): all at once
+    auto* sg = static_cast<SparkGens*>(c->spark_cache);
+    std::vector<size_t> idx;
+    for (size_t ell : {s.v_ops, s.v_mem, s.v_derefs}) {
+      const size_t R = (size_t)1 << (ell - ell / 2);
+      if (R + 1 < sg->g.size()) { idx.push_back(R); idx.push_back(R + 1); }
+    }
+#pragma omp parallel for schedule(dynamic, 1) num_threads(host_threads())
+    for (long k = 0; k < (long)idx.size(); k++) { FixedBase warm(sg->g[idx[(size_t)k]]); (void)warm; }
+  }
   if (!rc) rc = get_view(c, s.v_ops, &g);
   if (!rc) rc = get_view(c, s.v_mem, &g);
   if (!rc) rc = get_view(c, s.v_derefs, &g);

@@ -390,7 +390,7 @@ static int sat_gens_v(vpin_ctx* c, size_t num_vars, SatGensV** out) {
   sg.L = (size_t)1 << left;
   sg.R = (size_t)1 << (sg.ell - left);
   const size_t nb = sg.R + 2 < 5 ? 5 : sg.R + 2;
-  derive_gens(sg.g, nb, "gens_r1cs_sat");
+  derive_gens(sg.g, nb, "gens_r1cs_sat", c);
   for (int i = 0; i < 5; i++) sg.fb[i] = FixedBase(sg.g[i]);
   int rc = make_pc(c, "gens_r1cs_sat", sg.g, sg.ell, 0, sg.pc);
   if (rc) return rc;
@@ -409,7 +409,7 @@ static int eval_view_v(vpin_ctx* c, size_t ell, const PcGens** out) {
   if (it != vc->eval_views.end()) { *out = it->second.get(); return VPIN_OK; }
   VSpan vs("setup: eval generators");
   const size_t nb = ((size_t)1 << (ell - ell / 2)) + 2;
-  if (vc->g_eval.size() < nb) derive_gens(vc->g_eval, nb, "gens_r1cs_eval");
+  if (vc->g_eval.size() < nb) derive_gens(vc->g_eval, nb, "gens_r1cs_eval", c);
   std::unique_ptr<PcGens> v(new PcGens());
   int rc = make_pc(c, "gens_r1cs_eval", vc->g_eval, ell, 0, *v);
   if (rc) return rc;

@@ -975,8 +975,12 @@ def main():
                       f"over the commitment rows (as rayon in the reference), single-threaded sum-checks; {s_all:.1f} s on {all_cores} "
                       f"threads, {s_one:.1f} s on 1",
             "single_thread": {"value": sample_cons / s_one, "cores": 1, "seconds": round(s_one, 2),
-                              "note": "comparable with the single-core profile of Spartan/README.md:338-377 (2^20 constraints: "
-                                      "SNARK::prove 39.1 s = 26.8 k constraints/s on one i7-1065G7 core)"},
+                              "note": "beside the single-core profile of Spartan/README.md:338-377 (2^20 constraints: SNARK::prove "
+                                      "39.1 s = 26.8 k constraints/s on one i7-1065G7 core) mind the shape: that instance has one "
+                                      "non-zero entry per constraint and matrix (N = 2^20 = num_cons), vPIN's point-mult gadget 1.5 / 1.3 / "
+                                      "0.9 in A / B / C, so SPARK -- 90 % of the time, proportional to N = next_pow2(max nnz) -- runs over "
+                                      "N = 2.4 x the unpadded constraints (2 x the padded ones): per non-zero entry the port proves about as "
+                                      "fast as the published profile"},
             "spans_ms_mult": {kk: round(vv * 1e3, 1) for kk, vv in tm_all.items()},
             "spans_ms_mult_single_thread": {kk: round(vv * 1e3, 1) for kk, vv in tm_one.items()},
         }

@@ -33,20 +33,21 @@ static int consts_ready = 0;
 static void fe_0(fe_t *r) { memset(r, 0, sizeof *r); }
 static void fe_1(fe_t *r) { fe_0(r); r->l[0] = 1; }
 
-static void fe_carry(fe_t *r) {
+/* one pass: limbs 1..4 below 2^51, limb 0 below 2^51 + 19 * 2^13 (inputs with limbs below 2^64 / 19) */
+static inline void fe_carry1(fe_t *r) {
   uint64_t c;
-  for (int k = 0; k < 2; k++) {
-    c = r->l[0] >> 51; r->l[0] &= MASK51; r->l[1] += c;
-    c = r->l[1] >> 51; r->l[1] &= MASK51; r->l[2] += c;
-    c = r->l[2] >> 51; r->l[2] &= MASK51; r->l[3] += c;
-    c = r->l[3] >> 51; r->l[3] &= MASK51; r->l[4] += c;
-    c = r->l[4] >> 51; r->l[4] &= MASK51; r->l[0] += 19 * c;
-  }
+  c = r->l[0] >> 51; r->l[0] &= MASK51; r->l[1] += c;
+  c = r->l[1] >> 51; r->l[1] &= MASK51; r->l[2] += c;
+  c = r->l[2] >> 51; r->l[2] &= MASK51; r->l[3] += c;
+  c = r->l[3] >> 51; r->l[3] &= MASK51; r->l[4] += c;
+  c = r->l[4] >> 51; r->l[4] &= MASK51; r->l[0] += 19 * c;
 }
+static void fe_carry(fe_t *r) { fe_carry1(r); fe_carry1(r); }
 
+/* sums and differences are carried once: every limb stays below 2^52, which fe_mul / fe_sq / fe_sub accept */
 static void fe_add(fe_t *r, const fe_t *a, const fe_t *b) {
   for (int i = 0; i < 5; i++) r->l[i] = a->l[i] + b->l[i];
-  fe_carry(r);
+  fe_carry1(r);
 }
 
 static void fe_sub(fe_t *r, const fe_t *a, const fe_t *b) {
@@ -54,7 +55,7 @@ static void fe_sub(fe_t *r, const fe_t *a, const fe_t *b) {
   static const uint64_t fourp0 = 4 * ((1ULL << 51) - 19), fourp = 4 * ((1ULL << 51) - 1);
   r->l[0] = a->l[0] + fourp0 - b->l[0];
   for (int i = 1; i < 5; i++) r->l[i] = a->l[i] + fourp - b->l[i];
-  fe_carry(r);
+  fe_carry1(r);
 }
 
 static void fe_neg(fe_t *r, const fe_t *a) { fe_t z; fe_0(&z); fe_sub(r, &z, a); }
@@ -77,7 +78,24 @@ static void fe_mul(fe_t *r, const fe_t *a, const fe_t *b) {
   c = r->l[0] >> 51; r->l[0] &= MASK51; r->l[1] += c;
 }
 
-static void fe_sq(fe_t *r, const fe_t *a) { fe_mul(r, a, a); }
+/* the same product with the 10 off-diagonal terms taken once, doubled */
+static void fe_sq(fe_t *r, const fe_t *a) {
+  const uint64_t *x = a->l;
+  const uint64_t x0_2 = 2 * x[0], x1_2 = 2 * x[1], x1_38 = 38 * x[1], x2_38 = 38 * x[2], x3_38 = 38 * x[3], x3_19 = 19 * x[3], x4_19 = 19 * x[4];
+  u128 t0 = (u128)x[0] * x[0] + (u128)x1_38 * x[4] + (u128)x2_38 * x[3];
+  u128 t1 = (u128)x0_2 * x[1] + (u128)x2_38 * x[4] + (u128)x3_19 * x[3];
+  u128 t2 = (u128)x0_2 * x[2] + (u128)x[1] * x[1] + (u128)x3_38 * x[4];
+  u128 t3 = (u128)x0_2 * x[3] + (u128)x1_2 * x[2] + (u128)x4_19 * x[4];
+  u128 t4 = (u128)x0_2 * x[4] + (u128)x1_2 * x[3] + (u128)x[2] * x[2];
+  uint64_t c;
+  t1 += (uint64_t)(t0 >> 51); r->l[0] = (uint64_t)t0 & MASK51;
+  t2 += (uint64_t)(t1 >> 51); r->l[1] = (uint64_t)t1 & MASK51;
+  t3 += (uint64_t)(t2 >> 51); r->l[2] = (uint64_t)t2 & MASK51;
+  t4 += (uint64_t)(t3 >> 51); r->l[3] = (uint64_t)t3 & MASK51;
+  c = (uint64_t)(t4 >> 51); r->l[4] = (uint64_t)t4 & MASK51;
+  r->l[0] += 19 * c;
+  c = r->l[0] >> 51; r->l[0] &= MASK51; r->l[1] += c;
+}
 
 void fe_from_bytes(fe_t *r, const uint8_t b[32]) {
   uint64_t w[4];

@@ -60,10 +60,10 @@ void* vpin_ctx_stream(vpin_ctx* ctx);
  * when the whole sat part is), so that a caller running other proofs on other contexts can hold them back while
  * the phase-1 kernels of this one are being timed.  NULL clears it. */
 int vpin_ctx_set_progress_flag(vpin_ctx* ctx, int* flag);
-/* Several contexts prove on this device at the same time (a service, bench.py's lanes): the long VALU-bound kernels of
- * this context then leave a third of every CU's wave slots to the others (the row-commitment MSM runs 2 instead of 3
- * workgroups per CU: 3 % slower alone, but a large instance's commitment no longer stalls every other stream for its
- * whole duration). */
+/* Several contexts prove on this device at the same time (a service, bench.py's lanes): the long VALU-bound row-commitment
+ * kernels of this context then run ONE workgroup per CU instead of three (a wave per SIMD), so that a large instance's
+ * commitment no longer stalls every other stream for its whole duration and the latency-bound proofs of the other lanes
+ * keep most of every CU (LeNet step on four lanes: 451 -> 435 ms against two workgroups per CU, 513 before any limit). */
 int vpin_ctx_set_shared_device(vpin_ctx* ctx, int on);
 /* How many proofs the generator window tables built through this context will serve: 0 (default) = many -- the widest
  * windows the table budget allows (fewest additions per scalar; the table costs ~0.2 s to build for the largest

@@ -331,6 +331,9 @@ __device__ __forceinline__ void table_mul_acc_range(ge_ext& acc, const fq& s_in,
 // ---- row-batched commitment -------------------------------------------------------------
 
 constexpr int kMsmBlock = 256;
+// extra dynamic LDS of the row-commitment kernels when other contexts prove on the device (vpin_ctx_set_shared_device): with
+// it one workgroup per CU instead of three (a wave per SIMD), the rest of every CU stays with the other lanes' kernels
+constexpr unsigned kSharedPad = 40000u;
 // ---- block tree with four lanes per addition -----------------------------------------------------------------
 // The few-row MSMs are latency bound: one wave per SIMD issues a modular product in ~0.5 us, and an addition of two
 // extended points is nine of them in a row on one lane.  Here the four products of each half of the addition
@@ -1220,7 +1223,7 @@ static int msm_rows(vpin_ctx* c, const vpin_gens* g, const fq* dZ, size_t rows, 
     // unused dynamic LDS lowers the workgroups per CU from 3 to 2 on a shared device (vpin_ctx_set_shared_device);
     // VPIN_MSM_LDS_PAD overrides (experiments)
     static const int env_pad = [] { const char* e = getenv("VPIN_MSM_LDS_PAD"); return e ? atoi(e) : -1; }();
-    const unsigned pad = env_pad >= 0 ? (unsigned)env_pad : (c->shared_device ? 20000u : 0u);
+    const unsigned pad = env_pad >= 0 ? (unsigned)env_pad : (c->shared_device ? kSharedPad : 0u);
     if (msm_ten_limbs())
       hipLaunchKernelGGL(msm_rows_kernel<true>, dim3((unsigned)rows, (unsigned)chunks), dim3(kMsmBlock), pad, c->stream, dZ, stride,
                          ncols, d_extra, n_extra, extra_base0, view(g), dst);
@@ -1308,7 +1311,7 @@ int hyrax_commit_derefs_hot(vpin_ctx* c, const vpin_gens* g, const vpin_table* Z
   {
     ProfScope ps(c, VPIN_K_MSM, 32.0 * (double)(nrows * R), VPIN_K_MSM_ROWS);
     static const int env_pad = [] { const char* e = getenv("VPIN_MSM_LDS_PAD"); return e ? atoi(e) : -1; }();
-    const unsigned pad = env_pad >= 0 ? (unsigned)env_pad : (c->shared_device ? 20000u : 0u);
+    const unsigned pad = env_pad >= 0 ? (unsigned)env_pad : (c->shared_device ? kSharedPad : 0u);
     if (msm_ten_limbs())
       hipLaunchKernelGGL(msm_rows_hot_kernel<true>, dim3((unsigned)nrows, (unsigned)chunks), dim3(kMsmBlock), pad, c->stream, zbase,
                          R, R, view(g), hr, chunks > 1 ? (ge_ext*)dparts.p : (ge_ext*)dpts.p, row0, row_step, z_compact);

@@ -80,3 +80,33 @@ def test_edge_inputs_match_the_oracle(ctx):
     halves += [bytes(rng.integers(0, 256, 32, dtype=np.uint8)) for _ in range(23)]
     stream = b"".join(a + b for a in halves for b in halves[:8])
     assert compress_xyzt(map_on_device(ctx, stream)) == oracle_map(stream)
+
+
+def test_concurrent_requests_for_one_table_build_it_once(ctx):
+    """vpin_gens_shared: the registry is unlocked while a table is built; a second thread asking for the same (or a shorter)
+    stream of the label meanwhile waits for that table instead of building its own"""
+    import threading
+    import vpin_amd
+    L = vpin_amd.lib()
+    label = b"test-concurrent-build"
+    nb = 700
+    xyzt = np.zeros((nb, 128), dtype=np.uint8)
+    L.vpin_host_gens_derive.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p]
+    assert L.vpin_host_gens_derive(label, nb, xyzt.ctypes.data_as(C.c_void_p)) == 0
+    L.vpin_gens_shared.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t, C.c_size_t, C.POINTER(C.c_void_p)]
+    ctx2 = vpin_amd.Context(0)
+    got, rcs = [None] * 4, [None] * 4
+
+    def ask(i, cx, n):
+        h = C.c_void_p()
+        rcs[i] = L.vpin_gens_shared(cx.h, label, xyzt.ctypes.data_as(C.c_void_p), n, 1, C.byref(h))
+        got[i] = h.value
+
+    ts = [threading.Thread(target=ask, args=(0, ctx, nb)), threading.Thread(target=ask, args=(1, ctx2, nb)),
+          threading.Thread(target=ask, args=(2, ctx2, nb - 100)), threading.Thread(target=ask, args=(3, ctx, nb))]
+    # contexts are single-threaded objects: one thread per context at a time
+    ts[0].start(); ts[1].start(); ts[0].join(); ts[1].join()
+    ts[2].start(); ts[3].start(); ts[2].join(); ts[3].join()
+    assert rcs == [0, 0, 0, 0]
+    assert got[0] == got[1] == got[2] == got[3] and got[0]
+    ctx2.close()

@@ -17,6 +17,7 @@
 // an LDS tree.  Integer-ALU bound (~8 field multiplies per table add); no MFMA.
 #include <algorithm>
 #include <cstdlib>
+#include <condition_variable>
 #include <cstring>
 #include <memory>
 #include <mutex>
@@ -1117,8 +1118,11 @@ int vpin_gens_map_stream(vpin_ctx* c, const uint8_t* stream64, size_t nb, uint8_
 // built; superseded (shorter) ones stay alive because other contexts may still hold them.
 namespace {
 struct RegEntry { int device; std::string label; vpin_gens* g; };
+struct Building { int device; std::string label; size_t nb; };
 std::mutex g_reg_mu;
+std::condition_variable g_reg_cv;
 std::vector<RegEntry> g_reg;
+std::vector<Building> g_building;  // tables under construction (the registry is unlocked meanwhile)
 }  // namespace
 
 int vpin_gens_shared(vpin_ctx* c, const char* label, const uint8_t* gens_xyzt, size_t nb, size_t budget_gb,
@@ -1131,20 +1135,32 @@ int vpin_gens_shared(vpin_ctx* c, const char* label, const uint8_t* gens_xyzt, s
     return best;
   };
   {
-    std::lock_guard<std::mutex> lock(g_reg_mu);
-    if (const vpin_gens* best = lookup()) { *out = best; return VPIN_OK; }
+    std::unique_lock<std::mutex> lock(g_reg_mu);
+    for (;;) {
+      if (const vpin_gens* best = lookup()) { *out = best; return VPIN_OK; }
+      // another thread is building a table that will cover this request: wait for it instead of building a second one
+      // (tens of GB each); a shorter or different one under way does not help
+      bool covered = false;
+      for (auto& b : g_building) covered = covered || (b.device == c->device && b.label == label && b.nb >= nb);
+      if (!covered) break;
+      g_reg_cv.wait(lock);
+    }
+    if (!gens_xyzt) return VPIN_EINVAL;
+    g_building.push_back(Building{c->device, label, nb});
   }
-  if (!gens_xyzt) return VPIN_EINVAL;
-  // Built with the registry unlocked: another context of the process (vpin_prove builds the tables of its second, larger
-  // instance on a context of its own while the first is being proven) keeps finding and building tables meanwhile.  Two
-  // threads that miss the same table both build it; both tables stay registered (a handle may already be out).
+  // Built with the registry unlocked: other contexts of the process keep finding their tables, and building tables of other
+  // labels, meanwhile.
   vpin_gens* g = nullptr;
-  int rc = gens_build(c, gens_xyzt, nb, budget_gb ? (budget_gb << 30) : default_budget(), &g);
-  if (rc) return rc;
+  const int rc = gens_build(c, gens_xyzt, nb, budget_gb ? (budget_gb << 30) : default_budget(), &g);
   std::lock_guard<std::mutex> lock(g_reg_mu);
-  g_reg.push_back(RegEntry{c->device, label, g});
-  *out = g;
-  return VPIN_OK;
+  for (size_t i = 0; i < g_building.size(); i++)
+    if (g_building[i].device == c->device && g_building[i].label == label && g_building[i].nb == nb) { g_building.erase(g_building.begin() + (long)i); break; }
+  if (!rc) {
+    g_reg.push_back(RegEntry{c->device, label, g});
+    *out = g;
+  }
+  g_reg_cv.notify_all();  // also on failure: the waiters then build for themselves
+  return rc;
 }
 
 void vpin_gens_shared_clear(void) {

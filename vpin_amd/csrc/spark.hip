@@ -251,6 +251,28 @@ __global__ __launch_bounds__(kBlock) void tree_level_kernel(fq* __restrict__ for
     fq_store(dst + i, fq_mul(fq_load(src + i), fq_load(src + h + i)));
 }
 
+// Three levels per pass.  The source level has 2h entries and a node's children sit half a level apart (product_tree.rs:18-35),
+// so with q = h/4 the eight entries i + j*q (j = 0..7) give four nodes of the next level (i + j*q, j < 4), two of the one
+// after (i, i + q) and one of the third (i): the tree is read once per three levels (2h entries in, 1.75 h out instead of
+// 2h + h + h/2 in, 1.75 h out) -- the tree build is bound by HBM, 65 GB per proof of the 2^25 instance level by level.
+__global__ __launch_bounds__(kBlock) void tree_level3_kernel(fq* __restrict__ forest, size_t stride, size_t src_off, size_t d1_off,
+                                                             size_t d2_off, size_t d3_off, size_t h) {
+  fq* t = forest + (size_t)blockIdx.y * stride;
+  const fq* src = t + src_off;
+  fq *d1 = t + d1_off, *d2 = t + d2_off, *d3 = t + d3_off;
+  const size_t q = h / 4;
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < q; i += (size_t)gridDim.x * kBlock) {
+    const fq a0 = fq_mul(fq_load(src + i), fq_load(src + h + i));
+    const fq a1 = fq_mul(fq_load(src + q + i), fq_load(src + h + q + i));
+    const fq a2 = fq_mul(fq_load(src + 2 * q + i), fq_load(src + h + 2 * q + i));
+    const fq a3 = fq_mul(fq_load(src + 3 * q + i), fq_load(src + h + 3 * q + i));
+    fq_store(d1 + i, a0); fq_store(d1 + q + i, a1); fq_store(d1 + 2 * q + i, a2); fq_store(d1 + 3 * q + i, a3);
+    const fq b0 = fq_mul(a0, a2), b1 = fq_mul(a1, a3);
+    fq_store(d2 + i, b0); fq_store(d2 + q + i, b1);
+    fq_store(d3 + i, fq_mul(b0, b1));
+  }
+}
+
 // the top of every tree in one workgroup: levels from `h0` outputs down to 1 (h0 <= 1024)
 constexpr int kTopBlock = 1024;
 __global__ __launch_bounds__(kTopBlock) void tree_top_kernel(fq* __restrict__ forest, size_t stride, size_t n2, size_t h0) {
@@ -661,7 +683,15 @@ static int build_levels(vpin_ctx* c, SparkForest* f) {
   const size_t n2 = 2 * f->n;
   size_t h = f->n / 2;  // entries of the level being built
   int l = 0;
+  static const bool one_by_one = getenv("VPIN_TREE_LEVEL_BY_LEVEL") != nullptr;
   while (h > (size_t)kTopBlock) {
+    if (!one_by_one && h / 4 > (size_t)kTopBlock) {  // three levels per pass while the third is still a grid's worth
+      hipLaunchKernelGGL(tree_level3_kernel, dim3(grid_for(h / 4), f->ncirc), dim3(kBlock), 0, c->stream, f->base, f->stride(),
+                         f->level_off(l), f->level_off(l + 1), f->level_off(l + 2), f->level_off(l + 3), h);
+      h >>= 3;
+      l += 3;
+      continue;
+    }
     hipLaunchKernelGGL(tree_level_kernel, dim3(grid_for(h), f->ncirc), dim3(kBlock), 0, c->stream, f->base, f->stride(),
                        f->level_off(l), f->level_off(l + 1), h);
     h >>= 1;
@@ -686,6 +716,8 @@ int spark_build_forests(vpin_ctx* c, const vpin_spark_decomm* d, const fq* comb_
   {
     // leaves: 6 gathers of (addr, ts, val) -> 12 N leaves; 2 x (ts, mem) -> 4 M leaves; then 1 product per inner node
     ProfScope ps(c, VPIN_K_SPARK_BUILD, (double)d->N * (6 * (8.0 + 32.0) + 12 * 32.0 + 12 * 64.0) + (double)d->M * (2 * 36.0 + 4 * 32.0 + 4 * 64.0));
+    // (leaves and the first three levels in ONE pass -- eight strided leaves per thread -- were measured and dropped: 21.2 ms
+    // against 18.7 ms for the 2^25 instance with the leaf kernels below and three tree levels per pass after them)
     hipLaunchKernelGGL(hash_ops_kernel, dim3(grid_for(d->N), 6), dim3(kBlock), 0, c->stream, (const uint32_t*)d->idx, comb_derefs,
                        d->N, hp, ops->base);
     hipLaunchKernelGGL(hash_mem_kernel, dim3(grid_for(d->M), 2), dim3(kBlock), 0, c->stream,

@@ -147,7 +147,7 @@ static void fe_pow_bits(fe_t *r, const fe_t *a, const uint8_t e[32]) {
   *r = acc;
 }
 
-static void fe_invert(fe_t *r, const fe_t *a) {
+static __attribute__((unused)) void fe_invert(fe_t *r, const fe_t *a) {
   /* a^(p-2), p-2 = 2^255 - 21 */
   uint8_t e[32]; memset(e, 0xff, 32); e[0] = 0xeb; e[31] = 0x7f;
   fe_pow_bits(r, a, e);

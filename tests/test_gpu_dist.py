@@ -206,3 +206,36 @@ def test_staged_device_allgather_threads():
         cm.destroy()
     for c in ctxs:
         c.close()
+
+
+def test_peer_failure_in_the_middle_of_a_proof_fails_the_others_fast_and_leaves_them_usable():
+    """Rank 1 of 2 never joins the proof and takes the group down a few milliseconds into rank 0's proof (vpin_comm_abort:
+    what the library does itself when a rank leaves a collective proof with VPIN_ENOMEM / VPIN_EHIP).  Rank 0 is then inside
+    a round exchange, with its persistent round kernel resident: it must come back with VPIN_ECOMM within seconds -- not
+    after the 120 s timeout --, its resident kernel must drain, and the same context must prove the instance alone afterwards."""
+    import vpin_amd
+    from vpin_amd import Comm
+    ctx = vpin_amd.Context(0)
+    g = _build(ctx, "3_32", "mult", None)
+    dec, _ = g.spark_encode()
+    want = ctx.snark_prove_resident(g.r1cs, dec, g.vars_para, g.vars_input, g.vars, g.inputs, SEED_C, SEED_P)["proof"]
+    for delay in (0.0, 0.004, 0.012):
+        comms = Comm.local(2)
+        ctx.set_comm(comms[0])
+        killer = threading.Timer(delay, comms[1].abort)
+        t0 = time.time()
+        killer.start()
+        with pytest.raises(vpin_amd.VpinError) as ei:
+            ctx.snark_prove_resident(g.r1cs, dec, g.vars_para, g.vars_input, g.vars, g.inputs, SEED_C, SEED_P)
+        dt = time.time() - t0
+        killer.join()
+        assert ei.value.code == -7, ei.value
+        assert dt < 20.0, dt
+        ctx.set_comm(None)
+        for cm in comms:
+            cm.destroy()
+        again = ctx.snark_prove_resident(g.r1cs, dec, g.vars_para, g.vars_input, g.vars, g.inputs, SEED_C, SEED_P)["proof"]
+        assert again == want
+    dec.free()
+    g.free()
+    ctx.close()

@@ -239,3 +239,58 @@ def test_peer_failure_in_the_middle_of_a_proof_fails_the_others_fast_and_leaves_
     dec.free()
     g.free()
     ctx.close()
+
+
+def _dying_worker(name, rank, world, q):
+    """rank 0 proves; rank 1 attaches to the group and then dies without a word, a few milliseconds into rank 0's proof"""
+    for p in (ROOT, os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    try:
+        import vpin_amd
+        from vpin_amd import Comm
+        with vpin_amd.Context(0) as ctx:
+            g = _build(ctx, "3_32", "mult", None)
+            dec, _ = g.spark_encode()
+            cm = Comm.shm(name, rank, world)
+            if rank == 1:
+                time.sleep(0.05)
+                os._exit(17)  # no abort, no destroy: a killed process
+            ctx.set_comm(cm)
+            t0 = time.time()
+            try:
+                ctx.snark_prove_resident(g.r1cs, dec, g.vars_para, g.vars_input, g.vars, g.inputs, SEED_C, SEED_P)
+                q.put((rank, "proved", 0.0))
+            except vpin_amd.VpinError as e:
+                dt = time.time() - t0
+                ctx.set_comm(None)
+                # the context survives the dead group: the same instance alone
+                alone = ctx.snark_prove_resident(g.r1cs, dec, g.vars_para, g.vars_input, g.vars, g.inputs, SEED_C, SEED_P)
+                q.put((rank, e.code, dt, hashlib.sha256(alone["proof"]).hexdigest()))
+            cm.destroy()
+            dec.free()
+            g.free()
+    except BaseException as e:  # noqa: BLE001
+        q.put((rank, "error: " + repr(e), 0.0))
+
+
+def test_a_killed_process_is_noticed_within_the_timeout():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    name = f"/vpin-dying-{os.getpid()}-{int(time.time() * 1e3) & 0xffffff}"
+    os.environ["VPIN_COMM_TIMEOUT_S"] = "3"
+    os.environ.setdefault("VPIN_GENS_BUDGET_GB", "8")
+    os.environ.setdefault("VPIN_SPARK_GENS_BUDGET_GB", "8")
+    try:
+        ps = [ctx.Process(target=_dying_worker, args=(name, r, 2, q)) for r in range(2)]
+        [p.start() for p in ps]
+        res = q.get(timeout=300)
+        [p.join(60) for p in ps]
+    finally:
+        del os.environ["VPIN_COMM_TIMEOUT_S"]
+    assert res[0] == 0 and res[1] == -7, res          # VPIN_ECOMM on the survivor
+    assert 2.0 < res[2] < 30.0, res                   # after the timeout, not after the default 120 s
+    with open(os.path.join(ROOT, "tests", "golden", "config_digests.json")) as f:
+        want = json.load(f)["cases"]["3_32-mult"]["snark_sha256"]
+    assert res[3] == want
+    assert ps[1].exitcode == 17

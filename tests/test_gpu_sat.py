@@ -136,3 +136,22 @@ def test_unsatisfied_witness_gives_the_reference_bytes(ctx):
         bad[k] = t
     assert not O.is_sat(bad)
     assert ctx.sat_prove(bad, SEED_C, SEED_P)["proof"] == O.sat_prove(bad, SEED_C, SEED_P)["proof"]
+
+
+def test_every_region_of_the_sat_proof_is_checked(ctx):
+    """One flipped bit every 61 bytes of the sat proof -- row commitments, both ZK sum-checks (comm_polys, comm_evals and the
+    delta / beta / z / z_delta / z_beta of every round's DotProductProof), the knowledge / product / equality proofs, the
+    evaluation proof -- must be rejected by the product's verifier (which collects the rounds' group equations and checks
+    them after the transcript pass) exactly as by the oracle's, which checks them in place."""
+    inst = GM.instance_new(GM.build_point_add(GM.synthetic_add_ops(0x5650494E + 9, 24, rz_one_every=4)))
+    sat = ctx.sat_prove(inst, SEED_C, SEED_P)
+    assert ctx.sat_verify(inst, sat) and O.sat_verify(inst, sat) == 1
+    p = sat["proof"]
+    positions = list(range(3, len(p), 61))
+    assert len(positions) > 100
+    for k, pos in enumerate(positions):
+        bad = bytearray(p)
+        bad[pos] ^= 1 << (k % 8)
+        assert not ctx.sat_verify(inst, sat, proof=bytes(bad)), pos
+        if k % 7 == 0:  # the oracle's verifier is slower: a seventh of the positions
+            assert O.sat_verify(inst, sat, proof=bytes(bad)) == 0, pos

@@ -120,3 +120,21 @@ def test_mid_size_snark_verifies_with_both_verifiers(ctx):
     bad = bytearray(got["proof"])
     bad[len(bad) * 2 // 3] ^= 0x10
     assert not ctx.snark_verify(d, got, proof=bytes(bad))
+
+
+def test_every_region_of_the_snark_is_checked(ctx):
+    """One flipped bit every 211 bytes of the whole SNARK (sat proof, inst_evals, derefs commitment, the two batched
+    product-circuit proofs, the hash-layer claims, the three evaluation proofs) is rejected by the product's verifier;
+    a tenth of the positions also go through the oracle's verifier"""
+    inst = GM.instance_new(GM.build_point_add(GM.synthetic_add_ops(0x5650494E + 11, 40, rz_one_every=5)))
+    got = ctx.snark_prove(inst, SEED_C, SEED_P)
+    assert ctx.snark_verify(inst, got)
+    p = got["proof"]
+    positions = list(range(5, len(p), 211))
+    assert len(positions) > 150
+    for k, pos in enumerate(positions):
+        bad = bytearray(p)
+        bad[pos] ^= 1 << (k % 8)
+        assert not ctx.snark_verify(inst, got, proof=bytes(bad)), pos
+        if k % 10 == 0:
+            assert O.snark_verify(inst, got, proof=bytes(bad)) == 0, pos

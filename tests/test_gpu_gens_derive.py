@@ -24,14 +24,7 @@ def ctx():
 
 
 def map_on_device(ctx, stream):
-    import vpin_amd
-    nb = len(stream) // 64
-    L = vpin_amd.lib()
-    L.vpin_gens_map_stream.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
-    buf = np.frombuffer(stream, dtype=np.uint8).copy()
-    out = np.zeros((nb, 128), dtype=np.uint8)
-    assert L.vpin_gens_map_stream(ctx.h, buf.ctypes.data_as(C.c_void_p), nb, out.ctypes.data_as(C.c_void_p)) == 0
-    return out
+    return ctx.gens_map_stream(stream)
 
 
 def compress_xyzt(rows):

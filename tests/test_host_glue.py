@@ -101,14 +101,11 @@ def test_gadget_shape_matches_the_built_instances():
     """vpin_gadget_shape (what vpin_prove sizes the generator sets of its second instance with before reading the witness)
     against the instances the host builders really produce"""
     from vpin_amd import gadgets as G
-    L = vpin_amd.lib()
-    L.vpin_gadget_shape.argtypes = [C.c_int, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
     for kind, n in (("mult", 1), ("mult", 3), ("add", 1), ("add", 6), ("add", 100)):
         inp = G.synthetic_mult_inputs("3_32", n) if kind == "mult" else G.synthetic_add_inputs("3_32", n)
         inst = G.point_mult(*inp) if kind == "mult" else G.point_add(*inp)
         d = inst.as_dict()
-        nc, nv, nnz = C.c_size_t(), C.c_size_t(), (C.c_size_t * 3)()
-        assert L.vpin_gadget_shape(1 if kind == "mult" else 0, n, C.byref(nc), C.byref(nv), nnz) == 0
-        assert (nc.value, nv.value) == (d["num_cons"], d["num_vars"]), (kind, n)
-        assert [nnz[0], nnz[1], nnz[2]] == [len(d[m][0]) for m in ("A", "B", "C")], (kind, n)
+        nc, nv, nnz = vpin_amd.gadget_shape(kind, n)
+        assert (nc, nv) == (d["num_cons"], d["num_vars"]), (kind, n)
+        assert nnz == [len(d[m][0]) for m in ("A", "B", "C")], (kind, n)
         inst.free()

@@ -7,8 +7,8 @@ arithmetic of its own and NO CPU fallback: loading fails loudly when the HIP lib
 missing, and every call fails with VPIN_ENODEV when no gfx950 device is usable.
 """
 from .capi import (  # noqa: F401
-    VpinError, Context, Table, Gens, Comm, dist_plan, lib, lib_path, KERNEL_CLASSES, exported_symbols, declared_symbols,
+    VpinError, Context, Table, Gens, Comm, dist_plan, gadget_shape, lib, lib_path, KERNEL_CLASSES, exported_symbols, declared_symbols,
 )
 
-__all__ = ["VpinError", "Context", "Table", "Gens", "Comm", "dist_plan", "lib", "lib_path", "KERNEL_CLASSES",
+__all__ = ["VpinError", "Context", "Table", "Gens", "Comm", "dist_plan", "gadget_shape", "lib", "lib_path", "KERNEL_CLASSES",
            "exported_symbols", "declared_symbols"]

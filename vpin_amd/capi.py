@@ -474,6 +474,16 @@ class Comm:
             self.h = None
 
 
+def gadget_shape(kind, n_ops):
+    """(num_cons, num_vars, [nnz A, B, C]) of the instance a point-mult ("mult") / point-add gadget builds for n_ops
+    operations (vpin_gadget_shape)"""
+    L = lib()
+    L.vpin_gadget_shape.argtypes = [C.c_int, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+    nc, nv, nnz = C.c_size_t(), C.c_size_t(), (C.c_size_t * 3)()
+    _chk(L.vpin_gadget_shape(1 if kind == "mult" else 0, n_ops, C.byref(nc), C.byref(nv), nnz), "vpin_gadget_shape")
+    return nc.value, nv.value, [nnz[0], nnz[1], nnz[2]]
+
+
 def dist_plan(world):
     """owners of the 12 ops circuits, the 6 dot-product halves and the 4 mem circuits (vpin_dist_plan)"""
     a, b, c = (C.c_int * 12)(), (C.c_int * 6)(), (C.c_int * 4)()
@@ -523,6 +533,23 @@ class Context:
     def set_shared_device(self, on=True):
         """other contexts prove on this device concurrently: leave them a share of every CU"""
         _chk(lib().vpin_ctx_set_shared_device(self.h, 1 if on else 0), "vpin_ctx_set_shared_device")
+
+    def set_expected_proofs(self, n):
+        """generator window tables built through this context will serve n proofs (0 = a service: widest windows)"""
+        L = lib()
+        L.vpin_ctx_set_expected_proofs.argtypes = [C.c_void_p, C.c_int]
+        _chk(L.vpin_ctx_set_expected_proofs(self.h, int(n)), "vpin_ctx_set_expected_proofs")
+
+    def gens_map_stream(self, stream):
+        """RistrettoPoint::from_uniform_bytes on the device: 64 bytes of a label's SHAKE256 stream per generator ->
+        (n, 128) uint8 X|Y|Z|T (vpin_gens_map_stream)"""
+        L = lib()
+        L.vpin_gens_map_stream.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        buf = np.frombuffer(bytes(stream), dtype=np.uint8).copy()
+        n = buf.size // 64
+        out = np.zeros((n, 128), dtype=np.uint8)
+        _chk(L.vpin_gens_map_stream(self.h, buf.ctypes.data_as(C.c_void_p), n, out.ctypes.data_as(C.c_void_p)), "vpin_gens_map_stream")
+        return out
 
     # ---- tables ----
     def upload(self, arr):

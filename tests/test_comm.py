@@ -218,3 +218,61 @@ def test_plan_is_balanced_and_complete():
         assert max(mem.count(r) for r in range(world)) == -(-4 // world)
     ops, dotp, mem = vpin_amd.dist_plan(8)
     assert max(4 * ops.count(r) + 3 * dotp.count(r) for r in range(8)) == 10  # of 66: the ops phase at 1/6.6 per rank
+
+
+def test_ranks_that_disagree_on_a_collective_fail_promptly():
+    """ADVICE r3: every rank publishes what it believes the collective IS (size, call site) next to its sequence number;
+    a rank that took another protocol branch is refused at the first collective the ranks disagree on, on both sides,
+    instead of its slot being read at the wrong size."""
+    comms = Comm.local(2)
+    out = {}
+
+    def body(cm, n):
+        try:
+            cm.allgather(b"s" * 8)          # in step
+            cm.allgather(b"x" * n)          # rank 0: 96 bytes, rank 1: 64 bytes
+            out[cm.rank] = "no error"
+        except vpin_amd.VpinError as e:
+            out[cm.rank] = e.code
+            msgs.append(str(e))
+
+    msgs = []
+    t0 = time.time()
+    ts = [threading.Thread(target=body, args=(cm, n)) for cm, n in zip(comms, (96, 64))]
+    [t.start() for t in ts]
+    [t.join(60) for t in ts]
+    assert out == {0: -7, 1: -7}, out     # VPIN_ECOMM on both ranks
+    assert time.time() - t0 < 10          # not the 120 s timeout
+    assert any("disagree" in m for m in msgs), msgs   # vpin_last_error() is per thread: the rank that saw the mismatch
+    for cm in comms:
+        cm.destroy()
+
+
+def _stale_then_fresh_worker(name, rank, world, delay, q):
+    os.environ["VPIN_COMM_TIMEOUT_S"] = "20"
+    time.sleep(delay)
+    try:
+        cm = Comm.shm(name, rank, world, slot_bytes=4096)
+        got = cm.allgather(bytes([rank]) * 4)
+        cm.destroy()
+        q.put((rank, got))
+    except BaseException as e:  # noqa: BLE001
+        q.put((rank, repr(e)))
+
+
+def test_shm_leftover_of_a_dead_job_is_not_attached_to():
+    """a segment left under the same name by a job that died (here: a file of the right size whose header never
+    gets initialised, opened by rank 1 BEFORE rank 0 replaces it) must not swallow the late rank: it notices that the name
+    moved on, re-opens, and the group forms."""
+    name = f"/vpin-test-stale-{os.getpid()}-{int(time.time() * 1e3) & 0xffffff}"
+    with open("/dev/shm" + name, "wb") as f:
+        f.truncate(1 << 20)   # larger than the real segment: passes the size check
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_stale_then_fresh_worker, args=(name, 1, 2, 0.0, q)),   # maps the leftover first
+          ctx.Process(target=_stale_then_fresh_worker, args=(name, 0, 2, 1.0, q))]   # replaces it a second later
+    [p.start() for p in ps]
+    res = dict(q.get(timeout=90) for _ in range(2))
+    [p.join(30) for p in ps]
+    assert res == {0: bytes([0] * 4 + [1] * 4), 1: bytes([0] * 4 + [1] * 4)}, res
+    assert not os.path.exists("/dev/shm" + name)

@@ -89,8 +89,14 @@ int dev_alloc(vpin_ctx* c, size_t bytes, void** out) {
       std::vector<vpin_ctx*> others;
       {
         std::lock_guard<std::mutex> g(g_ctx_mu);  // only to copy and pin the list
+        // not the peers of a collective proof, nor a context whose persistent tail kernel is resident: releasing their
+        // blocks synchronises their stream, and that stream may be waiting for a reply which depends on THIS rank's next
+        // all-gather -- both ranks would sit out the comm timeout instead of recovering memory
         for (auto* x : g_live_ctxs)
-          if (x != c && x->device == c->device) { x->pins.fetch_add(1, std::memory_order_acq_rel); others.push_back(x); }
+          if (x != c && x->device == c->device && x->comm == nullptr && x->tail_rounds == 0) {
+            x->pins.fetch_add(1, std::memory_order_acq_rel);
+            others.push_back(x);
+          }
       }
       for (auto* x : others) { pool_release_unlocked(x); x->pins.fetch_sub(1, std::memory_order_acq_rel); }
       if (hipMalloc(&p, cls) != hipSuccess) { (void)hipGetLastError(); return VPIN_ENOMEM; }

@@ -33,6 +33,12 @@ struct alignas(64) CommSlotHdr {
   std::atomic<uint64_t> seq;  // last collective whose piece is complete in data[seq & 1]
   double busy_s[2];           // this rank's section before that collective, by the same parity (a fast rank publishes
                               // collective k + 1 while a slow one still reads k)
+  // what this rank believes collective k IS, by the same parity: the whole message's size and the call site.  Every rank
+  // compares its peers' values with its own before it copies a byte: ranks that took different protocol branches (a
+  // per-process environment knob, an asymmetric early return) fail with VPIN_ECOMM at the first collective they disagree
+  // on instead of reading each other's slots at the wrong size.
+  uint64_t total_bytes[2];
+  uint64_t tag_hash[2];
 };
 
 struct alignas(64) CommSeg {
@@ -41,6 +47,7 @@ struct alignas(64) CommSeg {
   uint64_t slot_bytes;
   std::atomic<uint32_t> attached, abort_flag, token, detached;
   std::atomic<uint32_t> serialize;  // ranks that asked for the token mode
+  double created_unix_s;            // when rank 0 initialised the segment (a leftover is older than any attach timeout)
 };
 
 static inline size_t seg_slot_stride(size_t slot_bytes) { return sizeof(CommSlotHdr) + 2 * ((slot_bytes + 63) & ~(size_t)63); }
@@ -79,11 +86,29 @@ struct Spinner {
   }
 };
 
+// FNV-1a of the call-site tag (0 for an untagged collective)
+static uint64_t tag_hash_of(const char* tag) {
+  if (!tag) return 0;
+  uint64_t h = 0xcbf29ce484222325ull;
+  for (const char* p = tag; *p; p++) { h ^= (uint8_t)*p; h *= 0x100000001b3ull; }
+  return h ? h : 1;
+}
+
+static int comm_disagree(vpin_comm* cm, int peer, uint64_t peer_bytes, uint64_t peer_tag, uint64_t bytes, uint64_t tagh, const char* tag) {
+  char msg[256];
+  snprintf(msg, sizeof msg, "vpin_comm: rank %d and rank %d disagree on collective %llu: %llu bytes tag %016llx (%s) here, %llu bytes tag %016llx there",
+           cm->rank, peer, (unsigned long long)cm->seq, (unsigned long long)bytes, (unsigned long long)tagh, tag ? tag : "-",
+           (unsigned long long)peer_bytes, (unsigned long long)peer_tag);
+  set_last_error(msg, hipErrorUnknown);
+  return VPIN_ECOMM;
+}
+
 static void seg_init(CommSeg* s, int world, size_t slot_bytes) {
   s->world = (uint32_t)world;
   s->slot_bytes = slot_bytes;
   s->attached.store(0); s->abort_flag.store(0); s->token.store(kNoHolder); s->detached.store(0); s->serialize.store(0);
   for (int r = 0; r < world; r++) { slot_hdr(s, r)->seq.store(0); slot_hdr(s, r)->busy_s[0] = slot_hdr(s, r)->busy_s[1] = 0.0; }
+  s->created_unix_s = std::chrono::duration<double>(std::chrono::system_clock::now().time_since_epoch()).count();
   s->magic.store(kCommMagic, std::memory_order_release);
 }
 
@@ -109,12 +134,14 @@ static void token_release(vpin_comm* cm) {
 
 // one piece of at most slot_bytes per rank
 static int seg_allgather_piece(vpin_comm* cm, const uint8_t* send, uint8_t* recv, size_t bytes, size_t recv_stride, double busy,
-                               double* max_busy) {
+                               double* max_busy, uint64_t total_bytes, uint64_t tagh, const char* tag) {
   CommSeg* s = cm->seg;
   const uint64_t k = ++cm->seq;
   const int parity = (int)(k & 1);
   if (bytes) memcpy(slot_data(s, cm->rank, parity), send, bytes);
   slot_hdr(s, cm->rank)->busy_s[parity] = busy;
+  slot_hdr(s, cm->rank)->total_bytes[parity] = total_bytes;
+  slot_hdr(s, cm->rank)->tag_hash[parity] = tagh;
   slot_hdr(s, cm->rank)->seq.store(k, std::memory_order_release);
   double mb = busy;
   for (int i = 0; i < cm->world; i++) {
@@ -124,6 +151,11 @@ static int seg_allgather_piece(vpin_comm* cm, const uint8_t* send, uint8_t* recv
       while (slot_hdr(s, r)->seq.load(std::memory_order_acquire) < k) {
         if (s->abort_flag.load(std::memory_order_relaxed)) return VPIN_ECOMM;
         if (!sp.step()) { s->abort_flag.store(1); return VPIN_ECOMM; }
+      }
+      const uint64_t pb = slot_hdr(s, r)->total_bytes[parity], pt = slot_hdr(s, r)->tag_hash[parity];
+      if (pb != total_bytes || pt != tagh) {
+        s->abort_flag.store(1, std::memory_order_release);
+        return comm_disagree(cm, r, pb, pt, total_bytes, tagh, tag);
       }
       const double b = slot_hdr(s, r)->busy_s[parity];
       if (b > mb) mb = b;
@@ -140,22 +172,29 @@ int comm_allgather(vpin_comm* cm, const void* send, void* recv, size_t bytes, co
   const double busy = cm->t_last_exit > 0.0 ? t_in - cm->t_last_exit : 0.0;
   int rc = VPIN_OK;
   double max_busy = busy;
+  const uint64_t tagh = tag_hash_of(tag);
   if (cm->world == 1) {
     if (bytes) memcpy(recv, send, bytes);
   } else if (cm->kind == 2) {
-    // the caller's fabric: the section times ride in front of the payload
-    std::vector<uint8_t> sb(8 + bytes), rb((size_t)cm->world * (8 + bytes));
-    memcpy(sb.data(), &busy, 8);
-    if (bytes) memcpy(sb.data() + 8, send, bytes);
-    rc = cm->cb(cm->cb_user, sb.data(), rb.data(), 8 + bytes);
+    // the caller's fabric: the section time, the size and the call site ride in front of the payload (a fabric that
+    // survives ranks sending different sizes hands the mismatch back here; one that does not fails in the callback)
+    constexpr size_t kHdr = 24;
+    std::vector<uint8_t> sb(kHdr + bytes), rb((size_t)cm->world * (kHdr + bytes));
+    const uint64_t b64 = bytes;
+    memcpy(sb.data(), &busy, 8); memcpy(sb.data() + 8, &b64, 8); memcpy(sb.data() + 16, &tagh, 8);
+    if (bytes) memcpy(sb.data() + kHdr, send, bytes);
+    rc = cm->cb(cm->cb_user, sb.data(), rb.data(), kHdr + bytes);
     if (rc) rc = VPIN_ECOMM;
-    for (int r = 0; r < cm->world && !rc; r++) {
-      double b;
-      memcpy(&b, rb.data() + (size_t)r * (8 + bytes), 8);
-      if (b > max_busy) max_busy = b;
-      if (bytes) memcpy((uint8_t*)recv + (size_t)r * bytes, rb.data() + (size_t)r * (8 + bytes) + 8, bytes);
-    }
     cm->seq++;
+    for (int r = 0; r < cm->world && !rc; r++) {
+      const uint8_t* pr = rb.data() + (size_t)r * (kHdr + bytes);
+      double b;
+      uint64_t pb, pt;
+      memcpy(&b, pr, 8); memcpy(&pb, pr + 8, 8); memcpy(&pt, pr + 16, 8);
+      if (pb != b64 || pt != tagh) { rc = comm_disagree(cm, r, pb, pt, b64, tagh, tag); break; }
+      if (b > max_busy) max_busy = b;
+      if (bytes) memcpy((uint8_t*)recv + (size_t)r * bytes, pr + kHdr, bytes);
+    }
   } else if (cm->seg->abort_flag.load(std::memory_order_relaxed)) {
     rc = VPIN_ECOMM;  // a rank gave up earlier: the group is dead, whatever the slots still hold
   } else {
@@ -166,7 +205,7 @@ int comm_allgather(vpin_comm* cm, const void* send, void* recv, size_t bytes, co
     do {
       const size_t n = bytes - off < piece ? bytes - off : piece;
       double mb = 0.0;
-      rc = seg_allgather_piece(cm, (const uint8_t*)send + off, (uint8_t*)recv + off, n, bytes, off == 0 ? busy : 0.0, &mb);
+      rc = seg_allgather_piece(cm, (const uint8_t*)send + off, (uint8_t*)recv + off, n, bytes, off == 0 ? busy : 0.0, &mb, bytes, tagh, tag);
       if (rc) break;
       if (mb > max_busy) max_busy = mb;
       off += n;
@@ -290,34 +329,58 @@ int vpin_comm_create_shm(const char* name, int rank, int world, size_t slot_byte
   const size_t bytes = seg_size(world, slot_bytes);
   const double timeout = env_timeout();
   int fd = -1;
+  void* p = MAP_FAILED;
+  CommSeg* s = nullptr;
   if (rank == 0) {
     (void)shm_unlink(name);  // a leftover of a job that died with this name
     fd = shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600);
     if (fd < 0 || ftruncate(fd, (off_t)bytes) != 0) { if (fd >= 0) close(fd); return VPIN_ECOMM; }
+    p = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (p == MAP_FAILED) return VPIN_ECOMM;
+    s = static_cast<CommSeg*>(p);
+    seg_init(s, world, slot_bytes);
   } else {
+    // The name may still point at the segment of a job that died with it (rank 0 replaces it, but this rank can get there
+    // first): such a leftover passes every check below -- size, magic, world.  So after the segment looks initialised the
+    // name is resolved AGAIN, before this rank counts itself in: rank 0 keeps the name until everybody is attached, so at
+    // that moment the name must still lead to the very object mapped here.  If it does not (replaced, or gone), this was
+    // a leftover: unmap and start over.  (Callers should still make the name unique per job; bench.py does.)
     Spinner sp(timeout);
     for (;;) {
       fd = shm_open(name, O_RDWR, 0600);
+      struct stat st_mine;
+      if (fd >= 0 && !(fstat(fd, &st_mine) == 0 && (size_t)st_mine.st_size >= bytes)) { close(fd); fd = -1; }  // not sized yet
       if (fd >= 0) {
-        struct stat stt;
-        if (fstat(fd, &stt) == 0 && (size_t)stt.st_size >= bytes) break;  // rank 0 has sized it
+        p = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
         close(fd);
-        fd = -1;
+        if (p == MAP_FAILED) return VPIN_ECOMM;
+        s = static_cast<CommSeg*>(p);
+        auto still_named = [&]() {  // does the name still lead to the object mapped here?
+          const int fd2 = shm_open(name, O_RDWR, 0600);
+          struct stat st_now;
+          const bool y = fd2 >= 0 && fstat(fd2, &st_now) == 0 && st_now.st_ino == st_mine.st_ino && st_now.st_dev == st_mine.st_dev;
+          if (fd2 >= 0) close(fd2);
+          return y;
+        };
+        bool ready = false, same = true;
+        long polls = 0;
+        while (!(ready = s->magic.load(std::memory_order_acquire) == kCommMagic)) {
+          if ((++polls & 1023) == 0 && !(same = still_named())) break;  // replaced while we waited: a leftover
+          if (!sp.step()) break;
+        }
+        if (ready) {
+          const double age = std::chrono::duration<double>(std::chrono::system_clock::now().time_since_epoch()).count() - s->created_unix_s;
+          same = age <= timeout + 5.0 && still_named();  // older than any rank would wait, or no longer named: a leftover
+        }
+        if (ready && same) break;
+        munmap(p, bytes);
+        p = MAP_FAILED;
+        s = nullptr;
       }
       if (!sp.step()) return VPIN_ECOMM;
       usleep(200);
     }
-  }
-  void* p = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
-  close(fd);
-  if (p == MAP_FAILED) return VPIN_ECOMM;
-  CommSeg* s = static_cast<CommSeg*>(p);
-  if (rank == 0) {
-    seg_init(s, world, slot_bytes);
-  } else {
-    Spinner sp(timeout);
-    while (s->magic.load(std::memory_order_acquire) != kCommMagic)
-      if (!sp.step()) { munmap(p, bytes); return VPIN_ECOMM; }
     if (s->world != (uint32_t)world || s->slot_bytes != slot_bytes) { munmap(p, bytes); return VPIN_ECOMM; }
   }
   vpin_comm* cm = new (std::nothrow) vpin_comm();

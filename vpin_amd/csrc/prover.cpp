@@ -493,6 +493,34 @@ namespace vpin_prover {
 
 // my_lib_prove up to and including the Ar/Br/Cr claims.  tr_out / tape_out (optional) receive the
 // transcript and the RandomTape as they stand afterwards, for R1CSEvalProof::prove (spark.cpp).
+// what a rank is about to prove and which per-process switches shape its collective sequence
+static int dist_fingerprint_check(vpin_ctx* c, size_t nv, size_t ncons, size_t ni, const uint8_t seed_commit64[64],
+                                  const uint8_t seed_proof64[64]) {
+  vpin_comm* cm = c->comm;
+  auto fnv = [](const uint8_t* p, size_t n) { uint64_t h = 0xcbf29ce484222325ull; for (size_t i = 0; i < n; i++) { h ^= p[i]; h *= 0x100000001b3ull; } return h; };
+  auto env_num = [](const char* name, long dflt) { const char* e = getenv(name); return e ? atol(e) : dflt; };
+  uint64_t fp[10] = {
+      (uint64_t)nv, (uint64_t)ncons, (uint64_t)ni, fnv(seed_commit64, 64), fnv(seed_proof64, 64),
+      (uint64_t)(getenv("VPIN_DIST_NO_SAT_SPLIT") != nullptr), (uint64_t)(getenv("VPIN_DIST_BY_CIRCUIT") != nullptr),
+      (uint64_t)env_num("VPIN_SPARK_TAIL_PAIRS", 1024), (uint64_t)(getenv("VPIN_NO_HOT_COLS") != nullptr),
+      (uint64_t)(getenv("VPIN_BULLET_CLASSIC") != nullptr)};
+  std::vector<uint64_t> all((size_t)cm->world * 10);
+  int rc = vpin::comm_allgather_ctx(c, fp, all.data(), sizeof fp, "fingerprint");
+  if (rc) return rc;
+  static const char* what[10] = {"num_vars", "num_cons", "num_inputs", "seed_commit", "seed_proof", "VPIN_DIST_NO_SAT_SPLIT",
+                                 "VPIN_DIST_BY_CIRCUIT", "VPIN_SPARK_TAIL_PAIRS", "VPIN_NO_HOT_COLS", "VPIN_BULLET_CLASSIC"};
+  for (int r = 0; r < cm->world; r++)
+    for (int k = 0; k < 10; k++)
+      if (all[(size_t)r * 10 + k] != fp[k]) {
+        char msg[200];
+        snprintf(msg, sizeof msg, "collective proof: rank %d and rank %d differ in %s (%llu vs %llu)", cm->rank, r, what[k],
+                 (unsigned long long)fp[k], (unsigned long long)all[(size_t)r * 10 + k]);
+        vpin::set_last_error(msg, hipErrorUnknown);
+        return VPIN_ECOMM;
+      }
+  return VPIN_OK;
+}
+
 int sat_prove_core(vpin_ctx* c, const vpin_r1cs_dev* dinst, size_t nv, size_t ncons, size_t ni,
                    const vpin_table* d_para, const vpin_table* d_input, const vpin_table* d_vars, const uint8_t* inputs,
                    const uint8_t seed_commit64[64], const uint8_t seed_proof64[64], uint8_t* proof_out, size_t proof_cap,
@@ -517,6 +545,11 @@ int sat_prove_core(vpin_ctx* c, const vpin_r1cs_dev* dinst, size_t nv, size_t nc
   // dense_mlpoly.rs:166-173), so every rank commits a contiguous block of rows of both polynomials and the 32-byte results
   // are all-gathered; the blinds are drawn in full by everyone (the tape is part of the deterministic protocol state).
   vpin_comm* cm = (c->comm && c->comm->world > 1) ? c->comm : nullptr;
+  // Before anything is split: the ranks must be about to run the SAME protocol.  Several branches below and in spark_prove
+  // are chosen per process (environment knobs, the instance's shape, the seeds): ranks that differ would issue different
+  // collective sequences and, at best, stall until the timeout.  One all-gather of a fingerprint makes that a prompt
+  // VPIN_ECOMM with a message instead.
+  if (cm && (rc = dist_fingerprint_check(c, nv, ncons, ni, seed_commit64, seed_proof64))) return rc;
   // rank r commits rows r, r + world, ..: the rows differ in cost (the padding tail of the assignment is all zeros)
   const size_t nrows = cm ? vpin::comm_strided_count(L, cm->rank, cm->world) : L;
   vpin::CommitPairState* cps = nullptr;

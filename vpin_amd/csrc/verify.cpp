@@ -314,11 +314,14 @@ static bool polyeval_verify(vpin_ctx* c, const DpLogP& pf, const PcGens& pc, Tra
   host_eq(r + left, right, Rv.data());
   CG C_LZ;
   static const bool host_only = getenv("VPIN_VERIFY_HOST_MSM") != nullptr;
+  bool on_device = false;
   if (pc.L >= 128 && !host_only) {
     // <L, C> over the row commitments on the device (msm_var.hip): decompression and the scalar multiplications, one lane each
     const int rc = vpin_msm(c, B(Lv.data()), comm[0].b, pc.L, C_LZ.b, nullptr);
-    if (rc) return false;  // VPIN_EVERIFY: a commitment that does not decode
-  } else {
+    if (rc == VPIN_EVERIFY) return false;  // a commitment that does not decode: the proof's fault
+    on_device = rc == VPIN_OK;             // VPIN_ENOMEM / VPIN_EHIP are the machine's fault: the host path decides
+  }
+  if (!on_device) {
     std::vector<Point> Cd(pc.L);
     bool ok = true;
 #pragma omp parallel for schedule(static) num_threads(pc.L >= 64 ? host_threads() : 1) reduction(&& : ok)
@@ -452,12 +455,17 @@ static bool sat_verify(vpin_ctx* c, Reader& r, size_t num_cons, size_t num_vars,
   // (proof_point_mult.rs:75-80; my_lib_verify recombines com_1 + com_2, commit_test.rs:369-375)
   std::vector<CG> combined(L);
   static const bool host_only = getenv("VPIN_VERIFY_HOST_MSM") != nullptr;
+  bool on_device = false;
   if (L >= 128 && !host_only) {
     // 2L decompressions, L additions and L compressions: one lane per row on the device (msm_var.hip)
-    if (vpin_points_add(c, comm_para, comm_input, L, combined[0].b)) return false;
-    for (size_t i = 0; i < L; i++)
-      if (!same(combined[i], comm_vars[i])) return false;
-  } else {
+    const int rc = vpin_points_add(c, comm_para, comm_input, L, combined[0].b);
+    if (rc == VPIN_EVERIFY) return false;
+    on_device = rc == VPIN_OK;  // any other failure is an infrastructure error, not a rejection: recombine on the host
+    if (on_device)
+      for (size_t i = 0; i < L; i++)
+        if (!same(combined[i], comm_vars[i])) return false;
+  }
+  if (!on_device) {
     for (size_t i = 0; i < L; i++) {
       CG a, b;
       memcpy(a.b, comm_para + 32 * i, 32);

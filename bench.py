@@ -65,6 +65,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-mult", type=int, default=32, help="point-mults in the CPU baseline sample")
     ap.add_argument("--cpu-sample-add", type=int, default=256)
+    ap.add_argument("--cpu-full-label", default="A", help="BASELINE configuration the CPU baseline proves at full size on all host "
+                    "threads (A = configs[1], ~30 s); none: the small sample only")
     ap.add_argument("--serial", action="store_true", help="one instance at a time, one host thread")
     ap.add_argument("--host-buffers", action="store_true",
                     help="time vpin_sat_prove (instance + witness start in host memory: PCIe-inclusive; never the headline)")
@@ -898,7 +900,7 @@ def main():
         if not args.no_span:
             for cx in ctxs:
                 cx.set_shared_device(False)  # one proof at a time from here on
-            span = {}
+            span, dead_commit, dead_digest_bytes, digest_rate = {}, {}, {}, {}
             ts = time.perf_counter()
             for li, names in enumerate(lane_names):
                 for name in names:
@@ -909,13 +911,59 @@ def main():
                     r = g.snark_prove(SEED_C, SEED_P)
                     span[name] = round((time.perf_counter() - t1) * 1e3, 2)
                     assert r["proof"] == last_proof[name]["proof"], f"{name}: reference-span proof differs from the timed region's"
+                    # what the reference computes inside this span and never uses, timed beside it --
+                    # (i) the third commitment my_dense_mlpoly_commit (proof_point_mult.rs:58-59; only row 0 is read, by an assert)
+                    t2 = time.perf_counter()
+                    third = ctxs[li].dense_mlpoly_commit_sum(g.vars, SEED_C)
+                    dead_commit[name] = round((time.perf_counter() - t2) * 1e3, 2)
+                    assert bytes(third[0]) == bytes(ctxs[li].points_add(r["comm_para"][:1], r["comm_input"][:1])[0]), name  # :69-73
+                    # (ii) Instance::new's digest: zlib over bincode(A, B, C) (lib.rs:232-243, r1csinstance.rs:154-158), 48 B per
+                    # entry, consumed by the NIZK path only.  Host work; compressed here for the smallest instance of each
+                    # gadget met (<= 4 M entries) and priced per byte for the others (3.7 GB of triplets for L5-mult: a minute of one core).
+                    dead_digest_bytes[name] = 48 * sum(g.nnz) + 3 * 8 + 3 * (2 * 8 + 8)
+                    if kind not in digest_rate and sum(g.nnz) <= 4_000_000:
+                        import zlib
+                        t3 = time.perf_counter()
+                        buf = bytearray(np.array([g.num_cons, g.num_vars, g.num_inputs], dtype="<u8").tobytes())
+                        for m in range(3):
+                            row, col, val = g.triplets(m)
+                            ent = np.zeros(len(row), dtype=[("row", "<u8"), ("col", "<u8"), ("val", "<u8", (4,))])
+                            ent["row"], ent["col"], ent["val"] = row, col, val
+                            buf += np.array([g.num_cons.bit_length() - 1, (2 * g.num_vars).bit_length() - 1, len(row)], dtype="<u8").tobytes()
+                            buf += ent.tobytes()
+                        t4 = time.perf_counter()
+                        z = zlib.compress(bytes(buf), 6)  # flate2's default level
+                        t5 = time.perf_counter()
+                        digest_rate[kind] = {"instance": name, "bytes": len(buf), "compressed_bytes": len(z),
+                                             "triplets_to_host_ms": round((t4 - t3) * 1e3, 1), "zlib_ms": round((t5 - t4) * 1e3, 1),
+                                             "MB_per_s": len(buf) / (t5 - t4) / 1e6}
                     g.free()
-            span_s = time.perf_counter() - ts
+            span_s = time.perf_counter() - ts - sum(dead_commit.values()) / 1e3 - sum(
+                (v["triplets_to_host_ms"] + v["zlib_ms"]) / 1e3 for v in digest_rate.values())
             line["value_reference_span"] = total_cons_step / span_s  # the reference's own timed span, see reference_span.scope
             line["reference_span"] = {
                 "ms_per_trace": round(span_s * 1e3, 1), "constraints_per_s": total_cons_step / span_s, "ms": span,
                 "scope": "per instance, serially: witness inputs in host memory -> gadget + witness synthesis + Instance::new "
                          "(device) -> is_sat -> SNARK::encode -> my_lib_prove -> proof bytes on the host; generator tables warm",
+            }
+            # the same span WITH the work the reference does inside it and never uses
+            digest_ms = {}
+            for name, nbytes in dead_digest_bytes.items():
+                rate = digest_rate.get(inputs_of[name][0])
+                if rate:
+                    digest_ms[name] = round(nbytes / (rate["MB_per_s"] * 1e6) * 1e3, 1)
+            dead_s = sum(dead_commit.values()) / 1e3 + sum(digest_ms.values()) / 1e3
+            line["reference_span"]["dead_work"] = {
+                "third_commitment_ms": dead_commit, "third_commitment_ms_total": round(sum(dead_commit.values()), 1),
+                "digest_ms_priced": digest_ms, "digest_ms_total_priced": round(sum(digest_ms.values()), 1), "digest_measured_on": digest_rate,
+                "ms_per_trace_with": round((span_s + dead_s) * 1e3, 1), "constraints_per_s_with": total_cons_step / (span_s + dead_s),
+                "ms_per_trace_without": round(span_s * 1e3, 1),
+                "note": "inside the reference's 'Proof generation time' and dropped by this build because no proof byte depends on it: "
+                        "(i) my_dense_mlpoly_commit of the whole assignment (proof_point_mult.rs:58-59; its row 0 feeds an assert, "
+                        "reproduced here) -- measured per instance on the device (vpin_dense_mlpoly_commit_sum); the poly_prime loop of "
+                        ":61-67 is a vector addition nobody reads; (ii) the zlib digest of bincode(A, B, C) in Instance::new "
+                        "(lib.rs:232-243) -- one host core, measured on the smallest instance of each gadget (digest_measured_on) and "
+                        "priced per byte for the rest; is_sat (the other N4 item) is INSIDE the span on both sides",
             }
             if len(lanes) > 1:
                 # the same span with the trace's instances on the bench's lanes (streams) instead of one after the other
@@ -956,7 +1004,7 @@ def main():
         sample_cons = (sm.num_cons_unpadded if sm else 0) + sa.num_cons_unpadded
         dm, da = (sm.as_dict() if sm else None), sa.as_dict()
 
-        def cpu_run(threads):
+        def cpu_run(threads, dm=dm, da=da):
             """the C oracle (restated reference prover) on the sample; SNARK::encode excluded on both sides"""
             os.environ["OMP_NUM_THREADS"] = str(threads)
             t0 = time.perf_counter()
@@ -973,12 +1021,37 @@ def main():
 
         s_all, tm_all = cpu_run(all_cores)
         s_one, tm_one = cpu_run(1)
-        line["cpu_baseline"] = {
-            "value": sample_cons / s_all, "unit": "constraints/s", "cores": all_cores, "kind": "port",
-            "sample": f"{args.cpu_sample_mult if sm else 0} point-mults + {sa.num_cons_unpadded // 10} point-adds drawn like layer {lab} "
+        sample_txt = (f"{args.cpu_sample_mult if sm else 0} point-mults + {sa.num_cons_unpadded // 10} point-adds drawn like layer {lab} "
                       f"({sample_cons} constraints; 2^17 padded for the point-mult instance), C oracle (restated reference prover): OpenMP "
                       f"over the commitment rows (as rayon in the reference), single-threaded sum-checks; {s_all:.1f} s on {all_cores} "
-                      f"threads, {s_one:.1f} s on 1",
+                      f"threads, {s_one:.1f} s on 1")
+        value, full = sample_cons / s_all, None
+        flab = args.cpu_full_label
+        if flab != "none" and args.snark:
+            # a BASELINE configuration at full size beside it: CNN A's whole trace (configs[1]: 178 point-mults
+            # = 616,592 constraints, 2^20 padded, + 2144 point-adds) on all host threads -- ~30 s of the box's cores
+            fm = G.synthetic_mult_instance(flab) if G.CONFIGS[flab]["n_mult"] else None
+            fa = G.synthetic_add_instance(flab)
+            full_cons = (fm.num_cons_unpadded if fm else 0) + fa.num_cons_unpadded
+            s_full, tm_full = cpu_run(all_cores, fm.as_dict() if fm else None, fa.as_dict())
+            if fm:
+                fm.free()
+            fa.free()
+            value = full_cons / s_full
+            full = {"label": flab, "constraints": full_cons, "seconds": round(s_full, 2), "cores": all_cores, "value": value,
+                    "spans_ms_mult": {kk: round(vv * 1e3, 1) for kk, vv in tm_full.items()},
+                    "note": "the same trace on the GPU: bench.py --trace " + flab + " (profiles/r0x_bench_" + flab + ".json)"}
+            sample_txt = (f"CNN {flab}'s whole trace at full size ({full_cons} constraints: {G.CONFIGS[flab]['n_mult']} point-mults + "
+                          f"{G.CONFIGS[flab]['n_add']} point-adds), C oracle (restated reference prover; OpenMP over the commitment rows as "
+                          f"rayon in the reference, single-threaded sum-checks), {s_full:.1f} s on {all_cores} threads; and a small sample "
+                          "on 1 and all threads (small_sample): " + sample_txt)
+        line["cpu_baseline"] = {
+            "value": value, "unit": "constraints/s", "cores": all_cores, "kind": "port",
+            "sample": sample_txt,
+            "full_config": full,
+            "small_sample": {"value": sample_cons / s_all, "cores": all_cores, "seconds": round(s_all, 2), "constraints": sample_cons},
+            "third_point": "the 2^25-constraint instance (L5-mult, 20,784,000 constraints) through the same oracle on 16 host threads: "
+                           "profiles/r03_l5full_oracle_host.log (SNARK::encode + prove 644 s = 32 k constraints/s, 94 GB)",
             "single_thread": {"value": sample_cons / s_one, "cores": 1, "seconds": round(s_one, 2),
                               "note": "beside the single-core profile of Spartan/README.md:338-377 (2^20 constraints: SNARK::prove "
                                       "39.1 s = 26.8 k constraints/s on one i7-1065G7 core) mind the shape: that instance has one "

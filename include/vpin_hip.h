@@ -270,6 +270,14 @@ int vpin_sat_prove_resident(vpin_ctx* ctx, const vpin_r1cs_dev* inst, const vpin
                             size_t proof_cap, size_t* proof_len, uint8_t* comm_para_out, uint8_t* comm_input_out,
                             uint8_t inst_evals_out[96], uint8_t* rx_out, uint8_t* ry_out);
 size_t vpin_sat_proof_max_bytes(size_t num_cons, size_t num_vars);
+/* my_dense_mlpoly_commit (vPIN_proof_generation/src/commit_test.rs:27-57) as proof_point_{add,mult}.rs:58-59 call it: the
+ * Hyrax commitment of the WHOLE assignment under the element-wise sum of the blinds of the two commitments made before it
+ * (RandomTape::new(&[2]), labels b"poly_blinds" x L twice).  The reference computes it inside its timed span and then reads
+ * row 0 only (assert_eq!(c, c_prime), proof_point_mult.rs:69-73): the proof carries the row-wise sum of the two partial
+ * commitments, which is the same vector.  vpin_sat_prove* / vpin_snark_prove* therefore never compute it (SURVEY.md 8(f) row
+ * N4); this entry point exists so that a host which wants the reference's assert, or the reference's span "with" the dead
+ * work, can have it: out = L x 32 B, L = 2^(log2(len) / 2), equal to comm_para + comm_input row by row. */
+int vpin_dense_mlpoly_commit_sum(vpin_ctx* ctx, const vpin_table* vars, const uint8_t seed_commit64[64], uint8_t* out_compressed);
 /* R1CSGens::new (Spartan/src/r1csproof.rs:84-89) for this polynomial size ahead of the first proof: host
  * fixed-base tables + the shared device window table (built on demand by the prove calls otherwise). */
 int vpin_sat_prepare(vpin_ctx* ctx, size_t num_vars);

@@ -105,3 +105,31 @@ def test_cli_proof_matches_oracle(built, tmp_path):
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     assert open(tmp_path / "out2" / "T_add.proof", "rb").read() == O.sat_prove(inst_add, seeds["add"][:64], seeds["add"][64:])["proof"]
+
+
+@pytest.mark.gpu
+def test_several_labels_in_one_process_give_the_one_label_outputs(built, tmp_path):
+    """script.sh:205-211 runs the reference binary once per LeNet layer; `vpin_prove L1 L2 ...` proves them in ONE process
+    (HIP context, generator derivations and window tables built once, sized for the largest label of the run).  Every
+    label's stdout block and -- with --seed -- every proof file must be what the one-label runs give; a label without
+    point multiplications (L2 / L4, main.rs:24-31) prints the reference's zero block."""
+    specs = {"U": (5, 2), "L2": (9, 0), "V": (3, 1)}
+    for k, (label, (na, nm)) in enumerate(specs.items()):
+        write_witness(tmp_path, label, GM.synthetic_add_ops(100 + k, na, rz_one_every=4), GM.synthetic_mult_ops(200 + k, max(nm, 1)))
+    master = bytes((3 * i + 1) % 256 for i in range(128))
+    os.makedirs(tmp_path / "all")
+    r = subprocess.run([BIN, "U", "L2", "V", "--seed", master.hex(), "--write-proof", "all"], cwd=tmp_path, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    blocks = r.stdout.split("network: ")[1:]
+    assert [b.split("\n")[0] for b in blocks] == ["U", "L2", "V"]
+    assert "Number of Point Multiplications: 0" in blocks[1] and "Proof generation time: 0 ms" in blocks[1]
+    strip = lambda text: [l for l in text.splitlines() if l and " time: " not in l]   # times differ run to run
+    for label, block in zip(specs, blocks):
+        os.makedirs(tmp_path / ("one_" + label))
+        r1 = subprocess.run([BIN, label, "--seed", master.hex(), "--write-proof", "one_" + label], cwd=tmp_path, capture_output=True, text=True)
+        assert r1.returncode == 0, r1.stderr
+        assert strip("network: " + block) == strip(r1.stdout), label
+        assert block.count("Total proof generation time: ") == 1 and block.count("Proof verification successful!") == (1 if label == "L2" else 2)
+        for f in sorted(os.listdir(tmp_path / ("one_" + label))):
+            assert open(tmp_path / "all" / f, "rb").read() == open(tmp_path / ("one_" + label) / f, "rb").read(), f
+    assert subprocess.run([BIN, "U", "--bogus"], cwd=tmp_path, capture_output=True, text=True).returncode == 101

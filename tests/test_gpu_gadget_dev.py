@@ -176,3 +176,19 @@ def test_dev_instance_equals_host_path_at_config_size(ctx):
     assert got["comm"] == exp["comm"] and got["proof"] == exp["proof"]
     host.free()
     g.free()
+
+
+def test_third_commitment_is_the_rowwise_sum_of_the_two_partial_ones(ctx):
+    """proof_point_mult.rs:58-73: my_dense_mlpoly_commit of the whole assignment under the summed blinds -- dead work in the
+    reference's span (only row 0 is read, in an assert), never computed by the prover here; vpin_dense_mlpoly_commit_sum
+    computes it on request.  It must equal comm_para + comm_input in EVERY row (the reference's assert checks row 0), for
+    the point-mult and the point-add gadget."""
+    for g in (dev_mult(ctx, GM.synthetic_mult_ops(21, 3)), dev_add(ctx, GM.synthetic_add_ops(22, 40, rz_one_every=7))):
+        try:
+            got = g.snark_prove(SEED_C, SEED_P)
+            third = ctx.dense_mlpoly_commit_sum(g.vars, SEED_C)
+            assert np.array_equal(third, ctx.points_add(got["comm_para"], got["comm_input"]))
+            other = ctx.dense_mlpoly_commit_sum(g.vars, SEED_P)     # other blinds: another commitment
+            assert not np.array_equal(third, other)
+        finally:
+            g.free()

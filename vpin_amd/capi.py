@@ -677,6 +677,19 @@ class Context:
         _chk(L.vpin_msm(self.h, p(s), p(pts), s.shape[0], p(out), p(xyzt) if want_xyzt else None), "vpin_msm")
         return (out, xyzt) if want_xyzt else out
 
+    def dense_mlpoly_commit_sum(self, t_vars, seed_commit):
+        """vpin_dense_mlpoly_commit_sum: my_dense_mlpoly_commit of the whole assignment (the reference's third commitment,
+        proof_point_mult.rs:58-59) -> (L, 32) uint8"""
+        L = lib()
+        L.vpin_dense_mlpoly_commit_sum.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        nv = len(t_vars)
+        Ls = 1 << ((nv.bit_length() - 1) // 2)
+        out = np.zeros((Ls, 32), dtype=np.uint8)
+        sc = np.frombuffer(bytes(seed_commit), dtype=np.uint8).copy()
+        _chk(L.vpin_dense_mlpoly_commit_sum(self.h, t_vars.h, sc.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p)),
+             "vpin_dense_mlpoly_commit_sum")
+        return out
+
     def points_add(self, a, b):
         """vpin_points_add: compress(decompress(a[i]) + decompress(b[i]))"""
         a = np.ascontiguousarray(a, dtype=np.uint8).reshape(-1, 32)

@@ -295,39 +295,34 @@ void prepare_for_mult(vpin_ctx* ctx, const std::string& weight_path, bool sat_on
   lap("  vpin_sat_prepare");
 }
 
-}  // namespace
+// number of operations a label's point-mult instance will have (0: none / no file)
+size_t mult_ops_of(const std::string& network) {
+  if (network == "L2" || network == "L4") return 0;
+  return count_strings("rust_files/" + network + "/pointMult/weight.json");
+}
 
-int main(int argc, char** argv) {
-  std::string network = argc > 1 ? argv[1] : "1";  // main.rs:16
+struct Opts {
   std::string dump_dir;
   int device = 0;
+  bool have_seed = false, host_gadgets = false, no_prefetch = false;
   uint8_t seeds[128];
-  bool have_seed = false, host_gadgets = false, no_prefetch = getenv("VPIN_CLI_NO_PREFETCH") != nullptr;
-  for (int i = 2; i < argc; i++) {
-    std::string a = argv[i];
-    if (a == "--device" && i + 1 < argc) device = atoi(argv[++i]);
-    else if (a == "--write-proof" && i + 1 < argc) dump_dir = argv[++i];
-    else if (a == "--sat-only") g_sat_only = true;
-    else if (a == "--no-prefetch") no_prefetch = true;  // every instance builds its own generator sets, in its own span
-    else if (a == "--host-gadgets") host_gadgets = true;  // build instance + witness on the host cores, upload, then prove
-    else if (a == "--seed" && i + 1 < argc) {
-      std::string h = argv[++i];  // hex, repeated cyclically to 128 bytes: commit seed | proof seed
-      size_t usable = h.size() & ~(size_t)1;
-      if (usable == 0) die("--seed needs hex bytes");
-      for (size_t k = 0; k < 128; k++) seeds[k] = (uint8_t)strtol(h.substr((2 * k) % usable, 2).c_str(), nullptr, 16);
-      have_seed = true;
-    }
-  }
+};
+
+// One label = what one `cargo run -- <label>` of the reference does (main.rs:14-46): the point-add SNARK, the point-mult
+// SNARK, the totals block.  *pctx is created inside the first label's point-add span (as a process per label would) and
+// kept for the labels after it; `prefetch_largest` names the label whose point-mult shape the generator sets are prepared
+// for before the first proof (the largest of the run: every smaller set is a prefix of it).
+void run_label(const std::string& network, const Opts& o, vpin_ctx** pctx, const std::string& prefetch_label, size_t n_labels) {
   // one independent 128-byte seed per proof (a shared seed gives both SNARKs the same blinds)
   uint8_t seeds_add[128], seeds_mult[128];
-  if (!have_seed) {  // OsRng (Spartan/src/random.rs:17), drawn per proof
+  if (!o.have_seed) {  // OsRng (Spartan/src/random.rs:17), drawn per proof
     std::random_device rd;
     for (auto& b : seeds_add) b = (uint8_t)rd();
     for (auto& b : seeds_mult) b = (uint8_t)rd();
   } else {
     auto derive = [&](const char* domain, uint8_t out[128]) {
       vpin_host::Shake256 sh;
-      sh.absorb(seeds, 128);
+      sh.absorb(o.seeds, 128);
       sh.absorb(reinterpret_cast<const uint8_t*>(domain), strlen(domain));
       sh.finalize();
       sh.squeeze(out, 128);
@@ -335,11 +330,8 @@ int main(int argc, char** argv) {
     derive("vPIN/point_add", seeds_add);
     derive("vPIN/point_mult", seeds_mult);
   }
-  fprintf(stderr, g_sat_only ? "vpin_prove: R1CS satisfiability proof only (--sat-only)\n"
-                             : "vpin_prove: whole SNARK (sat proof + SPARK evaluation proof)\n");
-
   printf("network: %s\n", network.c_str());
-  vpin_ctx* ctx = nullptr;
+  vpin_ctx*& ctx = *pctx;
   const std::string base = "rust_files/" + network + "/";
 
   // ---- point addition (proof_point_add.rs) ----
@@ -354,20 +346,21 @@ int main(int argc, char** argv) {
   printf("Point Addition Gadget...\n");
   printf("Number of Point Additions: %zu\n", n1);
   Lap lap;
-  {
+  if (!ctx) {
     const char* pe = getenv("VPIN_CLI_MAIN_PRIO");
-    check(vpin_ctx_create_prio(device, pe ? atoi(pe) : 0, &ctx), "vpin_ctx_create");
-  }
-  lap("ctx_create");
-  // this process proves once per instance and exits: generator tables sized for that (VPIN_CLI_FULL_TABLES: the service's)
-  if (!getenv("VPIN_CLI_FULL_TABLES")) check(vpin_ctx_set_expected_proofs(ctx, 1), "vpin_ctx_set_expected_proofs");
-  if (!(network == "L2" || network == "L4") && !no_prefetch) {
-    prepare_for_mult(ctx, base + "pointMult/weight.json", g_sat_only);
-    lap("generator sets (mult size)");
+    check(vpin_ctx_create_prio(o.device, pe ? atoi(pe) : 0, &ctx), "vpin_ctx_create");
+    lap("ctx_create");
+    // this process proves n_labels times per instance shape at most and exits: generator tables sized for that
+    // (VPIN_CLI_FULL_TABLES: the service's)
+    if (!getenv("VPIN_CLI_FULL_TABLES")) check(vpin_ctx_set_expected_proofs(ctx, (int)n_labels), "vpin_ctx_set_expected_proofs");
+    if (!prefetch_label.empty() && !o.no_prefetch) {
+      prepare_for_mult(ctx, "rust_files/" + prefetch_label + "/pointMult/weight.json", g_sat_only);
+      lap("generator sets (mult size)");
+    }
   }
   Result ra;
-  const std::string add_prefix = dump_dir.empty() ? "" : dump_dir + "/" + network + "_add";
-  if (host_gadgets || n1 == 0) {
+  const std::string add_prefix = o.dump_dir.empty() ? "" : o.dump_dir + "/" + network + "_add";
+  if (o.host_gadgets || n1 == 0) {
     vpin_instance* add = nullptr;
     check(vpin_gadget_point_add(apx.data(), apy.data(), arx.data(), ary.data(), arz.data(), n1, &add), "vpin_gadget_point_add");
     lap("gadget_point_add");
@@ -401,8 +394,8 @@ int main(int argc, char** argv) {
     printf("Number of Point Multiplications: %zu\n", nw);
     printf("Generating Proof...\n");
     lap("load mult json");
-    const std::string mult_prefix = dump_dir.empty() ? "" : dump_dir + "/" + network + "_mult";
-    if (host_gadgets || nw == 0) {
+    const std::string mult_prefix = o.dump_dir.empty() ? "" : o.dump_dir + "/" + network + "_mult";
+    if (o.host_gadgets || nw == 0) {
       vpin_instance* mult = nullptr;
       check(vpin_gadget_point_mult(w.data(), mpx.data(), mpy.data(), nw, &mult), "vpin_gadget_point_mult");
       lap("gadget_point_mult");
@@ -423,6 +416,51 @@ int main(int argc, char** argv) {
   printf("Total proof generation time: %lld ms\n", ra.gen_ms + rm.gen_ms);
   printf("Total proof verification time: %lld ms\n", ra.ver_ms + rm.ver_ms);
   printf("====================================\n");
+  fflush(stdout);
+}
+
+}  // namespace
+
+// vpin_prove <label> [<label> ...] [options]
+// One label: the reference binary (`cargo run -- <label>`, main.rs:14-46).  Several labels: what script.sh:205-211 does with
+// a process per label (L1 .. L7 of a LeNet trace), in ONE process -- the HIP context, the generator derivations, the host
+// fixed-base tables and the device window tables are built once, for the largest instance of the run, and every label
+// prints the reference's stdout block unchanged (with --seed the proofs are the ones the one-label runs give).
+int main(int argc, char** argv) {
+  std::vector<std::string> labels;
+  Opts o;
+  o.no_prefetch = getenv("VPIN_CLI_NO_PREFETCH") != nullptr;
+  for (int i = 1; i < argc; i++) {
+    std::string a = argv[i];
+    if (a == "--device" && i + 1 < argc) o.device = atoi(argv[++i]);
+    else if (a == "--write-proof" && i + 1 < argc) o.dump_dir = argv[++i];
+    else if (a == "--sat-only") g_sat_only = true;
+    else if (a == "--no-prefetch") o.no_prefetch = true;  // every instance builds its own generator sets, in its own span
+    else if (a == "--host-gadgets") o.host_gadgets = true;  // build instance + witness on the host cores, upload, then prove
+    else if (a == "--seed" && i + 1 < argc) {
+      std::string h = argv[++i];  // hex, repeated cyclically to 128 bytes: commit seed | proof seed
+      size_t usable = h.size() & ~(size_t)1;
+      if (usable == 0) die("--seed needs hex bytes");
+      for (size_t k = 0; k < 128; k++) o.seeds[k] = (uint8_t)strtol(h.substr((2 * k) % usable, 2).c_str(), nullptr, 16);
+      o.have_seed = true;
+    } else if (a.rfind("--", 0) == 0) die(("unknown option " + a).c_str());
+    else labels.push_back(a);
+  }
+  if (labels.empty()) labels.push_back("1");  // main.rs:16
+  fprintf(stderr, g_sat_only ? "vpin_prove: R1CS satisfiability proof only (--sat-only)\n"
+                             : "vpin_prove: whole SNARK (sat proof + SPARK evaluation proof)\n");
+  // the label with the most point multiplications: its generator sets are prepared first
+  std::string largest;
+  size_t most = 0;
+  for (auto& l : labels) {
+    const size_t n = mult_ops_of(l);
+    if (n > most) { most = n; largest = l; }
+  }
+  vpin_ctx* ctx = nullptr;
+  for (size_t k = 0; k < labels.size(); k++) {
+    if (k) printf("\n");
+    run_label(labels[k], o, &ctx, largest, labels.size());
+  }
   // hand every block back explicitly: VRAM released by hipFree is wiped by the driver in the background, VRAM
   // reclaimed at process teardown is wiped when the next process allocates it (tools/ubench_malloc*.hip)
   vpin_ctx_destroy(ctx);

@@ -494,13 +494,15 @@ __global__ __launch_bounds__(64) void scalar_times_bases_kernel(const fq* __rest
 template <bool TEN>
 __global__ __launch_bounds__(kMsmBlock, 3) void msm_rows_hot_kernel(const fq* __restrict__ Z, size_t stride, size_t ncols, TableView tv,
                                                                  HotRows hr, ge_ext* __restrict__ out, size_t row_base, size_t row_step,
-                                                                 int z_compact) {
+                                                                 int z_compact, const uint8_t* __restrict__ strip_flag) {
   const size_t row = row_base + (size_t)blockIdx.x * row_step;  // row of the polynomial; out[] is indexed by blockIdx.x
   // z_compact: Z holds only this launch's rows, densely (a rank's rows of a split commitment gathered on their own)
   const fq* zr = Z + (z_compact ? (size_t)blockIdx.x : row) * stride;
   RowAcc<TEN> acc;
+  // strip_flag[row of this launch] != 0: the table walks of this row are msm_strip_kernel's; only its hot entries are added here
+  const bool hot_only = strip_flag && strip_flag[blockIdx.x];
   // a row of one repeated scalar (padding tails): s * (g_0 + ... + g_{ncols-1}), as in msm_rows_kernel
-  if (ncols >= 256 && (ncols & (ncols - 1)) == 0 && ((size_t)1 << (tv.nbt - tv.sum0 - 1)) >= ncols) {
+  if (!hot_only && ncols >= 256 && (ncols & (ncols - 1)) == 0 && ((size_t)1 << (tv.nbt - tv.sum0 - 1)) >= ncols) {
     const fq first = fq_load(zr);
     if (fq_same(first, fq_load(zr + 1)) && fq_same(first, fq_load(zr + ncols / 2)) && fq_same(first, fq_load(zr + ncols - 1))) {
       int same = 1;
@@ -542,7 +544,7 @@ __global__ __launch_bounds__(kMsmBlock, 3) void msm_rows_hot_kernel(const fq* __
     for (size_t j = seg + threadIdx.x; j < seg_end; j += kMsmBlock) {
       if (fq_is_zero(fq_load(zr + j))) continue;
       if (idx && idx[j] == hot) list[kSeg - 1 - atomicAdd(&n_back, 1u)] = (uint16_t)(j - seg);
-      else list[atomicAdd(&n_front, 1u)] = (uint16_t)(j - seg);
+      else if (!hot_only) list[atomicAdd(&n_front, 1u)] = (uint16_t)(j - seg);
     }
     __syncthreads();
     const uint32_t nf = n_front, nb = n_back;
@@ -567,6 +569,124 @@ __global__ __launch_bounds__(kMsmBlock, 3) void msm_rows_hot_kernel(const fq* __
     ge_ext* o = out + (size_t)blockIdx.x * gridDim.y + blockIdx.y;
     fp_store(&o->X, av.X); fp_store(&o->Y, av.Y); fp_store(&o->Z, av.Z); fp_store(&o->T, av.T);
   }
+}
+
+
+// ---- row per lane: the table walks of a LARGE commitment out of L2 instead of HBM -------------------------------------------
+// Under the row kernels above the chip sits at its power limit: tools/ubench_msm_variants (profiles/r04_ubench_msm_variants.txt)
+// measured the point addition alone at 31.3 G/s and 2.39 GHz, the same loop with the table walk's gathers at 22.6 G/s with
+// the clock down to 1.79 GHz at 1390 W -- a 96-byte entry out of a 71 GB table costs about as much energy as a third of the
+// addition it feeds.  Every row of a commitment walks the SAME generators, so the fix is to make thousands of lanes want the
+// same 196 KB block (one window of one generator: 2048 multiples) at the same moment: here a LANE is a row, a workgroup is
+// 256 rows, and all workgroups of a "strip" (a run of ncols / S generators) step through (generator, window) together, each
+// lane adding the multiple its own digit selects.  A block is then read ~rows / 2048 times within microseconds, i.e. once
+// from HBM and otherwise from L2 (workgroup b works on strip b mod S; workgroups are dealt round-robin to the 8 XCDs and S is a
+// multiple of 8, so a strip stays on one XCD's L2).  Measured on the synthetic walk: 26.4 G additions/s at 2.06 GHz.
+// Rows whose walks are irregular stay with msm_rows_hot_kernel (constant rows, rows with many zero scalars or hot entries:
+// a lane that skips idles while its wave-mates walk); the hot entries of the rows taken here are added by that kernel too
+// (hot_only), and strip_combine_kernel sums the S partial points of a row into it.
+
+// flag[i] = 1: row i of the launch goes to msm_strip_kernel
+__global__ __launch_bounds__(kMsmBlock) void strip_classify_kernel(const fq* __restrict__ Z, size_t stride, size_t ncols, HotRows hr,
+                                                                    size_t row_base, size_t row_step, int z_compact,
+                                                                    uint8_t* __restrict__ flag) {
+  const size_t row = row_base + (size_t)blockIdx.x * row_step;
+  const fq* zr = Z + (z_compact ? (size_t)blockIdx.x : row) * stride;
+  const uint32_t* idx = nullptr;
+  uint32_t hot = 0xffffffffu;
+  if (hr.rows_per_vec && row >= hr.row0 && row < hr.row0 + 3 * hr.rows_per_vec) {
+    const size_t m = (row - hr.row0) / hr.rows_per_vec;
+    if (hr.hot[m] != 0xffffffffu) { hot = hr.hot[m]; idx = hr.idx[m] + (row - hr.row0 - m * hr.rows_per_vec) * ncols; }
+  }
+  const fq first = fq_load(zr);
+  int same = 1;
+  uint32_t skipped = 0;
+  for (size_t j = threadIdx.x; j < ncols; j += kMsmBlock) {
+    const fq v = fq_load(zr + j);
+    same &= fq_same(first, v) ? 1 : 0;
+    skipped += (fq_is_zero(v) || (idx && idx[j] == hot)) ? 1u : 0u;
+  }
+  __shared__ uint32_t sh[kMsmBlock];
+  sh[threadIdx.x] = skipped;
+  const int all_same = __syncthreads_and(same);
+  for (int st = kMsmBlock / 2; st >= 1; st >>= 1) {
+    if ((int)threadIdx.x < st) sh[threadIdx.x] += sh[threadIdx.x + st];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) flag[blockIdx.x] = (!all_same && sh[0] * 8 <= ncols) ? 1 : 0;
+}
+
+// list = the flagged rows in ascending order, *count = how many (one workgroup of 1024 threads; nrows <= 2^20)
+__global__ __launch_bounds__(1024) void strip_list_kernel(const uint8_t* __restrict__ flag, size_t nrows, uint32_t* __restrict__ list,
+                                                           uint32_t* __restrict__ count) {
+  __shared__ uint32_t base[1024];
+  const size_t per = (nrows + 1023) / 1024, r0 = (size_t)threadIdx.x * per, r1 = r0 + per < nrows ? r0 + per : nrows;
+  uint32_t n = 0;
+  for (size_t r = r0; r < r1; r++) n += flag[r] ? 1u : 0u;
+  base[threadIdx.x] = n;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t run = 0;
+    for (int t = 0; t < 1024; t++) { const uint32_t v = base[t]; base[t] = run; run += v; }
+    *count = run;
+  }
+  __syncthreads();
+  uint32_t o = base[threadIdx.x];
+  for (size_t r = r0; r < r1; r++)
+    if (flag[r]) list[o++] = (uint32_t)r;
+}
+
+// parts[li * S + s] = sum over strip s of the table walks of listed row li (ten-limb accumulator)
+__global__ __launch_bounds__(kMsmBlock, 3) void msm_strip_kernel(const fq* __restrict__ Z, size_t stride, size_t ncols, TableView tv, HotRows hr,
+                                                                  const uint32_t* __restrict__ list, const uint32_t* __restrict__ list_count,
+                                                                  int S, size_t row_base, size_t row_step, int z_compact,
+                                                                  ge_ext* __restrict__ parts) {
+  const uint32_t n = *list_count;
+  const uint32_t s = blockIdx.x % (uint32_t)S, grp = blockIdx.x / (uint32_t)S;
+  if (grp * kMsmBlock >= n) return;
+  const uint32_t li = grp * kMsmBlock + threadIdx.x;
+  const bool live = li < n;
+  const uint32_t i = list[live ? li : n - 1];
+  const size_t row = row_base + (size_t)i * row_step;
+  const fq* zr = Z + (z_compact ? (size_t)i : row) * stride;
+  const uint32_t* idx = nullptr;
+  uint32_t hot = 0xffffffffu;
+  if (hr.rows_per_vec && row >= hr.row0 && row < hr.row0 + 3 * hr.rows_per_vec) {
+    const size_t m = (row - hr.row0) / hr.rows_per_vec;
+    if (hr.hot[m] != 0xffffffffu) { hot = hr.hot[m]; idx = hr.idx[m] + (row - hr.row0 - m * hr.rows_per_vec) * ncols; }
+  }
+  const size_t per = (ncols + (size_t)S - 1) / (size_t)S, j0 = (size_t)s * per, j1 = j0 + per < ncols ? j0 + per : ncols;
+  ge10 acc = ge10_identity();
+  for (size_t j = j0; j < j1; j++) {
+    fq v = fq_load(zr + j);
+    const bool act = live && !fq_is_zero(v) && !(idx && idx[j] == hot);
+    if (__builtin_amdgcn_ballot_w64(act) == 0) continue;  // nobody in the wave walks this generator
+    fq sc = fq_from_mont(v);
+    if (!act) sc = fq_zero();  // all digits zero: the walk below adds nothing for this lane, in step with its wave-mates
+    table_mul_acc10(acc, sc, tv, j);
+  }
+  if (live) {
+    const ge_ext av = ge10_to_ext(acc);
+    ge_ext* o = parts + (size_t)li * (size_t)S + s;
+    fp_store(&o->X, av.X); fp_store(&o->Y, av.Y); fp_store(&o->Z, av.Z); fp_store(&o->T, av.T);
+  }
+}
+
+// out[list[li]] += sum_s parts[li * S + s]
+__global__ __launch_bounds__(64) void strip_combine_kernel(const ge_ext* __restrict__ parts, const uint32_t* __restrict__ list,
+                                                            const uint32_t* __restrict__ list_count, int S, ge_ext* __restrict__ out) {
+  const uint32_t li = blockIdx.x * 64 + threadIdx.x;
+  if (li >= *list_count) return;
+  ge_ext* o = out + list[li];
+  ge_ext a;
+  a.X = fp_load(&o->X); a.Y = fp_load(&o->Y); a.Z = fp_load(&o->Z); a.T = fp_load(&o->T);
+  for (int s = 0; s < S; s++) {
+    const ge_ext* p = parts + (size_t)li * (size_t)S + s;
+    ge_ext q;
+    q.X = fp_load(&p->X); q.Y = fp_load(&p->Y); q.Z = fp_load(&p->Z); q.T = fp_load(&p->T);
+    a = ge_add(a, q);
+  }
+  fp_store(&o->X, a.X); fp_store(&o->Y, a.Y); fp_store(&o->Z, a.Z); fp_store(&o->T, a.T);
 }
 
 // Profiling aid (vpin_prof_enable(ctx, 2)): the affine table additions msm_rows_kernel performs for the same
@@ -1324,19 +1444,65 @@ int hyrax_commit_derefs_hot(vpin_ctx* c, const vpin_gens* g, const vpin_table* Z
   const int chunks = env_chunks > 0 ? env_chunks : (int)std::max<size_t>(1, std::min<size_t>(8, R / kSeg));
   DevBuf dparts(c);
   if (chunks > 1 && dparts.alloc(nrows * (size_t)chunks * sizeof(ge_ext))) return VPIN_ENOMEM;
+  // Row per lane (msm_strip_kernel) for a commitment of enough regular rows to keep every strip's block hot in L2 and the
+  // chip full: the 2^25-constraint instance's 16384 x 16384 derefs polynomial (9.5 k of its rows qualify).  Smaller ones,
+  // and a rank's share of a split commitment, stay with one workgroup per row.
+  // VPIN_MSM_STRIP = 0: off, S: number of strips; VPIN_MSM_STRIP_MIN = n: take the path from n rows on (tests, A/B runs; read per
+  // call so that a test can switch it)
+  const char* es = getenv("VPIN_MSM_STRIP");
+  const char* em = getenv("VPIN_MSM_STRIP_MIN");
+  const int env_strip = es ? atoi(es) : -1;
+  const size_t min_rows = em ? (size_t)atol(em) : 8192, min_list = em ? (size_t)1 : 4096, min_R = em ? (size_t)64 : 4096;
+  int S = env_strip > 0 ? env_strip : 16;
+  DevBuf dflag(c), dlist(c), dsparts(c);
+  uint32_t n_strip = 0;
+  if (env_strip != 0 && msm_ten_limbs() && nrows >= min_rows && R >= min_R && R <= g->split && S % 8 == 0 && (size_t)S <= R / 8) {
+    if (dflag.alloc(nrows) || dlist.alloc((nrows + 1) * sizeof(uint32_t))) return VPIN_ENOMEM;
+    uint32_t* d_list = (uint32_t*)dlist.p;
+    uint32_t* d_count = d_list + nrows;
+    hipLaunchKernelGGL(strip_classify_kernel, dim3((unsigned)nrows), dim3(kMsmBlock), 0, c->stream, zbase, R, R, hr, row0, row_step, z_compact,
+                       (uint8_t*)dflag.p);
+    hipLaunchKernelGGL(strip_list_kernel, dim3(1), dim3(1024), 0, c->stream, (const uint8_t*)dflag.p, nrows, d_list, d_count);
+    VPIN_HIP_TRY(hipMemcpyAsync(&n_strip, d_count, sizeof n_strip, hipMemcpyDeviceToHost, c->stream));
+    VPIN_HIP_TRY(hipStreamSynchronize(c->stream));
+    if (n_strip < min_list) n_strip = 0;  // too few rows to share a block's fetch: the row kernel takes everything
+    if (n_strip && env_strip < 0) {
+      // Strip count: groups x S workgroups should fill the chip's workgroup slots in whole rounds (9480 rows = 38 groups: 16
+      // strips are 608 workgroups for 768 slots, a fifth of the chip idle; 40 strips are two rounds of 760), S a multiple of 8
+      // so that a strip's workgroups share an XCD, strips of at least 128 generators.
+      const size_t groups = (n_strip + kMsmBlock - 1) / kMsmBlock;
+      const size_t slots = (size_t)c->num_cus * (c->shared_device ? 1 : 3);
+      double best = 0.0;
+      for (int cand = 8; cand <= 64 && (size_t)cand * 128 <= R; cand += 8) {
+        const size_t wgs = groups * (size_t)cand, rounds = (wgs + slots - 1) / slots;
+        const double fill = (double)wgs / (double)(rounds * slots) - 0.002 * (double)rounds;  // ties: fewer rounds (more rows in step)
+        if (fill > best) { best = fill; S = cand; }
+      }
+    }
+    if (n_strip && dsparts.alloc((size_t)n_strip * (size_t)S * sizeof(ge_ext))) return VPIN_ENOMEM;
+  }
+  const uint8_t* d_flag = n_strip ? (const uint8_t*)dflag.p : nullptr;
   {
     ProfScope ps(c, VPIN_K_MSM, 32.0 * (double)(nrows * R), VPIN_K_MSM_ROWS);
     static const int env_pad = [] { const char* e = getenv("VPIN_MSM_LDS_PAD"); return e ? atoi(e) : -1; }();
     const unsigned pad = env_pad >= 0 ? (unsigned)env_pad : (c->shared_device ? kSharedPad : 0u);
+    if (n_strip) {
+      const unsigned groups = (unsigned)((n_strip + kMsmBlock - 1) / kMsmBlock);
+      hipLaunchKernelGGL(msm_strip_kernel, dim3(groups * (unsigned)S), dim3(kMsmBlock), pad, c->stream, zbase, R, R, view(g), hr,
+                         (const uint32_t*)dlist.p, (const uint32_t*)dlist.p + nrows, S, row0, row_step, z_compact, (ge_ext*)dsparts.p);
+    }
     if (msm_ten_limbs())
       hipLaunchKernelGGL(msm_rows_hot_kernel<true>, dim3((unsigned)nrows, (unsigned)chunks), dim3(kMsmBlock), pad, c->stream, zbase,
-                         R, R, view(g), hr, chunks > 1 ? (ge_ext*)dparts.p : (ge_ext*)dpts.p, row0, row_step, z_compact);
+                         R, R, view(g), hr, chunks > 1 ? (ge_ext*)dparts.p : (ge_ext*)dpts.p, row0, row_step, z_compact, d_flag);
     else
       hipLaunchKernelGGL(msm_rows_hot_kernel<false>, dim3((unsigned)nrows, (unsigned)chunks), dim3(kMsmBlock), pad, c->stream, zbase,
-                         R, R, view(g), hr, chunks > 1 ? (ge_ext*)dparts.p : (ge_ext*)dpts.p, row0, row_step, z_compact);
+                         R, R, view(g), hr, chunks > 1 ? (ge_ext*)dparts.p : (ge_ext*)dpts.p, row0, row_step, z_compact, d_flag);
     if (chunks > 1)
       hipLaunchKernelGGL(ge_sum_chunks_kernel, dim3((unsigned)((nrows + 63) / 64)), dim3(64), 0, c->stream, (const ge_ext*)dparts.p, nrows,
                          chunks, (ge_ext*)dpts.p);
+    if (n_strip)
+      hipLaunchKernelGGL(strip_combine_kernel, dim3((n_strip + 63) / 64), dim3(64), 0, c->stream, (const ge_ext*)dsparts.p,
+                         (const uint32_t*)dlist.p, (const uint32_t*)dlist.p + nrows, S, (ge_ext*)dpts.p);
   }
   hipLaunchKernelGGL(ge_compress_kernel, dim3((unsigned)((nrows + 63) / 64)), dim3(64), 0, c->stream, (const ge_ext*)dpts.p, nrows,
                      (fp*)dout.p, (fp*)nullptr);

@@ -789,6 +789,25 @@ int vpin_sat_prove_resident(vpin_ctx* c, const vpin_r1cs_dev* dinst, const vpin_
                                                                comm_input_out, inst_evals_out, rx_out, ry_out, nullptr, nullptr));
 }
 
+// my_dense_mlpoly_commit (vPIN_proof_generation/src/commit_test.rs:27-57) as proof_point_{add,mult}.rs:58-59 call it
+int vpin_dense_mlpoly_commit_sum(vpin_ctx* c, const vpin_table* vars, const uint8_t seed_commit64[64], uint8_t* out_compressed) {
+  if (!c || !vars || !vars->d || !seed_commit64 || !out_compressed) return VPIN_EINVAL;
+  const size_t nv = vars->len;
+  if (!vpin::is_pow2(nv) || nv < 2) return VPIN_ESHAPE;
+  (void)hipSetDevice(c->device);
+  SatGens* sg = nullptr;
+  int rc = get_gens(c, nv, &sg);
+  if (rc) return rc;
+  const size_t L = sg->L, R = sg->R;
+  const uint8_t two = 2;
+  Transcript tape1 = make_tape(&two, 1, seed_commit64);                       // RandomTape::new(&[2u8]), proof_point_mult.rs:44
+  std::vector<Fq> blind_para = tape1.challenge_vector("poly_blinds", L);     // the blinds of the two commitments before it
+  std::vector<Fq> blind_input = tape1.challenge_vector("poly_blinds", L);
+  std::vector<Fq> blind_sum(L);
+  for (size_t i = 0; i < L; i++) blind_sum[i] = blind_para[i] + blind_input[i];  // commit_test.rs:42-46
+  return vpin_hyrax_commit(c, sg->dev, vars, B(blind_sum.data()), L, R + 1, out_compressed);  // commit_inner(&blinds, &gens.gens.gens_n)
+}
+
 int vpin_sat_prove(vpin_ctx* c, const vpin_r1cs* inst, const uint8_t* vars_para, const uint8_t* vars_input,
                    const uint8_t* vars, const uint8_t* inputs, const uint8_t seed_commit64[64],
                    const uint8_t seed_proof64[64], uint8_t* proof_out, size_t proof_cap, size_t* proof_len,

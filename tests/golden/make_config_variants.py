@@ -1,0 +1,129 @@
+"""More than one transcript per configuration -> tests/golden/config_variants.json.
+
+    python tests/golden/make_config_variants.py            # every case below (about ten minutes of the oracle on 8 cores)
+
+tests/golden/config_digests.json pins every instance of every BASELINE configuration under ONE seed pair and on
+satisfied witnesses.  This file adds, through the same chain (synthetic inputs -> tests/gadgets_model.py -> oracle/):
+
+  seeds     conv f=3 and CNN A (both gadgets) under two more (seed_commit, seed_proof) pairs: other blinds, other
+            challenges, other round polynomials from the first transcript byte on;
+  unsat     witnesses that do NOT satisfy their instance, at configuration size -- the reference's prover does not check
+            (is_sat is an assert of the gadget builders, point_mult.rs:650-651), a proof comes out, and the leading-
+            coefficient shortcut of the device's phase-1 rounds must step aside:
+              * built from inputs (device path): a point addition with R == P and a point multiplication of a point with
+                y == 0 -- the gadgets' inverse-of-zero convention (Scalar::invert(0) = 0) breaks `c * (Rx - Px) = 1`
+                resp. `c * 2Py = 1`;
+              * an assignment entry changed after synthesis (host-buffer path), conv f=3 and CNN A's 2^20-constraint instance;
+  rz_heavy  conv f=7's point additions with 86 of 96 accumulators at infinity (rz = 1 fraction 86/96), the
+            `t2 = px * rz` / `(1 - rz)` branches of the gadget carrying the result.
+"""
+import hashlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(HERE))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+
+import make_config_golden as MG  # noqa: E402
+
+OUT = os.path.join(HERE, "config_variants.json")
+
+SEED_PAIRS = {
+    "s1": (bytes((13 * i + 1) % 256 for i in range(64)), bytes((31 * i + 7) % 256 for i in range(64))),
+    "s2": (hashlib.sha512(b"vpin seed_commit 2").digest(), hashlib.sha512(b"vpin seed_proof 2").digest()),
+}
+
+
+def variant_inputs(name):
+    """-> (kind, witness inputs, host-side tamper or None): the ONE definition the tests rebuild their inputs from"""
+    from vpin_amd import gadgets as G
+    if name in ("3_32-add#RequalsP", ):
+        px, py, rx, ry, rz = G.synthetic_add_inputs("3_32")
+        rx[5], ry[5], rz[5] = px[5], py[5], 0          # R == P: the chord's denominator vanishes
+        return "add", (px, py, rx, ry, rz), None
+    if name == "3_32-mult#yzero":
+        w, x, y = G.synthetic_mult_inputs("3_32")
+        y[2] = 0                                        # the doubling's denominator 2Py vanishes in the first step
+        w = list(w)
+        w[2] = 5
+        return "mult", (w, x, y), None
+    if name == "7_256-add#rz86":
+        px, py, rx, ry, rz = G.synthetic_add_inputs("7_256")
+        idx = [i for i in range(96) if i % 10 != 9][:86]
+        for i in idx:
+            rz[i] = 1
+            rx[i] = 0
+            ry[i] = 0
+        assert int(rz.sum()) == 86
+        return "add", (px, py, rx, ry, rz), None
+    label, rest = name.split("-", 1)
+    kind, tag = rest.split("#")
+    inp = G.synthetic_mult_inputs(label) if kind == "mult" else G.synthetic_add_inputs(label)
+    if tag == "tampered":
+        # one entry of the assignment changed after synthesis: position = a third of the way into the unpadded variables
+        return kind, inp, "third"
+    return kind, inp, None
+
+
+def tamper(inst):
+    """vars_input[k] += 1 and vars[k] += 1 (vars = para + input stays consistent), k = num_vars_unpadded // 3"""
+    import pymodel as M
+    k = inst["num_vars_unpadded"] // 3
+    for key in ("vars_input", "vars"):
+        tab = np.array(inst[key], dtype=np.uint64).reshape(-1, 4)
+        v = (M.from_mont_limbs(tab[k]) + 1) % M.Q
+        tab[k] = M.to_mont_limbs(v)
+        inst[key] = tab
+    return k
+
+
+CASES = [(f"{lab}-{kind}#{s}", s) for lab in ("3_32", "A") for kind in ("add", "mult") for s in SEED_PAIRS] + [
+    ("3_32-add#RequalsP", None), ("3_32-mult#yzero", None), ("3_32-mult#tampered", None), ("3_32-add#tampered", None),
+    ("A-mult#tampered", None), ("7_256-add#rz86", None)]
+
+
+def one(name, seed_key):
+    import oracle_lib as O
+    t0 = time.time()
+    kind, inp, tam = variant_inputs(name)
+    inst = MG.model_instance(kind, inp)
+    tam_at = tamper(inst) if tam else None
+    sc, sp = SEED_PAIRS[seed_key] if seed_key else (MG.SEED_C, MG.SEED_P)
+    t1 = time.time()
+    res = O.snark_prove(inst, sc, sp, threads=os.cpu_count() or 1)
+    sat = O.is_sat(inst) if hasattr(O, "is_sat") else None
+    ok = O.snark_verify(inst, res)
+    ent = {"kind": kind, "ops": len(inp[0]), "num_cons": inst["num_cons"], "num_vars": inst["num_vars"],
+           "seed_commit_hex": sc.hex(), "seed_proof_hex": sp.hex(), "inputs_sha256": MG.inputs_digest(kind, inp),
+           "tampered_at": tam_at, "oracle_is_sat": sat, "oracle_verifier_accepts": int(ok),
+           "snark_len": len(res["proof"]), "snark_sha256": hashlib.sha256(res["proof"]).hexdigest(),
+           "comm_sha256": hashlib.sha256(res["comm"]).hexdigest(),
+           "comm_para_sha256": hashlib.sha256(res["comm_para"].tobytes()).hexdigest(),
+           "comm_input_sha256": hashlib.sha256(res["comm_input"].tobytes()).hexdigest(),
+           "oracle_s": round(time.time() - t1, 1), "model_s": round(t1 - t0, 1)}
+    print(name, json.dumps(ent), flush=True)
+    return ent
+
+
+def main():
+    doc = {"_source": "tests/golden/make_config_variants.py: oracle/ on instances built by tests/gadgets_model.py; see its docstring",
+           "cases": {}}
+    only = sys.argv[1:]
+    if only and os.path.exists(OUT):
+        doc = json.load(open(OUT))
+    for name, s in CASES:
+        if only and name not in only:
+            continue
+        doc["cases"][name] = one(name, s)
+        with open(OUT, "w") as f:
+            json.dump(doc, f, indent=1, sort_keys=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,92 @@
+"""More than one transcript per configuration (tests/golden/config_variants.json <- tests/golden/make_config_variants.py):
+two more seed pairs for conv f=3 and CNN A, unsatisfied witnesses at configuration size (built from inputs on the device,
+and tampered after synthesis through the host-buffer entry), conv f=7's point additions with 86 of 96 accumulators at
+infinity.  Every case: the library's SNARK, computation commitment and witness commitments hash to the oracle's."""
+import hashlib
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+import make_config_variants as MV  # noqa: E402  (the ONE definition of the variant inputs; nothing of it runs the oracle here)
+
+with open(os.path.join(HERE, "golden", "config_variants.json")) as f:
+    GOLD = json.load(f)["cases"]
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import vpin_amd
+    c = vpin_amd.Context(0)
+    yield c
+    c.close()
+
+
+def check(got, g, name):
+    assert len(got["proof"]) == g["snark_len"], name
+    assert hashlib.sha256(got["comm"]).hexdigest() == g["comm_sha256"], name + ": computation commitment"
+    assert hashlib.sha256(got["comm_para"].tobytes()).hexdigest() == g["comm_para_sha256"], name + ": comm_para"
+    assert hashlib.sha256(got["comm_input"].tobytes()).hexdigest() == g["comm_input_sha256"], name + ": comm_input"
+    assert hashlib.sha256(got["proof"]).hexdigest() == g["snark_sha256"], name + ": SNARK bytes"
+
+
+def test_fixture_covers_the_asked_cases():
+    names = set(GOLD)
+    assert {f"{lab}-{kind}#{s}" for lab in ("3_32", "A") for kind in ("add", "mult") for s in ("s1", "s2")} <= names
+    assert {"3_32-add#RequalsP", "3_32-mult#yzero", "3_32-mult#tampered", "3_32-add#tampered", "A-mult#tampered", "7_256-add#rz86"} <= names
+    for n in ("3_32-add#RequalsP", "3_32-mult#yzero", "3_32-mult#tampered", "3_32-add#tampered", "A-mult#tampered"):
+        assert GOLD[n]["oracle_is_sat"] == 0 and GOLD[n]["oracle_verifier_accepts"] == 0, n   # unsatisfied, and no verifier is fooled
+    assert GOLD["7_256-add#rz86"]["oracle_is_sat"] == 1
+
+
+def test_oracle_reproduces_the_small_variants():
+    """CPU: the committed digests are what the oracle gives today (conv f=3 sizes)"""
+    import oracle_lib as O
+    for name in ("3_32-add#s2", "3_32-add#RequalsP", "3_32-add#tampered", "7_256-add#rz86"):
+        g = GOLD[name]
+        kind, inp, tam = MV.variant_inputs(name)
+        assert MV.MG.inputs_digest(kind, inp) == g["inputs_sha256"]
+        inst = MV.MG.model_instance(kind, inp)
+        if tam:
+            assert MV.tamper(inst) == g["tampered_at"]
+        res = O.snark_prove(inst, bytes.fromhex(g["seed_commit_hex"]), bytes.fromhex(g["seed_proof_hex"]), threads=4)
+        check(res, g, name)
+        assert O.is_sat(inst) == g["oracle_is_sat"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(n for n in GOLD if not n.endswith("#tampered")))
+def test_device_built_variants_match_the_oracle(ctx, name):
+    g = GOLD[name]
+    kind, inp, _ = MV.variant_inputs(name)
+    assert MV.MG.inputs_digest(kind, inp) == g["inputs_sha256"]
+    d = ctx.gadget_point_mult_dev(*inp) if kind == "mult" else ctx.gadget_point_add_dev(*inp)
+    try:
+        assert d.is_sat() == bool(g["oracle_is_sat"])
+        got = d.snark_prove(bytes.fromhex(g["seed_commit_hex"]), bytes.fromhex(g["seed_proof_hex"]))
+        meta = {"inputs": d.inputs, "num_inputs": d.num_inputs}
+    finally:
+        d.free()
+    check(got, g, name)
+    assert ctx.snark_verify(meta, got) == bool(g["oracle_verifier_accepts"])  # the product's verifier: same verdict as the oracle's
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(n for n in GOLD if n.endswith("#tampered")))
+def test_tampered_assignments_through_the_host_buffer_entry(ctx, name):
+    """an assignment that does not satisfy the instance, proven through vpin_snark_prove (host buffers): the prover does not
+    check satisfiability (neither does the reference's), the bytes are the oracle's, the verifier rejects"""
+    from vpin_amd import gadgets as G
+    g = GOLD[name]
+    kind, inp, _ = MV.variant_inputs(name)
+    inst = G.point_mult(*inp) if kind == "mult" else G.point_add(*inp)
+    d = inst.as_dict()
+    inst.free()
+    assert MV.tamper(d) == g["tampered_at"]
+    got = ctx.snark_prove(d, bytes.fromhex(g["seed_commit_hex"]), bytes.fromhex(g["seed_proof_hex"]))
+    check(got, g, name)
+    assert not ctx.snark_verify({"inputs": d["inputs"], "num_inputs": d["num_inputs"]}, got)

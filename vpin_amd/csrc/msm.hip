@@ -1456,7 +1456,13 @@ int hyrax_commit_derefs_hot(vpin_ctx* c, const vpin_gens* g, const vpin_table* Z
   int S = env_strip > 0 ? env_strip : 16;
   DevBuf dflag(c), dlist(c), dsparts(c);
   uint32_t n_strip = 0;
-  if (env_strip != 0 && msm_ten_limbs() && nrows >= min_rows && R >= min_R && R <= g->split && S % 8 == 0 && (size_t)S <= R / 8) {
+  // Not on a shared device (vpin_ctx_set_shared_device: other contexts prove at the same time and the row kernels run one
+  // workgroup per CU): with a single wave per SIMD nothing hides the strip kernel's per-generator chain scalar load ->
+  // Montgomery conversion -> first gather, and its workgroups no longer step together: the default LeNet step of bench.py
+  // measured 469-473 ms with it against 438-442 ms without (profiles/r04_ab_strip.txt), while the 2^25 instance proven alone
+  // gains (313 -> 303 ms).  VPIN_MSM_STRIP > 0 forces it (A/B runs).
+  if (env_strip != 0 && (env_strip > 0 || !c->shared_device) && msm_ten_limbs() && nrows >= min_rows && R >= min_R && R <= g->split &&
+      S % 8 == 0 && (size_t)S <= R / 8) {
     if (dflag.alloc(nrows) || dlist.alloc((nrows + 1) * sizeof(uint32_t))) return VPIN_ENOMEM;
     uint32_t* d_list = (uint32_t*)dlist.p;
     uint32_t* d_count = d_list + nrows;
@@ -1466,19 +1472,6 @@ int hyrax_commit_derefs_hot(vpin_ctx* c, const vpin_gens* g, const vpin_table* Z
     VPIN_HIP_TRY(hipMemcpyAsync(&n_strip, d_count, sizeof n_strip, hipMemcpyDeviceToHost, c->stream));
     VPIN_HIP_TRY(hipStreamSynchronize(c->stream));
     if (n_strip < min_list) n_strip = 0;  // too few rows to share a block's fetch: the row kernel takes everything
-    if (n_strip && env_strip < 0) {
-      // Strip count: groups x S workgroups should fill the chip's workgroup slots in whole rounds (9480 rows = 38 groups: 16
-      // strips are 608 workgroups for 768 slots, a fifth of the chip idle; 40 strips are two rounds of 760), S a multiple of 8
-      // so that a strip's workgroups share an XCD, strips of at least 128 generators.
-      const size_t groups = (n_strip + kMsmBlock - 1) / kMsmBlock;
-      const size_t slots = (size_t)c->num_cus * (c->shared_device ? 1 : 3);
-      double best = 0.0;
-      for (int cand = 8; cand <= 64 && (size_t)cand * 128 <= R; cand += 8) {
-        const size_t wgs = groups * (size_t)cand, rounds = (wgs + slots - 1) / slots;
-        const double fill = (double)wgs / (double)(rounds * slots) - 0.002 * (double)rounds;  // ties: fewer rounds (more rows in step)
-        if (fill > best) { best = fill; S = cand; }
-      }
-    }
     if (n_strip && dsparts.alloc((size_t)n_strip * (size_t)S * sizeof(ge_ext))) return VPIN_ENOMEM;
   }
   const uint8_t* d_flag = n_strip ? (const uint8_t*)dflag.p : nullptr;

@@ -1049,6 +1049,7 @@ struct TailArgs {
   const uint32_t* abort_flag;
   uint32_t seq0;           // round j publishes / waits for seq0 + (j - j0) + 1
   unsigned long long* trace;  // VPIN_TAIL_TRACE: pinned, per round {start, published, reply seen, -} in 100 MHz ticks (instance 0)
+  uint32_t poll_sleep;        // VPIN_TAIL_SLEEP=1: s_sleep between two polls of the mailbox (A/B of what the polling wave costs its CU)
 };
 
 constexpr int kTailBlock = 512;
@@ -1214,6 +1215,7 @@ __global__ __launch_bounds__(kTailBlock) void spark_tail_kernel(TailArgs a) {
         // pieces only once the first carries the round's sequence number
         u32x4 c0 = load16_system(a.down), c1, c2;
         if (c0.x != seq) {
+          if (a.poll_sleep) __builtin_amdgcn_s_sleep(16);  // ~1024 cycles off the SIMD's arbiter
           if ((spin & 15) == 15 && __hip_atomic_load(a.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) break;
           continue;
         }
@@ -1268,6 +1270,8 @@ int spark_tail_launch(vpin_ctx* c, const SparkForest* f, int level, int k, int j
   a.abort_flag = w; a.down = w + 16;
   w[0] = 0;
   a.seq0 = c->tail_seq;
+  static const uint32_t poll_sleep = getenv("VPIN_TAIL_SLEEP") ? 1u : 0u;
+  a.poll_sleep = poll_sleep;
   static const bool trace_on = getenv("VPIN_TAIL_TRACE") != nullptr;
   a.trace = trace_on ? reinterpret_cast<unsigned long long*>(c->h_spark + kTailTrace) : nullptr;
   if (trace_on) memset(c->h_spark + kTailTrace, 0, 64 * 32);

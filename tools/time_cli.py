@@ -38,6 +38,25 @@ def main():
     labels = [a for a in sys.argv[1:] if not a.startswith("--")] or ["A"]
     from vpin_amd import gadgets as G
     binp = os.path.join(ROOT, "vpin_amd", "bin", "vpin_prove")
+    if "--one-process" in sys.argv:
+        # vpin_prove <label> <label> ...: every label in ONE process (script.sh:205-211 starts one per label)
+        import re
+        with tempfile.TemporaryDirectory() as d:
+            for lab in labels:
+                G.write_witness_files(d, lab)
+            if "--scrub" in sys.argv:
+                scrub()
+            t0 = time.perf_counter()
+            r = subprocess.run([binp, *labels, "--seed", "00112233445566778899aabbccddeeff"], cwd=d, capture_output=True, text=True,
+                               env=dict(os.environ, VPIN_CLI_TRACE="1"))
+            wall = time.perf_counter() - t0
+            print(r.stdout)
+            print(r.stderr)
+            gen = [int(x) for x in re.findall(r"Total proof generation time: (\d+) ms", r.stdout)]
+            ver = [int(x) for x in re.findall(r"Total proof verification time: (\d+) ms", r.stdout)]
+            print(f"== one process, labels {labels}: exit {r.returncode}, process wall {wall:.2f} s; "
+                  f"'Total proof generation time' summed over the labels {sum(gen)} ms {gen}, verification {sum(ver)} ms", flush=True)
+        return
     with tempfile.TemporaryDirectory() as d:
         for lab in labels:
             # VRAM freed by an earlier process is wiped by the driver before it can be allocated again (~30 GB/s);

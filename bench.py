@@ -84,6 +84,9 @@ def parse():
                          "instead of finishing every step before the next starts (measured: 3 %% faster, +15 GB of pooled memory)")
     ap.add_argument("--concurrent", default=None, help="K or K1,K2,..: K independent copies of the (small) trace proven at once on one "
                     "GPU, one context each; reports traces/s and constraints/s at every K beside the single-trace latency")
+    ap.add_argument("--gate", type=int, default=int(os.environ.get("VPIN_BENCH_GATE", "1")), choices=[1, 2, 3],
+                    help="when the other lanes start: 1 = the largest instance's phase-1 sum-check is done (its MSMs then share every CU "
+                         "with them), 2 = its derefs commitment is done, 3 = it is proven; with 2 and 3 it runs on an exclusive context until then")
     ap.add_argument("--no-span", action="store_true", help="skip the reference-span pass after the timed region")
     ap.add_argument("--no-strong", action="store_true", help="N > 1: skip the strong-scaling sub-record (one trace over all ranks)")
     ap.add_argument("--only", choices=["mult", "add"], default=None, help="keep only the point-mult / point-add instances of the trace")
@@ -272,19 +275,43 @@ def main_concurrent(args):
     traces at once.  Reports the single-trace latency and, per K, the sustained constraints/s and the latency of a trace under
     that load.  One GPU."""
     import hashlib
-    import vpin_amd
     trace, work = _strong_work(args)
     total_cons = sum(w[3] for w in work)
     ks = sorted({int(x) for x in str(args.concurrent).split(",") if int(x) > 0})
-    kmax = max(ks)
+    if len(ks) > 1:
+        # One K per PROCESS: memory a context frees is wiped lazily by the driver and slows the next context's allocations
+        # (DESIGN.md section 3), and idle contexts' streams share the hardware queues of the busy ones -- a sweep inside one
+        # process measured K = 8 at 1.0x of the single-trace rate where a fresh process gives 3x.  This parent never touches
+        # the GPU; it starts one child per K, one after the other, and merges their lines.
+        import subprocess
+        rows, single, oks, envs = [], None, [], {}
+        for K in ks:
+            cmd = [sys.executable, os.path.abspath(__file__), "--trace", trace, "--concurrent", str(K), "--steps", str(args.steps),
+                   "--warmup", str(args.warmup)] + (["--only", args.only] if args.only else [])
+            out = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+            if out.returncode != 0:
+                raise SystemExit(f"--concurrent {K}: child failed\n{out.stderr[-2000:]}")
+            d = json.loads(out.stdout.strip().splitlines()[-1])
+            rows += d["concurrent"]
+            single = single or d["single_trace"]
+            oks.append(d["bytes_equal_oracle_digest"])
+            envs[K] = {"host_threads_per_context": d["host_threads_per_context"], "GPU_MAX_HW_QUEUES": d["GPU_MAX_HW_QUEUES"]}
+        best = max(rows, key=lambda r: r["constraints_per_s"])
+        d.update({"value": best["constraints_per_s"], "ms_per_step": best["ms_per_trace_under_load"], "single_trace": single, "concurrent": rows,
+                  "bytes_equal_oracle_digest": all(oks), "per_K_environment": envs})
+        d["config"]["workload"] = f"vPIN trace '{trace}' x K concurrent copies on one GPU (K contexts / streams / host threads; a fresh process per K), best K = {best['K']}"
+        print(json.dumps(d))
+        return
+    import vpin_amd
+    K = ks[0]
     gold = _golden_digests()
-    ctxs = [vpin_amd.Context(0) for _ in range(kmax)]
-    if kmax > 1:
+    order = [w[0] for w in sorted(work, key=lambda w: -w[3])]
+    ctxs = [vpin_amd.Context(0) for _ in range(K)]
+    if K > 1:
         for cx in ctxs:
             cx.set_shared_device(True)
     built = [{w[0]: _build_resident(cx, w) for w in work} for cx in ctxs]
-    order = [w[0] for w in sorted(work, key=lambda w: -w[3])]
-    ok = {}
+    ok, rows = {}, []
 
     def run_trace(k, n):
         for _ in range(n):
@@ -294,20 +321,18 @@ def main_concurrent(args):
 
     run_trace(0, args.warmup)
     t0 = time.perf_counter()
-    run_trace(0, args.steps)
+    run_trace(0, args.steps)   # the single-trace latency: one context busy, the others idle
     single_s = (time.perf_counter() - t0) / args.steps
-    rows = []
-    for K in ks:
-        th = [threading.Thread(target=run_trace, args=(k, 1)) for k in range(K)]   # warm every context
-        [t.start() for t in th]
-        [t.join() for t in th]
-        th = [threading.Thread(target=run_trace, args=(k, args.steps)) for k in range(K)]
-        t0 = time.perf_counter()
-        [t.start() for t in th]
-        [t.join() for t in th]
-        el = time.perf_counter() - t0
-        rows.append({"K": K, "traces_per_s": K * args.steps / el, "constraints_per_s": K * args.steps * total_cons / el,
-                     "ms_per_trace_under_load": el / args.steps * 1e3, "x_single_trace_rate": (K * args.steps / el) * single_s})
+    th = [threading.Thread(target=run_trace, args=(k, args.warmup)) for k in range(K)]   # warm every context
+    [t.start() for t in th]
+    [t.join() for t in th]
+    th = [threading.Thread(target=run_trace, args=(k, args.steps)) for k in range(K)]
+    t0 = time.perf_counter()
+    [t.start() for t in th]
+    [t.join() for t in th]
+    el = time.perf_counter() - t0
+    rows.append({"K": K, "traces_per_s": K * args.steps / el, "constraints_per_s": K * args.steps * total_cons / el,
+                 "ms_per_trace_under_load": el / args.steps * 1e3, "x_single_trace_rate": (K * args.steps / el) * single_s})
     best = max(rows, key=lambda r: r["constraints_per_s"])
     print(json.dumps({
         "metric": "R1CS constraints/sec, whole Spartan SNARK (sat proof + SPARK evaluation proof; vPIN point-mult + point-add instances)",
@@ -318,12 +343,8 @@ def main_concurrent(args):
                    "constraints_unpadded_per_trace": total_cons, "inputs": "resident in HBM"},
         "single_trace": {"ms": single_s * 1e3, "constraints_per_s": total_cons / single_s},
         "concurrent": rows,
-        "bytes_equal_oracle_digest": all(ok.values()), "host_threads": os.cpu_count()}))
-    for k, cx in enumerate(ctxs):
-        for g, dec in built[k].values():
-            dec.free()
-            g.free()
-        cx.close()
+        "bytes_equal_oracle_digest": all(ok.values()), "host_cores": os.cpu_count(),
+        "host_threads_per_context": os.environ.get("VPIN_HOST_THREADS"), "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES")}))
 
 
 def _golden_digests():
@@ -523,9 +544,16 @@ def main():
     if args.scaling == "strong":
         return main_strong(args)
     if args.concurrent:
-        if "VPIN_HOST_THREADS" not in os.environ:  # K proving threads share the host's cores
-            kmax = max(int(x) for x in str(args.concurrent).split(","))
-            os.environ["VPIN_HOST_THREADS"] = str(max(1, min(8, (os.cpu_count() or 8) // max(1, kmax))))
+        ks = [int(x) for x in str(args.concurrent).split(",")]
+        if len(ks) == 1:  # (a sweep's parent only starts children)
+            if "VPIN_HOST_THREADS" not in os.environ:
+                # K proving threads share the host's cores; a one-GPU box gets 16 of them whatever os.cpu_count() says, and
+                # 8 contexts x 8 OpenMP threads on 16 cores measured 1.0x of the single-trace rate where 8 x 2 gives 3x
+                cores = min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 8))
+                os.environ["VPIN_HOST_THREADS"] = str(max(1, min(4, cores // max(1, ks[0]))))
+            # one hardware queue per stream: with the runtime's default of 4, streams 5.. share a queue with another stream and a
+            # resident round kernel of one proof holds up the other's launches
+            os.environ.setdefault("GPU_MAX_HW_QUEUES", str(max(4, min(24, ks[0]))))
         return main_concurrent(args)
     args.snark = not args.sat_only and not args.host_buffers
     import torch
@@ -672,9 +700,15 @@ def main():
             progress[0] = 0
             gate = threading.Event()
 
+            if args.gate > 1:
+                ctxs[0].set_shared_device(False)  # the largest instance has the chip to itself until the gate opens
+
             def watch():
-                while progress[0] == 0 and not gate.is_set():
+                while progress[0] < min(args.gate, 2) and not gate.is_set():
                     time.sleep(0.0005)
+                if args.gate == 3:   # ... until the largest instance is proven
+                    gate.wait()
+                ctxs[0].set_shared_device(True)
                 gate.set()
             ts = [threading.Thread(target=run_lane, args=(li, gate)) for li in range(1, len(lanes))] + [threading.Thread(target=watch)]
             for t in ts:
@@ -827,7 +861,7 @@ def main():
         achieved = k["alg_bytes"] / (k["ms"] * 1e-3) / 1e9
         traffic = args.pmc_traffic
         pmc_all, pmc_l5 = {}, {}
-        for pmc in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):  # separate rocprofv3 --pmc passes, see the file's _how
+        for pmc in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):  # separate rocprofv3 --pmc passes, see the file's _how
             pth = os.path.join(ROOT, "profiles", pmc)
             if os.path.exists(pth):
                 with open(pth) as f:
@@ -945,7 +979,7 @@ def main():
             # addition on a register-resident dependent chain at the kernel's occupancy, no table loads, no digit logic
             # (tools/ubench_fpmul -> profiles/r03_ubench_fpmul.txt, its JSON line).
             isa, chain = {}, {}
-            for nm in ("r03_isa_counts.json", "r02_isa_counts.json"):
+            for nm in ("r04_isa_counts.json", "r03_isa_counts.json", "r02_isa_counts.json"):
                 pth = os.path.join(ROOT, "profiles", nm)
                 if os.path.exists(pth):
                     with open(pth) as f:
@@ -958,6 +992,21 @@ def main():
                             chain = json.loads(ln[5:])
             except OSError:
                 pass
+            # (3) round 4: what the chip sustains under each instruction mix -- sclk and socket power sampled from the card's hwmon
+            # files while the loop runs (tools/ubench_msm_variants -> profiles/r04_ubench_msm_variants.txt)
+            power = {}
+            try:
+                with open(os.path.join(ROOT, "profiles", "r04_ubench_msm_variants.txt")) as f:
+                    for ln in f:
+                        if ln.startswith("JSON "):
+                            uj = json.loads(ln[5:])
+                            pick = lambda k: {kk: uj[k][kk] for kk in ("G_per_s", "sclk_mhz", "watts")} if k in uj else None
+                            power = {"point_addition_on_registers": pick("point addition, extended + affine entry (ref)"),
+                                     "with_the_table_walk_gathers_shipped_layout": pick("walk [w][j][d], 96 B, prefetch 1 (shipped layout)"),
+                                     "row_per_lane_walk": pick("walk ROW PER LANE (same (w,j) chip-wide), 96 B"),
+                                     "source": "profiles/r04_ubench_msm_variants.txt (replayed; measured by tools/ubench_msm_variants, not in this run)"}
+            except (OSError, ValueError):
+                pass
             m = st.get("msm_rows")
             if m and m["ms"] > 0 and m["units"] > 0:
                 ipa = isa.get("msm_rows_kernel", {}).get("valu_per_table_add", 1850)
@@ -965,7 +1014,10 @@ def main():
                 adds_s = m["units"] / (m["ms"] * 1e-3)
                 pm = pmc_l5.get("msm_rows_kernel (>= 1 GB fetched)", {})
                 sec.append({"kernel": "msm_rows_kernel (row commitments of >= 128 rows: witness, derefs, SNARK::encode shapes)",
-                            "bound": "valu-issue", "achieved": adds_s / 1e9, "peak": peak_adds / 1e9, "unit": "G table adds/s",
+                            "bound": "valu-issue", "limiter": "socket power: the walk's 96-byte gathers out of a 71 GB table push the card to its "
+                            "~1.39 kW cap and the clock to ~1.8 GHz; the same additions without gathers run at 2.39 GHz (power)",
+                            "power": power,
+                            "achieved": adds_s / 1e9, "peak": peak_adds / 1e9, "unit": "G table adds/s",
                             "frac": adds_s / peak_adds, "launches": m["launches"], "ms": round(m["ms"], 3),
                             "table_adds": m["units"], "valu_instructions_per_add": ipa,
                             "frac_of_measured_chain": (adds_s / 1e9 / chain["point_adds_Gps_10x25"]) if chain.get("point_adds_Gps_10x25") else None,

@@ -57,8 +57,9 @@ void vpin_ctx_destroy(vpin_ctx* ctx);
 /* hipStream_t the ctx launches on (as void*), for callers that time with HIP events */
 void* vpin_ctx_stream(vpin_ctx* ctx);
 /* Optional progress word in host memory: a proof stores 1 to it when its phase-1 sum-check is over (and again
- * when the whole sat part is), so that a caller running other proofs on other contexts can hold them back while
- * the phase-1 kernels of this one are being timed.  NULL clears it. */
+ * when the whole sat part is) and 2 when its derefs commitment -- the largest MSM of a SNARK -- is done, so that a
+ * caller running other proofs on other contexts can hold them back while the phase-1 kernels of this one are being
+ * timed, or until its power-bound MSM has had the chip to itself.  NULL clears it. */
 int vpin_ctx_set_progress_flag(vpin_ctx* ctx, int* flag);
 /* Several contexts prove on this device at the same time (a service, bench.py's lanes): the long VALU-bound row-commitment
  * kernels of this context then run ONE workgroup per CU instead of three (a wave per SIMD), so that a large instance's

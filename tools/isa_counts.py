@@ -71,7 +71,7 @@ def main():
     big = max(ls, key=lambda l: l["valu"])
     res["prod_round_kernel<true, true>"] = {"valu_per_pair": big["valu"], "v_mad_u64_u32_per_pair": big["v_mad_u64_u32"],
                                             "loads_per_pair": big["vmem_loads"], "stores_per_pair": big["vmem_stores"]}
-    out = os.path.join(ROOT, "profiles", "r03_isa_counts.json")
+    out = os.path.join(ROOT, "profiles", os.environ.get("VPIN_ISA_OUT", "r04_isa_counts.json"))
     with open(out, "w") as f:
         json.dump(res, f, indent=1)
     print(json.dumps(res, indent=1))

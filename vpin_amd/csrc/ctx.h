@@ -100,7 +100,7 @@ struct vpin_ctx {
   uint32_t bullet_seq = 0;   // sequence number of the last fused bullet round (mailbox_dev.h)
   // one proof over several GPUs (include/vpin_hip.h, vpin_ctx_set_comm): proofs on this context are collective calls
   vpin_comm* comm = nullptr;
-  volatile int* progress_flag = nullptr;  // optional host word: set to 1 when a SNARK's sat part is done
+  volatile int* progress_flag = nullptr;  // optional host word: 1 when a SNARK's sat part is done, 2 after its derefs commitment
 };
 
 namespace vpin {

@@ -976,6 +976,7 @@ static int spark_prove(vpin_ctx* c, const vpin_spark_decomm* d, const std::vecto
   append_polycomm(tr, "comm_poly_row_col_ops_val", comm_derefs);
   tr.append_message("derefs_commitment", "end_derefs_commitment");
   g_spark_timings[1] = secs(t0, Clock::now());
+  if (c->progress_flag) *c->progress_flag = 2;  // the proof's largest MSM is done (a scheduler may let other streams in now)
 
   // ---- PolyEvalNetwork::new (sparse_mlpoly.rs:681-696) ----
   t0 = Clock::now();

@@ -538,9 +538,13 @@ def lib_nnz(g):
 def main():
     args = parse()
     world_env = int(os.environ.get("WORLD_SIZE", "1"))
-    if world_env > 1 and "VPIN_HOST_THREADS" not in os.environ:
-        # the library's OpenMP teams (blind terms, generator derivation) are sized per lane; N ranks x 4 lanes share the node's cores
-        os.environ["VPIN_HOST_THREADS"] = str(max(2, min(8, (os.cpu_count() or 8) // (world_env * 4))))
+    if "VPIN_HOST_THREADS" not in os.environ:
+        # The library's OpenMP teams (blind terms of the ZK rounds, generator derivation) are sized per context: 8 threads by
+        # default.  A step runs four lanes (contexts) per rank and a one-GPU box has 16 cores: 4 x 8 threads oversubscribe them
+        # and the lanes' host sections wait for each other -- measured on the default step: 436-443 ms with 8 threads per lane,
+        # 405-408 ms with 2, 3 or 4, 413 ms with 6 (profiles/r04_ab_host_threads.txt).  N ranks share the node's cores.
+        cores = (os.cpu_count() or 16) if world_env > 1 else min(16, os.cpu_count() or 16)
+        os.environ["VPIN_HOST_THREADS"] = str(max(2, min(4, cores // (world_env * 4))))
     if args.scaling == "strong":
         return main_strong(args)
     if args.concurrent:

@@ -640,7 +640,7 @@ __global__ __launch_bounds__(1024) void strip_list_kernel(const uint8_t* __restr
 __global__ __launch_bounds__(kMsmBlock, 3) void msm_strip_kernel(const fq* __restrict__ Z, size_t stride, size_t ncols, TableView tv, HotRows hr,
                                                                   const uint32_t* __restrict__ list, const uint32_t* __restrict__ list_count,
                                                                   int S, size_t row_base, size_t row_step, int z_compact,
-                                                                  ge_ext* __restrict__ parts) {
+                                                                  ge_ext* __restrict__ parts, uint32_t* __restrict__ sync, int lag) {
   const uint32_t n = *list_count;
   const uint32_t s = blockIdx.x % (uint32_t)S, grp = blockIdx.x / (uint32_t)S;
   if (grp * kMsmBlock >= n) return;
@@ -657,13 +657,36 @@ __global__ __launch_bounds__(kMsmBlock, 3) void msm_strip_kernel(const fq* __res
   }
   const size_t per = (ncols + (size_t)S - 1) / (size_t)S, j0 = (size_t)s * per, j1 = j0 + per < ncols ? j0 + per : ncols;
   ge10 acc = ge10_identity();
+  // Keeping a strip's workgroups in step (sync != nullptr): a workgroup counts every generator it has finished, and starts
+  // generator j only when all `groups` workgroups of its strip have finished generator j - lag -- the L2 then holds the few
+  // blocks between the slowest and the fastest workgroup instead of losing them.  All workgroups of the launch are resident
+  // (2 or 3 per CU by construction); should they not be (another stream on the device), the bounded wait gives up and the
+  // workgroup runs on unsynchronised -- the result does not depend on the order.
+  const uint32_t groups = (n + kMsmBlock - 1) / kMsmBlock;
+  uint32_t* my_sync = sync ? sync + (size_t)s * (per + 1) : nullptr;
+  __shared__ int sh_nosync;
+  if (threadIdx.x == 0) sh_nosync = 0;
+  __syncthreads();
   for (size_t j = j0; j < j1; j++) {
+    if (my_sync && j - j0 >= (size_t)lag) {
+      if (threadIdx.x == 0 && !sh_nosync) {
+        long spin = 0;
+        while (__hip_atomic_load(my_sync + (j - j0 - (size_t)lag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < groups)
+          if (++spin > (1L << 22)) { sh_nosync = 1; break; }
+      }
+      __syncthreads();
+    }
     fq v = fq_load(zr + j);
     const bool act = live && !fq_is_zero(v) && !(idx && idx[j] == hot);
-    if (__builtin_amdgcn_ballot_w64(act) == 0) continue;  // nobody in the wave walks this generator
-    fq sc = fq_from_mont(v);
-    if (!act) sc = fq_zero();  // all digits zero: the walk below adds nothing for this lane, in step with its wave-mates
-    table_mul_acc10(acc, sc, tv, j);
+    if (__builtin_amdgcn_ballot_w64(act) != 0) {  // somebody in the wave walks this generator
+      fq sc = fq_from_mont(v);
+      if (!act) sc = fq_zero();  // all digits zero: the walk below adds nothing for this lane, in step with its wave-mates
+      table_mul_acc10(acc, sc, tv, j);
+    }
+    if (my_sync) {
+      __syncthreads();
+      if (threadIdx.x == 0) __hip_atomic_fetch_add(my_sync + (j - j0), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
   if (live) {
     const ge_ext av = ge10_to_ext(acc);
@@ -1454,8 +1477,9 @@ int hyrax_commit_derefs_hot(vpin_ctx* c, const vpin_gens* g, const vpin_table* Z
   const int env_strip = es ? atoi(es) : -1;
   const size_t min_rows = em ? (size_t)atol(em) : 8192, min_list = em ? (size_t)1 : 4096, min_R = em ? (size_t)64 : 4096;
   int S = env_strip > 0 ? env_strip : 16;
-  DevBuf dflag(c), dlist(c), dsparts(c);
+  DevBuf dflag(c), dlist(c), dsparts(c), dsync(c);
   uint32_t n_strip = 0;
+  bool uniform_shape = false;  // every strip workgroup of the launch is resident at once: they may wait for each other
   // Not on a shared device (vpin_ctx_set_shared_device: other contexts prove at the same time and the row kernels run one
   // workgroup per CU): with a single wave per SIMD nothing hides the strip kernel's per-generator chain scalar load ->
   // Montgomery conversion -> first gather, and its workgroups no longer step together: the default LeNet step of bench.py
@@ -1472,6 +1496,31 @@ int hyrax_commit_derefs_hot(vpin_ctx* c, const vpin_gens* g, const vpin_table* Z
     VPIN_HIP_TRY(hipMemcpyAsync(&n_strip, d_count, sizeof n_strip, hipMemcpyDeviceToHost, c->stream));
     VPIN_HIP_TRY(hipStreamSynchronize(c->stream));
     if (n_strip < min_list) n_strip = 0;  // too few rows to share a block's fetch: the row kernel takes everything
+    if (n_strip && env_strip < 0) {
+      // Every CU must run the SAME number of strip workgroups, or the workgroups of a strip drift apart (a CU with two of them
+      // runs each 1.5x faster than a CU with three) and a table block is long evicted from L2 when the slow ones want it: the
+      // PMC pass of the first version (608 workgroups on 768 slots) showed 95 B of L2 misses per addition, more than the row
+      // kernel's 34 B.  The eligible rows beyond the chosen shape go back to the row kernel.
+      // Choose the strips: every eligible row (G = ceil(n / 256) groups), S the largest multiple of 8 (a strip stays on one
+      // XCD) with G x S workgroups all RESIDENT (3 per CU) -- they wait for each other (msm_strip_kernel's sync) -- and strips of
+      // at least 128 generators.  Measured on the 2^25 instance (7844 eligible rows; profiles/r04_ab_strip.txt): free-running
+      // workgroups 85.8 ms and 139 M FETCH_SIZE units per dispatch, one generator of slack 81.6 ms and 91 M, two 82.6 / 103, four
+      // 85.0 / 111.
+      const uint32_t found = n_strip;
+      const size_t slots = (size_t)c->num_cus * 3, G = ((size_t)n_strip + kMsmBlock - 1) / kMsmBlock;
+      size_t bestG = 0;
+      int bestS = 0;
+      for (int cand = 8; cand <= 64 && (size_t)cand * 128 <= R; cand += 8)
+        if (G * (size_t)cand <= slots) { bestG = G; bestS = cand; }
+      const uint32_t n_use = bestG ? n_strip : 0;
+      if (n_use == 0) {
+        n_strip = 0;
+      } else {
+        S = bestS;
+        uniform_shape = !c->shared_device;
+      }
+      if (getenv("VPIN_MSM_STRIP_TRACE")) fprintf(stderr, "[strip] %zu rows: %u eligible, %u taken as %zu groups x %d strips\n", nrows, found, n_use, bestG, bestS);
+    }
     if (n_strip && dsparts.alloc((size_t)n_strip * (size_t)S * sizeof(ge_ext))) return VPIN_ENOMEM;
   }
   const uint8_t* d_flag = n_strip ? (const uint8_t*)dflag.p : nullptr;
@@ -1481,8 +1530,18 @@ int hyrax_commit_derefs_hot(vpin_ctx* c, const vpin_gens* g, const vpin_table* Z
     const unsigned pad = env_pad >= 0 ? (unsigned)env_pad : (c->shared_device ? kSharedPad : 0u);
     if (n_strip) {
       const unsigned groups = (unsigned)((n_strip + kMsmBlock - 1) / kMsmBlock);
+      const size_t per = (R + (size_t)S - 1) / (size_t)S;
+      const char* el = getenv("VPIN_MSM_STRIP_LAG");  // generators a workgroup may run ahead of its strip's slowest; 0: no sync
+      const int lag = el ? atoi(el) : 1;
+      uint32_t* d_sync = nullptr;
+      if (lag > 0 && uniform_shape) {
+        if (dsync.alloc((size_t)S * (per + 1) * sizeof(uint32_t))) return VPIN_ENOMEM;
+        d_sync = (uint32_t*)dsync.p;
+        VPIN_HIP_TRY(hipMemsetAsync(d_sync, 0, (size_t)S * (per + 1) * sizeof(uint32_t), c->stream));
+      }
       hipLaunchKernelGGL(msm_strip_kernel, dim3(groups * (unsigned)S), dim3(kMsmBlock), pad, c->stream, zbase, R, R, view(g), hr,
-                         (const uint32_t*)dlist.p, (const uint32_t*)dlist.p + nrows, S, row0, row_step, z_compact, (ge_ext*)dsparts.p);
+                         (const uint32_t*)dlist.p, (const uint32_t*)dlist.p + nrows, S, row0, row_step, z_compact, (ge_ext*)dsparts.p,
+                         d_sync, lag);
     }
     if (msm_ten_limbs())
       hipLaunchKernelGGL(msm_rows_hot_kernel<true>, dim3((unsigned)nrows, (unsigned)chunks), dim3(kMsmBlock), pad, c->stream, zbase,

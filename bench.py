@@ -110,6 +110,8 @@ def parse():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend of the N>1 runs (gloo: rehearsal with ranks sharing a GPU)")
     ap.add_argument("--no-roofline-pass", action="store_true",
                     help="skip the serial pass after the timed region that fills roofline.secondary (largest instance alone)")
+    ap.add_argument("--no-live-pmc", action="store_true", help="do not measure roofline.traffic with two rocprofv3 --pmc child passes at the "
+                    "end of the default run (the value is then replayed from profiles/, and labelled so)")
     ap.add_argument("--pmc-traffic", type=float, default=None,
                     help="HBM bytes per launch of the roofline kernel from a separate rocprofv3 --pmc pass")
     return ap.parse_args()
@@ -527,6 +529,51 @@ def strong_rehearse(args):
         "plan": dict(zip(("owner_ops", "owner_dotp", "owner_mem"), vpin_amd.dist_plan(W))),
     }))
     ctx0.close()
+
+
+def live_pmc_traffic(timeout_s=240):
+    """HBM bytes per launch of the roofline kernel, MEASURED: two child processes under `rocprofv3 --pmc` (FETCH_SIZE, then
+    WRITE_SIZE: the two counters do not fit one pass; no tracing option beside --pmc) prove the largest instance of the trace
+    alone -- the launches `roofline` is scoped to -- and the kernel's dispatches are averaged.  gfx950 corrections as in
+    tools/pmc_summary.py / MI355X_MICROARCH.md: counters in KiB, FETCH_SIZE counts half the bytes of wide coalesced reads:
+    hbm_bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024.  The caller must have released the GPU's memory (the children build their
+    own tables and instance) and must not need the GPU afterwards.  Returns (bytes per launch, dict) or (None, reason)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(prof):
+        return None, "rocprofv3 not found"
+    out = {}
+    tmp = tempfile.mkdtemp(prefix="vpin_pmc_", dir="/tmp")
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, ctr)
+            cmd = [prof, "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable, os.path.abspath(__file__),
+                   "--trace", "L5", "--only", "mult", "--serial", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-span",
+                   "--no-verify", "--no-roofline-pass", "--no-live-pmc"]
+            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=timeout_s)
+            if r.returncode != 0:
+                return None, f"rocprofv3 --pmc {ctr}: exit {r.returncode}: {r.stderr[-300:]}"
+            files = sorted(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True))
+            if not files:
+                return None, f"rocprofv3 --pmc {ctr}: no counter_collection.csv"
+            vals = []
+            with open(files[0]) as f:
+                for row in csv.DictReader(f):
+                    if row["Counter_Name"] == ctr and "sc_cubic3_kernel<true, true>" in row["Kernel_Name"]:
+                        vals.append(float(row["Counter_Value"]))
+            if not vals:
+                return None, f"rocprofv3 --pmc {ctr}: the roofline kernel was not dispatched"
+            out[ctr] = {"dispatches": len(vals), "avg_KiB": sum(vals) / len(vals)}
+        traffic = (2.0 * out["FETCH_SIZE"]["avg_KiB"] + out["WRITE_SIZE"]["avg_KiB"]) * 1024.0
+        return traffic, out
+    except (subprocess.TimeoutExpired, OSError) as e:
+        return None, repr(e)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def lib_nnz(g):
@@ -1252,6 +1299,29 @@ def main():
                 rec["speedup_note"] = ("a rank's own trace on its own GPU (the weak line's ms_per_step: the four-lane step, what N = 1 "
                                        "delivers) over the time ONE trace takes on all ranks together")
                 line["strong"] = rec
+
+    # ---- roofline.traffic measured in THIS run (it used to be replayed from a profile file) ----
+    # Last thing before the line is printed: every context is closed and the shared window tables are released, so the two
+    # rocprofv3 --pmc children have the GPU to themselves; this process does not touch the GPU afterwards.
+    if (rank == 0 and world == 1 and "roofline" in line and trace == "lenet" and not args.no_live_pmc and not args.no_roofline_pass
+            and args.pmc_traffic is None and not args.only and not args.serial):
+        for cx in ctxs:
+            cx.close()
+        ctxs = []
+        vpin_amd.lib().vpin_gens_shared_clear()
+        t_p = time.perf_counter()
+        live, info = live_pmc_traffic()
+        if live is not None:
+            line["roofline"]["traffic_replayed"] = {"value": line["roofline"].get("traffic"), "source": line["roofline"].get("traffic_source")}
+            line["roofline"]["traffic"] = live
+            line["roofline"]["traffic_source"] = ("measured in this run: two child processes under rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE "
+                                                  "(separate passes, no tracing beside them) proving the largest instance alone; "
+                                                  "(2 * FETCH_SIZE + WRITE_SIZE) * 1024 averaged over the kernel's dispatches "
+                                                  f"({info['FETCH_SIZE']['dispatches']}); {time.perf_counter() - t_p:.0f} s")
+            line["roofline"]["traffic_counters"] = info
+            line["roofline"]["traffic_over_algorithmic"] = live / line["roofline"]["alg_bytes_per_launch"]
+        else:
+            line["roofline"]["traffic_live_error"] = info
 
     if rank == 0:
         print(json.dumps(line))

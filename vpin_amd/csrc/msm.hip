@@ -1485,7 +1485,8 @@ int hyrax_commit_derefs_hot(vpin_ctx* c, const vpin_gens* g, const vpin_table* Z
   // Montgomery conversion -> first gather, and its workgroups no longer step together: the default LeNet step of bench.py
   // measured 469-473 ms with it against 438-442 ms without (profiles/r04_ab_strip.txt), while the 2^25 instance proven alone
   // gains (313 -> 303 ms).  VPIN_MSM_STRIP > 0 forces it (A/B runs).
-  if (env_strip != 0 && (env_strip > 0 || !c->shared_device) && msm_ten_limbs() && nrows >= min_rows && R >= min_R && R <= g->split &&
+  const bool strip_shared = getenv("VPIN_MSM_STRIP_SHARED") != nullptr;  // A/B: also on a shared device, one workgroup per CU
+  if (env_strip != 0 && (env_strip > 0 || !c->shared_device || strip_shared) && msm_ten_limbs() && nrows >= min_rows && R >= min_R && R <= g->split &&
       S % 8 == 0 && (size_t)S <= R / 8) {
     if (dflag.alloc(nrows) || dlist.alloc((nrows + 1) * sizeof(uint32_t))) return VPIN_ENOMEM;
     uint32_t* d_list = (uint32_t*)dlist.p;
@@ -1507,7 +1508,7 @@ int hyrax_commit_derefs_hot(vpin_ctx* c, const vpin_gens* g, const vpin_table* Z
       // workgroups 85.8 ms and 139 M FETCH_SIZE units per dispatch, one generator of slack 81.6 ms and 91 M, two 82.6 / 103, four
       // 85.0 / 111.
       const uint32_t found = n_strip;
-      const size_t slots = (size_t)c->num_cus * 3, G = ((size_t)n_strip + kMsmBlock - 1) / kMsmBlock;
+      const size_t slots = (size_t)c->num_cus * (c->shared_device ? 1 : 3), G = ((size_t)n_strip + kMsmBlock - 1) / kMsmBlock;
       size_t bestG = 0;
       int bestS = 0;
       for (int cand = 8; cand <= 64 && (size_t)cand * 128 <= R; cand += 8)
@@ -1517,7 +1518,7 @@ int hyrax_commit_derefs_hot(vpin_ctx* c, const vpin_gens* g, const vpin_table* Z
         n_strip = 0;
       } else {
         S = bestS;
-        uniform_shape = !c->shared_device;
+        uniform_shape = true;
       }
       if (getenv("VPIN_MSM_STRIP_TRACE")) fprintf(stderr, "[strip] %zu rows: %u eligible, %u taken as %zu groups x %d strips\n", nrows, found, n_use, bestG, bestS);
     }

@@ -89,6 +89,8 @@ def parse():
                          "with them), 2 = its derefs commitment is done, 3 = it is proven; with 2 and 3 it runs on an exclusive context until then")
     ap.add_argument("--no-span", action="store_true", help="skip the reference-span pass after the timed region")
     ap.add_argument("--no-strong", action="store_true", help="N > 1: skip the strong-scaling sub-record (one trace over all ranks)")
+    ap.add_argument("--strong-timeout", type=float, default=300.0, help="N > 1: seconds after which the strong sub-record is given up "
+                    "(the line is printed with the failure recorded and every rank exits)")
     ap.add_argument("--only", choices=["mult", "add"], default=None, help="keep only the point-mult / point-add instances of the trace")
     ap.add_argument("--no-verify", action="store_true", help="skip the post-run verification of the last step's SNARKs")
     ap.add_argument("--no-prof", action="store_true", help="no HIP-event bracketing of kernels (no roofline object)")
@@ -1283,6 +1285,18 @@ def main():
             cx.close()
         ctxs = []
         os.environ.setdefault("VPIN_COMM_TIMEOUT_S", "60")  # a rank that fails must not hold the others for long
+        # RCCL at world > 1 has never run on this code (no multi-GPU hardware during the build): should its initialisation or a
+        # collective hang, the weak line above must still come out.  Every rank arms a watchdog; when it fires rank 0 prints the
+        # line with the failure recorded and every rank leaves at once (no rank can then be waited for).
+        def bail():
+            if rank == 0:
+                line["strong"] = {"error": f"timed out after {args.strong_timeout} s: a rank did not return from the strong sub-record "
+                                           "(RCCL initialisation or a collective); the weak numbers above are unaffected"}
+                print(json.dumps(line), flush=True)
+            os._exit(0)
+        watchdog = threading.Timer(args.strong_timeout, bail)
+        watchdog.daemon = True
+        watchdog.start()
         err, rec = None, None
         try:
             ndev = max(1, torch.cuda.device_count())
@@ -1290,6 +1304,7 @@ def main():
         except Exception as e:  # noqa: BLE001 -- reported in the line, the weak numbers above stand
             err = repr(e)
         errs = grp.gather_objects(err)
+        watchdog.cancel()
         if rank == 0:
             if any(errs):
                 line["strong"] = {"error": [e for e in errs if e]}
@@ -1303,8 +1318,9 @@ def main():
     # ---- roofline.traffic measured in THIS run (it used to be replayed from a profile file) ----
     # Last thing before the line is printed: every context is closed and the shared window tables are released, so the two
     # rocprofv3 --pmc children have the GPU to themselves; this process does not touch the GPU afterwards.
+    under_profiler = any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
     if (rank == 0 and world == 1 and "roofline" in line and trace == "lenet" and not args.no_live_pmc and not args.no_roofline_pass
-            and args.pmc_traffic is None and not args.only and not args.serial):
+            and args.pmc_traffic is None and not args.only and not args.serial and not under_profiler):  # (no profiler inside a profiler)
         for cx in ctxs:
             cx.close()
         ctxs = []

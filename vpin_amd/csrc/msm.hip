@@ -672,7 +672,7 @@ __global__ __launch_bounds__(kMsmBlock, 3) void msm_strip_kernel(const fq* __res
       if (threadIdx.x == 0 && !sh_nosync) {
         long spin = 0;
         while (__hip_atomic_load(my_sync + (j - j0 - (size_t)lag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < groups)
-          if (++spin > (1L << 22)) { sh_nosync = 1; break; }
+          if (++spin > (1L << 16)) { sh_nosync = 1; break; }  // ~0.1 s; a legitimate wait is one generator's walk (~150 us)
       }
       __syncthreads();
     }

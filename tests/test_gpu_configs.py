@@ -212,7 +212,7 @@ def test_hot_columns_are_found_and_taken_out_of_the_derefs_commitment(ctx):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("key,strips", [("A-mult", "16"), ("A-mult", "8"), ("E-mult", "32")])
+@pytest.mark.parametrize("key,strips", [("A-mult", "16"), ("A-mult", "8"), ("E-mult", "32"), ("A-mult", None), ("E-mult", None)])
 def test_row_per_lane_derefs_commitment_gives_the_same_bytes(ctx, key, strips):
     """msm_strip_kernel (a lane = a commitment row, the workgroups of a strip of generators walk the window table in step so
     that a table block is fetched once for thousands of rows) takes the regular rows of a derefs commitment from 8192 rows
@@ -220,7 +220,9 @@ def test_row_per_lane_derefs_commitment_gives_the_same_bytes(ctx, key, strips):
     rows with hot columns and padding tails split between the two kernels, same oracle digests."""
     g = GOLD[key]
     os.environ["VPIN_MSM_STRIP_MIN"] = "64"
-    os.environ["VPIN_MSM_STRIP"] = strips
+    if strips is not None:
+        os.environ["VPIN_MSM_STRIP"] = strips   # a forced strip count: free-running workgroups
+    # strips None: the library's own choice of strips, all workgroups resident and kept in step (the per-generator wait)
     try:
         d = build_dev(ctx, g)
         try:
@@ -228,7 +230,8 @@ def test_row_per_lane_derefs_commitment_gives_the_same_bytes(ctx, key, strips):
         finally:
             d.free()
     finally:
-        del os.environ["VPIN_MSM_STRIP_MIN"], os.environ["VPIN_MSM_STRIP"]
+        del os.environ["VPIN_MSM_STRIP_MIN"]
+        os.environ.pop("VPIN_MSM_STRIP", None)
     assert hashlib.sha256(got["proof"]).hexdigest() == g["snark_sha256"], "SNARK bytes"
     # and switched off: the row kernel alone
     os.environ["VPIN_MSM_STRIP"] = "0"

@@ -28,9 +28,18 @@ lanes, the add lane starts after the largest instance).  `--serial`: one instanc
 
 Beside the headline value the line carries
   roofline     : the fused phase-1 sum-check round kernel (sc_cubic3_kernel<true>), algorithmic bytes /
-                 HIP-event time over the timed region, against the 8 TB/s HBM3E peak;
-  cpu_baseline : the CPU oracle (a C restatement of the reference prover, oracle/) timed on
-                 this box's host cores on a bounded sample of the same workload.
+                 HIP-event time over the timed region, against the 8 TB/s HBM3E peak; `traffic` is measured by
+                 this run itself (two `rocprofv3 --pmc` child passes after everything else, N = 1 only);
+                 `secondary`: the kernels that own the step (row commitments: power-bound; product rounds);
+  cpu_baseline : the CPU oracle (a C restatement of the reference prover, oracle/) timed on this box's
+                 host cores: CNN A's whole trace at full size on all threads, a small sample on one;
+  reference_span (+ value_reference_span): the reference's own timed span per instance (witness inputs ->
+                 gadget -> is_sat -> encode -> prove -> bytes), and `dead_work`: the same WITH the work the
+                 reference does inside it and never uses (third commitment, zlib digest of the matrices);
+  strong       : N > 1 only -- the same trace ONCE over all ranks (one LeNet trace, its 2^25 instance
+                 proven by all ranks together; RCCL for device vectors), beside the weak headline.
+Other modes: `--scaling strong [--rehearse W]`, `--trace T --concurrent K1,K2,..` (K copies of a small
+trace at once on one GPU).
 """
 import argparse
 import json

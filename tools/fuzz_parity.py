@@ -1,0 +1,96 @@
+"""Differential run beyond the suite's fixed cases: random small instances of both gadgets -- random operation counts, weights
+(incl. 0, 1, 2^128 - 1, small and full-width), points (incl. repeated points, R = P, R = -P, y = 0, bytes >= q), rz patterns and
+seed pairs -- built on the device, proven as whole SNARKs, and byte-compared with the CPU oracle on instances built by the
+Python model of the reference's gadgets (tests/gadgets_model.py, itself pinned to the Rust text by tests/golden/gadget_pins.json).
+    python tools/fuzz_parity.py <cases> [seed]
+The oracle is test infrastructure; it is the CHECKER here, as in tests/."""
+import hashlib
+import os
+import random
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import vpin_amd  # noqa: E402
+import gadgets_model as GM  # noqa: E402
+import oracle_lib as O  # noqa: E402
+
+Q = GM.Q
+
+
+def b32(vals):
+    return np.frombuffer(b"".join(int(v).to_bytes(32, "little") for v in vals), dtype=np.uint8).reshape(-1, 32).copy()
+
+
+def rand_point(rng, pool):
+    r = rng.random()
+    if r < 0.70:
+        return rng.choice(pool)
+    if r < 0.80:
+        return (rng.choice(pool)[0], 0)                      # y = 0: the doubling's denominator vanishes
+    if r < 0.88:
+        return (rng.randrange(2**256), rng.randrange(2**256))  # off-curve, bytes >= q: from_bytes_mod_order reduces
+    if r < 0.94:
+        return (0, 0)
+    return (Q - 1, Q - 2)
+
+
+def main():
+    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 50
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 2024
+    rng = random.Random(seed)
+    pool = GM.synthetic_points(seed, 24)
+    bad, t0 = 0, time.time()
+    with vpin_amd.Context(0) as ctx:
+        for it in range(cases):
+            sc, sp = bytes(rng.randrange(256) for _ in range(64)), bytes(rng.randrange(256) for _ in range(64))
+            if rng.random() < 0.45:
+                n = rng.choice([1, 1, 2, 3, 5])
+                ops = []
+                for _ in range(n):
+                    w = rng.choice([0, 1, 2, 3, 2**128 - 1, 2**127, rng.randrange(2**16), rng.randrange(2**128), rng.randrange(2**128)])
+                    x, y = rand_point(rng, pool)
+                    ops.append((w, x, y))
+                kind = "mult"
+                g = ctx.gadget_point_mult_dev([o[0] for o in ops], b32(o[1] for o in ops), b32(o[2] for o in ops))
+                inst = GM.instance_new(GM.build_point_mult([(o[0], o[1] % 2**256, o[2] % 2**256) for o in ops]))
+            else:
+                n = rng.choice([1, 2, 3, 7, 16, 40, 100, 300])
+                ops = []
+                for _ in range(n):
+                    p, r = rand_point(rng, pool), rand_point(rng, pool)
+                    t = rng.random()
+                    if t < 0.08:
+                        r = p                                   # R = P: inverse of zero
+                    elif t < 0.12:
+                        r = (p[0], (Q - p[1]) % Q)              # R = -P
+                    rz = rng.choice([0, 0, 0, 1, 1, 5])
+                    ops.append((p[0], p[1], r[0], r[1], rz))
+                kind = "add"
+                g = ctx.gadget_point_add_dev(b32(o[0] for o in ops), b32(o[1] for o in ops), b32(o[2] for o in ops), b32(o[3] for o in ops),
+                                             np.array([o[4] for o in ops], dtype=np.uint8))
+                inst = GM.instance_new(GM.build_point_add([(o[0], o[1], o[2], o[3], 0 if o[4] == 0 else 1) for o in ops]))
+            try:
+                got = g.snark_prove(sc, sp)
+                sat_dev = g.is_sat()
+            finally:
+                g.free()
+            exp = O.snark_prove(inst, sc, sp, threads=8)
+            same = (got["proof"] == exp["proof"] and got["comm"] == exp["comm"] and np.array_equal(got["comm_para"], exp["comm_para"])
+                    and np.array_equal(got["comm_input"], exp["comm_input"]) and sat_dev == bool(O.is_sat(inst)))
+            if not same:
+                bad += 1
+                print(f"case {it}: MISMATCH {kind} n={n} ops={ops[:2]}... seeds {sc.hex()[:16]} {sp.hex()[:16]}", flush=True)
+            if it % 10 == 9:
+                print(f"{it + 1} cases, {bad} mismatches, {time.time() - t0:.0f} s", flush=True)
+    print(f"fuzz_parity: {cases} random instances (seed {seed}), {bad} mismatches against the oracle; sha of the run "
+          f"{hashlib.sha256(str((cases, seed)).encode()).hexdigest()[:12]}")
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()

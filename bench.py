@@ -1297,32 +1297,51 @@ def main():
         # RCCL at world > 1 has never run on this code (no multi-GPU hardware during the build): should its initialisation or a
         # collective hang, the weak line above must still come out.  Every rank arms a watchdog; when it fires rank 0 prints the
         # line with the failure recorded and every rank leaves at once (no rank can then be waited for).
+        phase = {"name": "staged"}
+
         def bail():
             if rank == 0:
-                line["strong"] = {"error": f"timed out after {args.strong_timeout} s: a rank did not return from the strong sub-record "
-                                           "(RCCL initialisation or a collective); the weak numbers above are unaffected"}
+                msg = (f"timed out after {args.strong_timeout} s in the '{phase['name']}' pass: a rank did not return (RCCL initialisation "
+                       "or a collective); the weak numbers above are unaffected")
+                if "strong" in line:
+                    line["strong"]["rccl_pass"] = {"error": msg}   # the staged pass had already delivered
+                else:
+                    line["strong"] = {"error": msg}
                 print(json.dumps(line), flush=True)
             os._exit(0)
         watchdog = threading.Timer(args.strong_timeout, bail)
         watchdog.daemon = True
         watchdog.start()
-        err, rec = None, None
-        try:
-            ndev = max(1, torch.cuda.device_count())
-            rec = _strong_core(args, grp, rank, world, local_rank % ndev, args.backend == "nccl", ndev, max(1, min(args.steps, 5)), 1)
-        except Exception as e:  # noqa: BLE001 -- reported in the line, the weak numbers above stand
-            err = repr(e)
-        errs = grp.gather_objects(err)
-        watchdog.cancel()
-        if rank == 0:
-            if any(errs):
-                line["strong"] = {"error": [e for e in errs if e]}
-            else:
-                weak_ms = line["ms_per_step"]
-                rec["speedup_vs_one_gpu_step_of_this_run"] = weak_ms / rec["ms_per_step"]
+        ndev = max(1, torch.cuda.device_count())
+        nsteps = max(1, min(args.steps, 5))
+
+        def one_pass(with_rccl):
+            err, rec = None, None
+            try:
+                rec = _strong_core(args, grp, rank, world, local_rank % ndev, with_rccl, ndev, nsteps, 1)
+            except Exception as e:  # noqa: BLE001 -- reported in the line, the weak numbers above stand
+                err = repr(e)
+            errs = grp.gather_objects(err)
+            if rank == 0 and not any(errs):
+                rec["speedup_vs_one_gpu_step_of_this_run"] = line["ms_per_step"] / rec["ms_per_step"]
                 rec["speedup_note"] = ("a rank's own trace on its own GPU (the weak line's ms_per_step: the four-lane step, what N = 1 "
                                        "delivers) over the time ONE trace takes on all ranks together")
-                line["strong"] = rec
+            return rec, [e for e in errs if e]
+
+        # Pass 1: device vectors staged through the shared-memory transport -- the path that has run (two and four processes on
+        # one GPU).  Pass 2: the same with RCCL carrying them (ncclAllGather), which no hardware has run yet: if it fails or hangs,
+        # pass 1's record stands.
+        rec, errs = one_pass(False)
+        if rank == 0:
+            line["strong"] = rec if not errs else {"error": errs}
+        if args.backend == "nccl" and ndev >= world and not errs:
+            phase["name"] = "rccl"
+            rec2, errs2 = one_pass(True)
+            if rank == 0:
+                line["strong"]["rccl_pass"] = ({"error": errs2} if errs2 else
+                                               {k: rec2[k] for k in ("value", "ms_per_step", "rccl", "bytes_equal_oracle_digest", "comm",
+                                                                     "speedup_vs_one_gpu_step_of_this_run")})
+        watchdog.cancel()
 
     # ---- roofline.traffic measured in THIS run (it used to be replayed from a profile file) ----
     # Last thing before the line is printed: every context is closed and the shared window tables are released, so the two

@@ -497,8 +497,10 @@ def main():
                                       num_inputs=env["num_inputs_1"], num_non_zero_entries=env["num_non_zero_entries_1"]))
     path = os.path.join(HERE, "gadget_pins.json")
     with open(path, "w") as f:
-        json.dump(out, f, indent=0, separators=(",", ":"))
-        f.write("\n")
+        txt = json.dumps(out, separators=(",", ":"))   # compact, one case per line
+        for key in ('{"name":', '"mult_shapes":', '"add_shapes":', '"add":['):
+            txt = txt.replace(key, "\n" + key)
+        f.write(txt + "\n")
     print("wrote", path, file=sys.stderr)
     if "--dump-py" in sys.argv:   # for inspection only; never committed
         sys.stdout.write(py_mult + "\n# ----\n" + py_add)

@@ -2,8 +2,9 @@
 (incl. 0, 1, 2^128 - 1, small and full-width), points (incl. repeated points, R = P, R = -P, y = 0, bytes >= q), rz patterns and
 seed pairs -- built on the device, proven as whole SNARKs, and byte-compared with the CPU oracle on instances built by the
 Python model of the reference's gadgets (tests/gadgets_model.py, itself pinned to the Rust text by tests/golden/gadget_pins.json).
-    python tools/fuzz_parity.py <cases> [seed]
-The oracle is test infrastructure; it is the CHECKER here, as in tests/."""
+    python tests/fuzz_parity.py <cases> [seed]
+Test infrastructure (it lives under tests/ because it loads the oracle, which only tests/, smoke() and bench.py's cpu_baseline leg
+may): the oracle is the CHECKER here."""
 import hashlib
 import os
 import random
@@ -14,7 +15,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))  # (this file's own directory)
 import vpin_amd  # noqa: E402
 import gadgets_model as GM  # noqa: E402
 import oracle_lib as O  # noqa: E402

@@ -7,13 +7,15 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
+import ctypes as C  # noqa: E402
 import vpin_amd  # noqa: E402
-import oracle_lib as O  # noqa: E402  (generator stream only)
 
 ctx = vpin_amd.Context(0)
 NB = 16386
-xyzt, _ = O.gens_stream_xyzt(NB, b"gens_r1cs_eval")
+xyzt = np.zeros((NB, 128), dtype=np.uint8)  # MultiCommitGens::new through the product's own host derivation
+L = vpin_amd.lib()
+L.vpin_host_gens_derive.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p]
+assert L.vpin_host_gens_derive(b"gens_r1cs_eval", NB, xyzt.ctypes.data_as(C.c_void_p)) == 0
 g = ctx.gens_shared("gens_r1cs_eval", xyzt, 80 if ctx.device_total_bytes() >= (200 << 30) else 24)
 rng = np.random.default_rng(1)
 top = 24

@@ -587,6 +587,59 @@ def live_pmc_traffic(timeout_s=240):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+class PowerSampler:
+    """sclk and socket power of THIS rank's card from its hwmon files (sysfs), sampled by a thread while the timed region runs:
+    the four-lane step is power-bound, and the line should say at which clock and power it actually ran."""
+
+    def __init__(self, device_index):
+        import glob
+        self.freq, self.power, self.samples, self.stop_flag, self.th = [], [], [], False, None
+        try:
+            import ctypes as C
+            hip = C.CDLL("libamdhip64.so")
+            buf = C.create_string_buffer(64)
+            if hip.hipDeviceGetPCIBusId(buf, 64, device_index) == 0:
+                base = "/sys/bus/pci/devices/" + buf.value.decode().lower()
+                self.freq = glob.glob(base + "/hwmon/hwmon*/freq1_input")
+                self.power = glob.glob(base + "/hwmon/hwmon*/power1_average") or glob.glob(base + "/hwmon/hwmon*/power1_input")
+        except OSError:
+            pass
+
+    @staticmethod
+    def _read(paths):
+        for p in paths:
+            try:
+                with open(p) as f:
+                    return float(f.read().strip())
+            except (OSError, ValueError):
+                continue
+        return None
+
+    def start(self):
+        if not (self.freq or self.power):
+            return
+
+        def loop():
+            while not self.stop_flag:
+                self.samples.append((self._read(self.freq), self._read(self.power)))
+                time.sleep(0.05)
+        self.th = threading.Thread(target=loop, daemon=True)
+        self.th.start()
+
+    def stop(self):
+        self.stop_flag = True
+        if self.th:
+            self.th.join()
+        f = sorted(x[0] / 1e6 for x in self.samples if x[0])
+        w = sorted(x[1] / 1e6 for x in self.samples if x[1])
+        if not f and not w:
+            return None
+        med = lambda v: v[len(v) // 2] if v else None
+        return {"samples": len(self.samples), "sclk_mhz_median": med(f), "sclk_mhz_min": f[0] if f else None, "sclk_mhz_max": f[-1] if f else None,
+                "watts_median": med(w), "watts_max": w[-1] if w else None,
+                "source": "hwmon freq1_input / power1_average of this rank's card, every 50 ms over the timed region"}
+
+
 def lib_nnz(g):
     import vpin_amd
     L = vpin_amd.lib()
@@ -851,7 +904,9 @@ def main():
     for cx in ctxs:
         cx.prof_reset()
         cx.prof_enable(not args.no_prof)
+    sampler = PowerSampler(local_rank)
     barrier()
+    sampler.start()
     t0 = time.perf_counter()
     if pipelined:
         run_pipelined(args.steps, False)
@@ -862,6 +917,7 @@ def main():
         cx.sync()
     barrier()
     elapsed = time.perf_counter() - t0
+    power_rec = sampler.stop()
     stats, stats_lane0 = {}, {}
     for ci, cx in enumerate(ctxs):
         per_ctx = cx.prof_read()
@@ -976,6 +1032,8 @@ def main():
                               "GBps_alg": (v["alg_bytes"] / (v["ms"] * 1e-3) / 1e9) if v["ms"] else None}
                        for name, v in stats.items()}
     line["spans_ms_last_step"] = {n: {kk: round(vv * 1e3, 3) for kk, vv in sp.items()} for n, sp in last_spans.items()}
+    if power_rec:
+        line["power_during_timed_region"] = power_rec  # rank 0's card
     line["setup_s"] = {"synthetic_witness_inputs": round(setup_s, 3),
                        "device_gadgets_generator_tables_encode": round(upload_s, 3)}
     line["proof_bytes"] = proof_bytes

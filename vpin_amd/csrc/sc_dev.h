@@ -94,6 +94,31 @@ struct Acc<4> {
   }
 };
 
+// The two sums of the leading-coefficient rounds (lead_bc / lead_bcd above) with the products accumulated unreduced
+// (fq_dev.h fqw_mac): e[0] += E * X, e[1] += E * Y, reduced every seven pairs and once at the end.
+struct LeadAcc {
+  fq_wide w[2];
+  int n;
+  __device__ __forceinline__ void init() { fqw_zero(w[0]); fqw_zero(w[1]); n = 0; }
+  __device__ __forceinline__ void add(fq* e, const fq& E, const fq& X, const fq& Y) {
+#ifdef VPIN_NO_LAZY_ACC  // A/B builds: every product reduced at once, as before round 4
+    e[0] = fq_add(e[0], fq_mul(E, X));
+    e[1] = fq_add(e[1], fq_mul(E, Y));
+#else
+    fqw_mac(w[0], E, X);
+    fqw_mac(w[1], E, Y);
+    if (++n == 7) flush(e);
+#endif
+  }
+  __device__ __forceinline__ void flush(fq* e) {
+    if (n == 0) return;
+    e[0] = fq_add(e[0], fqw_reduce(w[0]));
+    e[1] = fq_add(e[1], fqw_reduce(w[1]));
+    fqw_zero(w[0]); fqw_zero(w[1]);
+    n = 0;
+  }
+};
+
 template <>
 struct Acc<2> {
   static constexpr int NE = 2;

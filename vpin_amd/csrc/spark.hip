@@ -398,18 +398,21 @@ __global__ __launch_bounds__(kBlock, kMinWaves) void prod_round_kernel(fq* __res
   fq* B = A + h;
   Acc<4> acc;
   acc.init();
+  LeadAcc lacc;
+  if (LEAD) lacc.init();
   for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < pairs; i += (size_t)gridDim.x * kBlock) {
     fq u[3], p1, d1, p2, d2;
     if (BIND && LEAD) { fold_pd_c(A, i, pairs, tt, p1, d1); fold_pd_c(B, i, pairs, tt, p2, d2); }
     else if (BIND) { fold_pd(A, i, pairs, r, p1, d1); fold_pd(B, i, pairs, r, p2, d2); }
     else { load_pd(A, i, pairs, p1, d1); load_pd(B, i, pairs, p2, d2); }
     if (LEAD) {
-      acc.lead_bc(p1, d1, p2, d2, fq_load(E + i));
+      lacc.add(acc.e, fq_load(E + i), fq_mul(p1, p2), fq_mul(d1, d2));  // lead_bc, the two products by E unreduced
     } else {
       acc.stage_bc(u, p1, d1, p2, d2);
       acc.stage_e(u, fq_load(E + i));
     }
   }
+  if (LEAD) lacc.flush(acc.e);
   finish_block(acc.e, fin);
 }
 

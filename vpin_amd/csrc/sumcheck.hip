@@ -114,7 +114,8 @@ __global__ __launch_bounds__(kBlock, kMinWaves) void sc_cubic3_kernel(Tabs<3> ta
       if (BIND) fold_pd_c(tabs.t[2], i, pairs, tt, p3, d3);
       else load_pd(tabs.t[2], i, pairs, p3, d3);
       const fq e = fq_load(E + i);
-      acc.lead_bcd(p1, d1, p2, d2, p3, e);
+      acc.lead_bcd(p1, d1, p2, d2, p3, e);  // (the lazily reduced sums of spark.hip's product rounds do not pay here: same-box
+                                            //  A/B 162.3 against 151.9-162.6 us per launch, profiles/r04_ab_lazy.txt)
       if (!BIND) acc.lead_one(p1, d1, p2, d2, p3, d3, e);
     } else {
       acc.stage_bc(u, p1, d1, p2, d2);

@@ -17,10 +17,10 @@ import tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def isa(src):
-    out = os.path.join(tempfile.gettempdir(), os.path.basename(src) + ".s")
+def isa(src, *defines):
+    out = os.path.join(tempfile.gettempdir(), os.path.basename(src) + "".join(defines) + ".s")
     subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fopenmp", "-I", os.path.join(ROOT, "include"),
-                           "--cuda-device-only", "-S", src, "-o", out], stderr=subprocess.DEVNULL)
+                           "--cuda-device-only", "-S", src, "-o", out] + list(defines), stderr=subprocess.DEVNULL)
     return open(out).read().split("\n")
 
 
@@ -69,8 +69,16 @@ def main():
     sp = isa(os.path.join(ROOT, "vpin_amd", "csrc", "spark.hip"))
     ls = loops(kernel_body(sp, "_ZN4vpin17prod_round_kernelILb1ELb1ELb1EE"))
     big = max(ls, key=lambda l: l["valu"])
-    res["prod_round_kernel<true, true>"] = {"valu_per_pair": big["valu"], "v_mad_u64_u32_per_pair": big["v_mad_u64_u32"],
-                                            "loads_per_pair": big["vmem_loads"], "stores_per_pair": big["vmem_stores"]}
+    # the loop holds the every-seventh-pair flush of the lazily reduced sums (sc_dev.h LeadAcc): price body and flush apart
+    spb = isa(os.path.join(ROOT, "vpin_amd", "csrc", "spark.hip"), "-DVPIN_LAZY_NO_FLUSH")
+    body = max(loops(kernel_body(spb, "_ZN4vpin17prod_round_kernelILb1ELb1ELb1EE")), key=lambda l: l["valu"])
+    eff = lambda k: round(body[k] + (big[k] - body[k]) / 7.0)
+    res["prod_round_kernel<true, true>"] = {"valu_per_pair": eff("valu"), "v_mad_u64_u32_per_pair": eff("v_mad_u64_u32"),
+                                            "loads_per_pair": big["vmem_loads"], "stores_per_pair": big["vmem_stores"],
+                                            "loop_with_flush": {"valu": big["valu"], "v_mad_u64_u32": big["v_mad_u64_u32"]},
+                                            "loop_without_flush": {"valu": body["valu"], "v_mad_u64_u32": body["v_mad_u64_u32"]},
+                                            "note": "per pair = the loop without the flush + a seventh of the flush (two Montgomery "
+                                                    "reductions every seven pairs)"}
     out = os.path.join(ROOT, "profiles", os.environ.get("VPIN_ISA_OUT", "r04_isa_counts.json"))
     with open(out, "w") as f:
         json.dump(res, f, indent=1)

@@ -107,7 +107,9 @@ struct LeadAcc {
 #else
     fqw_mac(w[0], E, X);
     fqw_mac(w[1], E, Y);
+#ifndef VPIN_LAZY_NO_FLUSH  // (tools/isa_counts.py compiles the loop once without the flush to price the two apart)
     if (++n == 7) flush(e);
+#endif
 #endif
   }
   __device__ __forceinline__ void flush(fq* e) {

@@ -93,9 +93,17 @@ def parse():
                          "instead of finishing every step before the next starts (measured: 3 %% faster, +15 GB of pooled memory)")
     ap.add_argument("--concurrent", default=None, help="K or K1,K2,..: K independent copies of the (small) trace proven at once on one "
                     "GPU, one context each; reports traces/s and constraints/s at every K beside the single-trace latency")
-    ap.add_argument("--gate", type=int, default=int(os.environ.get("VPIN_BENCH_GATE", "1")), choices=[1, 2, 3],
-                    help="when the other lanes start: 1 = the largest instance's phase-1 sum-check is done (its MSMs then share every CU "
+    ap.add_argument("--gate", type=int, default=int(os.environ.get("VPIN_BENCH_GATE", "1")), choices=[0, 1, 2, 3],
+                    help="when the other lanes start: 0 = at once (a spatial split: --cu-split), 1 = the largest instance's phase-1 sum-check is done (its MSMs then share every CU "
                          "with them), 2 = its derefs commitment is done, 3 = it is proven; with 2 and 3 it runs on an exclusive context until then")
+    ap.add_argument("--cu-split", default=os.environ.get("VPIN_BENCH_CU_SPLIT"),
+                    help="A,B[,layout]: spatial split of the chip between the lanes (vpin_ctx_create_cumask) -- the largest instance's stream "
+                         "gets A compute units of every XCD (0: every CU, unmasked), the other lanes' streams the LAST B of every XCD; "
+                         "layout i (default): mask bit k is CU k/8 of XCD k%%8, b: CU k%%32 of XCD k/32")
+    ap.add_argument("--small-queue", action="store_true", default=bool(os.environ.get("VPIN_BENCH_SMALL_QUEUE")),
+                    help="the lanes other than the first take their instances of a step from ONE queue, longest first (durations measured "
+                         "in the warm-up), instead of a fixed list per lane")
+    ap.add_argument("--skip", default=None, help="comma-separated instance names left out of the trace (experiments: L5-mult)")
     ap.add_argument("--no-span", action="store_true", help="skip the reference-span pass after the timed region")
     ap.add_argument("--no-strong", action="store_true", help="N > 1: skip the strong-scaling sub-record (one trace over all ranks)")
     ap.add_argument("--strong-timeout", type=float, default=300.0, help="N > 1: seconds after which the strong sub-record is given up "
@@ -698,6 +706,8 @@ def main():
         work.append((f"{lab}-add", "add", a, 10 * len(a[4])))
     if args.only:
         work = [w for w in work if w[1] == args.only]
+    if args.skip:
+        work = [w for w in work if w[0] not in args.skip.split(",")]
     setup_s = time.perf_counter() - t0
     cons = {w[0]: w[3] for w in work}
     total_cons_step = sum(cons.values())
@@ -729,10 +739,33 @@ def main():
     # the lanes of small, latency-bound instances get high-priority streams: their one-workgroup round
     # kernels are then dispatched ahead of the large instance's queued workgroups instead of behind them
     prios = [0] + [-1] * (len(lanes) - 1) if not os.environ.get("VPIN_BENCH_NO_PRIO") else [0] * len(lanes)
-    ctxs = [vpin_amd.Context(local_rank, priority=prios[li]) for li in range(len(lanes))]
-    if len(lanes) > 1:
-        for cx in ctxs:
-            cx.set_shared_device(True)  # the lanes share the GPU: the row-commitment MSM leaves room on every CU
+    cu_split = None
+    if args.cu_split:
+        parts = args.cu_split.split(",")
+        ca, cb, layout = int(parts[0]), int(parts[1]), (parts[2] if len(parts) > 2 else "i")
+        per_xcd, nx = 32, 8
+        pick = (lambda cu, x: cu * nx + x) if layout == "i" else (lambda cu, x: x * per_xcd + cu)
+        big = [pick(cu, x) for x in range(nx) for cu in range(ca)] if ca > 0 else None
+        small = [pick(cu, x) for x in range(nx) for cu in range(per_xcd - cb, per_xcd)]
+        if len(parts) > 3 and parts[3] == "same":  # experiments: the first lane on the other lanes' CUs too
+            big, ca = small, 0
+        after1 = len(parts) > 3 and parts[3] == "after1" and big is not None
+        cu_split = {"largest_instance_cus_per_xcd": ca or per_xcd, "other_lanes_cus_per_xcd": cb, "layout": layout,
+                    "disjoint": bool(ca) and ca + cb <= per_xcd,
+                    "largest_instance_masked": "after its phase-1 sum-check (vpin_ctx_set_cumask_after_phase1)" if after1 else "always"}
+        ctxs = [vpin_amd.Context(local_rank, cu_mask=big) if (big and not after1) else vpin_amd.Context(local_rank, priority=0)] + \
+               [vpin_amd.Context(local_rank, cu_mask=small) for _ in range(len(lanes) - 1)]
+        if after1:
+            ctxs[0].set_cumask_after_phase1(big)
+    else:
+        ctxs = [vpin_amd.Context(local_rank, priority=prios[li]) for li in range(len(lanes))]
+    # the lanes share the GPU: the row-commitment MSM leaves room on every CU -- unless the largest instance has CUs of its own
+    l0_shared = not (cu_split and cu_split["disjoint"]) and len(lanes) > 1
+    if os.environ.get("VPIN_BENCH_L0_SHARED"):
+        l0_shared = os.environ["VPIN_BENCH_L0_SHARED"] != "0"
+    small_shared = os.environ.get("VPIN_BENCH_SMALL_SHARED", "1") != "0"
+    for li, cx in enumerate(ctxs):
+        cx.set_shared_device(l0_shared if li == 0 else small_shared)
 
     def barrier():
         torch.cuda.synchronize()
@@ -801,9 +834,28 @@ def main():
         proof_bytes[name] = len(r["proof"])
         return len(r["proof"])
 
+    proof_ms = {}   # last measured duration per instance (the shared queue's order)
+    queue_state = {"lock": threading.Lock(), "order": [], "pos": 0, "all_on_every_lane": False}
+
     def run_lane(li, gate):
         if gate is not None:
             gate.wait()
+        if args.small_queue and li > 0 and len(lanes) >= 3:
+            if queue_state["all_on_every_lane"]:   # warm-up: every context meets every instance size once
+                for name in queue_state["order"]:
+                    prove(li, name)
+                return
+            while True:
+                with queue_state["lock"]:
+                    k = queue_state["pos"]
+                    queue_state["pos"] += 1
+                if k >= len(queue_state["order"]):
+                    return
+                name = queue_state["order"][k]
+                t1 = time.perf_counter()
+                prove(li, name)
+                proof_ms[name] = (time.perf_counter() - t1) * 1e3
+            return
         for name in lane_names[li]:
             prove(li, name)
 
@@ -814,6 +866,10 @@ def main():
         if len(lanes) >= 3:
             progress[0] = 0
             gate = threading.Event()
+            if args.small_queue:
+                small = [n for l in lane_names[1:] for n in l]
+                queue_state["order"] = sorted(small, key=lambda n: -proof_ms.get(n, cons[n] * 1e-4))
+                queue_state["pos"] = 0
 
             if args.gate > 1:
                 ctxs[0].set_shared_device(False)  # the largest instance has the chip to itself until the gate opens
@@ -823,7 +879,7 @@ def main():
                     time.sleep(0.0005)
                 if args.gate == 3:   # ... until the largest instance is proven
                     gate.wait()
-                ctxs[0].set_shared_device(True)
+                ctxs[0].set_shared_device(l0_shared)
                 gate.set()
             ts = [threading.Thread(target=run_lane, args=(li, gate)) for li in range(1, len(lanes))] + [threading.Thread(target=watch)]
             for t in ts:
@@ -898,6 +954,10 @@ def main():
         for _ in range(args.warmup):
             run_pipelined(1, True)
     else:
+        if args.small_queue and len(lanes) >= 3:
+            queue_state["all_on_every_lane"] = True
+            step()   # an extra warm-up pass: any lane may prove any of the small instances later
+            queue_state["all_on_every_lane"] = False
         for _ in range(args.warmup):
             step()
 
@@ -968,6 +1028,8 @@ def main():
             "inputs": "host buffers (PCIe-inclusive, CSR/CSC built per proof)" if args.host_buffers else "resident in HBM",
         },
     }
+    if cu_split:
+        line["config"]["cu_split"] = cu_split
 
     # ---- roofline of the fused sum-check round kernel ----
     # with several streams the event time of a kernel on one stream includes waiting for CUs taken by the
@@ -1089,7 +1151,7 @@ def main():
             st = cx.prof_read()
             cx.prof_enable(False)
             if len(lanes) > 1:
-                cx.set_shared_device(True)
+                cx.set_shared_device(l0_shared)
             sec = []
             cus, clk = cx.device_props()  # compute units, shader clock in Hz
             # Reference rates of the VALU-bound kernels.  (1) A static one: one wave-instruction per SIMD per 4 cycles over the

@@ -53,6 +53,18 @@ int vpin_ctx_create(int device, vpin_ctx** out);
 /* Same with a stream priority: < 0 high (its kernels are dispatched ahead of other streams' queued
  * workgroups), 0 normal, > 0 low.  For running latency-bound small proofs beside a large one. */
 int vpin_ctx_create_prio(int device, int priority, vpin_ctx** out);
+/* Same with the context's stream confined to a subset of the device's compute units (hipExtStreamCreateWithCUMask): bit i
+ * of cu_mask (n_words x 32 bits) enables CU i in the runtime's numbering -- on an 8-XCD part consecutive bits go round-robin
+ * over the XCDs, so the first 8k bits are k CUs of every XCD.  A service that proves one large instance beside many small
+ * ones gives each side its own CUs (a spatial split) instead of letting their workgroups share every CU; the row-commitment
+ * kernels size their grids to the enabled CUs.  A masked stream has normal priority. */
+int vpin_ctx_create_cumask(int device, const uint32_t* cu_mask, uint32_t n_words, vpin_ctx** out);
+/* A second stream for an (unmasked) context, confined to the CUs of cu_mask: every proof on the context moves to it when
+ * its phase-1 sum-check is over -- the point where the progress word (vpin_ctx_set_progress_flag) becomes 1 -- and returns
+ * to the first stream when the call returns.  For a scheduler that holds other contexts back during phase 1 and gives the
+ * chip a spatial split afterwards: the large proof's commitments then own their CUs (row-per-lane strips stay in step).
+ * cu_mask = NULL removes the second stream. */
+int vpin_ctx_set_cumask_after_phase1(vpin_ctx* ctx, const uint32_t* cu_mask, uint32_t n_words);
 void vpin_ctx_destroy(vpin_ctx* ctx);
 /* hipStream_t the ctx launches on (as void*), for callers that time with HIP events */
 void* vpin_ctx_stream(vpin_ctx* ctx);

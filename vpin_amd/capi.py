@@ -75,6 +75,8 @@ def lib():
     L.vpin_abi_version.restype = C.c_int
     L.vpin_ctx_create.argtypes = [C.c_int, C.POINTER(vp)]
     L.vpin_ctx_create_prio.argtypes = [C.c_int, C.c_int, C.POINTER(vp)]
+    L.vpin_ctx_create_cumask.argtypes = [C.c_int, vp, C.c_uint32, C.POINTER(vp)]
+    L.vpin_ctx_set_cumask_after_phase1.argtypes = [vp, vp, C.c_uint32]
     L.vpin_ctx_destroy.argtypes = [vp]
     L.vpin_ctx_destroy.restype = None
     L.vpin_ctx_stream.argtypes = [vp]
@@ -492,10 +494,32 @@ def dist_plan(world):
 
 
 class Context:
-    def __init__(self, device=0, priority=0):
-        """priority < 0: high-priority stream (latency-bound small proofs beside a large one); > 0: low."""
+    def __init__(self, device=0, priority=0, cu_mask=None):
+        """priority < 0: high-priority stream (latency-bound small proofs beside a large one); > 0: low.
+        cu_mask: iterable of enabled CU numbers (the runtime's numbering, see vpin_ctx_create_cumask): the stream is
+        confined to them (normal priority)."""
         self.h = C.c_void_p()
+        if cu_mask is not None:
+            words = self._mask_words(cu_mask)
+            _chk(lib().vpin_ctx_create_cumask(device, words.ctypes.data_as(C.c_void_p), len(words), C.byref(self.h)), "vpin_ctx_create_cumask")
+            return
         _chk(lib().vpin_ctx_create_prio(device, priority, C.byref(self.h)), "vpin_ctx_create_prio")
+
+    @staticmethod
+    def _mask_words(cu_mask):
+        cus = sorted(set(int(x) for x in cu_mask))
+        words = np.zeros((cus[-1] // 32) + 1, dtype=np.uint32)
+        for x in cus:
+            words[x // 32] |= np.uint32(1 << (x % 32))
+        return words
+
+    def set_cumask_after_phase1(self, cu_mask):
+        """second stream confined to the CUs of cu_mask; proofs move to it after their phase-1 sum-check (None: remove it)"""
+        if cu_mask is None:
+            _chk(lib().vpin_ctx_set_cumask_after_phase1(self.h, None, 0), "vpin_ctx_set_cumask_after_phase1")
+            return
+        words = self._mask_words(cu_mask)
+        _chk(lib().vpin_ctx_set_cumask_after_phase1(self.h, words.ctypes.data_as(C.c_void_p), len(words)), "vpin_ctx_set_cumask_after_phase1")
 
     def close(self):
         if self.h:

@@ -118,6 +118,17 @@ void dev_free(vpin_ctx* c, void* p) {
 
 void dev_pool_release(vpin_ctx* c) { pool_release_unlocked(c); }
 
+static void ctx_switch_stream(vpin_ctx* c, hipStream_t to, int cus, bool masked) {
+  if (!to || c->stream == to) return;
+  (void)hipEventRecord(c->stream_switch_ev, c->stream);
+  (void)hipStreamWaitEvent(to, c->stream_switch_ev, 0);
+  c->stream = to;
+  c->num_cus = cus;
+  c->cu_masked = masked;
+}
+void ctx_enter_alt(vpin_ctx* c) { if (c && c->stream_alt) ctx_switch_stream(c, c->stream_alt, c->cus_alt, true); }
+void ctx_leave_alt(vpin_ctx* c) { if (c && c->stream_alt) ctx_switch_stream(c, c->stream_main, c->cus_main, false); }
+
 ProfScope::ProfScope(vpin_ctx* c, int kclass, double bytes, int also, double units) : ctx(c) {
   if (!c->prof) return;
   ProfRec r;
@@ -160,12 +171,16 @@ const char* vpin_last_error(void) { return g_last_error.c_str(); }
 
 int vpin_abi_version(void) { return 2; }
 
-static int ctx_create(int device, int priority, vpin_ctx** out);
+static int ctx_create(int device, int priority, const uint32_t* cu_mask, uint32_t n_words, vpin_ctx** out);
 
-int vpin_ctx_create(int device, vpin_ctx** out) { return ctx_create(device, 0, out); }
-int vpin_ctx_create_prio(int device, int priority, vpin_ctx** out) { return ctx_create(device, priority, out); }
+int vpin_ctx_create(int device, vpin_ctx** out) { return ctx_create(device, 0, nullptr, 0, out); }
+int vpin_ctx_create_prio(int device, int priority, vpin_ctx** out) { return ctx_create(device, priority, nullptr, 0, out); }
+int vpin_ctx_create_cumask(int device, const uint32_t* cu_mask, uint32_t n_words, vpin_ctx** out) {
+  if (!cu_mask || n_words == 0) return VPIN_EINVAL;
+  return ctx_create(device, 0, cu_mask, n_words, out);
+}
 
-static int ctx_create(int device, int priority, vpin_ctx** out) {
+static int ctx_create(int device, int priority, const uint32_t* cu_mask, uint32_t n_words, vpin_ctx** out) {
   if (!out) return VPIN_EINVAL;
   // host OpenMP teams must wait passively (see prover.cpp host_threads); set before the runtime starts
   setenv("KMP_BLOCKTIME", "0", 0);
@@ -188,8 +203,25 @@ static int ctx_create(int device, int priority, vpin_ctx** out) {
   int lo = 0, hi = 0;  // numerically: hi <= 0 <= lo
   (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
   int prio = priority < 0 ? hi : priority > 0 ? lo : 0;
-  hipError_t e = hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio);
+  hipError_t e;
+  if (cu_mask) {
+    // the enabled CUs are what the row-commitment kernels size their grids to (msm.hip: resident strip workgroups)
+    int enabled = 0;
+    for (uint32_t w = 0; w < n_words; w++) {
+      uint32_t bits = cu_mask[w];
+      if ((w + 1) * 32 > (uint32_t)c->num_cus) bits &= (w * 32 >= (uint32_t)c->num_cus) ? 0u : ((1u << (c->num_cus - w * 32)) - 1u);
+      enabled += __builtin_popcount(bits);
+    }
+    if (enabled == 0) { delete c; return VPIN_EINVAL; }
+    e = hipExtStreamCreateWithCUMask(&c->stream, n_words, cu_mask);
+    c->num_cus = enabled;
+    c->cu_masked = true;
+  } else {
+    e = hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio);
+  }
   if (e != hipSuccess) { set_last_error("hipStreamCreate", e); delete c; return VPIN_EHIP; }
+  c->stream_main = c->stream;
+  c->cus_main = c->num_cus;
   c->partials_cap = (size_t)18 * 4096 * 3;  // kSparkMaxInst x kRoundBlocks x 3 (spark.hip); sumcheck.hip needs kMaxBlocks x 3
   if (hipMalloc(&c->d_partials, c->partials_cap * sizeof(fq)) != hipSuccess ||
       hipMalloc(&c->d_out, 8 * sizeof(fq)) != hipSuccess ||
@@ -206,6 +238,7 @@ void vpin_ctx_destroy(vpin_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
+  ctx_leave_alt(c);
   if (c->prover_cache_free) c->prover_cache_free(c);
   if (c->spark_cache_free) c->spark_cache_free(c);
   if (c->verify_cache_free) c->verify_cache_free(c);
@@ -230,11 +263,36 @@ void vpin_ctx_destroy(vpin_ctx* c) {
   if (c->d_out) (void)hipFree(c->d_out);
   if (c->h_out) (void)hipHostFree(c->h_out);
   if (c->h_bullet) (void)hipHostFree(c->h_bullet);
-  if (c->stream) (void)hipStreamDestroy(c->stream);
+  if (c->stream_alt) { (void)hipStreamSynchronize(c->stream_alt); (void)hipStreamDestroy(c->stream_alt); }
+  if (c->stream_switch_ev) (void)hipEventDestroy(c->stream_switch_ev);
+  if (c->stream_main) (void)hipStreamDestroy(c->stream_main);
   delete c;
 }
 
 void* vpin_ctx_stream(vpin_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
+int vpin_ctx_set_cumask_after_phase1(vpin_ctx* c, const uint32_t* cu_mask, uint32_t n_words) {
+  if (!c || c->cu_masked || c->stream != c->stream_main) return VPIN_EINVAL;
+  (void)hipSetDevice(c->device);
+  if (c->stream_alt) {  // replace / clear
+    VPIN_HIP_TRY(hipStreamSynchronize(c->stream_alt));
+    (void)hipStreamDestroy(c->stream_alt);
+    c->stream_alt = nullptr;
+    c->cus_alt = 0;
+  }
+  if (!cu_mask || n_words == 0) return VPIN_OK;
+  int enabled = 0;
+  for (uint32_t w = 0; w < n_words; w++) {
+    uint32_t bits = cu_mask[w];
+    if ((w + 1) * 32 > (uint32_t)c->cus_main) bits &= (w * 32 >= (uint32_t)c->cus_main) ? 0u : ((1u << (c->cus_main - w * 32)) - 1u);
+    enabled += __builtin_popcount(bits);
+  }
+  if (enabled == 0) return VPIN_EINVAL;
+  if (!c->stream_switch_ev) VPIN_HIP_TRY(hipEventCreateWithFlags(&c->stream_switch_ev, hipEventDisableTiming));
+  VPIN_HIP_TRY(hipExtStreamCreateWithCUMask(&c->stream_alt, n_words, cu_mask));
+  c->cus_alt = enabled;
+  return VPIN_OK;
+}
 
 int vpin_ctx_set_progress_flag(vpin_ctx* c, int* flag) {
   if (!c) return VPIN_EINVAL;

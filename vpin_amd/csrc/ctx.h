@@ -53,7 +53,13 @@ struct vpin_gens;
 struct vpin_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
-  int num_cus = 256;
+  int num_cus = 256;        // compute units the stream may use (the enabled ones of a CU-masked context)
+  bool cu_masked = false;   // created by vpin_ctx_create_cumask, or on the second stream of vpin_ctx_set_cumask_after_phase1
+  // vpin_ctx_set_cumask_after_phase1: a second, CU-masked stream a proof moves to after its phase-1 sum-check (capi.hip
+  // ctx_enter_alt / ctx_leave_alt; `stream` is always the stream in use)
+  hipStream_t stream_main = nullptr, stream_alt = nullptr;
+  hipEvent_t stream_switch_ev = nullptr;
+  int cus_main = 256, cus_alt = 0;
   // scratch for block partials of the round reductions and the final 3 scalars
   vpin::fq* d_partials = nullptr;
   size_t partials_cap = 0;  // in fq elements
@@ -113,6 +119,17 @@ struct ProfScope {
   ~ProfScope();
 };
 
+// Move the context's work to its CU-masked second stream / back (no-ops without one).  Work issued afterwards is ordered
+// behind everything issued before (an event), so pooled blocks and tables carry over; the caller must not have a
+// persistent tail kernel resident.  AltStreamGuard: a proof entry point leaves the second stream however it returns.
+void ctx_enter_alt(vpin_ctx* c);
+void ctx_leave_alt(vpin_ctx* c);
+struct AltStreamGuard {
+  vpin_ctx* c;
+  explicit AltStreamGuard(vpin_ctx* ctx) : c(ctx) {}
+  ~AltStreamGuard() { ctx_leave_alt(c); }
+};
+
 // pooled device allocation (see vpin_ctx::pool_free_lists)
 int dev_alloc(vpin_ctx* c, size_t bytes, void** out);
 void dev_free(vpin_ctx* c, void* p);
@@ -155,6 +172,14 @@ int r1cs_eval_table_strided(vpin_ctx* c, const vpin_r1cs_dev* d, const vpin_tabl
 // DensePolynomial::bound split by row blocks over the ranks of c->comm (poly.hip)
 // z_rows != nullptr: the rows rank, rank + world, .. stored densely (otherwise a contiguous block of Z's rows per rank)
 int poly_bound_dist(vpin_ctx* c, const vpin_table* Z, const uint8_t* Lvec, size_t L_size, uint8_t* out_LZ, const fq* z_rows = nullptr);
+
+// the hash layer's slice evaluations and DensePolynomial::bound from one pass over a combined polynomial (poly.hip):
+// Z = S slices of N = T * Rs scalars; Ltop = eq(r_top, .) (T scalars), Rv = eq(r_bot, .) (Rs scalars), host memory, Montgomery.
+// d_LZs (S * Rs scalars, device) <- LZ_s; ev_out (S scalars, host) <- Z_s(r).  Then, with the combining challenges known,
+// out_LZ (Rs scalars, host) <- sum_s coef[s] LZ_s.
+int slices_bound(vpin_ctx* c, const fq* Z, size_t N, int S, size_t Rs, const uint8_t* Ltop, size_t T, const uint8_t* Rv, fq* d_LZs,
+                 uint8_t* ev_out);
+int slices_combine(vpin_ctx* c, const fq* d_LZs, int S, size_t Rs, const uint8_t* coef, uint8_t* out_LZ);
 
 inline bool is_pow2(size_t x) { return x && !(x & (x - 1)); }
 

@@ -636,6 +636,14 @@ __global__ __launch_bounds__(1024) void strip_list_kernel(const uint8_t* __restr
     if (flag[r]) list[o++] = (uint32_t)r;
 }
 
+// the listed rows from n_use on go back to the row kernel: flags cleared, *count = n_use (launched after strip_list_kernel)
+__global__ __launch_bounds__(256) void strip_trim_kernel(const uint32_t* __restrict__ list, uint32_t* __restrict__ count, uint32_t n_use,
+                                                          uint32_t n_all, uint8_t* __restrict__ flag) {
+  const uint32_t li = n_use + blockIdx.x * 256 + threadIdx.x;
+  if (li < n_all) flag[list[li]] = 0;
+  if (blockIdx.x == 0 && threadIdx.x == 0) *count = n_use;
+}
+
 // parts[li * S + s] = sum over strip s of the table walks of listed row li (ten-limb accumulator)
 __global__ __launch_bounds__(kMsmBlock, 3) void msm_strip_kernel(const fq* __restrict__ Z, size_t stride, size_t ncols, TableView tv, HotRows hr,
                                                                   const uint32_t* __restrict__ list, const uint32_t* __restrict__ list_count,
@@ -1496,7 +1504,10 @@ int hyrax_commit_derefs_hot(vpin_ctx* c, const vpin_gens* g, const vpin_table* Z
   // measured 469-473 ms with it against 438-442 ms without (profiles/r04_ab_strip.txt), while the 2^25 instance proven alone
   // gains (313 -> 303 ms).  VPIN_MSM_STRIP > 0 forces it (A/B runs).
   const bool strip_shared = getenv("VPIN_MSM_STRIP_SHARED") != nullptr;  // A/B: also on a shared device, one workgroup per CU
-  if (env_strip != 0 && (env_strip > 0 || !c->shared_device || strip_shared) && msm_ten_limbs() && nrows >= min_rows && R >= min_R && R <= g->split &&
+  // Nor for a rank's share of a split commitment (c->comm set: at W = 2 the share of 16384 rows is exactly min_rows, and
+  // rehearsal ranks share one GPU without saying so): its workgroups would not all be resident and the bounded wait below
+  // would be sat out per generator.
+  if (env_strip != 0 && (env_strip > 0 || ((!c->shared_device || strip_shared) && c->comm == nullptr)) && msm_ten_limbs() && nrows >= min_rows && R >= min_R && R <= g->split &&
       S % 8 == 0 && (size_t)S <= R / 8) {
     if (dflag.alloc(nrows) || dlist.alloc((nrows + 1) * sizeof(uint32_t))) return VPIN_ENOMEM;
     uint32_t* d_list = (uint32_t*)dlist.p;
@@ -1523,14 +1534,30 @@ int hyrax_commit_derefs_hot(vpin_ctx* c, const vpin_gens* g, const vpin_table* Z
       int bestS = 0;
       for (int cand = 8; cand <= 64 && (size_t)cand * 128 <= R; cand += 8)
         if (G * (size_t)cand <= slots) { bestG = G; bestS = cand; }
-      const uint32_t n_use = bestG ? n_strip : 0;
+      // On a context confined to some of the CUs (vpin_ctx_create_cumask) "every eligible row" can leave the CUs unevenly
+      // loaded (31 groups x 16 strips on 576 slots): take fewer groups and more strips when that fills more slots; the rows
+      // beyond the shape go back to the row kernel.  VPIN_MSM_STRIP_SHAPE=G,S forces a shape (A/B runs).
+      if (c->cu_masked)
+        for (int cand = 8; cand <= 64 && (size_t)cand * 128 <= R; cand += 8) {
+          const size_t g2 = std::min(G, slots / (size_t)cand);
+          if (g2 * kMsmBlock >= min_list && g2 * (size_t)cand > bestG * (size_t)bestS) { bestG = g2; bestS = cand; }
+        }
+      if (const char* eshape = getenv("VPIN_MSM_STRIP_SHAPE")) {
+        int eg = 0, esn = 0;
+        if (sscanf(eshape, "%d,%d", &eg, &esn) == 2 && eg > 0 && esn > 0 && esn % 8 == 0 && (size_t)esn <= R / 8) { bestG = std::min(G, (size_t)eg); bestS = esn; }
+      }
+      const uint32_t n_use = bestG ? (uint32_t)std::min<size_t>(n_strip, bestG * kMsmBlock) : 0;
       if (n_use == 0) {
         n_strip = 0;
       } else {
+        if (n_use < n_strip)
+          hipLaunchKernelGGL(strip_trim_kernel, dim3((n_strip - n_use + 255) / 256), dim3(256), 0, c->stream, (const uint32_t*)d_list, d_count,
+                             n_use, n_strip, (uint8_t*)dflag.p);
+        n_strip = n_use;
         S = bestS;
         uniform_shape = true;
       }
-      if (getenv("VPIN_MSM_STRIP_TRACE")) fprintf(stderr, "[strip] %zu rows: %u eligible, %u taken as %zu groups x %d strips\n", nrows, found, n_use, bestG, bestS);
+      if (getenv("VPIN_MSM_STRIP_TRACE")) fprintf(stderr, "[strip] %zu rows: %u eligible, %u taken as %zu groups x %d strips on %zu slots\n", nrows, found, n_use, bestG, bestS, slots);
     }
     if (n_strip && dsparts.alloc((size_t)n_strip * (size_t)S * sizeof(ge_ext))) return VPIN_ENOMEM;
   }

@@ -36,6 +36,111 @@ __global__ __launch_bounds__(kPB) void poly_bound_reduce_kernel(const fq* __rest
   fq_store(out + i, acc);
 }
 
+// ---- the hash layer's slice evaluations and its DensePolynomial::bound in ONE pass over the table ----------------------
+// HashLayerProof::prove (sparse_mlpoly.rs:740-849) evaluates every slice Z_s (length N) of a combined polynomial at the
+// same point r (DensePolynomial::evaluate), draws the combining challenges c from the transcript and then proves the
+// combined polynomial's evaluation at (c, r): PolyEvalProof::prove's first step is LZ = L^T Z with L = eq((c, r)[..left])
+// (dense_mlpoly.rs:340-349) -- a second pass over the same 8N / 16N / 2M scalars.  The slice index is the top of the row
+// index, so with r = (r_top, r_bot) split where the rows end,
+//     LZ_s[i] = sum_t eq(r_top, t) Z_s[t * R + i]                 (needs no challenge: computed first, one pass)
+//     Z_s(r)  = sum_i eq(r_bot, i) LZ_s[i]                        (the slice evaluations)
+//     LZ[i]   = sum_s eq(c, s) LZ_s[i]                            (after the challenges: S x R scalars, no table pass)
+// exact field arithmetic, so the same elements as the two passes (and the big eq(r, .) tables are never built).
+// partial[(chunk * S + s) * Rs + i] = sum_{t in chunk} Ltop[t] * Z[s * N + t * Rs + i], products accumulated unreduced
+// (fq_wide: one Montgomery reduction per seven terms)
+__global__ __launch_bounds__(kPB) void slices_bound_kernel(const fq* __restrict__ Z, size_t N, const fq* __restrict__ Ltop, size_t T,
+                                                           size_t Rs, size_t rows_per_chunk, fq* __restrict__ partial) {
+  const size_t i = (size_t)blockIdx.x * kPB + threadIdx.x;
+  if (i >= Rs) return;
+  const fq* zs = Z + (size_t)blockIdx.z * N;
+  size_t j0 = (size_t)blockIdx.y * rows_per_chunk, j1 = j0 + rows_per_chunk;
+  if (j1 > T) j1 = T;
+  fq acc = fq_zero();
+  fq_wide w;
+  fqw_zero(w);
+  int n = 0;
+  for (size_t j = j0; j < j1; j++) {
+    const fq z = fq_load(zs + j * Rs + i);
+    if (fq_is_zero(z)) continue;
+    fqw_mac(w, fq_load(Ltop + j), z);
+    if (++n == 7) { acc = fq_add(acc, fqw_reduce(w)); fqw_zero(w); n = 0; }
+  }
+  if (n) acc = fq_add(acc, fqw_reduce(w));
+  fq_store(partial + ((size_t)blockIdx.y * gridDim.z + blockIdx.z) * Rs + i, acc);
+}
+
+// ev[s] = sum_i Rv[i] * LZs[s * Rs + i]; one workgroup per slice
+__global__ __launch_bounds__(kPB) void slices_eval_kernel(const fq* __restrict__ LZs, const fq* __restrict__ Rv, size_t Rs,
+                                                          fq* __restrict__ ev) {
+  const fq* lz = LZs + (size_t)blockIdx.x * Rs;
+  fq acc = fq_zero();
+  fq_wide w;
+  fqw_zero(w);
+  int n = 0;
+  for (size_t i = threadIdx.x; i < Rs; i += kPB) {
+    fqw_mac(w, fq_load(Rv + i), fq_load(lz + i));
+    if (++n == 7) { acc = fq_add(acc, fqw_reduce(w)); fqw_zero(w); n = 0; }
+  }
+  if (n) acc = fq_add(acc, fqw_reduce(w));
+  acc = fq_wave_sum(acc);
+  __shared__ fq sh[kPB / 64];
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    fq t = sh[0];
+    for (int k = 1; k < kPB / 64; k++) t = fq_add(t, sh[k]);
+    fq_store(ev + blockIdx.x, t);
+  }
+}
+
+// out[i] = sum_s coef[s] * LZs[s * Rs + i]
+__global__ __launch_bounds__(kPB) void slices_combine_kernel(const fq* __restrict__ LZs, const fq* __restrict__ coef, int S, size_t Rs,
+                                                             fq* __restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * kPB + threadIdx.x;
+  if (i >= Rs) return;
+  fq acc = fq_zero();
+  for (int s = 0; s < S; s++) acc = fq_add(acc, fq_mul(fq_load(coef + s), fq_load(LZs + (size_t)s * Rs + i)));
+  fq_store(out + i, acc);
+}
+
+int slices_bound(vpin_ctx* c, const fq* Z, size_t N, int S, size_t Rs, const uint8_t* Ltop, size_t T, const uint8_t* Rv, fq* d_LZs,
+                 uint8_t* ev_out) {
+  if (!c || !Z || S < 1 || !Ltop || !Rv || !d_LZs || !ev_out || T == 0 || Rs == 0 || T * Rs != N) return VPIN_EINVAL;
+  (void)hipSetDevice(c->device);
+  const size_t rows_per_chunk = T / 64 ? T / 64 : 1;
+  const int chunks = (int)((T + rows_per_chunk - 1) / rows_per_chunk);
+  DevBuf bL(c), bR(c), bpart(c), bev(c);
+  if (bL.alloc(T * 32) || bR.alloc(Rs * 32) || bpart.alloc((size_t)chunks * S * Rs * 32) || bev.alloc((size_t)S * 32)) return VPIN_ENOMEM;
+  VPIN_HIP_TRY(hipMemcpyAsync(bL.p, Ltop, T * 32, hipMemcpyHostToDevice, c->stream));
+  VPIN_HIP_TRY(hipMemcpyAsync(bR.p, Rv, Rs * 32, hipMemcpyHostToDevice, c->stream));
+  {
+    ProfScope ps(c, VPIN_K_SPARK_BUILD, 32.0 * (double)S * (double)N);
+    hipLaunchKernelGGL(slices_bound_kernel, dim3((unsigned)((Rs + kPB - 1) / kPB), (unsigned)chunks, (unsigned)S), dim3(kPB), 0, c->stream, Z,
+                       N, (const fq*)bL.p, T, Rs, rows_per_chunk, (fq*)bpart.p);
+  }
+  hipLaunchKernelGGL(poly_bound_reduce_kernel, dim3((unsigned)(((size_t)S * Rs + kPB - 1) / kPB)), dim3(kPB), 0, c->stream,
+                     (const fq*)bpart.p, (size_t)S * Rs, chunks, d_LZs);
+  hipLaunchKernelGGL(slices_eval_kernel, dim3((unsigned)S), dim3(kPB), 0, c->stream, (const fq*)d_LZs, (const fq*)bR.p, Rs, (fq*)bev.p);
+  VPIN_HIP_TRY(hipGetLastError());
+  VPIN_HIP_TRY(hipMemcpyAsync(ev_out, bev.p, (size_t)S * 32, hipMemcpyDeviceToHost, c->stream));
+  VPIN_HIP_TRY(hipStreamSynchronize(c->stream));  // Ltop / Rv / ev_out are the caller's
+  return VPIN_OK;
+}
+
+int slices_combine(vpin_ctx* c, const fq* d_LZs, int S, size_t Rs, const uint8_t* coef, uint8_t* out_LZ) {
+  if (!c || !d_LZs || S < 1 || !coef || !out_LZ || Rs == 0) return VPIN_EINVAL;
+  (void)hipSetDevice(c->device);
+  DevBuf bc(c), bout(c);
+  if (bc.alloc((size_t)S * 32) || bout.alloc(Rs * 32)) return VPIN_ENOMEM;
+  VPIN_HIP_TRY(hipMemcpyAsync(bc.p, coef, (size_t)S * 32, hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(slices_combine_kernel, dim3((unsigned)((Rs + kPB - 1) / kPB)), dim3(kPB), 0, c->stream, d_LZs, (const fq*)bc.p, S, Rs,
+                     (fq*)bout.p);
+  VPIN_HIP_TRY(hipGetLastError());
+  VPIN_HIP_TRY(hipMemcpyAsync(out_LZ, bout.p, Rs * 32, hipMemcpyDeviceToHost, c->stream));
+  VPIN_HIP_TRY(hipStreamSynchronize(c->stream));
+  return VPIN_OK;
+}
+
 // rows [row0, row0 + nrows) of the same sum, as a device vector of Rs scalars (zeros when nrows == 0): one polynomial bound
 // split across ranks by row blocks; dL = the L_size coefficients on the device
 static int poly_bound_rows(vpin_ctx* c, const fq* Z, const fq* dL, size_t Rs, size_t row0, size_t nrows, fq* d_out) {

@@ -635,6 +635,7 @@ int sat_prove_core(vpin_ctx* c, const vpin_r1cs_dev* dinst, size_t nv, size_t nc
                    &tau, d_pyr, lw);
   if (rc) return rc;
   if ((rc = vpin::comm_mark(c, "sat_phase1_rest"))) return rc;
+  vpin::ctx_enter_alt(c);  // vpin_ctx_set_cumask_after_phase1: the rest of the proof runs on the context's own CUs
   if (c->progress_flag) *c->progress_flag = 1;  // phase 1 (the roofline kernel's launches) is over: other streams may start
   g_timings[1] = secs(t0, Clock::now());
 
@@ -784,6 +785,7 @@ int vpin_sat_prove_resident(vpin_ctx* c, const vpin_r1cs_dev* dinst, const vpin_
   size_t nv, ncons, ni;
   vpin_r1cs_dims(dinst, &ncons, &nv, &ni);
   if (vars_para->len != nv || vars_input->len != nv || vars->len != nv || (ni && !inputs)) return VPIN_ESHAPE;
+  vpin::AltStreamGuard alt_guard(c);
   return vpin::comm_leave(c->comm, vpin_prover::sat_prove_core(c, dinst, nv, ncons, ni, vars_para, vars_input, vars, inputs, seed_commit64,
                                                                seed_proof64, proof_out, proof_cap, proof_len, comm_para_out,
                                                                comm_input_out, inst_evals_out, rx_out, ry_out, nullptr, nullptr));

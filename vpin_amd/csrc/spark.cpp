@@ -159,11 +159,19 @@ static Fq combine_bot(std::vector<Fq> e, const std::vector<Fq>& ch) {
 // PolyEvalProof::prove with blinds None, blind_Zr None (dense_mlpoly.rs:326-379)
 // z_rows (one proof over several GPUs, split by residue class): this rank's rows rank, rank + world, .. of Z stored densely; Z then
 // only gives the shape
+// lz_pre / rv_pre (single GPU, SlicePass below): LZ = L^T Z and R = eq(r[left..], .) already known from the pass that evaluated
+// the slices -- the table is not read again
 static int polyeval_prove_plain(vpin_ctx* c, const PcGens& pc, const vpin_table* Z, const std::vector<Fq>& r, const Fq& Zr,
-                                Transcript& tr, Transcript& tape, DpLog& out, const vpin::fq* z_rows = nullptr) {
+                                Transcript& tr, Transcript& tape, DpLog& out, const vpin::fq* z_rows = nullptr,
+                                const std::vector<Fq>* lz_pre = nullptr, const std::vector<Fq>* rv_pre = nullptr) {
   if (r.size() != pc.ell || Z->len != ((size_t)1 << pc.ell)) return VPIN_ESHAPE;
   tr.append_protocol_name("polynomial evaluation proof");
   const size_t left = pc.ell / 2, right = pc.ell - left;
+  if (lz_pre && rv_pre) {
+    if (lz_pre->size() != pc.R || rv_pre->size() != pc.R) return VPIN_ESHAPE;
+    TraceSpan ts("  dplog");
+    return dplog_prove(c, pc, tr, tape, *lz_pre, Fq::zero(), *rv_pre, Zr, Fq::zero(), out);
+  }
   std::vector<Fq> Lv(pc.L), Rv(pc.R), LZ(pc.R);
   host_eq(r.data(), left, Lv.data());
   host_eq(r.data() + left, right, Rv.data());
@@ -179,6 +187,40 @@ static int polyeval_prove_plain(vpin_ctx* c, const PcGens& pc, const vpin_table*
   TraceSpan ts("  dplog");
   return dplog_prove(c, pc, tr, tape, LZ, Fq::zero(), Rv, Zr, Fq::zero(), out);
 }
+
+// Single GPU: the slice evaluations of a combined polynomial and, later, the LZ vector of its evaluation proof from ONE pass
+// over the table (poly.hip slices_bound / slices_combine).  nbits = log2 of the slice count, used = slices that are not
+// identically zero, rand = the point the slices are evaluated at (log2 of the slice length challenges).
+struct SlicePass {
+  vpin::DevBuf lzs;
+  std::vector<Fq> Rv;
+  int used = 0, nbits = 0;
+  bool on = false;
+  explicit SlicePass(vpin_ctx* c) : lzs(c) {}
+  static bool fits(const PcGens& pc, int nbits, const std::vector<Fq>& rand) {
+    static const bool off = getenv("VPIN_HASH_TWO_PASS") != nullptr;  // A/B: the separate evaluation and bound passes
+    return !off && pc.ell / 2 >= (size_t)nbits && rand.size() + (size_t)nbits == pc.ell;
+  }
+  int run(vpin_ctx* c, const PcGens& pc, const vpin::fq* table, int nbits_, int used_, const std::vector<Fq>& rand, Fq* ev) {
+    nbits = nbits_; used = used_;
+    const size_t left = pc.ell / 2, T = pc.L >> nbits, N = (size_t)1 << rand.size();
+    std::vector<Fq> Ltop(T);
+    host_eq(rand.data(), left - (size_t)nbits, Ltop.data());
+    Rv.resize(pc.R);
+    host_eq(rand.data() + (left - (size_t)nbits), pc.ell - left, Rv.data());
+    if (lzs.alloc((size_t)used * pc.R * 32)) return VPIN_ENOMEM;
+    int rc = vpin::slices_bound(c, table, N, used, pc.R, B(Ltop.data()), T, B(Rv.data()), (vpin::fq*)lzs.p, B(ev));
+    on = rc == VPIN_OK;
+    return rc;
+  }
+  // LZ of the combined polynomial at (ch, rand): sum_s eq(ch, s) LZ_s
+  int combine(vpin_ctx* c, const PcGens& pc, const std::vector<Fq>& ch, std::vector<Fq>& LZ) {
+    std::vector<Fq> coef((size_t)1 << nbits);
+    host_eq(ch.data(), (size_t)nbits, coef.data());
+    LZ.resize(pc.R);
+    return vpin::slices_combine(c, (const vpin::fq*)lzs.p, used, pc.R, B(coef.data()), B(LZ.data()));
+  }
+};
 
 // ---- one proof over several GPUs: who owns which circuit, and the per-round exchange -------------------------------
 // The 12 "ops" circuits and the 6 dot-product halves are proven in the same rounds, so they are dealt together (longest
@@ -1121,7 +1163,11 @@ static int spark_prove(vpin_ctx* c, const vpin_spark_decomm* d, const std::vecto
   t0 = Clock::now();
   tr.append_protocol_name("Sparse polynomial hash layer proof");
   vpin_table *eq_ops = nullptr, *eq_mem = nullptr;
-  {
+  // single GPU: slice evaluations and the evaluation proofs' LZ vectors from one pass per combined polynomial (SlicePass)
+  const bool one_pass = !dz && SlicePass::fits(*g_derefs, 3, rand_ops) && SlicePass::fits(*g_ops, 4, rand_ops) &&
+                        SlicePass::fits(*g_mem, 1, rand_mem);
+  SlicePass sp_derefs(c), sp_ops(c), sp_mem(c);
+  if (!one_pass) {
     TraceSpan ts("hash: eq tables");
     // split by residue class: eq(rand, rank + k W) = eq(rand_hi, k) * eq(rand_lo, rank), so the local table is the table of
     // the first lg - lw challenges and the rank's sums are scaled by one constant
@@ -1187,6 +1233,9 @@ static int spark_prove(vpin_ctx* c, const vpin_spark_decomm* d, const std::vecto
     for (int i = 0; i < 6; i++) ev_derefs[i] = pick(i);
     for (int i = 0; i < 15; i++) ev_ops[i] = pick(6 + i);
     for (int i = 0; i < 2; i++) ev_mem[i] = pick(21 + i);
+  } else if (one_pass) {
+    TraceSpan ts("hash: derefs slices (one pass)");
+    if ((rc = sp_derefs.run(c, *g_derefs, comb->d, 3, 6, rand_ops, ev_derefs))) return rc;
   } else {
     TraceSpan ts("hash: derefs slice evals");
     if ((rc = vpin::spark_slice_evals(c, comb->d, N, 6, eq_ops->d))) return rc;
@@ -1205,10 +1254,17 @@ static int spark_prove(vpin_ctx* c, const vpin_spark_decomm* d, const std::vecto
     rj.insert(rj.end(), rand_ops.begin(), rand_ops.end());
     tr.append_scalar("joint_claim_eval", joint);
     TraceSpan ts("hash: polyeval derefs");
-    if ((rc = polyeval_prove_plain(c, *g_derefs, comb, rj, joint, tr, tape, pe_derefs, st ? comb_rows : nullptr))) return rc;
+    std::vector<Fq> lz;
+    if (sp_derefs.on && (rc = sp_derefs.combine(c, *g_derefs, ch, lz))) return rc;
+    if ((rc = polyeval_prove_plain(c, *g_derefs, comb, rj, joint, tr, tape, pe_derefs, st ? comb_rows : nullptr,
+                                   sp_derefs.on ? &lz : nullptr, sp_derefs.on ? &sp_derefs.Rv : nullptr))) return rc;
     if ((rc = vpin::comm_mark(c, "hash_bullet"))) return rc;
   }
-  if (!dz) {
+  if (one_pass) {
+    TraceSpan ts("hash: ops+mem slices (one pass)");
+    if ((rc = sp_ops.run(c, *g_ops, d->comb_ops->d, 4, 15, rand_ops, ev_ops))) return rc;
+    if ((rc = sp_mem.run(c, *g_mem, d->comb_mem->d, 1, 2, rand_mem, ev_mem))) return rc;
+  } else if (!dz) {
     TraceSpan ts("hash: ops+mem slice evals");
     if ((rc = vpin::spark_slice_evals(c, d->comb_ops->d, N, 15, eq_ops->d))) return rc;
     for (int i = 0; i < 15; i++) ev_ops[i] = hs[3 * i];
@@ -1225,7 +1281,10 @@ static int spark_prove(vpin_ctx* c, const vpin_spark_decomm* d, const std::vecto
     rj.insert(rj.end(), rand_ops.begin(), rand_ops.end());
     tr.append_scalar("joint_claim_eval_ops", joint);
     TraceSpan ts("hash: polyeval ops");
-    if ((rc = polyeval_prove_plain(c, *g_ops, d->comb_ops, rj, joint, tr, tape, pe_ops))) return rc;
+    std::vector<Fq> lz;
+    if (sp_ops.on && (rc = sp_ops.combine(c, *g_ops, ch, lz))) return rc;
+    if ((rc = polyeval_prove_plain(c, *g_ops, d->comb_ops, rj, joint, tr, tape, pe_ops, nullptr, sp_ops.on ? &lz : nullptr,
+                                   sp_ops.on ? &sp_ops.Rv : nullptr))) return rc;
     if ((rc = vpin::comm_mark(c, "hash_bullet"))) return rc;
   }
   {
@@ -1237,7 +1296,10 @@ static int spark_prove(vpin_ctx* c, const vpin_spark_decomm* d, const std::vecto
     rj.insert(rj.end(), rand_mem.begin(), rand_mem.end());
     tr.append_scalar("joint_claim_eval_mem", joint);
     TraceSpan ts("hash: polyeval mem");
-    if ((rc = polyeval_prove_plain(c, *g_mem, d->comb_mem, rj, joint, tr, tape, pe_mem))) return rc;
+    std::vector<Fq> lz;
+    if (sp_mem.on && (rc = sp_mem.combine(c, *g_mem, ch, lz))) return rc;
+    if ((rc = polyeval_prove_plain(c, *g_mem, d->comb_mem, rj, joint, tr, tape, pe_mem, nullptr, sp_mem.on ? &lz : nullptr,
+                                   sp_mem.on ? &sp_mem.Rv : nullptr))) return rc;
     if ((rc = vpin::comm_mark(c, "hash_bullet"))) return rc;
   }
   g_spark_timings[4] = secs(t0, Clock::now());
@@ -1485,6 +1547,7 @@ int vpin_snark_prove_resident(vpin_ctx* c, const vpin_r1cs_dev* dinst, const vpi
   if (vars_para->len != nv || vars_input->len != nv || vars->len != nv || (ni && !inputs)) return VPIN_ESHAPE;
   if (decomm->num_cons != ncons || decomm->num_vars != nv || decomm->num_inputs != ni) return VPIN_ESHAPE;
   auto t0 = Clock::now();
+  vpin::AltStreamGuard alt_guard(c);  // vpin_ctx_set_cumask_after_phase1: back on the first stream however this returns
   Transcript tr("snark_example"), tape("snark_example");
   uint8_t ie[96];
   std::vector<Fq> rx(log2z(ncons)), ry(log2z(2 * nv));

@@ -97,9 +97,11 @@ def parse():
                     help="when the other lanes start: 0 = at once (a spatial split: --cu-split), 1 = the largest instance's phase-1 sum-check is done (its MSMs then share every CU "
                          "with them), 2 = its derefs commitment is done, 3 = it is proven; with 2 and 3 it runs on an exclusive context until then")
     ap.add_argument("--cu-split", default=os.environ.get("VPIN_BENCH_CU_SPLIT"),
-                    help="A,B[,layout]: spatial split of the chip between the lanes (vpin_ctx_create_cumask) -- the largest instance's stream "
-                         "gets A compute units of every XCD (0: every CU, unmasked), the other lanes' streams the LAST B of every XCD; "
-                         "layout i (default): mask bit k is CU k/8 of XCD k%%8, b: CU k%%32 of XCD k/32")
+                    help="A,B[,layout[,after1]] or none: spatial split of the chip between the lanes (vpin_ctx_create_cumask) -- the largest "
+                         "instance's stream gets A compute units of every XCD (0: every CU, unmasked), the other lanes' streams the LAST B of "
+                         "every XCD; layout se (default): whole shader engines (8 CUs each), spread: consecutive CUs go round the four "
+                         "engines; after1: the largest instance is confined only after its phase-1 sum-check "
+                         "(vpin_ctx_set_cumask_after_phase1).  Default for the four-lane LeNet step: 24,8,se,after1")
     ap.add_argument("--small-queue", action="store_true", default=bool(os.environ.get("VPIN_BENCH_SMALL_QUEUE")),
                     help="the lanes other than the first take their instances of a step from ONE queue, longest first (durations measured "
                          "in the warm-up), instead of a fixed list per lane")
@@ -740,17 +742,28 @@ def main():
     # kernels are then dispatched ahead of the large instance's queued workgroups instead of behind them
     prios = [0] + [-1] * (len(lanes) - 1) if not os.environ.get("VPIN_BENCH_NO_PRIO") else [0] * len(lanes)
     cu_split = None
-    if args.cu_split:
+    default_split = (args.cu_split is None and trace == "lenet" and args.snark and len(lanes) == 4 and not args.serial
+                     and not args.only and not args.skip and not args.pipeline and (world == 1 or args.backend == "nccl"))
+    if default_split:
+        args.cu_split = "24,8,se,after1"
+    if args.cu_split and args.cu_split != "none":
+        # Spatial split (round 5).  Mask bit k of hipExtStreamCreateWithCUMask is, on this 8-XCD part, CU k/8 of XCD k%8, and CU n
+        # of an XCD sits in shader engine n%4 (tools/ubench_cumask -> profiles/r05_cumask_map.txt); an XCD without any bit set
+        # gets ALL its CUs, so whole XCDs cannot be taken away from a stream, only CUs of every XCD.
         parts = args.cu_split.split(",")
-        ca, cb, layout = int(parts[0]), int(parts[1]), (parts[2] if len(parts) > 2 else "i")
-        per_xcd, nx = 32, 8
-        pick = (lambda cu, x: cu * nx + x) if layout == "i" else (lambda cu, x: x * per_xcd + cu)
-        big = [pick(cu, x) for x in range(nx) for cu in range(ca)] if ca > 0 else None
-        small = [pick(cu, x) for x in range(nx) for cu in range(per_xcd - cb, per_xcd)]
+        ca, cb, layout = int(parts[0]), int(parts[1]), (parts[2] if len(parts) > 2 else "se")
+        per_xcd, nx, nse = 32, 8, 4
+        if layout in ("se", "b"):      # whole shader engines: CUs 0..ca-1 in SE-major order (SE = n // 8)
+            bit = lambda n, x: x + nx * ((n // (per_xcd // nse)) + nse * (n % (per_xcd // nse)))
+        else:                          # "i" / "spread": the runtime's own order, consecutive CUs go round the SEs
+            bit = lambda n, x: n * nx + x
+        big = [bit(n, x) for x in range(nx) for n in range(ca)] if ca > 0 else None
+        small = [bit(n, x) for x in range(nx) for n in range(per_xcd - cb, per_xcd)]
         if len(parts) > 3 and parts[3] == "same":  # experiments: the first lane on the other lanes' CUs too
             big, ca = small, 0
         after1 = len(parts) > 3 and parts[3] == "after1" and big is not None
-        cu_split = {"largest_instance_cus_per_xcd": ca or per_xcd, "other_lanes_cus_per_xcd": cb, "layout": layout,
+        cu_split = {"largest_instance_cus_per_xcd": ca or per_xcd, "other_lanes_cus_per_xcd": cb,
+                    "layout": "whole shader engines" if layout in ("se", "b") else "spread over the shader engines",
                     "disjoint": bool(ca) and ca + cb <= per_xcd,
                     "largest_instance_masked": "after its phase-1 sum-check (vpin_ctx_set_cumask_after_phase1)" if after1 else "always"}
         ctxs = [vpin_amd.Context(local_rank, cu_mask=big) if (big and not after1) else vpin_amd.Context(local_rank, priority=0)] + \
@@ -763,7 +776,9 @@ def main():
     l0_shared = not (cu_split and cu_split["disjoint"]) and len(lanes) > 1
     if os.environ.get("VPIN_BENCH_L0_SHARED"):
         l0_shared = os.environ["VPIN_BENCH_L0_SHARED"] != "0"
-    small_shared = os.environ.get("VPIN_BENCH_SMALL_SHARED", "1") != "0"
+    # ... and the other lanes' row commitments run three workgroups per CU on THEIR CUs when the split is disjoint (measured:
+    # 394 -> 386 ms against one per CU, profiles/r05_ab_cumask.txt)
+    small_shared = os.environ.get("VPIN_BENCH_SMALL_SHARED", "0" if (cu_split and cu_split["disjoint"]) else "1") != "0"
     for li, cx in enumerate(ctxs):
         cx.set_shared_device(l0_shared if li == 0 else small_shared)
 
@@ -816,11 +831,15 @@ def main():
     if args.snark and len(lanes) >= 3:
         ctxs[0].set_progress_flag(progress)
 
+    proof_ms = {}   # last measured duration per instance (the lane plan after the warm-up, the shared queue's order)
+
     def prove(li, name):
         cx = ctxs[li]
         if args.snark:
             di, tp, ti, tv, inp = resident[name]
+            t_p = time.perf_counter()
             r = cx.snark_prove_resident(di, decomms[name], tp, ti, tv, inp, SEED_C, SEED_P)
+            proof_ms[name] = (time.perf_counter() - t_p) * 1e3
             last_spans[name] = dict(cx.sat_timings(), **{"spark_" + k: v for k, v in cx.spark_timings().items() if k != "_"})
             proof_bytes[name] = len(r["proof"])
             last_proof[name] = r
@@ -834,7 +853,6 @@ def main():
         proof_bytes[name] = len(r["proof"])
         return len(r["proof"])
 
-    proof_ms = {}   # last measured duration per instance (the shared queue's order)
     queue_state = {"lock": threading.Lock(), "order": [], "pos": 0, "all_on_every_lane": False}
 
     def run_lane(li, gate):
@@ -958,8 +976,18 @@ def main():
             queue_state["all_on_every_lane"] = True
             step()   # an extra warm-up pass: any lane may prove any of the small instances later
             queue_state["all_on_every_lane"] = False
-        for _ in range(args.warmup):
+        for wi in range(max(args.warmup, 2 if (args.snark and len(lanes) == 4 and not args.lanes_spec and not args.small_queue) else 0)):
             step()
+            if wi == 0 and args.snark and len(lanes) == 4 and not args.lanes_spec and not args.small_queue and len(lane_names[1]) + len(lane_names[2]) > 2:
+                # the two lanes of the smaller point-mult instances, re-planned from the durations just measured (longest
+                # first onto the lane that is free first): constraint counts misjudge them -- padding, latency-bound phases
+                names = sorted(lane_names[1] + lane_names[2], key=lambda n: -proof_ms.get(n, 0.0))
+                plan, load = [[], []], [0.0, 0.0]
+                for n in names:
+                    k = 0 if load[0] <= load[1] else 1
+                    plan[k].append(n)
+                    load[k] += proof_ms.get(n, 0.0)
+                lane_names[1], lane_names[2] = plan
 
     for cx in ctxs:
         cx.prof_reset()
@@ -1030,6 +1058,7 @@ def main():
     }
     if cu_split:
         line["config"]["cu_split"] = cu_split
+    line["config"]["lanes"] = lane_names
 
     # ---- roofline of the fused sum-check round kernel ----
     # with several streams the event time of a kernel on one stream includes waiting for CUs taken by the

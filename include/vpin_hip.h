@@ -78,6 +78,9 @@ int vpin_ctx_set_progress_flag(vpin_ctx* ctx, int* flag);
  * commitment no longer stalls every other stream for its whole duration and the latency-bound proofs of the other lanes
  * keep most of every CU (LeNet step on four lanes: 451 -> 435 ms against two workgroups per CU, 513 before any limit). */
 int vpin_ctx_set_shared_device(vpin_ctx* ctx, int on);
+/* commitment rows this context has handed to the row-per-lane kernel (msm_strip_kernel) since it was created: lets a test
+ * or a scheduler see that the path it asked for is the one that ran */
+unsigned long long vpin_ctx_strip_rows_taken(vpin_ctx* ctx);
 /* How many proofs the generator window tables built through this context will serve: 0 (default) = many -- the widest
  * windows the table budget allows (fewest additions per scalar; the table costs ~0.2 s to build for the largest
  * instance); n > 0 = a process that proves n times and exits (vpin_prove: a process per label, like `cargo run -- <label>`):
@@ -231,6 +234,14 @@ int vpin_gens_msm_parts(vpin_ctx* ctx, const vpin_gens* g, const uint8_t* scalar
 /* DensePolynomial::bound (Spartan/src/dense_mlpoly.rs:220-227): LZ[i] = sum_j L[j]*Z[j*R+i],
  * Lvec = L_size host scalars, out = R = len/L_size host scalars. */
 int vpin_poly_bound(vpin_ctx* ctx, const vpin_table* Z, const uint8_t* Lvec, size_t L_size, uint8_t* out_LZ);
+/* The hash layer's slice pass (sparse_mlpoly.rs:740-849; single GPU): Z holds 2^nbits slices of N = 2^r_len scalars each.
+ * One pass over the first `used` slices yields (i) their evaluations at r -- DensePolynomial::evaluate, dense_mlpoly.rs:
+ * 239-253 -- in evals_out (used x 32 bytes) and (ii), for combining challenges ch (nbits scalars; NULL: skip), what
+ * PolyEvalProof::prove's first step computes for the whole Z at the point (ch, r): LZ = L^T Z with L = eq((ch, r)[..left])
+ * (dense_mlpoly.rs:340-349; R = 2^(ell - ell/2) scalars in LZ_out), without reading Z again.  The slices from `used` on must be
+ * zero (the reference pads the combined polynomials with zero slices).  Needs ell / 2 >= nbits (ell = r_len + nbits). */
+int vpin_poly_slices_bound(vpin_ctx* ctx, const vpin_table* Z, int nbits, int used, const uint8_t* r, size_t r_len,
+                           const uint8_t* ch, uint8_t* evals_out, uint8_t* LZ_out);
 
 /* ---- the sat proof (host orchestration over the kernels above) ------------------------ */
 /* R1CSInstance after Instance::new's padding and column remap (Spartan/src/lib.rs:138-244):
@@ -337,8 +348,10 @@ typedef struct vpin_spark_decomm vpin_spark_decomm;
  * to the single-GPU proof.  Without a comm (or with world == 1) the calls are the single-GPU ones.
  *
  * Transports for the small host-side exchanges (results are already on the host, where the transcript lives):
- *   vpin_comm_create_shm        ranks = processes of one node; a POSIX shared-memory segment `name` (unique per job;
- *                               rank 0 creates it, unlinks it once everyone is attached).  A flat all-gather of a few
+ *   vpin_comm_create_shm        ranks = processes of one node; a POSIX shared-memory segment `name`, which MUST be unique per
+ *                               job (two live jobs under one name attach to each other; only the segment of a job that
+ *                               has died is recognised and replaced).  Rank 0 creates it and unlinks it once everyone is
+ *                               attached.  A flat all-gather of a few
  *                               hundred bytes costs ~1-3 us, against ~20-30 us for a RCCL kernel launch.
  *   vpin_comm_create_local      `world` handles for the threads of one process (rehearsals, tests)
  *   vpin_comm_create_callbacks  the caller's own all-gather (gloo in the CPU tests; a host's existing fabric)

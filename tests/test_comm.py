@@ -276,3 +276,70 @@ def test_shm_leftover_of_a_dead_job_is_not_attached_to():
     [p.join(30) for p in ps]
     assert res == {0: bytes([0] * 4 + [1] * 4), 1: bytes([0] * 4 + [1] * 4)}, res
     assert not os.path.exists("/dev/shm" + name)
+
+
+def _die_as_rank0(name):
+    os.environ["VPIN_COMM_TIMEOUT_S"] = "60"
+    Comm.shm(name, 0, 2, slot_bytes=4096)  # initialises the segment, then waits for a rank 1 that never comes: killed by the test
+
+
+def test_shm_segment_of_a_job_that_just_died_is_not_attached_to():
+    """the leftover is a FULLY initialised segment (magic, world, a fresh time stamp) whose creator was killed a
+    moment ago -- it passes the size / magic / age / still-named checks.  The late rank of the next job must recognise it by
+    its dead creator, wait for rank 0 to replace it, and the group must form."""
+    name = f"/vpin-test-dead-{os.getpid()}-{int(time.time() * 1e3) & 0xffffff}"
+    ctx = mp.get_context("spawn")
+    dead = ctx.Process(target=_die_as_rank0, args=(name,))
+    dead.start()
+    t0 = time.time()
+    while not os.path.exists("/dev/shm" + name) and time.time() - t0 < 60:
+        time.sleep(0.05)
+    time.sleep(1.0)   # let it finish seg_init
+    dead.kill()
+    dead.join(10)
+    assert os.path.exists("/dev/shm" + name)   # the dead job's segment is still there, under the name the next job uses
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_stale_then_fresh_worker, args=(name, 1, 2, 0.0, q)),   # meets the dead job's segment first
+          ctx.Process(target=_stale_then_fresh_worker, args=(name, 0, 2, 1.5, q))]   # replaces it later
+    [p.start() for p in ps]
+    res = dict(q.get(timeout=90) for _ in range(2))
+    [p.join(30) for p in ps]
+    assert res == {0: bytes([0] * 4 + [1] * 4), 1: bytes([0] * 4 + [1] * 4)}, res
+    assert not os.path.exists("/dev/shm" + name)
+
+
+def test_callback_fabric_hands_a_size_mismatch_back_as_ecomm():
+    """the callback transport (kind 2) carries size and call site in front of the payload; a fabric that survives
+    ranks sending different sizes must make BOTH ranks fail with VPIN_ECOMM ('disagree'), not mix the slots up."""
+    world = 2
+    box, bar = [None] * world, threading.Barrier(world)
+
+    def fabric(rank):
+        def allgather(send):
+            box[rank] = send
+            bar.wait(30)
+            n = len(send)
+            out = b"".join((box[r] + b"\0" * n)[:n] for r in range(world))  # every rank's piece cut / padded to MY size
+            bar.wait(30)
+            return out
+        return allgather
+
+    comms = [Comm.callbacks(r, world, fabric(r)) for r in range(world)]
+    out, msgs = {}, []
+
+    def body(cm, n):
+        try:
+            assert cm.allgather(b"s" * 8) == b"s" * 16          # in step
+            cm.allgather(b"x" * n)                               # rank 0: 96 bytes, rank 1: 64 bytes
+            out[cm.rank] = "no error"
+        except vpin_amd.VpinError as e:
+            out[cm.rank] = e.code
+            msgs.append(str(e))
+
+    ts = [threading.Thread(target=body, args=(cm, n)) for cm, n in zip(comms, (96, 64))]
+    [t.start() for t in ts]
+    [t.join(60) for t in ts]
+    assert out == {0: -7, 1: -7}, out
+    assert any("disagree" in m for m in msgs), msgs
+    for cm in comms:
+        cm.destroy()

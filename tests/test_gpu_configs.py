@@ -223,6 +223,7 @@ def test_row_per_lane_derefs_commitment_gives_the_same_bytes(ctx, key, strips):
     if strips is not None:
         os.environ["VPIN_MSM_STRIP"] = strips   # a forced strip count: free-running workgroups
     # strips None: the library's own choice of strips, all workgroups resident and kept in step (the per-generator wait)
+    taken0 = ctx.strip_rows_taken()
     try:
         d = build_dev(ctx, g)
         try:
@@ -233,6 +234,8 @@ def test_row_per_lane_derefs_commitment_gives_the_same_bytes(ctx, key, strips):
         del os.environ["VPIN_MSM_STRIP_MIN"]
         os.environ.pop("VPIN_MSM_STRIP", None)
     assert hashlib.sha256(got["proof"]).hexdigest() == g["snark_sha256"], "SNARK bytes"
+    taken1 = ctx.strip_rows_taken()
+    assert taken1 > taken0, "the row-per-lane kernel took no row: the test compared the row kernel with itself (ADVICE r4)"
     # and switched off: the row kernel alone
     os.environ["VPIN_MSM_STRIP"] = "0"
     try:
@@ -244,3 +247,4 @@ def test_row_per_lane_derefs_commitment_gives_the_same_bytes(ctx, key, strips):
     finally:
         del os.environ["VPIN_MSM_STRIP"]
     assert hashlib.sha256(got["proof"]).hexdigest() == g["snark_sha256"]
+    assert ctx.strip_rows_taken() == taken1, "VPIN_MSM_STRIP=0 must keep every row on the row kernel"

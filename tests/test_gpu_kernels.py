@@ -243,3 +243,46 @@ def test_spark_batched_rounds_vs_oracle(ctx, lg_pairs, ncirc, with_dotp, lead):
         assert np.array_equal(dotp[0].read(0, 6 * N), derefs)
     for t in [forest_v, E_v] + (dotp or []):
         t.free()
+
+
+# ---- DensePolynomial::bound and the hash layer's one-pass slice evaluation (poly.hip) ------------------------------------
+
+def _oracle_poly_bound(Z, Lv, Ls, Rs):
+    out = np.zeros((Rs, 4), dtype=np.uint64)
+    O.lib().oracle_poly_bound(O.ptr(np.ascontiguousarray(Z)), O.ptr(np.ascontiguousarray(Lv)), Ls, Rs, O.ptr(out))
+    return out
+
+
+def _oracle_evaluate(Z, r):
+    """DensePolynomial::evaluate through the oracle's bound_poly_var_top, first challenge = top variable"""
+    t = np.array(Z, dtype=np.uint64)
+    for k in range(len(r)):
+        t = O.bound_top(t, r[k])
+    return t[0]
+
+
+@pytest.mark.parametrize("ell_slice,nbits,used,zero_frac", [(16, 3, 6, 0.0), (15, 4, 15, 0.3), (17, 1, 2, 0.0), (6, 3, 6, 0.0), (4, 4, 16, 0.5),
+                                                             (20, 3, 6, 0.1)])
+def test_slice_pass_vs_oracle(ctx, ell_slice, nbits, used, zero_frac):
+    """vpin_poly_slices_bound (slices_bound_kernel / slices_eval_kernel / slices_combine_kernel): the slice evaluations equal the
+    oracle's DensePolynomial::evaluate of every slice, and the LZ vector equals the oracle's DensePolynomial::bound
+    (dense_mlpoly.rs:220-227) of the whole table at L = eq((ch, r)[..left]) -- what the two-pass path computed; also
+    vpin_poly_bound itself against the same oracle function."""
+    rng = np.random.default_rng(1000 * ell_slice + nbits)
+    N, S = 1 << ell_slice, 1 << nbits
+    Z = fast_table(rng, N * S, zero_frac)
+    Z[used * N:] = 0                      # the reference pads the combined polynomials with zero slices
+    r = np.stack([rand_scalar(rng) for _ in range(ell_slice)])
+    ch = np.stack([rand_scalar(rng) for _ in range(nbits)])
+    t = ctx.upload(Z)
+    ev, lz = ctx.poly_slices_bound(t, nbits, used, r, ch)
+    for s in range(used):
+        assert np.array_equal(ev[s], _oracle_evaluate(Z[s * N:(s + 1) * N], r)), f"slice {s}"
+    ell = ell_slice + nbits
+    left = ell // 2
+    Ls, Rs = 1 << left, 1 << (ell - left)
+    Lv = O.eq_evals(np.concatenate([ch, r])[:left])
+    exp = _oracle_poly_bound(Z, Lv, Ls, Rs)
+    assert np.array_equal(lz, exp)
+    assert np.array_equal(ctx.poly_bound(t, Lv), exp)
+    t.free()

@@ -554,6 +554,13 @@ class Context:
         _chk(L.vpin_ctx_mem_info(self.h, C.byref(f), C.byref(t)), "vpin_ctx_mem_info")
         return t.value
 
+    def strip_rows_taken(self):
+        """rows handed to the row-per-lane commitment kernel so far (vpin_ctx_strip_rows_taken)"""
+        L = lib()
+        L.vpin_ctx_strip_rows_taken.argtypes = [C.c_void_p]
+        L.vpin_ctx_strip_rows_taken.restype = C.c_ulonglong
+        return int(L.vpin_ctx_strip_rows_taken(self.h))
+
     def set_shared_device(self, on=True):
         """other contexts prove on this device concurrently: leave them a share of every CU"""
         _chk(lib().vpin_ctx_set_shared_device(self.h, 1 if on else 0), "vpin_ctx_set_shared_device")
@@ -731,6 +738,20 @@ class Context:
         _chk(lib().vpin_poly_bound(self.h, Z.h, lv.ctypes.data_as(C.c_void_p), lv.shape[0],
                                    out.ctypes.data_as(C.c_void_p)), "vpin_poly_bound")
         return out
+
+    def poly_slices_bound(self, Z, nbits, used, r, ch=None):
+        """vpin_poly_slices_bound: (evaluations of the first `used` of Z's 2^nbits slices at r, LZ of the whole Z at (ch, r) or None)"""
+        rr = np.ascontiguousarray(r, dtype=np.uint64).reshape(-1, 4)
+        ell = rr.shape[0] + nbits
+        ev = np.zeros((used, 4), dtype=np.uint64)
+        lz = np.zeros((1 << (ell - ell // 2), 4), dtype=np.uint64) if ch is not None else None
+        cc = np.ascontiguousarray(ch, dtype=np.uint64).reshape(-1, 4) if ch is not None else None
+        L = lib()
+        L.vpin_poly_slices_bound.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
+        _chk(L.vpin_poly_slices_bound(self.h, Z.h, nbits, used, rr.ctypes.data_as(C.c_void_p), rr.shape[0],
+                                      cc.ctypes.data_as(C.c_void_p) if cc is not None else None, ev.ctypes.data_as(C.c_void_p),
+                                      lz.ctypes.data_as(C.c_void_p) if lz is not None else None), "vpin_poly_slices_bound")
+        return ev, lz
 
     # ---- sat proof ----
     def sat_prove(self, inst, seed_commit, seed_proof):

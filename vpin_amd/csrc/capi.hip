@@ -93,12 +93,19 @@ int dev_alloc(vpin_ctx* c, size_t bytes, void** out) {
         // blocks synchronises their stream, and that stream may be waiting for a reply which depends on THIS rank's next
         // all-gather -- both ranks would sit out the comm timeout instead of recovering memory
         for (auto* x : g_live_ctxs)
-          if (x != c && x->device == c->device && x->comm == nullptr && x->tail_rounds == 0) {
+          if (x != c && x->device == c->device && x->comm_pub.load(std::memory_order_acquire) == nullptr &&
+              x->tail_rounds.load(std::memory_order_acquire) == 0) {
             x->pins.fetch_add(1, std::memory_order_acq_rel);
             others.push_back(x);
           }
       }
-      for (auto* x : others) { pool_release_unlocked(x); x->pins.fetch_sub(1, std::memory_order_acq_rel); }
+      for (auto* x : others) {
+        // re-checked after pinning: the owner may have started a tail or joined a collective proof since the list was made
+        // (a tail that becomes resident after THIS check only delays the release by its rounds: the owner keeps replying)
+        if (x->comm_pub.load(std::memory_order_acquire) == nullptr && x->tail_rounds.load(std::memory_order_acquire) == 0)
+          pool_release_unlocked(x);
+        x->pins.fetch_sub(1, std::memory_order_acq_rel);
+      }
       if (hipMalloc(&p, cls) != hipSuccess) { (void)hipGetLastError(); return VPIN_ENOMEM; }
     }
   }
@@ -117,6 +124,15 @@ void dev_free(vpin_ctx* c, void* p) {
 }
 
 void dev_pool_release(vpin_ctx* c) { pool_release_unlocked(c); }
+
+void dev_release_block(vpin_ctx* c, void* p) {
+  if (!p) return;
+  {
+    std::lock_guard<std::mutex> g(c->pool_mu);
+    c->pool_sizes.erase(p);
+  }
+  (void)hipFree(p);
+}
 
 static void ctx_switch_stream(vpin_ctx* c, hipStream_t to, int cus, bool masked) {
   if (!to || c->stream == to) return;
@@ -299,6 +315,8 @@ int vpin_ctx_set_progress_flag(vpin_ctx* c, int* flag) {
   c->progress_flag = flag;
   return VPIN_OK;
 }
+
+unsigned long long vpin_ctx_strip_rows_taken(vpin_ctx* c) { return c ? c->strip_rows_taken : 0ull; }
 
 int vpin_ctx_set_shared_device(vpin_ctx* c, int on) {
   if (!c) return VPIN_EINVAL;

@@ -9,6 +9,8 @@
 #include <dlfcn.h>
 #include <fcntl.h>
 #include <sched.h>
+#include <errno.h>
+#include <signal.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -48,6 +50,7 @@ struct alignas(64) CommSeg {
   std::atomic<uint32_t> attached, abort_flag, token, detached;
   std::atomic<uint32_t> serialize;  // ranks that asked for the token mode
   double created_unix_s;            // when rank 0 initialised the segment (a leftover is older than any attach timeout)
+  int32_t creator_pid;              // rank 0's process: a segment whose creator is gone belongs to a job that died
 };
 
 static inline size_t seg_slot_stride(size_t slot_bytes) { return sizeof(CommSlotHdr) + 2 * ((slot_bytes + 63) & ~(size_t)63); }
@@ -109,6 +112,7 @@ static void seg_init(CommSeg* s, int world, size_t slot_bytes) {
   s->attached.store(0); s->abort_flag.store(0); s->token.store(kNoHolder); s->detached.store(0); s->serialize.store(0);
   for (int r = 0; r < world; r++) { slot_hdr(s, r)->seq.store(0); slot_hdr(s, r)->busy_s[0] = slot_hdr(s, r)->busy_s[1] = 0.0; }
   s->created_unix_s = std::chrono::duration<double>(std::chrono::system_clock::now().time_since_epoch()).count();
+  s->creator_pid = (int32_t)getpid();
   s->magic.store(kCommMagic, std::memory_order_release);
 }
 
@@ -371,7 +375,11 @@ int vpin_comm_create_shm(const char* name, int rank, int world, size_t slot_byte
         }
         if (ready) {
           const double age = std::chrono::duration<double>(std::chrono::system_clock::now().time_since_epoch()).count() - s->created_unix_s;
-          same = age <= timeout + 5.0 && still_named();  // older than any rank would wait, or no longer named: a leftover
+          // older than any rank would wait, no longer named, or created by a process that no longer exists (the segment of a job
+          // that died moments ago, which rank 0 of THIS job has not replaced yet: it passes every other check -- ADVICE r4):
+          // a leftover.  (kill(pid, 0): ESRCH = gone; EPERM = exists under another user.)
+          const bool creator_alive = s->creator_pid > 0 && (kill((pid_t)s->creator_pid, 0) == 0 || errno == EPERM);
+          same = age <= timeout + 5.0 && creator_alive && still_named();
         }
         if (ready && same) break;
         munmap(p, bytes);
@@ -546,6 +554,7 @@ int vpin_comm_latency(vpin_comm* cm, size_t bytes, int iters, double* seconds_pe
 int vpin_ctx_set_comm(vpin_ctx* c, vpin_comm* cm) {
   if (!c) return VPIN_EINVAL;
   c->comm = cm;
+  c->comm_pub.store(cm, std::memory_order_release);
   return VPIN_OK;
 }
 

@@ -96,15 +96,17 @@ struct vpin_ctx {
   int round_split = 0, round_split_grid = 0, round_split_ncirc = 0;  // the current group sums its partials in round_finish_kernel
   int round_group_ndotp = 0;  // dot-product halves announced for the current launch group (spark_prod_round)
   uint32_t tail_seq = 0;            // persistent tail kernel (spark.hip): sequence base of the current / next launch
-  int tail_rounds = 0;
+  std::atomic<int> tail_rounds{0};  // > 0 while a persistent tail kernel is resident (read by other threads: dev_alloc's reclaim)
   vpin::fq tail_sums[3 * 18];   // host copies of the current tail round's results (assembled from the mailbox pieces)
   vpin::fq tail_final[6 * 18];
+  unsigned long long strip_rows_taken = 0;  // rows handed to msm_strip_kernel so far (vpin_ctx_strip_rows_taken: tests)
   bool shared_device = false;  // other contexts prove on this device at the same time (vpin_ctx_set_shared_device)
   int expected_proofs = 0;     // proofs the window tables built through this context will serve; 0 = many (vpin_ctx_set_expected_proofs)
   double gens_scalars_per_proof = 0.0;  // set by the caller of vpin_gens_shared: full-size scalars one proof commits under the table
   void* h_bullet = nullptr;  // pinned staging of the bullet reduction's per-round results (bullet.hip), 64 KiB
   uint32_t bullet_seq = 0;   // sequence number of the last fused bullet round (mailbox_dev.h)
   // one proof over several GPUs (include/vpin_hip.h, vpin_ctx_set_comm): proofs on this context are collective calls
+  std::atomic<vpin_comm*> comm_pub{nullptr};  // == comm, for other threads (dev_alloc's reclaim skips the peers of a collective proof)
   vpin_comm* comm = nullptr;
   volatile int* progress_flag = nullptr;  // optional host word: 1 when a SNARK's sat part is done, 2 after its derefs commitment
 };
@@ -134,6 +136,9 @@ struct AltStreamGuard {
 int dev_alloc(vpin_ctx* c, size_t bytes, void** out);
 void dev_free(vpin_ctx* c, void* p);
 void dev_pool_release(vpin_ctx* c);
+// one block the caller holds (from dev_alloc) straight back to the driver, not to the pool; the caller has synchronised the
+// work that used it
+void dev_release_block(vpin_ctx* c, void* p);
 
 // scoped pooled buffer
 struct DevBuf {

@@ -1228,11 +1228,12 @@ static int gens_build_once(vpin_ctx* c, const uint8_t* gens_xyzt, size_t nb, siz
   // driver instead of staying in the context's pool, where nothing of its size comes to reuse it: 227.6 -> 219.5 GiB in use after
   // the LeNet step, the step unchanged, 0.8 s more set-up (the freed memory is wiped when it is next handed out).  Not in a one-shot
   // process, whose table build is inside the timed span.  VPIN_GENS_TMP_KEEP restores the old behaviour.
-  if (c->expected_proofs == 0 && !getenv("VPIN_GENS_TMP_KEEP") && b_prefix.p) {
+  // Only THIS block leaves the pool (the stream has been synchronised above, successfully): the context's other cached blocks
+  // stay where the next proofs find them, and no other lane's work is synchronised with.
+  if (e == hipSuccess && c->expected_proofs == 0 && !getenv("VPIN_GENS_TMP_KEEP") && b_prefix.p) {
     void* pp = b_prefix.p;
     b_prefix.p = nullptr;
-    dev_free(c, pp);
-    dev_pool_release(c);
+    dev_release_block(c, pp);
   }
   if (e != hipSuccess) {
     set_last_error("vpin_gens_create", e);
@@ -1567,6 +1568,7 @@ int hyrax_commit_derefs_hot(vpin_ctx* c, const vpin_gens* g, const vpin_table* Z
     static const int env_pad = [] { const char* e = getenv("VPIN_MSM_LDS_PAD"); return e ? atoi(e) : -1; }();
     const unsigned pad = env_pad >= 0 ? (unsigned)env_pad : (c->shared_device ? kSharedPad : 0u);
     if (n_strip) {
+      c->strip_rows_taken += n_strip;
       const unsigned groups = (unsigned)((n_strip + kMsmBlock - 1) / kMsmBlock);
       const size_t per = (R + (size_t)S - 1) / (size_t)S;
       const char* el = getenv("VPIN_MSM_STRIP_LAG");  // generators a workgroup may run ahead of its strip's slowest; 0: no sync

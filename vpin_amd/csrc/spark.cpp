@@ -198,7 +198,7 @@ struct SlicePass {
   bool on = false;
   explicit SlicePass(vpin_ctx* c) : lzs(c) {}
   static bool fits(const PcGens& pc, int nbits, const std::vector<Fq>& rand) {
-    static const bool off = getenv("VPIN_HASH_TWO_PASS") != nullptr;  // A/B: the separate evaluation and bound passes
+    const bool off = getenv("VPIN_HASH_TWO_PASS") != nullptr;  // A/B and tests: the separate evaluation and bound passes (read per proof)
     return !off && pc.ell / 2 >= (size_t)nbits && rand.size() + (size_t)nbits == pc.ell;
   }
   int run(vpin_ctx* c, const PcGens& pc, const vpin::fq* table, int nbits_, int used_, const std::vector<Fq>& rand, Fq* ev) {
@@ -1531,6 +1531,30 @@ size_t vpin_dev_instance_proof_max_bytes(const vpin_dev_instance* g) {
   r.num_cons = g->r1cs->num_cons; r.num_vars = g->r1cs->num_vars; r.num_inputs = g->num_inputs;
   for (int m = 0; m < 3; m++) r.nnz[m] = g->nnz[m];
   return vpin_snark_proof_max_bytes(&r);
+}
+
+// Kernel-level entry of the hash layer's one-pass slice evaluation (include/vpin_hip.h)
+int vpin_poly_slices_bound(vpin_ctx* c, const vpin_table* Z, int nbits, int used, const uint8_t* r, size_t r_len, const uint8_t* ch,
+                           uint8_t* evals_out, uint8_t* LZ_out) {
+  if (!c || !Z || !Z->d || nbits < 0 || nbits > 4 || used < 1 || used > (1 << nbits) || !r || !evals_out) return VPIN_EINVAL;
+  const size_t ell = r_len + (size_t)nbits;
+  if (Z->len != ((size_t)1 << ell) || ell / 2 < (size_t)nbits) return VPIN_ESHAPE;
+  PcGens pc;  // shape only
+  pc.ell = ell; pc.L = (size_t)1 << (ell / 2); pc.R = (size_t)1 << (ell - ell / 2);
+  std::vector<Fq> rand(r_len);
+  memcpy(rand.data(), r, r_len * 32);
+  SlicePass sp(c);
+  std::vector<Fq> ev((size_t)used);
+  int rc = sp.run(c, pc, Z->d, nbits, used, rand, ev.data());
+  if (rc) return rc;
+  memcpy(evals_out, ev.data(), (size_t)used * 32);
+  if (ch && LZ_out) {
+    std::vector<Fq> chv((size_t)nbits), LZ;
+    memcpy(chv.data(), ch, (size_t)nbits * 32);
+    if ((rc = sp.combine(c, pc, chv, LZ))) return rc;
+    memcpy(LZ_out, LZ.data(), pc.R * 32);
+  }
+  return VPIN_OK;
 }
 
 // my_lib_prove (commit_test.rs:59-133) in full: R1CSProof, inst_evals, R1CSEvalProof -> bincode(SNARK)

@@ -1349,7 +1349,7 @@ void spark_tail_end(vpin_ctx* c) {
   if (trace_on) {
     (void)hipStreamSynchronize(c->stream);
     const unsigned long long* t = reinterpret_cast<const unsigned long long*>(c->h_spark + kTailTrace);
-    fprintf(stderr, "[tail] %d rounds:", c->tail_rounds);
+    fprintf(stderr, "[tail] %d rounds:", c->tail_rounds.load());
     for (int i = 0; i < c->tail_rounds && i < 64; i++) {
       const double comp = (double)(t[4 * i + 1] - t[4 * i]) * 0.01, wait = t[4 * i + 2] ? (double)(t[4 * i + 2] - t[4 * i + 1]) * 0.01 : 0.0;
       fprintf(stderr, " %.1f+%.1f", comp, wait);

@@ -56,11 +56,12 @@ if "--rehearse" in sys.argv:
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "tools"))  # the other modes and the shared helpers: bench_common / bench_strong / bench_concurrent
+
+from bench_common import SEED_C, SEED_P, PowerSampler, _golden_digests, live_pmc_traffic  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
-SEED_C = bytes(range(64))
-SEED_P = bytes((7 * i + 3) % 256 for i in range(64))
 
 
 def parse():
@@ -106,7 +107,12 @@ def parse():
                     help="the lanes other than the first take their instances of a step from ONE queue, longest first (durations measured "
                          "in the warm-up), instead of a fixed list per lane")
     ap.add_argument("--skip", default=None, help="comma-separated instance names left out of the trace (experiments: L5-mult)")
+    ap.add_argument("--numa", choices=["local", "remote", "off"], default=os.environ.get("VPIN_BENCH_NUMA"),
+                    help="pin the process to the host cores next to its GPU (local: default for N > 1), to the others (remote: measures "
+                         "the sensitivity), or not at all (off: default for N = 1)")
     ap.add_argument("--no-span", action="store_true", help="skip the reference-span pass after the timed region")
+    ap.add_argument("--no-digest", action="store_true", help="reference-span pass: do not measure the zlib digest of bincode(A, B, C) "
+                    "(the reference's unused Instance::new digest; ~35 s of one host core for the 2^25 instance, run beside the PMC passes)")
     ap.add_argument("--no-strong", action="store_true", help="N > 1: skip the strong-scaling sub-record (one trace over all ranks)")
     ap.add_argument("--strong-timeout", type=float, default=300.0, help="N > 1: seconds after which the strong sub-record is given up "
                     "(the line is printed with the failure recorded and every rank exits)")
@@ -138,516 +144,62 @@ def parse():
     return ap.parse_args()
 
 
-def _strong_work(args):
-    from vpin_amd import gadgets as G
-    trace = args.label or args.trace
-    labels = list(G.LENET) if trace == "lenet" else trace.split(",")
-    work = []
-    for lab in labels:
-        m = G.synthetic_mult_inputs(lab)
-        if m is not None:
-            work.append((f"{lab}-mult", "mult", m, 3464 * len(m[0])))
-        a = G.synthetic_add_inputs(lab)
-        work.append((f"{lab}-add", "add", a, 10 * len(a[4])))
-    if args.only:
-        work = [w for w in work if w[1] == args.only]
-    work.sort(key=lambda w: -w[3])
-    return trace, work
+def parse_cpulist(txt):
+    out = []
+    for part in txt.strip().split(","):
+        if not part:
+            continue
+        a, _, b = part.partition("-")
+        out += list(range(int(a), int(b or a) + 1))
+    return out
 
 
-def _build_resident(cx, w):
-    g = cx.gadget_point_mult_dev(*w[2]) if w[1] == "mult" else cx.gadget_point_add_dev(*w[2])
-    cx.sat_prepare(g.num_vars)
-    dec, _ = g.spark_encode()
-    return g, dec
-
-
-def _prove_res(cx, g, dec):
-    return cx.snark_prove_resident(g.r1cs, dec, g.vars_para, g.vars_input, g.vars, g.inputs, SEED_C, SEED_P)
-
-
-def main_strong(args):
-    """--scaling strong: ONE trace over all ranks.  Instances of at least 2^--coop-log2 constraints are
-    proven by ALL ranks together (vpin_comm: row commitments by interleaved rows, sum-check tables and product circuits by
-    residue class over a power-of-two world, by circuit index otherwise, see include/vpin_hip.h), mid-size ones
-    (--sub-coop-log2) by the first half of the ranks, one after another; the small, latency-bound instances go to the rank
-    that is free first and are proven without any exchange (vpin_amd/dist.py plan_trace: a static plan every rank computes).
-    value = the trace's constraints x steps / slowest rank's time.
-    Ranks = processes (torch.distributed.run; the exchange goes through POSIX shared memory, device buffers through RCCL
-    when the backend is nccl)."""
-    if args.rehearse:
-        return strong_rehearse(args)
-    import hashlib
-    import torch
-    import vpin_amd
-    from vpin_amd import Comm
-    from vpin_amd.dist import Group, env_rank, plan_trace
-
-    rank, local_rank, world = env_rank()
-    ndev = max(1, torch.cuda.device_count())
-    dev = local_rank % ndev
-    use_nccl = args.backend == "nccl" and world > 1
-    if use_nccl:
-        torch.cuda.set_device(dev)
-    grp = Group(backend=args.backend, device=torch.device("cuda", dev) if use_nccl else None)
-    rec = _strong_core(args, grp, rank, world, dev, use_nccl, ndev, args.steps, args.warmup)
-    if rank == 0:
-        print(json.dumps(rec))
-    grp.close()
-
-
-def _strong_core(args, grp, rank, world, dev, use_nccl, ndev, steps, warmup):
-    """one trace over all ranks of `grp`: the JSON record on rank 0, None on the others (collective)"""
-    import hashlib
-    import torch
-    import vpin_amd
-    from vpin_amd import Comm
-    from vpin_amd.dist import plan_trace
-
-    trace, work = _strong_work(args)
-    total_cons = sum(w[3] for w in work)
-    coop_ix, small_ix, _ = plan_trace([w[3] for w in work], world, 0.5 * 2 ** args.coop_log2, 0.5 * 2 ** args.sub_coop_log2)
-    coop = [(work[i], g) for i, g in coop_ix]       # in proving order; the group of an entry is ranks [0, g)
-    mine = [work[i] for i in small_ix[rank]]
-
-    ctx = vpin_amd.Context(dev)
-    comms, rccl_failed, rccl_world = {}, [], {}
-    if world > 1:
-        name = grp.gather_objects(f"/vpin-{os.getpid()}-{int(time.time() * 1e3) & 0xffffff}")[0]  # rank 0's choice
-        for g in sorted({g for _, g in coop}, reverse=True):
-            if rank < g:
-                comms[g] = Comm.shm(f"{name}-g{g}", rank, g)
-                if use_nccl and ndev >= world:
-                    try:
-                        comms[g].enable_rccl(ctx)  # collective: every rank of the group gets the same verdict
-                        rccl_world[g] = g
-                    except vpin_amd.VpinError as e:
-                        rccl_failed.append(g)     # device vectors are then staged through the shared-memory transport
-                        if rank == 0:
-                            print(f"bench: RCCL not enabled for the group of {g} ({e}); device buffers staged through the host", file=sys.stderr)
-    built = {w[0]: _build_resident(ctx, w) for w in [w for w, g in coop if rank < g] + mine}
-    proof_sha = {}
-
-    def step():
-        for w, g in coop:
-            if rank < g:
-                ctx.set_comm(comms[g])
-                proof_sha[w[0]] = hashlib.sha256(_prove_res(ctx, *built[w[0]])["proof"]).hexdigest()
-        ctx.set_comm(None)
-        for w in mine:
-            proof_sha[w[0]] = hashlib.sha256(_prove_res(ctx, *built[w[0]])["proof"]).hexdigest()
-
-    def barrier():
-        torch.cuda.synchronize()
-        grp.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(warmup):
-        step()
-    for cm in comms.values():
-        cm.stats(reset=True)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        step()
-    ctx.sync()
-    barrier()
-    elapsed = grp.max_over_ranks(time.perf_counter() - t0)
-    gold = _golden_digests()
-    mine_ok = {k: (gold.get(k, {}).get("snark_sha256") == v) for k, v in proof_sha.items()}  # every rank checks what IT returned
-    per_rank = grp.gather_objects({"rank": rank, "bytes_equal_oracle_digest": mine_ok, "rccl_world": rccl_world})
-    st = {f"group_of_{g}": cm.stats() for g, cm in comms.items()} if comms else None
-    rec = None
-    if rank == 0:
-        all_ok = {}
-        for d in per_rank:
-            for k, v in d["bytes_equal_oracle_digest"].items():
-                all_ok[k] = all_ok.get(k, True) and v
-        rccl = bool(comms) and use_nccl and ndev >= world and not rccl_failed
-        rec = {
-            "metric": "R1CS constraints/sec, whole Spartan SNARK (sat proof + SPARK evaluation proof; vPIN point-mult + point-add instances)",
-            "value": total_cons * steps / elapsed, "unit": "constraints/s", "n_gpus": world, "steps": steps,
-            "warmup": warmup, "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": None, "dtype": "u256 (mod q = 2^252+..., mod p = 2^255-19; 32-bit limbs)", "data": "synthetic",
-            "config": {"workload": f"ONE vPIN trace '{trace}' over {world} rank(s): {len(work)} SNARKs per step",
-                       "constraints_unpadded_per_step": total_cons,
-                       "parallelism": f"cooperative proofs {[(w[0], g) for w, g in coop]} (instance, ranks [0, g) together: vpin_comm over "
-                                      f"shared memory{', device buffers over RCCL' if rccl else ''}: row commitments by interleaved rows; "
-                                      "sum-check tables, product circuits and slices by residue class when the group is a power of two, "
-                                      "by circuit index otherwise); the other instances go to the rank that is free first, no exchange",
-                       "small_instances_per_rank": [[work[i][0] for i in sh] for sh in small_ix]},
-            "bytes_equal_oracle_digest": all_ok,
-            "per_rank": per_rank,
-            "rccl": {"enabled": rccl, "world_by_group": rccl_world, "failed_groups": rccl_failed,
-                     "note": "ncclAllGather carries the device-resident partial vectors of the evaluation proofs; when it cannot be "
-                             "enabled (fewer GPUs than ranks, init failure) they are staged through the shared-memory transport"},
-            "comm": st}
-    for cm in comms.values():
-        cm.destroy()
-    for g, dec in built.values():
-        dec.free()
-        g.free()
-    ctx.close()
+def pin_to_gpu_numa_node(local_rank, world, mode):
+    """Pin this process (before the library's host threads exist: they inherit the mask) to the host cores next to its GPU:
+    /sys/bus/pci/devices/<the card's PCI id>/local_cpulist.  A LeNet step makes ~2,500 host<->GPU round trips through pinned
+    mailboxes; a rank whose threads and mailboxes sit on the other socket pays the inter-socket hop on each.
+    mode: local | remote (the cores NOT next to the GPU: to measure the sensitivity) | off.  Ranks whose GPUs share a node
+    split its cores evenly.  Returns a record for the bench line."""
+    rec = {"mode": mode}
+    if mode == "off" or not hasattr(os, "sched_setaffinity"):
+        return rec
+    try:
+        import ctypes as C
+        hip = C.CDLL("libamdhip64.so")
+        ndev = C.c_int(0)
+        hip.hipGetDeviceCount(C.byref(ndev))
+        lists = []
+        for d in range(max(1, ndev.value)):
+            buf = C.create_string_buffer(64)
+            if hip.hipDeviceGetPCIBusId(buf, 64, d) != 0:
+                return dict(rec, error="hipDeviceGetPCIBusId failed")
+            with open("/sys/bus/pci/devices/" + buf.value.decode().lower() + "/local_cpulist") as f:
+                lists.append(parse_cpulist(f.read()))
+        allowed = sorted(os.sched_getaffinity(0))
+        mine = [c for c in lists[local_rank % len(lists)] if c in allowed]
+        if mode == "remote":
+            mine = [c for c in allowed if c not in set(lists[local_rank % len(lists)])]
+        elif world > 1:
+            # the ranks (local ranks 0..world-1 -> devices 0..) whose GPU has the same core list share it in equal slices
+            peers = [r for r in range(world) if lists[r % len(lists)] == lists[local_rank % len(lists)]]
+            k, n = peers.index(local_rank), len(peers)
+            per = max(1, len(mine) // n)
+            mine = mine[k * per:(k + 1) * per] or mine
+        if not mine:
+            return dict(rec, error="no allowed core in the selected set", node_cpulist=len(lists[local_rank % len(lists)]))
+        os.sched_setaffinity(0, mine)
+        rec.update({"cores": len(mine), "first_core": mine[0], "last_core": mine[-1],
+                    "gpu_node_cores": len(lists[local_rank % len(lists)]), "allowed_before": len(allowed)})
+    except (OSError, ValueError, IndexError) as e:
+        rec["error"] = repr(e)
     return rec
 
 
-def main_concurrent(args):
-    """--concurrent K[,K2,..]: K independent copies of ONE small trace proven at the same time, each on its own context
-    (stream + host thread), whole SNARKs, inputs resident.  A small trace (configs 1-3: conv f=3, CNN A, conv f=7) is a latency
-    chain of ~800 host<->device round trips that leaves the chip mostly idle; a service hides the chain by proving several
-    traces at once.  Reports the single-trace latency and, per K, the sustained constraints/s and the latency of a trace under
-    that load.  One GPU."""
-    import hashlib
-    trace, work = _strong_work(args)
-    total_cons = sum(w[3] for w in work)
-    ks = sorted({int(x) for x in str(args.concurrent).split(",") if int(x) > 0})
-    if len(ks) > 1:
-        # One K per PROCESS: memory a context frees is wiped lazily by the driver and slows the next context's allocations
-        # (DESIGN.md section 3), and idle contexts' streams share the hardware queues of the busy ones -- a sweep inside one
-        # process measured K = 8 at 1.0x of the single-trace rate where a fresh process gives 3x.  This parent never touches
-        # the GPU; it starts one child per K, one after the other, and merges their lines.
-        import subprocess
-        rows, single, oks, envs = [], None, [], {}
-        for K in ks:
-            cmd = [sys.executable, os.path.abspath(__file__), "--trace", trace, "--concurrent", str(K), "--steps", str(args.steps),
-                   "--warmup", str(args.warmup)] + (["--only", args.only] if args.only else [])
-            out = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
-            if out.returncode != 0:
-                raise SystemExit(f"--concurrent {K}: child failed\n{out.stderr[-2000:]}")
-            d = json.loads(out.stdout.strip().splitlines()[-1])
-            rows += d["concurrent"]
-            single = single or d["single_trace"]
-            oks.append(d["bytes_equal_oracle_digest"])
-            envs[K] = {"host_threads_per_context": d["host_threads_per_context"], "GPU_MAX_HW_QUEUES": d["GPU_MAX_HW_QUEUES"]}
-        best = max(rows, key=lambda r: r["constraints_per_s"])
-        d.update({"value": best["constraints_per_s"], "ms_per_step": best["ms_per_trace_under_load"], "single_trace": single, "concurrent": rows,
-                  "bytes_equal_oracle_digest": all(oks), "per_K_environment": envs})
-        d["config"]["workload"] = f"vPIN trace '{trace}' x K concurrent copies on one GPU (K contexts / streams / host threads; a fresh process per K), best K = {best['K']}"
-        print(json.dumps(d))
-        return
-    import vpin_amd
-    K = ks[0]
-    gold = _golden_digests()
-    order = [w[0] for w in sorted(work, key=lambda w: -w[3])]
-    ctxs = [vpin_amd.Context(0) for _ in range(K)]
-    if K > 1:
-        for cx in ctxs:
-            cx.set_shared_device(True)
-    built = [{w[0]: _build_resident(cx, w) for w in work} for cx in ctxs]
-    ok, rows = {}, []
-
-    def run_trace(k, n):
-        for _ in range(n):
-            for name in order:
-                r = _prove_res(ctxs[k], *built[k][name])
-                ok[(k, name)] = hashlib.sha256(r["proof"]).hexdigest() == gold.get(name, {}).get("snark_sha256")  # every proof made
-
-    run_trace(0, args.warmup)
-    t0 = time.perf_counter()
-    run_trace(0, args.steps)   # the single-trace latency: one context busy, the others idle
-    single_s = (time.perf_counter() - t0) / args.steps
-    th = [threading.Thread(target=run_trace, args=(k, args.warmup)) for k in range(K)]   # warm every context
-    [t.start() for t in th]
-    [t.join() for t in th]
-    th = [threading.Thread(target=run_trace, args=(k, args.steps)) for k in range(K)]
-    t0 = time.perf_counter()
-    [t.start() for t in th]
-    [t.join() for t in th]
-    el = time.perf_counter() - t0
-    rows.append({"K": K, "traces_per_s": K * args.steps / el, "constraints_per_s": K * args.steps * total_cons / el,
-                 "ms_per_trace_under_load": el / args.steps * 1e3, "x_single_trace_rate": (K * args.steps / el) * single_s})
-    best = max(rows, key=lambda r: r["constraints_per_s"])
-    print(json.dumps({
-        "metric": "R1CS constraints/sec, whole Spartan SNARK (sat proof + SPARK evaluation proof; vPIN point-mult + point-add instances)",
-        "value": best["constraints_per_s"], "unit": "constraints/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": best["ms_per_trace_under_load"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "u256 (mod q = 2^252+..., mod p = 2^255-19; 32-bit limbs)", "data": "synthetic",
-        "config": {"workload": f"vPIN trace '{trace}' x K concurrent copies on one GPU (K contexts / streams / host threads), best K = {best['K']}",
-                   "constraints_unpadded_per_trace": total_cons, "inputs": "resident in HBM"},
-        "single_trace": {"ms": single_s * 1e3, "constraints_per_s": total_cons / single_s},
-        "concurrent": rows,
-        "bytes_equal_oracle_digest": all(ok.values()), "host_cores": os.cpu_count(),
-        "host_threads_per_context": os.environ.get("VPIN_HOST_THREADS"), "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES")}))
-
-
-def _golden_digests():
-    try:
-        with open(os.path.join(ROOT, "tests", "golden", "config_digests.json")) as f:
-            return json.load(f)["cases"]
-    except OSError:
-        return {}
-
-
-def strong_rehearse(args):
-    """--scaling strong --rehearse W: the critical path of a W-GPU run, measured on ONE GPU.  W ranks run as threads of this
-    process and prove each cooperative instance together with vpin_comm_set_serialize on: one rank computes at a time, so the
-    time a rank spends between two collectives is its own work and nothing else, and the W-GPU time of the proof is the sum over
-    the collectives of the slowest rank's section (crit_s) plus the exchanges themselves (collectives x the measured latency of
-    an all-gather among W threads).  The trace's time is the static plan of main_strong (plan_trace: which instances are proven
-    by all ranks, by half of them, by one) replayed with these modelled and measured times.  A MODEL of the multi-GPU run from
-    measured sections -- no multi-GPU hardware was used."""
-    import hashlib
-    import threading
-    import vpin_amd
-    from vpin_amd import Comm
-    from vpin_amd.dist import plan_trace, replay_trace
-
-    W = args.rehearse
-    trace, work = _strong_work(args)
-    total_cons = sum(w[3] for w in work)
-    cons = [w[3] for w in work]
-    if args.coop_all:  # every point-mult instance by all ranks (how each size scales)
-        coop_ix = [(i, W) for i, w in enumerate(work) if w[1] == "mult"]
-        _, small_ix, _ = plan_trace([0 if w[1] == "mult" else w[3] for w in work], W, float("inf"), float("inf"))
-        small_ix = [[i for i in sh if work[i][1] != "mult"] for sh in small_ix]
-    else:
-        coop_ix, small_ix, _ = plan_trace(cons, W, 0.5 * 2 ** args.coop_log2, 0.5 * 2 ** args.sub_coop_log2)
-    group = {work[i][0]: g for i, g in coop_ix}
-    gold = _golden_digests()
-    ctx0 = vpin_amd.Context(0)
-
-    # exchange latency among W threads (unserialised, 1728-byte pieces = 18 instances x 3 scalars)
-    comms = Comm.local(W)
-    lat = [0.0] * W
-
-    def pingpong(r):
-        lat[r] = comms[r].latency(1728, 5000)
-
-    ts = [threading.Thread(target=pingpong, args=(r,)) for r in range(W)]
-    [t.start() for t in ts]
-    [t.join() for t in ts]
-    for cm in comms:
-        cm.destroy()
-    t_ag = max(lat)
-
-    per = {}
-    single_ms = {}
-    for w in work:
-        g, dec = _build_resident(ctx0, w)
-        # the single-GPU proof runs on a context of its own, closed afterwards: its pooled temporaries (tens of GB for the
-        # largest instance) must not sit in HBM next to the W ranks' own
-        ctx1 = vpin_amd.Context(0)
-        _prove_res(ctx1, g, dec)  # warm: generator views, pools
-        best = 1e9
-        for _ in range(max(1, args.steps)):
-            t0 = time.perf_counter()
-            ref = _prove_res(ctx1, g, dec)
-            best = min(best, time.perf_counter() - t0)
-        ctx1.close()
-        single_ms[w[0]] = best * 1e3
-        sha = hashlib.sha256(ref["proof"]).hexdigest()
-        rec = {"single_gpu_ms": round(best * 1e3, 3), "bytes_equal_oracle_digest": gold.get(w[0], {}).get("snark_sha256") == sha}
-        if w[0] in group:
-            Wg = group[w[0]]
-            rec["ranks"] = Wg
-            ctxs = [ctx0] + [vpin_amd.Context(0) for _ in range(Wg - 1)]
-            comms = Comm.local(Wg)
-            out, errs, stats, tags = [None] * Wg, [], [None] * Wg, [None] * Wg
-            passes = [[] for _ in range(Wg)]
-
-            def body(r):
-                try:
-                    ctxs[r].set_comm(comms[r])
-                    for it in range(1 + args.rehearse_passes):  # first pass warms every rank's pools and generator views
-                        comms[r].set_serialize(True)
-                        comms[r].stats(reset=True)
-                        out[r] = _prove_res(ctxs[r], g, dec)
-                        ctxs[r].sync()
-                        comms[r].allgather(b"")  # closes the section after the proof's last collective
-                        st_r, tg_r = comms[r].stats(), comms[r].tag_stats()
-                        comms[r].set_serialize(False)
-                        # keep the quietest pass (allocation stalls and host scheduling only ever add time); every rank sees
-                        # the same crit_s, so every rank keeps the same pass
-                        if it >= 1:
-                            passes[r].append((st_r, tg_r))
-                            if stats[r] is None or st_r["crit_s"] < stats[r]["crit_s"]:
-                                stats[r], tags[r] = st_r, tg_r
-                    ctxs[r].set_comm(None)
-                except BaseException as e:  # noqa: BLE001
-                    errs.append((r, repr(e)))
-
-            ts = [threading.Thread(target=body, args=(r,)) for r in range(Wg)]
-            [t.start() for t in ts]
-            [t.join() for t in ts]
-            for cm in comms:
-                cm.destroy()
-            for cx in ctxs[1:]:
-                cx.close()
-            if errs:
-                rec["rehearsal_error"] = errs
-            else:
-                st = stats[0]
-                rec.update({
-                    "all_ranks_bytes_equal_single_gpu": all(o["proof"] == ref["proof"] for o in out),
-                    "collectives": st["collectives"],
-                    "crit_ms": round(st["crit_s"] * 1e3, 3),
-                    "exchange_ms": round(st["collectives"] * t_ag * 1e3, 3),
-                    "model_ms": round((st["crit_s"] + st["collectives"] * t_ag) * 1e3, 3),
-                    "busy_ms_per_rank": [round(s["busy_s"] * 1e3, 3) for s in stats],
-                    "crit_ms_by_step": {k: round(v["crit_s"] * 1e3, 3) for k, v in sorted(tags[0].items(), key=lambda kv: -kv[1]["crit_s"])},
-                    "busy_ms_by_step_per_rank": {k: [round(tags[r].get(k, {"busy_s": 0.0})["busy_s"] * 1e3, 3) for r in range(Wg)]
-                                                 for k in sorted(tags[0], key=lambda kk: -tags[0][kk]["crit_s"])[:10]},
-                })
-                # Per step of the protocol (tag): the library's crit_s is sum over the collectives of the slowest rank's section.
-                # On one GPU shared by W ranks two artefacts inflate it: a stall in one rank's section in one pass (allocation
-                # when the W ranks' temporaries nearly fill the 288 GB; host scheduling) -- so every step takes its quietest
-                # pass -- and, for REPLICATED steps (identical work on every rank), a rank that is slow in every pass for the
-                # same reason -- so those take the fastest rank's time.
-                replicated = {"sat_replicated", "sat_phase1_rest", "sat_phase2_rest", "derefs_gather", "network_alloc",
-                              "hash_eq_tables", "hash_bullet"}
-                tagq = {}
-                for k in tags[0]:
-                    v = min(tg[k]["crit_s"] for _st, tg in passes[0] if k in tg)
-                    ncoll = tags[0][k]["collectives"]
-                    quiet_r = [min(tg[k]["busy_s"] for _st, tg in passes[r] if k in tg) for r in range(Wg)]
-                    if k in replicated:
-                        v = min(v, sorted(quiet_r)[len(quiet_r) // 2])  # the MEDIAN rank (ADVICE r3: the fastest rank is a floor, not an estimate)
-                    else:
-                        # a sharded step: the slowest rank, each rank at its quietest pass (for the round steps -- hundreds of
-                        # collectives with the same work on every owner -- this drops only the per-round jitter)
-                        v = min(v, max(quiet_r))
-                    tagq[k] = v
-                tagged_best = sum(v["crit_s"] for v in tags[0].values())
-                untagged = max(0.0, st["crit_s"] - tagged_best)
-                quiet = sum(tagq.values()) + untagged
-                rec["crit_ms_quietest_pass_per_step"] = round(quiet * 1e3, 3)
-                rec["model_ms_quietest_pass_per_step"] = round((quiet + st["collectives"] * t_ag) * 1e3, 3)
-                rec["crit_ms_by_step_quietest"] = {k: round(v * 1e3, 3) for k, v in sorted(tagq.items(), key=lambda kv: -kv[1])}
-                # every pass of the three longest steps, per rank (how stable the rehearsal is)
-                rec["busy_ms_per_rank_every_pass"] = {
-                    k: [[round(passes[r][i][1].get(k, {"busy_s": 0.0})["busy_s"] * 1e3, 3) for r in range(Wg)] for i in range(len(passes[0]))]
-                    for k in sorted(tagq, key=lambda kk: -tagq[kk])[:3]}
-                rec["fraction_of_single_gpu"] = round(rec["model_ms"] / rec["single_gpu_ms"], 4)
-                rec["fraction_of_single_gpu_quietest"] = round(rec["model_ms_quietest_pass_per_step"] / rec["single_gpu_ms"], 4)
-        per[w[0]] = rec
-        dec.free()
-        g.free()
-    ok = all("model_ms_quietest_pass_per_step" in per[work[i][0]] for i, _ in coop_ix)
-    single = [single_ms[w[0]] for w in work]
-    # HEADLINE = the unfiltered model (every step at the slowest rank of the measured pass, as a real W-GPU run pays it); the
-    # quietest-pass figure is a LOWER BOUND beside it (ADVICE r3)
-    loads = replay_trace(coop_ix, small_ix, W, {(i, g): per[work[i][0]]["model_ms"] for i, g in coop_ix}, single) if ok else None
-    loads_q = replay_trace(coop_ix, small_ix, W, {(i, g): per[work[i][0]]["model_ms_quietest_pass_per_step"] for i, g in coop_ix}, single) if ok else None
-    model_ms = max(loads) if ok else None
-    model_q = max(loads_q) if ok else None
-    serial_ms = sum(single_ms.values())
-    step_ms = args.n1_step_ms  # the measured four-lane N = 1 step of the same trace (bench.py default), when given
-    print(json.dumps({
-        "metric": "critical-path MODEL of one vPIN trace proven by W GPUs (sections measured on one GPU, ranks serialised)",
-        "unmeasured_on_multi_gpu_hardware": True, "world": W, "trace": trace, "constraints_unpadded_per_step": total_cons,
-        "single_gpu_serial_ms": round(serial_ms, 3), "model_ms": None if model_ms is None else round(model_ms, 3),
-        "model_ms_lower_bound_quietest_pass": None if model_q is None else round(model_q, 3),
-        "model_speedup_vs_single_gpu_serial": None if model_ms is None else round(serial_ms / model_ms, 3),
-        "model_speedup_vs_n1_four_lane_step": None if (model_ms is None or not step_ms) else round(step_ms / model_ms, 3),
-        "n1_four_lane_step_ms": step_ms,
-        "speedup_note": "quote the speed-up against the four-lane N = 1 step (what one GPU delivers on the trace), not against the serial sum "
-                        "of the instances; model_ms is an estimate from one measured pass, model_ms_lower_bound_quietest_pass an optimistic bound",
-        "model_constraints_per_s": None if model_ms is None else total_cons / model_ms * 1e3,
-        "allgather_latency_us_among_threads": round(t_ag * 1e6, 2),
-        "cooperative": [[work[i][0], g] for i, g in coop_ix],
-        "small_instances_per_rank": [[work[i][0] for i in sh] for sh in small_ix],
-        "finish_ms_per_rank": None if loads is None else [round(x, 3) for x in loads], "instances": per,
-        "plan": dict(zip(("owner_ops", "owner_dotp", "owner_mem"), vpin_amd.dist_plan(W))),
-    }))
-    ctx0.close()
-
-
-def live_pmc_traffic(timeout_s=240):
-    """HBM bytes per launch of the roofline kernel, MEASURED: two child processes under `rocprofv3 --pmc` (FETCH_SIZE, then
-    WRITE_SIZE: the two counters do not fit one pass; no tracing option beside --pmc) prove the largest instance of the trace
-    alone -- the launches `roofline` is scoped to -- and the kernel's dispatches are averaged.  gfx950 corrections as in
-    tools/pmc_summary.py / MI355X_MICROARCH.md: counters in KiB, FETCH_SIZE counts half the bytes of wide coalesced reads:
-    hbm_bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024.  The caller must have released the GPU's memory (the children build their
-    own tables and instance) and must not need the GPU afterwards.  Returns (bytes per launch, dict) or (None, reason)."""
-    import csv
+def newest_profile(suffix):
+    """profiles/rNN_<suffix> of the newest round that has one (path, name) or (None, None)"""
     import glob
-    import shutil
-    import subprocess
-    import tempfile
-    prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
-    if not os.path.exists(prof):
-        return None, "rocprofv3 not found"
-    out = {}
-    tmp = tempfile.mkdtemp(prefix="vpin_pmc_", dir="/tmp")
-    try:
-        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
-            d = os.path.join(tmp, ctr)
-            cmd = [prof, "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable, os.path.abspath(__file__),
-                   "--trace", "L5", "--only", "mult", "--serial", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-span",
-                   "--no-verify", "--no-roofline-pass", "--no-live-pmc"]
-            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=timeout_s)
-            if r.returncode != 0:
-                return None, f"rocprofv3 --pmc {ctr}: exit {r.returncode}: {r.stderr[-300:]}"
-            files = sorted(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True))
-            if not files:
-                return None, f"rocprofv3 --pmc {ctr}: no counter_collection.csv"
-            vals = []
-            with open(files[0]) as f:
-                for row in csv.DictReader(f):
-                    if row["Counter_Name"] == ctr and "sc_cubic3_kernel<true, true>" in row["Kernel_Name"]:
-                        vals.append(float(row["Counter_Value"]))
-            if not vals:
-                return None, f"rocprofv3 --pmc {ctr}: the roofline kernel was not dispatched"
-            out[ctr] = {"dispatches": len(vals), "avg_KiB": sum(vals) / len(vals)}
-        traffic = (2.0 * out["FETCH_SIZE"]["avg_KiB"] + out["WRITE_SIZE"]["avg_KiB"]) * 1024.0
-        return traffic, out
-    except (subprocess.TimeoutExpired, OSError) as e:
-        return None, repr(e)
-    finally:
-        shutil.rmtree(tmp, ignore_errors=True)
-
-
-class PowerSampler:
-    """sclk and socket power of THIS rank's card from its hwmon files (sysfs), sampled by a thread while the timed region runs:
-    the four-lane step is power-bound, and the line should say at which clock and power it actually ran."""
-
-    def __init__(self, device_index):
-        import glob
-        self.freq, self.power, self.samples, self.stop_flag, self.th = [], [], [], False, None
-        try:
-            import ctypes as C
-            hip = C.CDLL("libamdhip64.so")
-            buf = C.create_string_buffer(64)
-            if hip.hipDeviceGetPCIBusId(buf, 64, device_index) == 0:
-                base = "/sys/bus/pci/devices/" + buf.value.decode().lower()
-                self.freq = glob.glob(base + "/hwmon/hwmon*/freq1_input")
-                self.power = glob.glob(base + "/hwmon/hwmon*/power1_average") or glob.glob(base + "/hwmon/hwmon*/power1_input")
-        except OSError:
-            pass
-
-    @staticmethod
-    def _read(paths):
-        for p in paths:
-            try:
-                with open(p) as f:
-                    return float(f.read().strip())
-            except (OSError, ValueError):
-                continue
-        return None
-
-    def start(self):
-        if not (self.freq or self.power):
-            return
-
-        def loop():
-            while not self.stop_flag:
-                self.samples.append((self._read(self.freq), self._read(self.power)))
-                time.sleep(0.05)
-        self.th = threading.Thread(target=loop, daemon=True)
-        self.th.start()
-
-    def stop(self):
-        self.stop_flag = True
-        if self.th:
-            self.th.join()
-        f = sorted(x[0] / 1e6 for x in self.samples if x[0])
-        w = sorted(x[1] / 1e6 for x in self.samples if x[1])
-        if not f and not w:
-            return None
-        med = lambda v: v[len(v) // 2] if v else None
-        return {"samples": len(self.samples), "sclk_mhz_median": med(f), "sclk_mhz_min": f[0] if f else None, "sclk_mhz_max": f[-1] if f else None,
-                "watts_median": med(w), "watts_max": w[-1] if w else None,
-                "source": "hwmon freq1_input / power1_average of this rank's card, every 50 ms over the timed region"}
+    c = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_" + suffix)))
+    return (c[-1], os.path.basename(c[-1])) if c else (None, None)
 
 
 def lib_nnz(g):
@@ -659,14 +211,21 @@ def lib_nnz(g):
 def main():
     args = parse()
     world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    # N > 1: every rank next to its own GPU (default for world > 1; --numa local / remote on one GPU measures the sensitivity)
+    numa_mode = args.numa or ("local" if world_env > 1 else "off")
+    affinity_rec = pin_to_gpu_numa_node(int(os.environ.get("LOCAL_RANK", "0")), world_env, numa_mode)
     if "VPIN_HOST_THREADS" not in os.environ:
         # The library's OpenMP teams (blind terms of the ZK rounds, generator derivation) are sized per context: 8 threads by
         # default.  A step runs four lanes (contexts) per rank and a one-GPU box has 16 cores: 4 x 8 threads oversubscribe them
         # and the lanes' host sections wait for each other -- measured on the default step: 436-443 ms with 8 threads per lane,
         # 405-408 ms with 2, 3 or 4, 413 ms with 6 (profiles/r04_ab_host_threads.txt).  N ranks share the node's cores.
-        cores = (os.cpu_count() or 16) if world_env > 1 else min(16, os.cpu_count() or 16)
+        if "cores" in affinity_rec:   # pinned: this rank's own cores
+            cores = affinity_rec["cores"] * world_env
+        else:
+            cores = (os.cpu_count() or 16) if world_env > 1 else min(16, os.cpu_count() or 16)
         os.environ["VPIN_HOST_THREADS"] = str(max(2, min(4, cores // (world_env * 4))))
     if args.scaling == "strong":
+        from bench_strong import main_strong
         return main_strong(args)
     if args.concurrent:
         ks = [int(x) for x in str(args.concurrent).split(",")]
@@ -679,6 +238,7 @@ def main():
             # one hardware queue per stream: with the runtime's default of 4, streams 5.. share a queue with another stream and a
             # resident round kernel of one proof holds up the other's launches
             os.environ.setdefault("GPU_MAX_HW_QUEUES", str(max(4, min(24, ks[0]))))
+        from bench_concurrent import main_concurrent
         return main_concurrent(args)
     args.snark = not args.sat_only and not args.host_buffers
     import torch
@@ -768,6 +328,7 @@ def main():
                     "largest_instance_masked": "after its phase-1 sum-check (vpin_ctx_set_cumask_after_phase1)" if after1 else "always"}
         ctxs = [vpin_amd.Context(local_rank, cu_mask=big) if (big and not after1) else vpin_amd.Context(local_rank, priority=0)] + \
                [vpin_amd.Context(local_rank, cu_mask=small) for _ in range(len(lanes) - 1)]
+        big_mask = big
         if after1:
             ctxs[0].set_cumask_after_phase1(big)
     else:
@@ -1059,6 +620,7 @@ def main():
     if cu_split:
         line["config"]["cu_split"] = cu_split
     line["config"]["lanes"] = lane_names
+    line["host_affinity"] = affinity_rec
 
     # ---- roofline of the fused sum-check round kernel ----
     # with several streams the event time of a kernel on one stream includes waiting for CUs taken by the
@@ -1070,13 +632,11 @@ def main():
         achieved = k["alg_bytes"] / (k["ms"] * 1e-3) / 1e9
         traffic = args.pmc_traffic
         pmc_all, pmc_l5 = {}, {}
-        for pmc in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):  # separate rocprofv3 --pmc passes, see the file's _how
-            pth = os.path.join(ROOT, "profiles", pmc)
-            if os.path.exists(pth):
-                with open(pth) as f:
-                    doc = json.load(f)
-                pmc_all, pmc_l5 = doc.get("bench_default", {}), doc.get("bench_L5_mult", {})
-                break
+        pth, pmc = newest_profile("pmc_traffic.json")  # separate rocprofv3 --pmc passes, see the file's _how
+        if pth:
+            with open(pth) as f:
+                doc = json.load(f)
+            pmc_all, pmc_l5 = doc.get("bench_default", {}), doc.get("bench_L5_mult", {})
         traffic_source = "--pmc-traffic (this invocation's caller)" if traffic is not None else None
         if traffic is None:
             # the largest instance's launches alone (bench_L5_mult section): the default run's average mixes every instance's
@@ -1086,13 +646,14 @@ def main():
         # VALU-issue ceiling of the same launches: pairs per second the chip can issue (one wave-instruction per SIMD per 4
         # cycles, tools/isa_counts.py: VALU instructions per pair of this kernel's loop)
         valu_per_pair, valu_frac = None, None
+        isa_path, isa_name = newest_profile("isa_counts.json")
         try:
-            with open(os.path.join(ROOT, "profiles", "r03_isa_counts.json")) as f:
+            with open(isa_path) as f:
                 valu_per_pair = json.load(f)["sc_cubic3_kernel<true, true>"]["valu_per_pair"]
             ncu, hz = ctxs[0].device_props()
             pairs_s = (k["alg_bytes"] / 384.0) / (k["ms"] * 1e-3)  # 4 tables x 32 B x 1.5 = 192 B per entry = 384 B per pair
             valu_frac = pairs_s / (ncu * 4 * 64 * hz / (4.0 * valu_per_pair))
-        except (OSError, KeyError, ZeroDivisionError):
+        except (OSError, KeyError, ZeroDivisionError, TypeError):
             pass
         # bytes the eq-factored kernel really moves per launch: 3 tables read (len) and written (len/2), the suffix
         # table read once per pair (len/4): 152*len against the 192*len of the reference's 4-table formulation
@@ -1103,10 +664,16 @@ def main():
                       "rounds with > 512 pairs)",
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
-            "limiter": "valu-issue", "limiter_frac": valu_frac, "valu_instructions_per_pair": valu_per_pair,
-            "limiter_note": "priced against HBM as the contract asks, but the kernel stops at the VALU-issue limit first: limiter_frac = "
-                            "achieved pairs/s over CUs x 4 SIMDs x 64 lanes x clock / (4 cycles x VALU instructions per pair); real HBM "
-                            "traffic is frac_actual of peak",
+            "limiter": "valu-issue", "limiter_frac": None, "limiter_frac_static_model": valu_frac,
+            "valu_instructions_per_pair_static": valu_per_pair, "static_model_source": isa_name,
+            "limiter_note": "priced against HBM as the contract asks, but the kernel stops at VALU issue first.  limiter_frac (round 5) is "
+                            "MEASURED: the share of SIMD-cycles in which a VALU instruction is in flight, from the SQ counters of the "
+                            "kernel's own dispatches (4 * SQ_ACTIVE_INST_VALU / (GRBM_GUI_ACTIVE / 8 x CUs x 4 SIMDs); a third rocprofv3 "
+                            "--pmc child pass of this run, or replayed from profiles/ when that pass is skipped) -- at most 1 by "
+                            "construction.  limiter_frac_static_model is the old yardstick (achieved pairs/s over CUs x 4 SIMDs x 64 lanes "
+                            "x nominal clock / (4 cycles x the loop's static VALU instruction count)): it exceeded 1 in round 4 because the "
+                            "static count of the loop body over-counts what a pair executes (measured_valu_instructions_per_pair); real "
+                            "HBM traffic is frac_actual of peak",
             "achieved_note": "algorithmic bytes of the reference's 4-table formulation (SURVEY.md 8(d): 4*32*1.5*len per launch) / HIP-event time",
             "achieved_actual": achieved_actual, "frac_actual": achieved_actual / HBM_PEAK_GBPS,
             "actual_note": "bytes this kernel really moves (3 tables + the suffix table, 152*len: the eq table is never read; PMC "
@@ -1119,6 +686,7 @@ def main():
                       f"{100.0 * k['alg_bytes'] / k_all['alg_bytes']:.1f}% of the kernel's algorithmic bytes in the timed region; the other "
                       "instances run concurrently on other streams" if len(lanes) > 1 else "all launches in the timed region"),
         }
+    digest_jobs = []  # (instance, bincode(A, B, C)): compressed at the end of the run (reference_span.dead_work)
     line["kernels"] = {name: {"launches": v["launches"], "ms": round(v["ms"], 4),
                               "GBps_alg": (v["alg_bytes"] / (v["ms"] * 1e-3) / 1e9) if v["ms"] else None}
                        for name, v in stats.items()}
@@ -1170,17 +738,59 @@ def main():
             big = lane_names[0][0]
             cx = ctxs[0]
             cx.set_shared_device(False)
+            if cu_split and cu_split["largest_instance_masked"].startswith("after"):
+                cx.set_cumask_after_phase1(None)   # alone = on every CU of the chip
             cx.prof_reset()
             cx.prof_enable(2)  # level 2: also count the table additions of the row commitments
             di, tp, ti, tv_, inp = resident[big]
+            psamp = PowerSampler(local_rank, interval_s=0.004)
+            psamp.start()
             t1 = time.perf_counter()
             cx.snark_prove_resident(di, decomms[big], tp, ti, tv_, inp, SEED_C, SEED_P)
             cx.sync()
             alone_ms = (time.perf_counter() - t1) * 1e3
+            tms = cx.spark_timings()
+            # the derefs commitment (the proof's largest row commitment) runs from the end of the sat part for derefs_commit seconds
+            msm_power = psamp.stop(t1 + tms.get("sat", 0.0) + 0.1 * tms.get("derefs_commit", 0.0), t1 + tms.get("sat", 0.0) + 0.9 * tms.get("derefs_commit", 0.0))
+            power_series = [(round((t - t1) * 1e3, 1), None if x[0] is None else round(x[0] / 1e6), None if x[1] is None else round(x[1] / 1e6))
+                            for t, x in zip(psamp.times, psamp.samples)]
             st = cx.prof_read()
+            # The card's hwmon power (and clock) readings are running averages over roughly a second: inside one 0.3 s proof they
+            # lag (the series above is kept as evidence).  So the row-commitment kernel's OPERATING POINT is measured on a loop:
+            # the production kernel and window table over a polynomial of 2^24 uniformly random full-width scalars (the shape of
+            # the derefs polynomial's regular rows), committed again and again for ~2 s; clock and power = medians over the
+            # second half of the loop, rate = counted table additions / HIP-event time of the same launches.
+            msm_steady = None
+            if not os.environ.get("VPIN_BENCH_NO_MSM_STEADY"):
+                rng = np.random.default_rng(7)
+                nz = 1 << 24
+                zr = rng.integers(0, 2**64, size=(nz, 4), dtype=np.uint64)
+                zr[:, 3] &= np.uint64((1 << 60) - 1)   # below 2^252 < q: every row is a canonical Montgomery image
+                tz = cx.upload(zr)
+                del zr
+                cx.dense_mlpoly_commit_sum(tz, SEED_C)   # warm
+                cx.prof_reset()
+                ps2 = PowerSampler(local_rank, interval_s=0.01)
+                ps2.start()
+                t_l = time.perf_counter()
+                n_loop = 0
+                while time.perf_counter() - t_l < 2.0:
+                    cx.dense_mlpoly_commit_sum(tz, SEED_C)
+                    n_loop += 1
+                t_e = time.perf_counter()
+                steady = ps2.stop(t_l + 0.5 * (t_e - t_l), t_e)
+                sm = cx.prof_read().get("msm_rows")
+                tz.free()
+                if sm and sm["ms"] > 0 and steady:
+                    msm_steady = dict(steady, G_adds_s=sm["units"] / (sm["ms"] * 1e-3) / 1e9, commitments=n_loop, scalars=nz,
+                                      ms_per_commitment=sm["ms"] / max(1, sm["launches"]),
+                                      what="msm_rows_kernel over 2^24 random full-width scalars (4096 rows x 4096), the production "
+                                           "window table, looped for 2 s; medians over the second half")
             cx.prof_enable(False)
             if len(lanes) > 1:
                 cx.set_shared_device(l0_shared)
+            if cu_split and cu_split["largest_instance_masked"].startswith("after"):
+                cx.set_cumask_after_phase1(big_mask)
             sec = []
             cus, clk = cx.device_props()  # compute units, shader clock in Hz
             # Reference rates of the VALU-bound kernels.  (1) A static one: one wave-instruction per SIMD per 4 cycles over the
@@ -1190,12 +800,9 @@ def main():
             # addition on a register-resident dependent chain at the kernel's occupancy, no table loads, no digit logic
             # (tools/ubench_fpmul -> profiles/r03_ubench_fpmul.txt, its JSON line).
             isa, chain = {}, {}
-            for nm in ("r04_isa_counts.json", "r03_isa_counts.json", "r02_isa_counts.json"):
-                pth = os.path.join(ROOT, "profiles", nm)
-                if os.path.exists(pth):
-                    with open(pth) as f:
-                        isa = json.load(f)
-                    break
+            if isa_path:
+                with open(isa_path) as f:
+                    isa = json.load(f)
             try:
                 with open(os.path.join(ROOT, "profiles", "r03_ubench_fpmul.txt")) as f:
                     for ln in f:
@@ -1258,6 +865,30 @@ def main():
                             "traffic": pp.get("hbm_bytes_per_launch"),
                             "traffic_note": "PMC bytes per launch of the same launches (kernel names prod_round_kernel<*, true, true>), "
                                             "profiles/r02_pmc_traffic.json section bench_L5_mult"})
+            # the same as scalars (the driver's record keeps scalar fields of `roofline`, not the nested list)
+            rf = line["roofline"]
+            rf["largest_instance_alone_ms"] = round(alone_ms, 2)
+            for e in sec:
+                if e["kernel"].startswith("msm_rows_kernel"):
+                    rf["msm_G_adds_s"] = e["achieved"]
+                    rf["msm_frac_of_static_valu_peak"] = e["frac"]
+                    rf["msm_frac_of_chain"] = e.get("frac_of_measured_chain")
+                    rf["msm_ms_per_proof"] = e["ms"]
+                    if msm_steady:
+                        rf["msm_watts"] = msm_steady.get("watts_median")
+                        rf["msm_sclk_mhz"] = msm_steady.get("sclk_mhz_median")
+                        rf["msm_steady_G_adds_s"] = msm_steady.get("G_adds_s")
+                        e["steady_state_measured_in_this_run"] = msm_steady
+                    if msm_power:
+                        e["power_measured_in_this_run"] = dict(msm_power, window="the middle 80 % of the derefs commitment of the "
+                                                               "largest instance proven alone (hwmon sampled every 4 ms)",
+                                                               series_ms_mhz_watts=power_series,
+                                                               phases_ms={"sat_until": round(tms.get("sat", 0.0) * 1e3, 1),
+                                                                          "derefs_commit_until": round((tms.get("sat", 0.0) + tms.get("derefs_commit", 0.0)) * 1e3, 1)})
+                elif e["kernel"].startswith("prod_round_kernel"):
+                    rf["prod_round_frac"] = e["frac"]
+                    rf["prod_round_valu_frac"] = e["valu_issue"]["frac"]
+                    rf["prod_round_ms_per_proof"] = e["ms"]
             line["roofline"]["secondary"] = sec
             line["roofline"]["secondary_scope"] = (f"{big} proven alone after the timed region ({alone_ms:.1f} ms, one stream, HIP events per launch, "
                                                    "table additions counted by vpin_prof_enable level 2)")
@@ -1268,13 +899,19 @@ def main():
         if not args.no_span:
             for cx in ctxs:
                 cx.set_shared_device(False)  # one proof at a time from here on
-            span, dead_commit, dead_digest_bytes, digest_rate = {}, {}, {}, {}
+            if cu_split and cu_split["largest_instance_masked"].startswith("after"):
+                ctxs[0].set_cumask_after_phase1(None)
+            # one after the other = on the whole chip: the first lane's context (the other lanes' may be confined to their CUs)
+            span_ctx = ctxs[0] if cu_split else None
+            span, dead_commit, dead_digest_bytes = {}, {}, {}
+            digest_prep_s = 0.0
             ts = time.perf_counter()
             for li, names in enumerate(lane_names):
                 for name in names:
                     t1 = time.perf_counter()
                     kind, inp = inputs_of[name]
-                    g = build_instance(ctxs[li], kind, inp)
+                    cxs = span_ctx or ctxs[li]
+                    g = build_instance(cxs, kind, inp)
                     assert g.is_sat()
                     r = g.snark_prove(SEED_C, SEED_P)
                     span[name] = round((time.perf_counter() - t1) * 1e3, 2)
@@ -1282,16 +919,17 @@ def main():
                     # what the reference computes inside this span and never uses, timed beside it --
                     # (i) the third commitment my_dense_mlpoly_commit (proof_point_mult.rs:58-59; only row 0 is read, by an assert)
                     t2 = time.perf_counter()
-                    third = ctxs[li].dense_mlpoly_commit_sum(g.vars, SEED_C)
+                    third = cxs.dense_mlpoly_commit_sum(g.vars, SEED_C)
                     dead_commit[name] = round((time.perf_counter() - t2) * 1e3, 2)
-                    assert bytes(third[0]) == bytes(ctxs[li].points_add(r["comm_para"][:1], r["comm_input"][:1])[0]), name  # :69-73
+                    assert bytes(third[0]) == bytes(cxs.points_add(r["comm_para"][:1], r["comm_input"][:1])[0]), name  # :69-73
                     # (ii) Instance::new's digest: zlib over bincode(A, B, C) (lib.rs:232-243, r1csinstance.rs:154-158), 48 B per
-                    # entry, consumed by the NIZK path only.  Host work; compressed here for the smallest instance of each
-                    # gadget met (<= 4 M entries) and priced per byte for the others (3.7 GB of triplets for L5-mult: a minute of one core).
+                    # entry, consumed by the NIZK path only.  Host work on one core per instance: the buffer is built here (the
+                    # triplets come back from the device) and compressed at the end of the run, every instance at FULL size
+                    # (round 5: 3.7 GB for L5-mult; round 4 priced it per byte from a small instance), in a thread of its own
+                    # beside the PMC child passes.
+                    t3 = time.perf_counter()
                     dead_digest_bytes[name] = 48 * sum(g.nnz) + 3 * 8 + 3 * (2 * 8 + 8)
-                    if kind not in digest_rate and sum(g.nnz) <= 4_000_000:
-                        import zlib
-                        t3 = time.perf_counter()
+                    if not args.no_digest:
                         buf = bytearray(np.array([g.num_cons, g.num_vars, g.num_inputs], dtype="<u8").tobytes())
                         for m in range(3):
                             row, col, val = g.triplets(m)
@@ -1299,44 +937,37 @@ def main():
                             ent["row"], ent["col"], ent["val"] = row, col, val
                             buf += np.array([g.num_cons.bit_length() - 1, (2 * g.num_vars).bit_length() - 1, len(row)], dtype="<u8").tobytes()
                             buf += ent.tobytes()
-                        t4 = time.perf_counter()
-                        z = zlib.compress(bytes(buf), 6)  # flate2's default level
-                        t5 = time.perf_counter()
-                        digest_rate[kind] = {"instance": name, "bytes": len(buf), "compressed_bytes": len(z),
-                                             "triplets_to_host_ms": round((t4 - t3) * 1e3, 1), "zlib_ms": round((t5 - t4) * 1e3, 1),
-                                             "MB_per_s": len(buf) / (t5 - t4) / 1e6}
+                            del ent, row, col, val
+                        assert len(buf) == dead_digest_bytes[name], (len(buf), dead_digest_bytes[name])
+                        digest_jobs.append((name, buf))
+                    digest_prep_s += time.perf_counter() - t3
                     g.free()
-            span_s = time.perf_counter() - ts - sum(dead_commit.values()) / 1e3 - sum(
-                (v["triplets_to_host_ms"] + v["zlib_ms"]) / 1e3 for v in digest_rate.values())
+            span_s = time.perf_counter() - ts - sum(dead_commit.values()) / 1e3 - digest_prep_s
             line["value_reference_span"] = total_cons_step / span_s  # the reference's own timed span, see reference_span.scope
             line["reference_span"] = {
                 "ms_per_trace": round(span_s * 1e3, 1), "constraints_per_s": total_cons_step / span_s, "ms": span,
                 "scope": "per instance, serially: witness inputs in host memory -> gadget + witness synthesis + Instance::new "
                          "(device) -> is_sat -> SNARK::encode -> my_lib_prove -> proof bytes on the host; generator tables warm",
             }
-            # the same span WITH the work the reference does inside it and never uses
-            digest_ms = {}
-            for name, nbytes in dead_digest_bytes.items():
-                rate = digest_rate.get(inputs_of[name][0])
-                if rate:
-                    digest_ms[name] = round(nbytes / (rate["MB_per_s"] * 1e6) * 1e3, 1)
-            dead_s = sum(dead_commit.values()) / 1e3 + sum(digest_ms.values()) / 1e3
+            # the same span WITH the work the reference does inside it and never uses; the digest figures
+            # are filled in when the compressions have finished (finish_dead_work below)
             line["reference_span"]["dead_work"] = {
                 "third_commitment_ms": dead_commit, "third_commitment_ms_total": round(sum(dead_commit.values()), 1),
-                "digest_ms_priced": digest_ms, "digest_ms_total_priced": round(sum(digest_ms.values()), 1), "digest_measured_on": digest_rate,
-                "ms_per_trace_with": round((span_s + dead_s) * 1e3, 1), "constraints_per_s_with": total_cons_step / (span_s + dead_s),
+                "digest_bytes": dead_digest_bytes, "triplets_to_host_and_bincode_s": round(digest_prep_s, 2),
                 "ms_per_trace_without": round(span_s * 1e3, 1),
                 "note": "inside the reference's 'Proof generation time' and dropped by this build because no proof byte depends on it: "
                         "(i) my_dense_mlpoly_commit of the whole assignment (proof_point_mult.rs:58-59; its row 0 feeds an assert, "
                         "reproduced here) -- measured per instance on the device (vpin_dense_mlpoly_commit_sum); the poly_prime loop of "
                         ":61-67 is a vector addition nobody reads; (ii) the zlib digest of bincode(A, B, C) in Instance::new "
-                        "(lib.rs:232-243) -- one host core, measured on the smallest instance of each gadget (digest_measured_on) and "
-                        "priced per byte for the rest; is_sat (the other N4 item) is INSIDE the span on both sides",
+                        "(lib.rs:232-243) -- one host core per instance, MEASURED on every instance at full size (zlib level 6 = flate2's "
+                        "default; digest_ms); is_sat (the other N4 item) is INSIDE the span on both sides",
             }
             if len(lanes) > 1:
                 # the same span with the trace's instances on the bench's lanes (streams) instead of one after the other
-                for cx in ctxs:
-                    cx.set_shared_device(True)
+                for li, cx in enumerate(ctxs):
+                    cx.set_shared_device(l0_shared if li == 0 else small_shared)
+                if cu_split and cu_split["largest_instance_masked"].startswith("after"):
+                    ctxs[0].set_cumask_after_phase1(big_mask)
                 errs = []
 
                 def span_lane(li):
@@ -1467,6 +1098,7 @@ def main():
         def one_pass(with_rccl):
             err, rec = None, None
             try:
+                from bench_strong import _strong_core
                 rec = _strong_core(args, grp, rank, world, local_rank % ndev, with_rccl, ndev, nsteps, 1)
             except Exception as e:  # noqa: BLE001 -- reported in the line, the weak numbers above stand
                 err = repr(e)
@@ -1491,30 +1123,95 @@ def main():
                                                {k: rec2[k] for k in ("value", "ms_per_step", "rccl", "bytes_equal_oracle_digest", "comm",
                                                                      "speedup_vs_one_gpu_step_of_this_run")})
         watchdog.cancel()
+        if rank == 0:
+            # the same as scalars (the driver's record keeps scalar fields)
+            st_rec = line.get("strong") or {}
+            rp = st_rec.get("rccl_pass") or {}
+            line["strong_ms_per_step"] = st_rec.get("ms_per_step")
+            line["strong_speedup_vs_one_gpu_step"] = st_rec.get("speedup_vs_one_gpu_step_of_this_run")
+            line["strong_bytes_ok"] = (all(st_rec.get("bytes_equal_oracle_digest", {}).values()) if st_rec.get("bytes_equal_oracle_digest") else None)
+            line["strong_rccl_ms_per_step"] = rp.get("ms_per_step")
+            line["strong_rccl_world"] = max(rp.get("rccl", {}).get("world_by_group", {}).values(), default=0) if rp.get("rccl") else 0
+            line["strong_rccl_bytes_ok"] = (all(rp.get("bytes_equal_oracle_digest", {}).values()) if rp.get("bytes_equal_oracle_digest") else None)
+            line["strong_error"] = st_rec.get("error") or rp.get("error")
 
-    # ---- roofline.traffic measured in THIS run (it used to be replayed from a profile file) ----
-    # Last thing before the line is printed: every context is closed and the shared window tables are released, so the two
+    # ---- reference_span.dead_work: the zlib digests (one thread per instance, started here so that they run beside the PMC
+    # child passes below: zlib releases the GIL) ----
+    digest_ms, digest_threads = {}, []
+    if digest_jobs:
+        import zlib
+
+        def compress(name, buf):
+            t_z = time.perf_counter()
+            z = zlib.compress(buf, 6)  # flate2's default level
+            digest_ms[name] = (round((time.perf_counter() - t_z) * 1e3, 1), len(z))
+        digest_threads = [threading.Thread(target=compress, args=job) for job in digest_jobs]
+        for t in digest_threads:
+            t.start()
+
+    # ---- roofline.traffic and the VALU-issue occupancy measured in THIS run (replayed figures, a ceiling the
+    # kernel exceeded) ----
+    # Last GPU work before the line is printed: every context is closed and the shared window tables are released, so the three
     # rocprofv3 --pmc children have the GPU to themselves; this process does not touch the GPU afterwards.
     under_profiler = any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
     if (rank == 0 and world == 1 and "roofline" in line and trace == "lenet" and not args.no_live_pmc and not args.no_roofline_pass
             and args.pmc_traffic is None and not args.only and not args.serial and not under_profiler):  # (no profiler inside a profiler)
+        ncu_dev = ctxs[0].device_props()[0] if ctxs else 256
         for cx in ctxs:
             cx.close()
         ctxs = []
         vpin_amd.lib().vpin_gens_shared_clear()
         t_p = time.perf_counter()
-        live, info = live_pmc_traffic()
+        live, info = live_pmc_traffic(cus=ncu_dev)
         if live is not None:
             line["roofline"]["traffic_replayed"] = {"value": line["roofline"].get("traffic"), "source": line["roofline"].get("traffic_source")}
             line["roofline"]["traffic"] = live
-            line["roofline"]["traffic_source"] = ("measured in this run: two child processes under rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE "
+            line["roofline"]["traffic_source"] = ("measured in this run: child processes under rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE "
                                                   "(separate passes, no tracing beside them) proving the largest instance alone; "
                                                   "(2 * FETCH_SIZE + WRITE_SIZE) * 1024 averaged over the kernel's dispatches "
-                                                  f"({info['FETCH_SIZE']['dispatches']}); {time.perf_counter() - t_p:.0f} s")
-            line["roofline"]["traffic_counters"] = info
+                                                  f"({info['FETCH_SIZE']['dispatches']}); {time.perf_counter() - t_p:.0f} s with the SQ pass")
+            line["roofline"]["traffic_counters"] = {k: v for k, v in info.items() if k != "VALU"}
             line["roofline"]["traffic_over_algorithmic"] = live / line["roofline"]["alg_bytes_per_launch"]
+            v = info.get("VALU", {})
+            if "valu_issue_frac" in v:
+                line["roofline"]["limiter_frac"] = v["valu_issue_frac"]
+                line["roofline"]["limiter_frac_source"] = "measured in this run (rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE, third child pass)"
+                line["roofline"]["limiter_counters"] = v
+                pairs = line["roofline"]["alg_bytes_per_launch"] / 384.0 * v["dispatches"]
+                line["roofline"]["measured_valu_instructions_per_pair"] = v["SQ_INSTS_VALU"] * 64.0 / pairs
+            elif v:
+                line["roofline"]["limiter_live_error"] = v
         else:
             line["roofline"]["traffic_live_error"] = info
+    if "roofline" in line and line["roofline"].get("limiter_frac") is None:
+        # not measured in this run: the newest profile that holds the kernel's SQ counters (tools/pmc_valu.py), else the static model
+        pth, nm = newest_profile("pmc_valu.json")
+        ent = None
+        if pth:
+            with open(pth) as f:
+                ent = json.load(f).get("kernels", {}).get("sc_cubic3_kernel<true, true>")
+        if ent:
+            line["roofline"]["limiter_frac"] = ent["valu_issue_frac"]
+            line["roofline"]["limiter_frac_source"] = f"replayed from profiles/{nm} (NOT measured in this run)"
+        else:
+            line["roofline"]["limiter_frac"] = line["roofline"].get("limiter_frac_static_model")
+            line["roofline"]["limiter_frac_source"] = "the static model (no SQ counters of this kernel at hand): a yardstick, not a bound"
+
+    for t in digest_threads:
+        t.join()
+    if digest_ms and "reference_span" in line:
+        dw = line["reference_span"]["dead_work"]
+        dw["digest_ms"] = {n: v[0] for n, v in digest_ms.items()}
+        dw["digest_compressed_bytes"] = {n: v[1] for n, v in digest_ms.items()}
+        dw["digest_ms_total"] = round(sum(v[0] for v in digest_ms.values()), 1)
+        big_n = max(digest_ms, key=lambda n: digest_ms[n][0])
+        dw["digest_MB_per_s_largest"] = dw["digest_bytes"][big_n] / (digest_ms[big_n][0] * 1e-3) / 1e6
+        dead_s = dw["third_commitment_ms_total"] / 1e3 + dw["digest_ms_total"] / 1e3
+        span_s = dw["ms_per_trace_without"] / 1e3
+        dw["ms_per_trace_with"] = round((span_s + dead_s) * 1e3, 1)
+        dw["constraints_per_s_with"] = total_cons_step / (span_s + dead_s)
+        dw["digest_note"] = ("every instance's bincode(A, B, C) compressed at full size, one Python thread (one host core) per instance, "
+                             "run beside the PMC child passes; the sum of the per-instance times is what the reference's serial span pays")
 
     if rank == 0:
         print(json.dumps(line))

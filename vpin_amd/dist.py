@@ -69,15 +69,18 @@ def plan_trace(cons, world, coop_min, sub_min):
     return coop, small, loads
 
 
-def replay_trace(coop, small, world, coop_ms, single_ms):
-    """finish time of every rank when the plan runs with the given times: coop_ms[(index, size)], single_ms[index]"""
+def replay_trace(coop, small, world, coop_ms, single_ms, overlap=False):
+    """finish time of every rank when the plan runs with the given times: coop_ms[(index, size)], single_ms[index].
+    overlap: a rank's small instances run on a second stream UNDER its cooperative proofs (bench_strong since round 5) and are
+    taken to hide completely behind them -- a LOWER bound; without it they follow the cooperative proofs -- an upper bound."""
     loads = [0.0] * world
     for i, g in coop:
         end = max(loads[:g]) + coop_ms[(i, g)]
         for r in range(g):
             loads[r] = end
     for r in range(world):
-        loads[r] += sum(single_ms[i] for i in small[r])
+        own = sum(single_ms[i] for i in small[r])
+        loads[r] = max(loads[r], own) if overlap else loads[r] + own
     return loads
 
 

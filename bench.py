@@ -144,6 +144,11 @@ def parse():
     return ap.parse_args()
 
 
+def ctypes_size_t():
+    import ctypes
+    return ctypes.c_size_t
+
+
 def parse_cpulist(txt):
     out = []
     for part in txt.strip().split(","):
@@ -384,6 +389,9 @@ def main():
                 comm_bytes[name] = len(comm)
                 verify_meta[name] = (comm, {"inputs": g.inputs, "num_inputs": g.num_inputs})
     upload_s = time.perf_counter() - t0
+    if not os.environ.get("VPIN_BENCH_NO_TRIM"):
+        for cx in ctxs:
+            cx.pool_trim()   # the set-up's temporaries (gadget synthesis, SNARK::encode) are of no use to the proofs
     lane_names = [[w[0] for w in lane] for lane in lanes]
 
     last_spans, proof_bytes = {}, {}
@@ -580,6 +588,23 @@ def main():
 
     free_b, total_b = torch.cuda.mem_get_info(local_rank)
     hbm_used_gb = round((total_b - free_b) / 2**30, 1)
+    # what the memory in use is made of: the shared window tables; per lane the pool's blocks that back live handles
+    # (instances, assignments, decommitments: the resident inputs of the step) and the blocks cached for the next proof's
+    # temporaries (forests, derefs, partials); the rest = runtime, torch, the HIP contexts' own allocations
+    L_ = vpin_amd.lib()
+    L_.vpin_gens_shared_bytes.restype = ctypes_size_t()
+    L_.vpin_gens_shared_bytes.argtypes = [__import__("ctypes").c_int]
+    gib = lambda b: round(b / 2**30, 2)
+    pools = [cx.pool_stats() for cx in ctxs]
+    tables_b = int(L_.vpin_gens_shared_bytes(local_rank))
+    hbm_breakdown = {
+        "window_tables_gib": gib(tables_b),
+        "resident_inputs_gib_per_lane": [gib(t - c_) for t, c_, _ in pools],
+        "cached_temporaries_gib_per_lane": [gib(c_) for _, c_, _ in pools],
+        "resident_inputs_gib": gib(sum(t - c_ for t, c_, _ in pools)), "cached_temporaries_gib": gib(sum(c_ for _, c_, _ in pools)),
+        "other_gib": gib((total_b - free_b) - tables_b - sum(t for t, _, _ in pools)),
+        "note": "after the timed region, no proof running: a lane's pool keeps the temporaries of its largest proof for the next one "
+                "(hipMalloc / hipFree per proof cost more than the proofs of the small instances)"}
     elapsed = grp.max_over_ranks(elapsed)
     value = total_cons_step * args.steps * world / elapsed
 
@@ -697,6 +722,7 @@ def main():
                        "device_gadgets_generator_tables_encode": round(upload_s, 3)}
     line["proof_bytes"] = proof_bytes
     line["hbm_in_use_gib_after_timed_region"] = hbm_used_gb  # instances, decommitments, generator tables, pooled temporaries
+    line["hbm_breakdown"] = hbm_breakdown
     if args.snark:
         line["encode_ms"] = encode_ms
         line["comm_bytes"] = comm_bytes

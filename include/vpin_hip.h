@@ -81,6 +81,13 @@ int vpin_ctx_set_shared_device(vpin_ctx* ctx, int on);
 /* commitment rows this context has handed to the row-per-lane kernel (msm_strip_kernel) since it was created: lets a test
  * or a scheduler see that the path it asked for is the one that ran */
 unsigned long long vpin_ctx_strip_rows_taken(vpin_ctx* ctx);
+/* the context's device memory pool: out = {bytes obtained from the driver and still held (handles + temporaries + cached
+ * blocks), bytes of those sitting in the free lists (reusable by the next proof), blocks}.  What bench.py's hbm_breakdown and a
+ * service's admission control are made of. */
+int vpin_ctx_pool_stats(vpin_ctx* ctx, size_t out[3]);
+/* hand the pool's cached (free) blocks back to the driver: after set-up work whose temporaries no proof will reuse (gadget
+ * synthesis, SNARK::encode), or when a service changes workload.  Synchronises the context's stream. */
+int vpin_ctx_pool_trim(vpin_ctx* ctx);
 /* How many proofs the generator window tables built through this context will serve: 0 (default) = many -- the widest
  * windows the table budget allows (fewest additions per scalar; the table costs ~0.2 s to build for the largest
  * instance); n > 0 = a process that proves n times and exits (vpin_prove: a process per label, like `cargo run -- <label>`):
@@ -184,6 +191,8 @@ int vpin_gens_shared(vpin_ctx* ctx, const char* label, const uint8_t* gens_xyzt,
                      const vpin_gens** out);
 /* frees every shared table; only when no context uses them any more */
 void vpin_gens_shared_clear(void);
+/* bytes of the process-wide window tables on `device` */
+size_t vpin_gens_shared_bytes(int device);
 void vpin_gens_free(vpin_ctx* ctx, vpin_gens* g);
 size_t vpin_gens_count(const vpin_gens* g);
 /* Window layout the table budget chose: out = {c, W, split, c_hi, W_hi, bases}: generators [0, split) have c-bit signed
@@ -242,6 +251,12 @@ int vpin_poly_bound(vpin_ctx* ctx, const vpin_table* Z, const uint8_t* Lvec, siz
  * zero (the reference pads the combined polynomials with zero slices).  Needs ell / 2 >= nbits (ell = r_len + nbits). */
 int vpin_poly_slices_bound(vpin_ctx* ctx, const vpin_table* Z, int nbits, int used, const uint8_t* r, size_t r_len,
                            const uint8_t* ch, uint8_t* evals_out, uint8_t* LZ_out);
+/* The same with the first n32 slices given as u32 values (host memory, n32 x 2^r_len: addresses and timestamps of the
+ * computation decommitment, sparse_mlpoly.rs:418-428, whose field images Scalar::from(v) the proof never forms: 4 bytes and
+ * eight 32-bit multiply-adds per entry instead of 32 bytes and a product mod q) and the remaining used - n32 slices as a table
+ * of field elements (Zfq, NULL when used == n32).  Same elements as vpin_poly_slices_bound over the field images. */
+int vpin_poly_slices_bound_u32(vpin_ctx* ctx, const uint32_t* slices_u32, int n32, const vpin_table* Zfq, int nbits, int used,
+                               const uint8_t* r, size_t r_len, const uint8_t* ch, uint8_t* evals_out, uint8_t* LZ_out);
 
 /* ---- the sat proof (host orchestration over the kernels above) ------------------------ */
 /* R1CSInstance after Instance::new's padding and column remap (Spartan/src/lib.rs:138-244):

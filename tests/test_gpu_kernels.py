@@ -286,3 +286,42 @@ def test_slice_pass_vs_oracle(ctx, ell_slice, nbits, used, zero_frac):
     assert np.array_equal(lz, exp)
     assert np.array_equal(ctx.poly_bound(t, Lv), exp)
     t.free()
+
+
+@pytest.mark.parametrize("ell_slice,nbits,n32,used", [(14, 4, 12, 15), (16, 1, 2, 2), (5, 4, 12, 15), (18, 4, 12, 15)])
+def test_slice_pass_u32_vs_field_images(ctx, ell_slice, nbits, n32, used):
+    """slices_bound_u32_kernel: addresses / timestamps as u32 (0, 1, 2^32 - 1, runs of zeros among them) give the elements the
+    field-image pass gives over Scalar::from(v) -- itself checked against the oracle above -- and the oracle's evaluate."""
+    rng = np.random.default_rng(77 + ell_slice)
+    N, S = 1 << ell_slice, 1 << nbits
+    u = rng.integers(0, 2**32, size=(n32, N), dtype=np.uint64).astype(np.uint32)
+    u[0, : N // 4] = 0
+    u[1, :] = rng.integers(0, 4, size=N, dtype=np.uint64).astype(np.uint32)     # small timestamps
+    u[n32 - 1, ::3] = 0xFFFFFFFF
+    fqs = fast_table(rng, (used - n32) * N, 0.2) if used > n32 else None
+    # the field images: v * R mod q as Montgomery limbs
+    images = M.ints_to_table([int(v) for v in u.reshape(-1)]) if N <= (1 << 14) else None
+    r = np.stack([rand_scalar(rng) for _ in range(ell_slice)])
+    ch = np.stack([rand_scalar(rng) for _ in range(nbits)])
+    tf = ctx.upload(np.concatenate([fqs, np.zeros(((1 << int(np.ceil(np.log2(max(1, used - n32))))) * N - len(fqs), 4), dtype=np.uint64)])) if fqs is not None else None
+    ev, lz = ctx.poly_slices_bound_u32(u, tf, nbits, used, r, ch)
+    if images is not None:
+        Z = np.zeros((S * N, 4), dtype=np.uint64)
+        Z[: n32 * N] = images
+        if fqs is not None:
+            Z[n32 * N: used * N] = fqs
+        t = ctx.upload(Z)
+        ev2, lz2 = ctx.poly_slices_bound(t, nbits, used, r, ch)
+        assert np.array_equal(ev, ev2) and np.array_equal(lz, lz2)
+        for s in (0, 1, n32 - 1):
+            assert np.array_equal(ev[s], _oracle_evaluate(Z[s * N:(s + 1) * N], r)), f"slice {s}"
+        t.free()
+    else:
+        # too long for the Python image builder: the first and the last u32 slice against the oracle through a device conversion-free
+        # identity -- a slice of constant value v evaluates to v (the eq weights sum to one)
+        const = np.full((n32, N), 0xFFFFFFFF, dtype=np.uint32)
+        const[1, :] = 7
+        evc, _ = ctx.poly_slices_bound_u32(const, tf, nbits, used, r, ch)
+        assert np.array_equal(evc[0], M.ints_to_table([0xFFFFFFFF])[0]) and np.array_equal(evc[1], M.ints_to_table([7])[0])
+    if tf is not None:
+        tf.free()

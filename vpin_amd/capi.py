@@ -554,6 +554,20 @@ class Context:
         _chk(L.vpin_ctx_mem_info(self.h, C.byref(f), C.byref(t)), "vpin_ctx_mem_info")
         return t.value
 
+    def pool_stats(self):
+        """(bytes held from the driver, bytes of them cached in the free lists, blocks) of this context's device pool"""
+        L = lib()
+        L.vpin_ctx_pool_stats.argtypes = [C.c_void_p, C.POINTER(C.c_size_t * 3)]
+        out = (C.c_size_t * 3)()
+        _chk(L.vpin_ctx_pool_stats(self.h, C.byref(out)), "vpin_ctx_pool_stats")
+        return int(out[0]), int(out[1]), int(out[2])
+
+    def pool_trim(self):
+        """cached blocks of this context's device pool back to the driver (vpin_ctx_pool_trim)"""
+        L = lib()
+        L.vpin_ctx_pool_trim.argtypes = [C.c_void_p]
+        _chk(L.vpin_ctx_pool_trim(self.h), "vpin_ctx_pool_trim")
+
     def strip_rows_taken(self):
         """rows handed to the row-per-lane commitment kernel so far (vpin_ctx_strip_rows_taken)"""
         L = lib()
@@ -751,6 +765,23 @@ class Context:
         _chk(L.vpin_poly_slices_bound(self.h, Z.h, nbits, used, rr.ctypes.data_as(C.c_void_p), rr.shape[0],
                                       cc.ctypes.data_as(C.c_void_p) if cc is not None else None, ev.ctypes.data_as(C.c_void_p),
                                       lz.ctypes.data_as(C.c_void_p) if lz is not None else None), "vpin_poly_slices_bound")
+        return ev, lz
+
+    def poly_slices_bound_u32(self, u32, Zfq, nbits, used, r, ch=None):
+        """vpin_poly_slices_bound_u32: u32 = (n32, N) uint32 slices, Zfq = Table of the other used - n32 slices (or None)"""
+        u = np.ascontiguousarray(u32, dtype=np.uint32)
+        rr = np.ascontiguousarray(r, dtype=np.uint64).reshape(-1, 4)
+        ell = rr.shape[0] + nbits
+        ev = np.zeros((used, 4), dtype=np.uint64)
+        lz = np.zeros((1 << (ell - ell // 2), 4), dtype=np.uint64) if ch is not None else None
+        cc = np.ascontiguousarray(ch, dtype=np.uint64).reshape(-1, 4) if ch is not None else None
+        L = lib()
+        L.vpin_poly_slices_bound_u32.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t,
+                                                 C.c_void_p, C.c_void_p, C.c_void_p]
+        _chk(L.vpin_poly_slices_bound_u32(self.h, u.ctypes.data_as(C.c_void_p), u.shape[0], Zfq.h if Zfq is not None else None, nbits, used,
+                                          rr.ctypes.data_as(C.c_void_p), rr.shape[0], cc.ctypes.data_as(C.c_void_p) if cc is not None else None,
+                                          ev.ctypes.data_as(C.c_void_p), lz.ctypes.data_as(C.c_void_p) if lz is not None else None),
+             "vpin_poly_slices_bound_u32")
         return ev, lz
 
     # ---- sat proof ----

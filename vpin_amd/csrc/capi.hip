@@ -63,6 +63,18 @@ static void pool_release_unlocked(vpin_ctx* c) {
   for (void* p : blocks) (void)hipFree(p);
 }
 
+// VPIN_POOL_TRACE=<MiB>: every allocation / release of at least that size on stderr with the bytes in use afterwards
+static size_t pool_trace_min() {
+  static const size_t v = [] { const char* e = getenv("VPIN_POOL_TRACE"); return e ? ((size_t)atol(e) << 20) : (size_t)0; }();
+  return v;
+}
+static std::atomic<long long> g_in_use{0};
+static void pool_trace(const char* what, size_t cls, bool fresh) {
+  if (!pool_trace_min() || cls < pool_trace_min()) return;
+  fprintf(stderr, "[pool] %-5s %8.1f MiB%s  in use %9.1f MiB\n", what, (double)cls / 1048576.0, fresh ? " (hipMalloc)" : "",
+          (double)g_in_use.load() / 1048576.0);
+}
+
 int dev_alloc(vpin_ctx* c, size_t bytes, void** out) {
   size_t cls = 256;
   while (cls < bytes) cls <<= 1;
@@ -76,6 +88,7 @@ int dev_alloc(vpin_ctx* c, size_t bytes, void** out) {
       if (it->second.empty()) continue;
       *out = it->second.back();
       it->second.pop_back();
+      if (pool_trace_min()) { g_in_use += (long long)it->first; pool_trace("alloc", it->first, false); }
       return VPIN_OK;
     }
   }
@@ -112,6 +125,7 @@ int dev_alloc(vpin_ctx* c, size_t bytes, void** out) {
   std::lock_guard<std::mutex> g(c->pool_mu);
   c->pool_sizes[p] = cls;
   *out = p;
+  if (pool_trace_min()) { g_in_use += (long long)cls; pool_trace("alloc", cls, true); }
   return VPIN_OK;
 }
 
@@ -121,6 +135,7 @@ void dev_free(vpin_ctx* c, void* p) {
   auto it = c->pool_sizes.find(p);
   if (it == c->pool_sizes.end()) { (void)hipFree(p); return; }
   c->pool_free_lists[it->second].push_back(p);
+  if (pool_trace_min()) { g_in_use -= (long long)it->second; pool_trace("free", it->second, false); }
 }
 
 void dev_pool_release(vpin_ctx* c) { pool_release_unlocked(c); }
@@ -317,6 +332,23 @@ int vpin_ctx_set_progress_flag(vpin_ctx* c, int* flag) {
 }
 
 unsigned long long vpin_ctx_strip_rows_taken(vpin_ctx* c) { return c ? c->strip_rows_taken : 0ull; }
+
+int vpin_ctx_pool_trim(vpin_ctx* c) {
+  if (!c) return VPIN_EINVAL;
+  (void)hipSetDevice(c->device);
+  dev_pool_release(c);
+  return VPIN_OK;
+}
+
+int vpin_ctx_pool_stats(vpin_ctx* c, size_t out[3]) {
+  if (!c || !out) return VPIN_EINVAL;
+  std::lock_guard<std::mutex> g(c->pool_mu);
+  size_t total = 0, cached = 0;
+  for (auto& kv : c->pool_sizes) total += kv.second;
+  for (auto& kv : c->pool_free_lists) cached += kv.first * kv.second.size();
+  out[0] = total; out[1] = cached; out[2] = c->pool_sizes.size();
+  return VPIN_OK;
+}
 
 int vpin_ctx_set_shared_device(vpin_ctx* c, int on) {
   if (!c) return VPIN_EINVAL;

@@ -182,8 +182,9 @@ int poly_bound_dist(vpin_ctx* c, const vpin_table* Z, const uint8_t* Lvec, size_
 // Z = S slices of N = T * Rs scalars; Ltop = eq(r_top, .) (T scalars), Rv = eq(r_bot, .) (Rs scalars), host memory, Montgomery.
 // d_LZs (S * Rs scalars, device) <- LZ_s; ev_out (S scalars, host) <- Z_s(r).  Then, with the combining challenges known,
 // out_LZ (Rs scalars, host) <- sum_s coef[s] LZ_s.
-int slices_bound(vpin_ctx* c, const fq* Z, size_t N, int S, size_t Rs, const uint8_t* Ltop, size_t T, const uint8_t* Rv, fq* d_LZs,
-                 uint8_t* ev_out);
+// Z32 / n32: the first n32 of the S slices held as u32 (addresses / timestamps: their field images are never formed); Z: the others
+int slices_bound(vpin_ctx* c, const uint32_t* Z32, int n32, const fq* Z, size_t N, int S, size_t Rs, const uint8_t* Ltop, size_t T,
+                 const uint8_t* Rv, fq* d_LZs, uint8_t* ev_out);
 int slices_combine(vpin_ctx* c, const fq* d_LZs, int S, size_t Rs, const uint8_t* coef, uint8_t* out_LZ);
 
 inline bool is_pow2(size_t x) { return x && !(x & (x - 1)); }

@@ -54,7 +54,7 @@ struct vpin_dev_instance {
 namespace vpin {
 
 // SNARK::encode's dense representation for a device-built instance: fills d->idx (12N + 2M u32) and the
-// val slices of d->comb_ops (allocated by the caller) in closed form from the template.
+// val slices d->vals (allocated by the caller) in closed form from the template.
 int gadget_fill_decomm(vpin_ctx* c, const vpin_dev_instance* g, vpin_spark_decomm* d);
 
 }  // namespace vpin

@@ -665,7 +665,7 @@ static fq fq_of_host(const Fq& x) {
 }  // namespace
 
 int gadget_fill_decomm(vpin_ctx* c, const vpin_dev_instance* g, vpin_spark_decomm* d) {
-  if (!c || !g || !d || !d->idx || !d->comb_ops) return VPIN_EINVAL;
+  if (!c || !g || !d || !d->idx || !d->vals) return VPIN_EINVAL;
   const size_t N = d->N, M = d->M, nv_pad = g->r1cs->num_vars;
   for (int m = 0; m < 3; m++)
     if (g->nnz[m] > N) return VPIN_ESHAPE;
@@ -689,7 +689,7 @@ int gadget_fill_decomm(vpin_ctx* c, const vpin_dev_instance* g, vpin_spark_decom
     tp.row0_upto = m < 2 ? base_row0[m + 1] : tot0[0];
     tp.col0_upto = m < 2 ? base_col0[m + 1] : tot0[1];
     hipLaunchKernelGGL(gd_trace_kernel, dim3(blocks(N)), dim3(kGB), 0, c->stream, g->tmpl[m], tp, m, g->oc, g->ov, g->n_ops, nv_pad,
-                       N, d->idx, d->comb_ops->d + (size_t)(12 + m) * N);
+                       N, d->idx, d->vals + (size_t)m * N);
     pad_before += N - g->nnz[m];
     spec_before[0] += (size_t)g->tmpl[m].S[0] * g->n_ops;
     spec_before[1] += (size_t)g->tmpl[m].S[1] * g->n_ops;

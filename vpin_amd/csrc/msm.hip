@@ -1325,6 +1325,16 @@ int vpin_gens_shared(vpin_ctx* c, const char* label, const uint8_t* gens_xyzt, s
   return rc;
 }
 
+size_t vpin_gens_shared_bytes(int device) {
+  std::lock_guard<std::mutex> lock(g_reg_mu);
+  size_t total = 0;
+  for (auto& e : g_reg)
+    if (e.device == device)
+      total += sizeof(niels_slot) * ((size_t)e.g->W * e.g->split * (size_t)e.g->E +
+                                     (e.g->split < e.g->nbt ? (size_t)e.g->W_hi * (e.g->nbt - e.g->split) * (size_t)e.g->E_hi : 0));
+  return total;
+}
+
 void vpin_gens_shared_clear(void) {
   std::lock_guard<std::mutex> lock(g_reg_mu);
   for (auto& e : g_reg) {

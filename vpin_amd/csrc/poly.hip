@@ -49,7 +49,8 @@ __global__ __launch_bounds__(kPB) void poly_bound_reduce_kernel(const fq* __rest
 // partial[(chunk * S + s) * Rs + i] = sum_{t in chunk} Ltop[t] * Z[s * N + t * Rs + i], products accumulated unreduced
 // (fq_wide: one Montgomery reduction per seven terms)
 __global__ __launch_bounds__(kPB) void slices_bound_kernel(const fq* __restrict__ Z, size_t N, const fq* __restrict__ Ltop, size_t T,
-                                                           size_t Rs, size_t rows_per_chunk, fq* __restrict__ partial) {
+                                                           size_t Rs, size_t rows_per_chunk, int S_total, int s0,
+                                                           fq* __restrict__ partial) {
   const size_t i = (size_t)blockIdx.x * kPB + threadIdx.x;
   if (i >= Rs) return;
   const fq* zs = Z + (size_t)blockIdx.z * N;
@@ -66,7 +67,52 @@ __global__ __launch_bounds__(kPB) void slices_bound_kernel(const fq* __restrict_
     if (++n == 7) { acc = fq_add(acc, fqw_reduce(w)); fqw_zero(w); n = 0; }
   }
   if (n) acc = fq_add(acc, fqw_reduce(w));
-  fq_store(partial + ((size_t)blockIdx.y * gridDim.z + blockIdx.z) * Rs + i, acc);
+  fq_store(partial + ((size_t)blockIdx.y * S_total + s0 + blockIdx.z) * Rs + i, acc);
+}
+
+// The same for slices held as u32 (addresses and timestamps of the computation decommitment; their field images are
+// Scalar::from(v) = v R mod q): Ltop[t] * (v R) R^-1 = Ltop[t] * v as an integer multiple -- eight 32 x 32 multiply-adds into a
+// 320-bit accumulator instead of a product mod q, and 4 bytes from HBM instead of 32.  The accumulator is brought back to
+// [0, q) once per (thread, chunk): lo + hi 2^256 = fq_mul(lo, R) + fq_mul(hi, R^2) (Montgomery products: x R R^-1 = x,
+// hi R^2 R^-1 = hi R), canonical, so the element is bit for bit the one the field-image pass computes.
+__device__ __forceinline__ fq fq_r2_poly() {  // R^2 mod q (ristretto255.rs:309-314)
+  fq r;
+  r.v[0] = 0x449c0f01u; r.v[1] = 0xa40611e3u; r.v[2] = 0x68859347u; r.v[3] = 0xd00e1ba7u;
+  r.v[4] = 0x17f5be65u; r.v[5] = 0xceec73d2u; r.v[6] = 0x7c309a3du; r.v[7] = 0x0399411bu;
+  return r;
+}
+__global__ __launch_bounds__(kPB) void slices_bound_u32_kernel(const uint32_t* __restrict__ Z32, size_t N, const fq* __restrict__ Ltop,
+                                                               size_t T, size_t Rs, size_t rows_per_chunk, int S_total,
+                                                               fq* __restrict__ partial) {
+  const size_t i = (size_t)blockIdx.x * kPB + threadIdx.x;
+  if (i >= Rs) return;
+  const uint32_t* zs = Z32 + (size_t)blockIdx.z * N;
+  size_t j0 = (size_t)blockIdx.y * rows_per_chunk, j1 = j0 + rows_per_chunk;
+  if (j1 > T) j1 = T;
+  uint32_t a[10];
+#pragma unroll
+  for (int k = 0; k < 10; k++) a[k] = 0;
+  for (size_t j = j0; j < j1; j++) {
+    const uint32_t v = zs[j * Rs + i];
+    if (v == 0) continue;
+    const fq l = fq_load(Ltop + j);
+    uint64_t carry = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const uint64_t t = (uint64_t)l.v[k] * v + a[k] + carry;   // < 2^64: (2^32-1)^2 + 2 (2^32-1)
+      a[k] = (uint32_t)t;
+      carry = t >> 32;
+    }
+    const uint64_t t8 = (uint64_t)a[8] + carry;
+    a[8] = (uint32_t)t8;
+    a[9] += (uint32_t)(t8 >> 32);   // T <= 2^28 rows of values below 2^32 q: the sum stays below 2^320
+  }
+  fq lo, hi = fq_zero();
+#pragma unroll
+  for (int k = 0; k < 8; k++) lo.v[k] = a[k];
+  hi.v[0] = a[8]; hi.v[1] = a[9];
+  const fq acc = fq_add(fq_mul(lo, fq_one()), fq_mul(hi, fq_r2_poly()));
+  fq_store(partial + ((size_t)blockIdx.y * S_total + blockIdx.z) * Rs + i, acc);
 }
 
 // ev[s] = sum_i Rv[i] * LZs[s * Rs + i]; one workgroup per slice
@@ -103,9 +149,12 @@ __global__ __launch_bounds__(kPB) void slices_combine_kernel(const fq* __restric
   fq_store(out + i, acc);
 }
 
-int slices_bound(vpin_ctx* c, const fq* Z, size_t N, int S, size_t Rs, const uint8_t* Ltop, size_t T, const uint8_t* Rv, fq* d_LZs,
-                 uint8_t* ev_out) {
-  if (!c || !Z || S < 1 || !Ltop || !Rv || !d_LZs || !ev_out || T == 0 || Rs == 0 || T * Rs != N) return VPIN_EINVAL;
+// Z32 / n32: the first n32 slices as u32 (nullptr / 0: none); Z: the following S - n32 slices as field elements
+int slices_bound(vpin_ctx* c, const uint32_t* Z32, int n32, const fq* Z, size_t N, int S, size_t Rs, const uint8_t* Ltop, size_t T,
+                 const uint8_t* Rv, fq* d_LZs, uint8_t* ev_out) {
+  if (!c || S < 1 || n32 < 0 || n32 > S || (n32 && !Z32) || (n32 < S && !Z) || !Ltop || !Rv || !d_LZs || !ev_out || T == 0 || Rs == 0 ||
+      T * Rs != N)
+    return VPIN_EINVAL;
   (void)hipSetDevice(c->device);
   const size_t rows_per_chunk = T / 64 ? T / 64 : 1;
   const int chunks = (int)((T + rows_per_chunk - 1) / rows_per_chunk);
@@ -114,9 +163,14 @@ int slices_bound(vpin_ctx* c, const fq* Z, size_t N, int S, size_t Rs, const uin
   VPIN_HIP_TRY(hipMemcpyAsync(bL.p, Ltop, T * 32, hipMemcpyHostToDevice, c->stream));
   VPIN_HIP_TRY(hipMemcpyAsync(bR.p, Rv, Rs * 32, hipMemcpyHostToDevice, c->stream));
   {
-    ProfScope ps(c, VPIN_K_SPARK_BUILD, 32.0 * (double)S * (double)N);
-    hipLaunchKernelGGL(slices_bound_kernel, dim3((unsigned)((Rs + kPB - 1) / kPB), (unsigned)chunks, (unsigned)S), dim3(kPB), 0, c->stream, Z,
-                       N, (const fq*)bL.p, T, Rs, rows_per_chunk, (fq*)bpart.p);
+    ProfScope ps(c, VPIN_K_SPARK_BUILD, (32.0 * (double)(S - n32) + 4.0 * (double)n32) * (double)N);
+    const unsigned gx = (unsigned)((Rs + kPB - 1) / kPB);
+    if (n32)
+      hipLaunchKernelGGL(slices_bound_u32_kernel, dim3(gx, (unsigned)chunks, (unsigned)n32), dim3(kPB), 0, c->stream, Z32, N,
+                         (const fq*)bL.p, T, Rs, rows_per_chunk, S, (fq*)bpart.p);
+    if (n32 < S)
+      hipLaunchKernelGGL(slices_bound_kernel, dim3(gx, (unsigned)chunks, (unsigned)(S - n32)), dim3(kPB), 0, c->stream, Z, N,
+                         (const fq*)bL.p, T, Rs, rows_per_chunk, S, n32, (fq*)bpart.p);
   }
   hipLaunchKernelGGL(poly_bound_reduce_kernel, dim3((unsigned)(((size_t)S * Rs + kPB - 1) / kPB)), dim3(kPB), 0, c->stream,
                      (const fq*)bpart.p, (size_t)S * Rs, chunks, d_LZs);

@@ -164,10 +164,10 @@ static Fq combine_bot(std::vector<Fq> e, const std::vector<Fq>& ch) {
 static int polyeval_prove_plain(vpin_ctx* c, const PcGens& pc, const vpin_table* Z, const std::vector<Fq>& r, const Fq& Zr,
                                 Transcript& tr, Transcript& tape, DpLog& out, const vpin::fq* z_rows = nullptr,
                                 const std::vector<Fq>* lz_pre = nullptr, const std::vector<Fq>* rv_pre = nullptr) {
-  if (r.size() != pc.ell || Z->len != ((size_t)1 << pc.ell)) return VPIN_ESHAPE;
+  if (r.size() != pc.ell || (!(lz_pre && rv_pre) && (!Z || Z->len != ((size_t)1 << pc.ell)))) return VPIN_ESHAPE;
   tr.append_protocol_name("polynomial evaluation proof");
   const size_t left = pc.ell / 2, right = pc.ell - left;
-  if (lz_pre && rv_pre) {
+  if (lz_pre && rv_pre) {  // (Z may be null: the table is not needed)
     if (lz_pre->size() != pc.R || rv_pre->size() != pc.R) return VPIN_ESHAPE;
     TraceSpan ts("  dplog");
     return dplog_prove(c, pc, tr, tape, *lz_pre, Fq::zero(), *rv_pre, Zr, Fq::zero(), out);
@@ -201,7 +201,9 @@ struct SlicePass {
     const bool off = getenv("VPIN_HASH_TWO_PASS") != nullptr;  // A/B and tests: the separate evaluation and bound passes (read per proof)
     return !off && pc.ell / 2 >= (size_t)nbits && rand.size() + (size_t)nbits == pc.ell;
   }
-  int run(vpin_ctx* c, const PcGens& pc, const vpin::fq* table, int nbits_, int used_, const std::vector<Fq>& rand, Fq* ev) {
+  // table32 / n32: the first n32 slices as u32 (the decommitment's addresses and timestamps); table: the other used - n32
+  int run(vpin_ctx* c, const PcGens& pc, const uint32_t* table32, int n32, const vpin::fq* table, int nbits_, int used_,
+          const std::vector<Fq>& rand, Fq* ev) {
     nbits = nbits_; used = used_;
     const size_t left = pc.ell / 2, T = pc.L >> nbits, N = (size_t)1 << rand.size();
     std::vector<Fq> Ltop(T);
@@ -209,7 +211,7 @@ struct SlicePass {
     Rv.resize(pc.R);
     host_eq(rand.data() + (left - (size_t)nbits), pc.ell - left, Rv.data());
     if (lzs.alloc((size_t)used * pc.R * 32)) return VPIN_ENOMEM;
-    int rc = vpin::slices_bound(c, table, N, used, pc.R, B(Ltop.data()), T, B(Rv.data()), (vpin::fq*)lzs.p, B(ev));
+    int rc = vpin::slices_bound(c, table32, n32, table, N, used, pc.R, B(Ltop.data()), T, B(Rv.data()), (vpin::fq*)lzs.p, B(ev));
     on = rc == VPIN_OK;
     return rc;
   }
@@ -459,7 +461,7 @@ static int batched_prove(vpin_ctx* c, vpin::SparkForest& f, DotpCtx* dotp, Trans
         const uint8_t* rprev = j ? B(&r[j - 1]) : nullptr;
         if (!tail_on && (h >> (j + 1)) <= tail_pairs) {
           if (runs && (rc = vpin::spark_tail_launch(c, &f, layer_id, k, j, len, pyr->d, rprev, ndl_here ? dotp->d->N : 0,
-                                                    ndl_here ? dotp->d->comb_ops->d + 12 * dotp->d->N : nullptr,
+                                                    ndl_here ? dotp->d->vals : nullptr,
                                                     ndl_here ? dotp->comb_derefs : nullptr, ndl_here ? dotp->scratch : nullptr,
                                                     halves, ndl_here)))
             return rc;
@@ -474,7 +476,7 @@ static int batched_prove(vpin_ctx* c, vpin::SparkForest& f, DotpCtx* dotp, Trans
           }
         } else if (runs) {
           if ((rc = vpin::spark_prod_round(c, &f, layer_id, len, E, rprev, ndl_here, lead_ok))) return rc;
-          if (ndl_here && (rc = vpin::spark_dotp_round(c, dotp->d->N, dotp->d->comb_ops->d + 12 * dotp->d->N, dotp->comb_derefs, dotp->scratch, len, j == 1, rprev, halves, ndl_here))) return rc;
+          if (ndl_here && (rc = vpin::spark_dotp_round(c, dotp->d->N, dotp->d->vals, dotp->comb_derefs, dotp->scratch, len, j == 1, rprev, halves, ndl_here))) return rc;
           if ((rc = vpin::spark_wait_flag(c))) return rc;
           res = reinterpret_cast<const Fq*>(c->h_spark);
         }
@@ -970,7 +972,7 @@ static int spark_prove(vpin_ctx* c, const vpin_spark_decomm* d, const std::vecto
     comb_loc = (vpin::fq*)b_cloc.p; comb_rows = (vpin::fq*)b_crows.p; vals_loc = (vpin::fq*)b_vloc.p;
     if ((rc = vpin::spark_gather_derefs_strided(c, d, mem_rx->d, mem_ry->d, rk, Wz, comb_loc, comb_rows, g_derefs->R, nrows_loc))) return rc;
     for (int m = 0; m < 3; m++)
-      if ((rc = vpin::spark_take_strided(c, d->comb_ops->d + (size_t)(12 + m) * N, Nl, rk, Wz, vals_loc + (size_t)m * Nl))) return rc;
+      if ((rc = vpin::spark_take_strided(c, d->vals + (size_t)m * N, Nl, rk, Wz, vals_loc + (size_t)m * Nl))) return rc;
     comb = &comb_shape;
   } else {
     if ((rc = vpin::table_alloc_uninit(c, 8 * N, &comb))) return rc;
@@ -1167,6 +1169,13 @@ static int spark_prove(vpin_ctx* c, const vpin_spark_decomm* d, const std::vecto
   const bool one_pass = !dz && SlicePass::fits(*g_derefs, 3, rand_ops) && SlicePass::fits(*g_ops, 4, rand_ops) &&
                         SlicePass::fits(*g_mem, 1, rand_mem);
   SlicePass sp_derefs(c), sp_ops(c), sp_mem(c);
+  // the combined polynomials as whole field tables: only the two-pass and the multi-GPU paths read them (this proof's own
+  // copies: the decommitment is shared with other contexts)
+  vpin_table *comb_ops = nullptr, *comb_mem = nullptr;
+  if (!one_pass) {
+    if ((rc = vpin::spark_comb_make(c, d, &comb_ops, &comb_mem))) return rc;
+    tg.add(comb_ops); tg.add(comb_mem);
+  }
   if (!one_pass) {
     TraceSpan ts("hash: eq tables");
     // split by residue class: eq(rand, rank + k W) = eq(rand_hi, k) * eq(rand_lo, rank), so the local table is the table of
@@ -1188,9 +1197,9 @@ static int spark_prove(vpin_ctx* c, const vpin_spark_decomm* d, const std::vecto
     Fq mine23[23], all23[23];
     if ((rc = vpin::spark_slice_evals(c, comb_loc, Nf, 6, eq_ops->d))) return rc;
     for (int i = 0; i < 6; i++) mine23[i] = hs[3 * i] * lo_ops[rk];
-    if ((rc = vpin::spark_slice_evals(c, d->comb_ops->d, N, 15, eq_ops->d, rk, Wz))) return rc;
+    if ((rc = vpin::spark_slice_evals(c, comb_ops->d, N, 15, eq_ops->d, rk, Wz))) return rc;
     for (int i = 0; i < 15; i++) mine23[6 + i] = hs[3 * i] * lo_ops[rk];
-    if ((rc = vpin::spark_slice_evals(c, d->comb_mem->d, M, 2, eq_mem->d, rk, Wz))) return rc;
+    if ((rc = vpin::spark_slice_evals(c, comb_mem->d, M, 2, eq_mem->d, rk, Wz))) return rc;
     for (int i = 0; i < 2; i++) mine23[21 + i] = hs[3 * i] * lo_mem[rk];
     if ((rc = dist_sum(c, *dz, mine23, 23, all23, "hash_slice_evals"))) return rc;
     for (int i = 0; i < 6; i++) ev_derefs[i] = all23[i];
@@ -1202,7 +1211,7 @@ static int spark_prove(vpin_ctx* c, const vpin_spark_decomm* d, const std::vecto
     // equal cost (a slice costs its length), evaluate, exchange 23 scalars.
     const size_t cost[3] = {N, N, M};
     const int cnts[3] = {6, 15, 2};
-    const vpin::fq* tabs[3] = {comb->d, d->comb_ops->d, d->comb_mem->d};
+    const vpin::fq* tabs[3] = {comb->d, comb_ops->d, comb_mem->d};
     const vpin::fq* eqs[3] = {eq_ops->d, eq_ops->d, eq_mem->d};
     size_t total = 0;
     for (int g = 0; g < 3; g++) total += cost[g] * (size_t)cnts[g];
@@ -1235,7 +1244,7 @@ static int spark_prove(vpin_ctx* c, const vpin_spark_decomm* d, const std::vecto
     for (int i = 0; i < 2; i++) ev_mem[i] = pick(21 + i);
   } else if (one_pass) {
     TraceSpan ts("hash: derefs slices (one pass)");
-    if ((rc = sp_derefs.run(c, *g_derefs, comb->d, 3, 6, rand_ops, ev_derefs))) return rc;
+    if ((rc = sp_derefs.run(c, *g_derefs, nullptr, 0, comb->d, 3, 6, rand_ops, ev_derefs))) return rc;
   } else {
     TraceSpan ts("hash: derefs slice evals");
     if ((rc = vpin::spark_slice_evals(c, comb->d, N, 6, eq_ops->d))) return rc;
@@ -1262,13 +1271,13 @@ static int spark_prove(vpin_ctx* c, const vpin_spark_decomm* d, const std::vecto
   }
   if (one_pass) {
     TraceSpan ts("hash: ops+mem slices (one pass)");
-    if ((rc = sp_ops.run(c, *g_ops, d->comb_ops->d, 4, 15, rand_ops, ev_ops))) return rc;
-    if ((rc = sp_mem.run(c, *g_mem, d->comb_mem->d, 1, 2, rand_mem, ev_mem))) return rc;
+    if ((rc = sp_ops.run(c, *g_ops, d->idx, 12, d->vals, 4, 15, rand_ops, ev_ops))) return rc;
+    if ((rc = sp_mem.run(c, *g_mem, d->idx + 12 * N, 2, nullptr, 1, 2, rand_mem, ev_mem))) return rc;
   } else if (!dz) {
     TraceSpan ts("hash: ops+mem slice evals");
-    if ((rc = vpin::spark_slice_evals(c, d->comb_ops->d, N, 15, eq_ops->d))) return rc;
+    if ((rc = vpin::spark_slice_evals(c, comb_ops->d, N, 15, eq_ops->d))) return rc;
     for (int i = 0; i < 15; i++) ev_ops[i] = hs[3 * i];
-    if ((rc = vpin::spark_slice_evals(c, d->comb_mem->d, M, 2, eq_mem->d))) return rc;
+    if ((rc = vpin::spark_slice_evals(c, comb_mem->d, M, 2, eq_mem->d))) return rc;
     for (int i = 0; i < 2; i++) ev_mem[i] = hs[3 * i];
   }
   {
@@ -1283,7 +1292,7 @@ static int spark_prove(vpin_ctx* c, const vpin_spark_decomm* d, const std::vecto
     TraceSpan ts("hash: polyeval ops");
     std::vector<Fq> lz;
     if (sp_ops.on && (rc = sp_ops.combine(c, *g_ops, ch, lz))) return rc;
-    if ((rc = polyeval_prove_plain(c, *g_ops, d->comb_ops, rj, joint, tr, tape, pe_ops, nullptr, sp_ops.on ? &lz : nullptr,
+    if ((rc = polyeval_prove_plain(c, *g_ops, comb_ops, rj, joint, tr, tape, pe_ops, nullptr, sp_ops.on ? &lz : nullptr,
                                    sp_ops.on ? &sp_ops.Rv : nullptr))) return rc;
     if ((rc = vpin::comm_mark(c, "hash_bullet"))) return rc;
   }
@@ -1298,7 +1307,7 @@ static int spark_prove(vpin_ctx* c, const vpin_spark_decomm* d, const std::vecto
     TraceSpan ts("hash: polyeval mem");
     std::vector<Fq> lz;
     if (sp_mem.on && (rc = sp_mem.combine(c, *g_mem, ch, lz))) return rc;
-    if ((rc = polyeval_prove_plain(c, *g_mem, d->comb_mem, rj, joint, tr, tape, pe_mem, nullptr, sp_mem.on ? &lz : nullptr,
+    if ((rc = polyeval_prove_plain(c, *g_mem, comb_mem, rj, joint, tr, tape, pe_mem, nullptr, sp_mem.on ? &lz : nullptr,
                                    sp_mem.on ? &sp_mem.Rv : nullptr))) return rc;
     if ((rc = vpin::comm_mark(c, "hash_bullet"))) return rc;
   }
@@ -1393,6 +1402,7 @@ void vpin_spark_decomm_free(vpin_ctx* c, vpin_spark_decomm* d) {
   if (c) {
     (void)hipSetDevice(c->device);
     if (d->idx) vpin::dev_free(c, d->idx);
+    if (d->vals) vpin::dev_free(c, d->vals);
     if (d->comb_ops) vpin_table_free(c, d->comb_ops);
     if (d->comb_mem) vpin_table_free(c, d->comb_mem);
   }
@@ -1412,7 +1422,11 @@ static int encode_commit(vpin_ctx* c, const Shape& s, std::unique_ptr<vpin_spark
     return fail(rc);
   lap("generators (views)");
   std::vector<CG> c_ops, c_mem;
+  if ((rc = vpin::spark_comb_tables(c, d.get()))) return fail(rc);
   if ((rc = commit_noblind(c, g_ops, d->comb_ops, c_ops)) || (rc = commit_noblind(c, g_mem, d->comb_mem, c_mem))) return fail(rc);
+  // (commit_noblind has synchronised the stream.)  A service (no expected proof count) hands the blocks back to the driver;
+  // a one-shot process keeps them pooled for its proof's temporaries (a hipFree / hipMalloc pair of 17 GB costs more there)
+  if (!getenv("VPIN_KEEP_COMB")) vpin::spark_comb_release(c, d.get(), c->expected_proofs == 0);
   lap("commit ops + mem");
   if ((rc = vpin::spark_find_hot_cols(c, d.get()))) return fail(rc);
   Writer w;
@@ -1473,13 +1487,10 @@ int vpin_spark_encode(vpin_ctx* c, const vpin_r1cs* inst, vpin_spark_decomm** ou
   if (hipMemcpyAsync(d->idx, idx.data(), idx.size() * 4, hipMemcpyHostToDevice, c->stream) != hipSuccess) return fail(VPIN_EHIP);
   // comb_ops = merge(row.ops_addr, row.read_ts, col.ops_addr, col.read_ts, val) padded to 16N (:418-426);
   // comb_mem = row.audit_ts ++ col.audit_ts (:427-428)
-  if ((rc = vpin::table_alloc_uninit(c, 16 * N, &d->comb_ops))) return fail(rc);
-  if ((rc = vpin::table_alloc_uninit(c, 2 * M, &d->comb_mem))) return fail(rc);
-  if ((rc = vpin::spark_u32_to_fq(c, d->idx, d->comb_ops->d, 12 * N))) return fail(rc);
-  if ((rc = vpin::spark_u32_to_fq(c, d->idx + 12 * N, d->comb_mem->d, 2 * M))) return fail(rc);
-  if (hipMemsetAsync(d->comb_ops->d + 12 * N, 0, 4 * N * 32, c->stream) != hipSuccess) return fail(VPIN_EHIP);
+  if ((rc = vpin::dev_alloc(c, 3 * N * 32, (void**)&d->vals))) return fail(rc);
+  if (hipMemsetAsync(d->vals, 0, 3 * N * 32, c->stream) != hipSuccess) return fail(VPIN_EHIP);
   for (int m = 0; m < 3; m++)
-    if (inst->nnz[m] && hipMemcpyAsync(d->comb_ops->d + (size_t)(12 + m) * N, inst->val[m], inst->nnz[m] * 32, hipMemcpyHostToDevice,
+    if (inst->nnz[m] && hipMemcpyAsync(d->vals + (size_t)m * N, inst->val[m], inst->nnz[m] * 32, hipMemcpyHostToDevice,
                                        c->stream) != hipSuccess)
       return fail(VPIN_EHIP);
   if (hipStreamSynchronize(c->stream) != hipSuccess) return fail(VPIN_EHIP);
@@ -1507,12 +1518,8 @@ int vpin_spark_encode_dev(vpin_ctx* c, const vpin_dev_instance* g, vpin_spark_de
   vpin::TraceLap lap(c, "spark_encode_dev");
   int rc;
   if ((rc = vpin::dev_alloc(c, (12 * N + 2 * M) * 4, (void**)&d->idx))) return fail(rc);
-  if ((rc = vpin::table_alloc_uninit(c, 16 * N, &d->comb_ops))) return fail(rc);
-  if ((rc = vpin::table_alloc_uninit(c, 2 * M, &d->comb_mem))) return fail(rc);
+  if ((rc = vpin::dev_alloc(c, 3 * N * 32, (void**)&d->vals))) return fail(rc);
   if ((rc = vpin::gadget_fill_decomm(c, g, d.get()))) return fail(rc);
-  if ((rc = vpin::spark_u32_to_fq(c, d->idx, d->comb_ops->d, 12 * N))) return fail(rc);
-  if ((rc = vpin::spark_u32_to_fq(c, d->idx + 12 * N, d->comb_mem->d, 2 * M))) return fail(rc);
-  if (hipMemsetAsync(d->comb_ops->d + 15 * N, 0, N * 32, c->stream) != hipSuccess) return fail(VPIN_EHIP);
   lap("trace + comb tables");
   return encode_commit(c, s, d, lap, num_cons, num_vars, g->num_inputs, out, comm_out, comm_cap, comm_len, t0);
 }
@@ -1545,7 +1552,36 @@ int vpin_poly_slices_bound(vpin_ctx* c, const vpin_table* Z, int nbits, int used
   memcpy(rand.data(), r, r_len * 32);
   SlicePass sp(c);
   std::vector<Fq> ev((size_t)used);
-  int rc = sp.run(c, pc, Z->d, nbits, used, rand, ev.data());
+  int rc = sp.run(c, pc, nullptr, 0, Z->d, nbits, used, rand, ev.data());
+  if (rc) return rc;
+  memcpy(evals_out, ev.data(), (size_t)used * 32);
+  if (ch && LZ_out) {
+    std::vector<Fq> chv((size_t)nbits), LZ;
+    memcpy(chv.data(), ch, (size_t)nbits * 32);
+    if ((rc = sp.combine(c, pc, chv, LZ))) return rc;
+    memcpy(LZ_out, LZ.data(), pc.R * 32);
+  }
+  return VPIN_OK;
+}
+
+// the same with the first n32 slices given as u32 (host memory, n32 x N values: the decommitment's addresses and timestamps,
+// whose field images Scalar::from(v) are never formed) and the other used - n32 slices as a table of field elements
+int vpin_poly_slices_bound_u32(vpin_ctx* c, const uint32_t* slices_u32, int n32, const vpin_table* Zfq, int nbits, int used,
+                               const uint8_t* r, size_t r_len, const uint8_t* ch, uint8_t* evals_out, uint8_t* LZ_out) {
+  if (!c || !slices_u32 || n32 < 1 || nbits < 0 || nbits > 4 || used < n32 || used > (1 << nbits) || !r || !evals_out) return VPIN_EINVAL;
+  const size_t ell = r_len + (size_t)nbits, N = (size_t)1 << r_len;
+  if (ell / 2 < (size_t)nbits || (used > n32 && (!Zfq || !Zfq->d || Zfq->len < (size_t)(used - n32) * N))) return VPIN_ESHAPE;
+  PcGens pc;  // shape only
+  pc.ell = ell; pc.L = (size_t)1 << (ell / 2); pc.R = (size_t)1 << (ell - ell / 2);
+  (void)hipSetDevice(c->device);
+  vpin::DevBuf b32(c);
+  if (b32.alloc((size_t)n32 * N * 4)) return VPIN_ENOMEM;
+  if (hipMemcpyAsync(b32.p, slices_u32, (size_t)n32 * N * 4, hipMemcpyHostToDevice, c->stream) != hipSuccess) return VPIN_EHIP;
+  std::vector<Fq> rand(r_len);
+  memcpy(rand.data(), r, r_len * 32);
+  SlicePass sp(c);
+  std::vector<Fq> ev((size_t)used);
+  int rc = sp.run(c, pc, (const uint32_t*)b32.p, n32, used > n32 ? Zfq->d : nullptr, nbits, used, rand, ev.data());
   if (rc) return rc;
   memcpy(evals_out, ev.data(), (size_t)used * 32);
   if (ch && LZ_out) {

@@ -626,6 +626,42 @@ int spark_u32_to_fq(vpin_ctx* c, const uint32_t* src, fq* dst, size_t n) {
   return VPIN_OK;
 }
 
+int spark_comb_make(vpin_ctx* c, const vpin_spark_decomm* d, vpin_table** ops, vpin_table** mem) {
+  if (!c || !d || !d->idx || !d->vals || !ops || !mem) return VPIN_EINVAL;
+  const size_t N = d->N, M = d->M;
+  int rc;
+  *ops = *mem = nullptr;
+  if ((rc = table_alloc_uninit(c, 16 * N, ops))) return rc;
+  if ((rc = table_alloc_uninit(c, 2 * M, mem))) { vpin_table_free(c, *ops); *ops = nullptr; return rc; }
+  if ((rc = spark_u32_to_fq(c, d->idx, (*ops)->d, 12 * N)) || (rc = spark_u32_to_fq(c, d->idx + 12 * N, (*mem)->d, 2 * M))) return rc;
+  VPIN_HIP_TRY(hipMemcpyAsync((*ops)->d + 12 * N, d->vals, 3 * N * sizeof(fq), hipMemcpyDeviceToDevice, c->stream));
+  VPIN_HIP_TRY(hipMemsetAsync((*ops)->d + 15 * N, 0, N * sizeof(fq), c->stream));
+  return VPIN_OK;
+}
+
+int spark_comb_tables(vpin_ctx* c, vpin_spark_decomm* d) {
+  if (!d) return VPIN_EINVAL;
+  if (d->comb_ops && d->comb_mem) return VPIN_OK;
+  spark_comb_release(c, d, false);
+  return spark_comb_make(c, d, &d->comb_ops, &d->comb_mem);
+}
+
+// to_driver: the blocks leave the context's pool too (SNARK::encode: nothing of a proof reuses 16N scalars; cached, they would
+// only inflate the pool -- the caller has synchronised the stream)
+void spark_comb_release(vpin_ctx* c, vpin_spark_decomm* d, bool to_driver) {
+  if (!d) return;
+  for (vpin_table** t : {&d->comb_ops, &d->comb_mem}) {
+    if (!*t) continue;
+    if (to_driver && (*t)->owned && (*t)->owner == c) {
+      dev_release_block(c, (*t)->d);
+      delete *t;
+    } else {
+      vpin_table_free(c, *t);
+    }
+    *t = nullptr;
+  }
+}
+
 // cnt[2m + k] += entries of matrix m's col slice equal to candidate k
 __global__ __launch_bounds__(kBlock) void count_cols_kernel(const uint32_t* __restrict__ idx, size_t N, uint32_t v0, uint32_t v1,
                                                             unsigned long long* __restrict__ cnt) {
@@ -969,7 +1005,7 @@ int spark_collect(vpin_ctx* c, const SparkForest* f, int level, const vpin_spark
   if (h < 2) return VPIN_ESHAPE;  // a 1-entry half has no second element; the host handles those layers
   c->spark_seq++;
   hipLaunchKernelGGL(collect_kernel, dim3(1), dim3(128), 0, c->stream, (const fq*)f->base, f->stride(), f->level_off(level), h,
-                     f->ncirc, comb_derefs, with_dotp ? (const fq*)(d->comb_ops->d + 12 * d->N) : (const fq*)nullptr,
+                     f->ncirc, comb_derefs, with_dotp ? (const fq*)d->vals : (const fq*)nullptr,
                      with_dotp ? d->N : (size_t)0, scratch, with_dotp, folded, c->h_spark, flag_ptr(c), c->spark_seq);
   VPIN_HIP_TRY(hipGetLastError());
   return spark_wait_flag(c);
@@ -977,7 +1013,7 @@ int spark_collect(vpin_ctx* c, const SparkForest* f, int level, const vpin_spark
 
 int spark_triple_sums(vpin_ctx* c, const vpin_spark_decomm* d, const fq* comb_derefs, const int* halves, int nh) {
   if (!d) return VPIN_EINVAL;
-  return spark_triple_sums_raw(c, comb_derefs, d->comb_ops->d + 12 * d->N, d->N, halves, nh);
+  return spark_triple_sums_raw(c, comb_derefs, d->vals, d->N, halves, nh);
 }
 
 int spark_triple_sums_raw(vpin_ctx* c, const fq* comb_derefs, const fq* vals, size_t N, const int* halves, int nh) {

@@ -11,8 +11,13 @@ struct vpin_spark_decomm {
   // u32 [row A,B,C | row_read_ts A,B,C | col A,B,C | col_read_ts A,B,C] (12 x N, the order of
   // comb_ops), then row_audit_ts (M), col_audit_ts (M)
   uint32_t* idx = nullptr;
-  vpin_table* comb_ops = nullptr;  // 16N: slices as idx (0..11), val A,B,C (12..14), zero (15)
-  vpin_table* comb_mem = nullptr;  // 2M: row_audit_ts | col_audit_ts
+  vpin::fq* vals = nullptr;        // 3N: val A,B,C (slices 12..14 of comb_ops), the only part of the two combined polynomials
+                                   // that is not a u32
+  // The combined polynomials as field elements (16N: idx as Scalar::from, vals, a zero slice; 2M: the audit timestamps) exist
+  // only while something needs them whole: SNARK::encode's commitment, the two-pass and the multi-GPU hash layer
+  // (spark_comb_tables below).  Round 5: they used to stay resident next to idx -- 17.2 + 2.1 GB for the 2^25 instance.
+  vpin_table* comb_ops = nullptr;
+  vpin_table* comb_mem = nullptr;
   // the column that carries a large share of matrix m's entries (the constant 1 in B and C of vPIN's gadgets), found once by
   // SNARK::encode; 0xffffffff: none.  The derefs commitment of every proof takes its entries out of the table walks.
   uint32_t hot_col[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu};
@@ -28,6 +33,12 @@ int spark_pinned(vpin_ctx* c);  // allocate ctx->h_spark on first use
 
 // dst[i] = Scalar::from(src[i]) (Montgomery form)
 int spark_u32_to_fq(vpin_ctx* c, const uint32_t* src, fq* dst, size_t n);
+// d->comb_ops / d->comb_mem built from idx and vals (no-op when they exist); spark_comb_release frees them again
+int spark_comb_tables(vpin_ctx* c, vpin_spark_decomm* d);
+// the same as two tables of the caller's (a proof that needs them whole must not touch the shared decommitment: other
+// contexts may be proving from it)
+int spark_comb_make(vpin_ctx* c, const vpin_spark_decomm* d, vpin_table** ops, vpin_table** mem);
+void spark_comb_release(vpin_ctx* c, vpin_spark_decomm* d, bool to_driver = false);
 
 // Derefs (sparse_mlpoly.rs:267-283,525-531): comb[m*N+i] = mem_rx[row_m[i]], comb[(3+m)*N+i] =
 // mem_ry[col_m[i]], comb[6N..8N) = 0

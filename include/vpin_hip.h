@@ -100,6 +100,13 @@ int vpin_ctx_device_props(vpin_ctx* ctx, int* num_cus, int* clock_khz);
 int vpin_ctx_mem_info(vpin_ctx* ctx, size_t* free_bytes, size_t* total_bytes);
 int vpin_ctx_sync(vpin_ctx* ctx);
 
+/* Host buffers that cross the bus often (a service's witness buffers, the triplets of an instance it proves again and again)
+ * can be page-locked once: the host-buffer entry points (vpin_r1cs_upload, vpin_table_upload, vpin_sat_prove, vpin_snark_prove)
+ * then copy at the bus rate instead of through the driver's staging buffers (CNN A's sat proof from host buffers: 18.9 -> see
+ * DESIGN.md section 5).  hipHostRegister / hipHostUnregister: the range must stay valid until unregistered. */
+int vpin_host_register(void* p, size_t bytes);
+int vpin_host_unregister(void* p);
+
 /* ---- tables: device-resident Vec<Scalar> ---------------------------------------- */
 /* DensePolynomial::new (Spartan/src/dense_mlpoly.rs:132-138): len must be a power of 2 */
 int vpin_table_upload(vpin_ctx* ctx, const uint8_t* mont32, size_t len, vpin_table** out);

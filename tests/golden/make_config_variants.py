@@ -85,7 +85,10 @@ def tamper(inst):
 
 CASES = [(f"{lab}-{kind}#{s}", s) for lab in ("3_32", "A") for kind in ("add", "mult") for s in SEED_PAIRS] + [
     ("3_32-add#RequalsP", None), ("3_32-mult#yzero", None), ("3_32-mult#tampered", None), ("3_32-add#tampered", None),
-    ("A-mult#tampered", None), ("7_256-add#rz86", None)]
+    ("A-mult#tampered", None), ("7_256-add#rz86", None),
+    # round 5: the large instances under a second seed pair too -- CNN E's and LeNet layer 3's point-mult
+    # instances (2^22 constraints, whole SNARK), and the sat half of LeNet layer 5's (2^25; `l5sat` below)
+    ("E-mult#s1", "s1"), ("L3-mult#s1", "s1")]
 
 
 def one(name, seed_key):
@@ -111,6 +114,29 @@ def one(name, seed_key):
     return ent
 
 
+def l5_sat_variant(seed_key="s1"):
+    """L5-mult (6000 ops, 2^25 constraints) under a second seed pair: the oracle's R1CS satisfiability proof (it fits this
+    container, the whole SNARK does not) = the first sat_len bytes of the SNARK (lib.rs:330-338) -> key L5-mult#sat_<seed>"""
+    import oracle_lib as O
+    from vpin_amd import gadgets as G
+    t0 = time.time()
+    inp = G.synthetic_mult_inputs("L5")
+    inst = MG.model_instance("mult", inp)
+    sc, sp = SEED_PAIRS[seed_key]
+    t1 = time.time()
+    res = O.sat_prove(inst, sc, sp, threads=os.cpu_count() or 1)
+    assert O.sat_verify(inst, res) == 1
+    ent = {"kind": "mult", "ops": len(inp[0]), "num_cons": inst["num_cons"], "num_vars": inst["num_vars"],
+           "seed_commit_hex": sc.hex(), "seed_proof_hex": sp.hex(), "inputs_sha256": MG.inputs_digest("mult", inp),
+           "sat_len": len(res["proof"]), "sat_sha256": hashlib.sha256(res["proof"]).hexdigest(),
+           "comm_para_sha256": hashlib.sha256(res["comm_para"].tobytes()).hexdigest(),
+           "comm_input_sha256": hashlib.sha256(res["comm_input"].tobytes()).hexdigest(),
+           "inst_evals_sha256": hashlib.sha256(res["inst_evals"].tobytes()).hexdigest(),
+           "oracle_s": round(time.time() - t1, 1), "model_s": round(t1 - t0, 1)}
+    print("L5-mult#sat_" + seed_key, json.dumps(ent), flush=True)
+    return ent
+
+
 def main():
     doc = {"_source": "tests/golden/make_config_variants.py: oracle/ on instances built by tests/gadgets_model.py; see its docstring",
            "cases": {}}
@@ -121,6 +147,10 @@ def main():
         if only and name not in only:
             continue
         doc["cases"][name] = one(name, s)
+        with open(OUT, "w") as f:
+            json.dump(doc, f, indent=1, sort_keys=True)
+    if not only or "L5-mult#sat_s1" in only:
+        doc["cases"]["L5-mult#sat_s1"] = l5_sat_variant("s1")
         with open(OUT, "w") as f:
             json.dump(doc, f, indent=1, sort_keys=True)
 

@@ -59,7 +59,7 @@ def test_oracle_reproduces_the_small_variants():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", sorted(n for n in GOLD if not n.endswith("#tampered")))
+@pytest.mark.parametrize("name", sorted(n for n in GOLD if not n.endswith("#tampered") and "#sat_" not in n))
 def test_device_built_variants_match_the_oracle(ctx, name):
     g = GOLD[name]
     kind, inp, _ = MV.variant_inputs(name)
@@ -90,3 +90,35 @@ def test_tampered_assignments_through_the_host_buffer_entry(ctx, name):
     got = ctx.snark_prove(d, bytes.fromhex(g["seed_commit_hex"]), bytes.fromhex(g["seed_proof_hex"]))
     check(got, g, name)
     assert not ctx.snark_verify({"inputs": d["inputs"], "num_inputs": d["num_inputs"]}, got)
+
+
+def test_fixture_covers_the_large_instances_under_a_second_seed_pair():
+    """round 5: CNN E's and LeNet layer 3's 2^22-constraint point-mult instances (whole SNARK) and the sat half of layer 5's
+    2^25-constraint instance, each under a seed pair of its own beside tests/golden/config_digests.json's"""
+    for n in ("E-mult#s1", "L3-mult#s1"):
+        assert n in GOLD and GOLD[n]["num_cons"] == 1 << 22 and GOLD[n]["oracle_verifier_accepts"] == 1, n
+    g = GOLD["L5-mult#sat_s1"]
+    assert g["num_cons"] == 1 << 25 and g["seed_commit_hex"] == GOLD["E-mult#s1"]["seed_commit_hex"]
+    with open(os.path.join(HERE, "golden", "config_digests.json")) as f:
+        base = json.load(f)["cases"]["L5-mult"]
+    assert g["inputs_sha256"] == base["inputs_sha256"] and g["sat_len"] == base["sat_len"] and g["sat_sha256"] != base["sat_sha256"]
+
+
+@pytest.mark.gpu
+def test_l5_mult_sat_half_under_the_second_seed_pair(ctx):
+    """6000 point-mults, 2^25 constraints, seed pair s1: the first sat_len bytes of the HIP SNARK are the oracle's R1CSProof
+    (both ZK sum-checks, the witness commitments, the evaluation proof), and the product's verifier accepts the whole"""
+    g = GOLD["L5-mult#sat_s1"]
+    kind, inp, _ = MV.variant_inputs("L5-mult#s1")
+    assert MV.MG.inputs_digest(kind, inp) == g["inputs_sha256"]
+    d = ctx.gadget_point_mult_dev(*inp)
+    try:
+        got = d.snark_prove(bytes.fromhex(g["seed_commit_hex"]), bytes.fromhex(g["seed_proof_hex"]))
+        meta = {"inputs": d.inputs, "num_inputs": d.num_inputs}
+    finally:
+        d.free()
+    assert hashlib.sha256(got["proof"][:g["sat_len"]]).hexdigest() == g["sat_sha256"], "sat half of the SNARK"
+    assert hashlib.sha256(got["comm_para"].tobytes()).hexdigest() == g["comm_para_sha256"]
+    assert hashlib.sha256(got["comm_input"].tobytes()).hexdigest() == g["comm_input_sha256"]
+    assert hashlib.sha256(bytes(got["proof"][g["sat_len"]:g["sat_len"] + 96])).hexdigest() == g["inst_evals_sha256"], "inst_evals follow the sat proof"
+    assert ctx.snark_verify(meta, got)

@@ -170,6 +170,22 @@ def lib():
     return L
 
 
+def host_register(arr):
+    """page-lock a numpy array's buffer (vpin_host_register); returns a token for host_unregister"""
+    L = lib()
+    L.vpin_host_register.argtypes = [C.c_void_p, C.c_size_t]
+    a = np.ascontiguousarray(arr)
+    assert a.ctypes.data == arr.ctypes.data, "host_register needs a contiguous array (the buffer itself is pinned)"
+    _chk(L.vpin_host_register(C.c_void_p(a.ctypes.data), a.nbytes), "vpin_host_register")
+    return a.ctypes.data
+
+
+def host_unregister(token):
+    L = lib()
+    L.vpin_host_unregister.argtypes = [C.c_void_p]
+    _chk(L.vpin_host_unregister(C.c_void_p(token)), "vpin_host_unregister")
+
+
 def declared_symbols():
     """Every function name declared in include/vpin_hip.h."""
     with open(HEADER) as f:

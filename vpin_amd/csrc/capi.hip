@@ -333,6 +333,17 @@ int vpin_ctx_set_progress_flag(vpin_ctx* c, int* flag) {
 
 unsigned long long vpin_ctx_strip_rows_taken(vpin_ctx* c) { return c ? c->strip_rows_taken : 0ull; }
 
+int vpin_host_register(void* p, size_t bytes) {
+  if (!p || !bytes) return VPIN_EINVAL;
+  VPIN_HIP_TRY(hipHostRegister(p, bytes, hipHostRegisterDefault));
+  return VPIN_OK;
+}
+int vpin_host_unregister(void* p) {
+  if (!p) return VPIN_EINVAL;
+  VPIN_HIP_TRY(hipHostUnregister(p));
+  return VPIN_OK;
+}
+
 int vpin_ctx_pool_trim(vpin_ctx* c) {
   if (!c) return VPIN_EINVAL;
   (void)hipSetDevice(c->device);

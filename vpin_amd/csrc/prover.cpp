@@ -819,13 +819,16 @@ int vpin_sat_prove(vpin_ctx* c, const vpin_r1cs* inst, const uint8_t* vars_para,
   const size_t nv = inst->num_vars;
   if (!vpin::is_pow2(nv) || !vpin::is_pow2(inst->num_cons) || inst->num_inputs >= nv) return VPIN_ESHAPE;
   vpin_r1cs_dev* dinst = nullptr;
+  vpin::TraceLap lap(c, "vpin_sat_prove");  // VPIN_CLI_TRACE=1
   int rc = vpin_r1cs_upload(c, inst, &dinst);
   if (rc) return rc;
+  lap("r1cs_upload");
   TableGuard tg(c);
   vpin_table *d_para = nullptr, *d_input = nullptr, *d_vars = nullptr;
   rc = vpin_table_upload(c, vars_para, nv, &d_para);
   if (!rc) { tg.add(d_para); rc = vpin_table_upload(c, vars_input, nv, &d_input); }
   if (!rc) { tg.add(d_input); rc = vpin_table_upload(c, vars, nv, &d_vars); }
+  lap("witness_upload");
   if (!rc) {
     tg.add(d_vars);
     rc = vpin_sat_prove_resident(c, dinst, d_para, d_input, d_vars, inputs, seed_commit64, seed_proof64, proof_out, proof_cap,

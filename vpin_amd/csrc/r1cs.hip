@@ -214,6 +214,145 @@ __global__ __launch_bounds__(kRB) void build_z_hi_kernel(fq* __restrict__ z, siz
   fq_store(z + nv + i, v);
 }
 
+// ---- triplets -> CSR / CSC on the device -------------------------------------------------------------------------------------
+// cnt_r[row] / cnt_c[col] += 1 (the callers pass rowptr + 1 / colptr + 1, so the inclusive scan leaves the pointers in place);
+// *bad = 1 on an index out of range
+// atomicAdd(base + key, 1) for every active lane, returning the value before the lane's own increment.  An R1CS has columns that
+// carry a large share of a matrix's entries (the constant 1: 37 % of B in vPIN's point-mult gadget): a wave's lanes then hit ONE
+// counter, and 64 serialised atomics per wave made this pass cost more than the proof's sum-checks.  The lanes that share the
+// first active lane's key are served by a single atomic (count = their number, rank = position among them); the others take
+// their own.
+__device__ __forceinline__ uint32_t wave_counted_inc(uint32_t* __restrict__ base, uint32_t key, bool active) {
+  const int lane = (int)(threadIdx.x & 63);
+  uint32_t res = 0u;
+  bool todo = active;
+  // peel off up to four groups of lanes with equal keys (the hot key is rarely the FIRST lane's, but it is the largest group, so
+  // it goes within a few rounds), then one atomic per remaining lane
+#pragma unroll 1
+  for (int round = 0; round < 4; round++) {
+    const unsigned long long act = __ballot(todo);
+    if (!act) return res;
+    const int leader = __ffsll((long long)act) - 1;
+    const uint32_t k0 = (uint32_t)__shfl((int)key, leader, 64);
+    const bool same = todo && key == k0;
+    const unsigned long long m = __ballot(same);
+    uint32_t first = 0u;
+    if (lane == leader) first = atomicAdd(base + k0, (uint32_t)__popcll(m));
+    first = (uint32_t)__shfl((int)first, leader, 64);
+    if (same) { res = first + (uint32_t)__popcll(m & ((1ull << lane) - 1ull)); todo = false; }
+  }
+  if (todo) res = atomicAdd(base + key, 1u);
+  return res;
+}
+
+__global__ __launch_bounds__(kRB) void triplet_hist_kernel(const uint32_t* __restrict__ row, const uint32_t* __restrict__ col, size_t nnz,
+                                                           uint32_t nrows, uint32_t ncols, uint32_t* __restrict__ cnt_r,
+                                                           uint32_t* __restrict__ cnt_c, uint32_t* __restrict__ bad) {
+  // (whole waves step through the loop together: the wave-level helper wants every lane of a wave to call it)
+  const size_t stride = (size_t)gridDim.x * kRB, rounds = (nnz + stride - 1) / stride;
+  for (size_t it = 0; it < rounds; it++) {
+    const size_t k = it * stride + (size_t)blockIdx.x * kRB + threadIdx.x;
+    const bool in = k < nnz;
+    const uint32_t r = in ? row[k] : 0u, cc = in ? col[k] : 0u;
+    const bool ok = in && r < nrows && cc < ncols;
+    if (in && !ok) *bad = 1u;
+    (void)wave_counted_inc(cnt_r, r, ok);
+    (void)wave_counted_inc(cnt_c, cc, ok);
+  }
+}
+
+__global__ __launch_bounds__(kRB) void triplet_scatter_kernel(const uint32_t* __restrict__ row, const uint32_t* __restrict__ col,
+                                                              const fq* __restrict__ val, size_t nnz, uint32_t nrows, uint32_t ncols,
+                                                              const uint32_t* __restrict__ rowptr, const uint32_t* __restrict__ colptr,
+                                                              uint32_t* __restrict__ rcur, uint32_t* __restrict__ ccur,
+                                                              uint32_t* __restrict__ csr_col, fq* __restrict__ csr_val,
+                                                              uint32_t* __restrict__ csc_row, fq* __restrict__ csc_val) {
+  const size_t stride = (size_t)gridDim.x * kRB, rounds = (nnz + stride - 1) / stride;
+  for (size_t it = 0; it < rounds; it++) {
+    const size_t k = it * stride + (size_t)blockIdx.x * kRB + threadIdx.x;
+    const bool in = k < nnz;
+    const uint32_t r = in ? row[k] : 0u, cc = in ? col[k] : 0u;
+    const bool ok = in && r < nrows && cc < ncols;  // (a bad index was reported by the histogram pass)
+    const uint32_t ir = wave_counted_inc(rcur, r, ok), ic = wave_counted_inc(ccur, cc, ok);
+    if (!ok) continue;
+    const fq v = fq_load(val + k);
+    const uint32_t pr = rowptr[r] + ir, pc = colptr[cc] + ic;
+    csr_col[pr] = cc; fq_store(csr_val + pr, v);
+    csc_row[pc] = r; fq_store(csc_val + pc, v);
+  }
+}
+
+// (column, first entry, end) of every column with more than kLongCol entries -> out[3 * (*count)++]; entries beyond cap are
+// counted but not written (the caller then walks colptr itself)
+__global__ __launch_bounds__(kRB) void long_cols_kernel(const uint32_t* __restrict__ colptr, size_t ncols, uint32_t* __restrict__ out,
+                                                        uint32_t* __restrict__ count, uint32_t cap) {
+  for (size_t i = (size_t)blockIdx.x * kRB + threadIdx.x; i < ncols; i += (size_t)gridDim.x * kRB) {
+    const uint32_t a = colptr[i], b = colptr[i + 1];
+    if (b - a > kLongCol) {
+      const uint32_t at = atomicAdd(count, 1u);
+      if (at < cap) { out[3 * at] = (uint32_t)i; out[3 * at + 1] = a; out[3 * at + 2] = b; }
+    }
+  }
+}
+
+// in-place inclusive prefix sum of n u32 (three launches: per-block scans of kScanElems, a one-workgroup scan of the block
+// totals, the offsets added back)
+constexpr int kScanThreads = 256, kScanPer = 8, kScanElems = kScanThreads * kScanPer;
+__global__ __launch_bounds__(kScanThreads) void scan_blocks_kernel(uint32_t* __restrict__ a, size_t n, uint32_t* __restrict__ sums) {
+  __shared__ uint32_t sh[kScanThreads];
+  const size_t base = (size_t)blockIdx.x * kScanElems + (size_t)threadIdx.x * kScanPer;
+  uint32_t v[kScanPer], run = 0;
+#pragma unroll
+  for (int i = 0; i < kScanPer; i++) { v[i] = base + i < n ? a[base + i] : 0u; run += v[i]; v[i] = run; }
+  sh[threadIdx.x] = run;
+  __syncthreads();
+  for (int st = 1; st < kScanThreads; st <<= 1) {  // Hillis-Steele over the per-thread totals
+    const uint32_t add = (int)threadIdx.x >= st ? sh[threadIdx.x - st] : 0u;
+    __syncthreads();
+    sh[threadIdx.x] += add;
+    __syncthreads();
+  }
+  const uint32_t before = threadIdx.x ? sh[threadIdx.x - 1] : 0u;
+#pragma unroll
+  for (int i = 0; i < kScanPer; i++)
+    if (base + i < n) a[base + i] = v[i] + before;
+  if (threadIdx.x == kScanThreads - 1) sums[blockIdx.x] = sh[kScanThreads - 1];
+}
+__global__ __launch_bounds__(1024) void scan_sums_kernel(uint32_t* __restrict__ sums, size_t nb) {
+  __shared__ uint32_t sh[1024];
+  const size_t per = (nb + 1023) / 1024, b0 = (size_t)threadIdx.x * per, b1 = b0 + per < nb ? b0 + per : nb;
+  uint32_t run = 0;
+  for (size_t b = b0; b < b1; b++) run += sums[b];
+  sh[threadIdx.x] = run;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t acc = 0;
+    for (int t = 0; t < 1024; t++) { const uint32_t x = sh[t]; sh[t] = acc; acc += x; }
+  }
+  __syncthreads();
+  uint32_t acc = sh[threadIdx.x];
+  for (size_t b = b0; b < b1; b++) { const uint32_t x = sums[b]; sums[b] = acc; acc += x; }  // exclusive block offsets
+}
+__global__ __launch_bounds__(kScanThreads) void scan_add_kernel(uint32_t* __restrict__ a, size_t n, const uint32_t* __restrict__ sums) {
+  const uint32_t off = sums[blockIdx.x];
+  const size_t base = (size_t)blockIdx.x * kScanElems + (size_t)threadIdx.x * kScanPer;
+#pragma unroll
+  for (int i = 0; i < kScanPer; i++)
+    if (base + i < n) a[base + i] += off;
+}
+static size_t scan_scratch_bytes(size_t n) { return ((n + kScanElems - 1) / kScanElems + 1) * sizeof(uint32_t); }
+static int scan_inclusive_u32(vpin_ctx* c, uint32_t* a, size_t n, uint32_t* sums) {
+  if (n == 0) return VPIN_OK;
+  const size_t nb = (n + kScanElems - 1) / kScanElems;
+  hipLaunchKernelGGL(scan_blocks_kernel, dim3((unsigned)nb), dim3(kScanThreads), 0, c->stream, a, n, sums);
+  if (nb > 1) {
+    hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(1024), 0, c->stream, sums, nb);
+    hipLaunchKernelGGL(scan_add_kernel, dim3((unsigned)nb), dim3(kScanThreads), 0, c->stream, a, n, (const uint32_t*)sums);
+  }
+  VPIN_HIP_TRY(hipGetLastError());
+  return VPIN_OK;
+}
+
 template <typename T>
 static int up(vpin_ctx* c, T** dst, const T* src, size_t n) {
   if (hipMalloc((void**)dst, (n ? n : 1) * sizeof(T)) != hipSuccess) return VPIN_ENOMEM;
@@ -245,55 +384,110 @@ void vpin_r1cs_free(vpin_ctx* c, vpin_r1cs_dev* d) {
   delete d;
 }
 
+// ---- CSR / CSC from the host's triplets, built on the device (round 5: the host used to counting-sort every matrix on one
+// thread: 80 ms of an 83 ms sat proof from host buffers for CNN A) ----------------------------------------------------------
+// histogram -> exclusive scan -> scatter with one atomic cursor per row / column.  The order of a row's (column's) entries is
+// whatever the atomics give: the kernels above add field elements, so any order yields the same bits.
+
 int vpin_r1cs_upload(vpin_ctx* c, const vpin_r1cs* inst, vpin_r1cs_dev** out) {
   if (!c || !inst || !out) return VPIN_EINVAL;
   if (!is_pow2(inst->num_cons) || !is_pow2(inst->num_vars) || inst->num_inputs >= inst->num_vars) return VPIN_ESHAPE;
+  const size_t nrows = inst->num_cons, ncols = 2 * inst->num_vars;
+  if (nrows >= ((size_t)1 << 32) || ncols >= ((size_t)1 << 32)) return VPIN_ESHAPE;
+  for (int m = 0; m < 3; m++)
+    if (inst->nnz[m] >= ((size_t)1 << 32) || (inst->nnz[m] && (!inst->row[m] || !inst->col[m] || !inst->val[m]))) return VPIN_EINVAL;
   (void)hipSetDevice(c->device);
   vpin_r1cs_dev* d = new (std::nothrow) vpin_r1cs_dev();
   if (!d) return VPIN_ENOMEM;
   d->num_cons = inst->num_cons; d->num_vars = inst->num_vars; d->num_inputs = inst->num_inputs;
-  const size_t nrows = inst->num_cons, ncols = 2 * inst->num_vars;
+  d->pooled = true;
   int rc = VPIN_OK;
+  TraceLap lap(c, "vpin_r1cs_upload");  // VPIN_CLI_TRACE=1
+  auto alloc = [&](auto** p, size_t n) { return dev_alloc(c, (n ? n : 1) * sizeof(**p), (void**)p); };
+  DevBuf b_err(c), b_long(c);
+  constexpr uint32_t kLongCap = 1u << 16;  // long columns found on the device; more than this: the host walks colptr
+  if (b_err.alloc(2 * sizeof(uint32_t)) || b_long.alloc((size_t)kLongCap * 3 * sizeof(uint32_t))) { vpin_r1cs_free(c, d); return VPIN_ENOMEM; }
+  uint32_t* d_flags = (uint32_t*)b_err.p;  // [0] bad index seen, [1] long columns found
   for (int m = 0; m < 3 && rc == VPIN_OK; m++) {
     const size_t nnz = inst->nnz[m];
     d->nnz[m] = nnz;
-    const uint32_t *row = inst->row[m], *col = inst->col[m];
-    const fq* val = reinterpret_cast<const fq*>(inst->val[m]);
-    for (size_t k = 0; k < nnz; k++)
-      if (row[k] >= nrows || col[k] >= ncols) { rc = VPIN_ESHAPE; break; }  // lib.rs:171-178 InvalidIndex
-    if (rc) break;
-    // counting sorts (stable): CSR by row, CSC by column
-    std::vector<uint32_t> rowptr(nrows + 1, 0), colptr(ncols + 1, 0);
-    for (size_t k = 0; k < nnz; k++) { rowptr[row[k] + 1]++; colptr[col[k] + 1]++; }
-    for (size_t i = 0; i < nrows; i++) rowptr[i + 1] += rowptr[i];
-    for (size_t i = 0; i < ncols; i++) colptr[i + 1] += colptr[i];
-    std::vector<uint32_t> ccol(nnz), crow(nnz), pos_r(rowptr.begin(), rowptr.end() - 1), pos_c(colptr.begin(), colptr.end() - 1);
-    std::vector<fq> rval(nnz), cval(nnz);
-    for (size_t k = 0; k < nnz; k++) {
-      uint32_t pr = pos_r[row[k]]++, pcn = pos_c[col[k]]++;
-      ccol[pr] = col[k]; rval[pr] = val[k];
-      crow[pcn] = row[k]; cval[pcn] = val[k];
+    DevBuf b_row(c), b_col(c), b_val(c), b_rcur(c), b_ccur(c), b_sums(c);
+    if ((rc = alloc(&d->rowptr[m], nrows + 1)) || (rc = alloc(&d->colptr[m], ncols + 1)) || (rc = alloc(&d->csr_col[m], nnz)) ||
+        (rc = alloc(&d->csr_val[m], nnz)) || (rc = alloc(&d->csc_row[m], nnz)) || (rc = alloc(&d->csc_val[m], nnz)))
+      break;
+    if (b_row.alloc((nnz ? nnz : 1) * 4) || b_col.alloc((nnz ? nnz : 1) * 4) || b_val.alloc((nnz ? nnz : 1) * 32) || b_rcur.alloc(nrows * 4) ||
+        b_ccur.alloc(ncols * 4) || b_sums.alloc(scan_scratch_bytes(std::max(nrows, ncols) + 1))) { rc = VPIN_ENOMEM; break; }
+    hipError_t e = hipSuccess;
+    if (nnz) {
+      e = hipMemcpyAsync(b_row.p, inst->row[m], nnz * 4, hipMemcpyHostToDevice, c->stream);
+      if (e == hipSuccess) e = hipMemcpyAsync(b_col.p, inst->col[m], nnz * 4, hipMemcpyHostToDevice, c->stream);
+      if (e == hipSuccess) e = hipMemcpyAsync(b_val.p, inst->val[m], nnz * 32, hipMemcpyHostToDevice, c->stream);
     }
+    if (e == hipSuccess) e = hipMemsetAsync(d->rowptr[m], 0, (nrows + 1) * 4, c->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(d->colptr[m], 0, (ncols + 1) * 4, c->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(b_rcur.p, 0, nrows * 4, c->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(b_ccur.p, 0, ncols * 4, c->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(d_flags, 0, 2 * sizeof(uint32_t), c->stream);
+    if (e != hipSuccess) { set_last_error("vpin_r1cs_upload", e); rc = VPIN_EHIP; break; }
+    lap("alloc + H2D + memsets");
+    const unsigned gb = (unsigned)std::min<size_t>(4096, (nnz + kRB - 1) / kRB + 1);
+    hipLaunchKernelGGL(triplet_hist_kernel, dim3(gb), dim3(kRB), 0, c->stream, (const uint32_t*)b_row.p, (const uint32_t*)b_col.p, nnz,
+                       (uint32_t)nrows, (uint32_t)ncols, d->rowptr[m] + 1, d->colptr[m] + 1, d_flags);
+    if ((rc = scan_inclusive_u32(c, d->rowptr[m] + 1, nrows, (uint32_t*)b_sums.p)) ||
+        (rc = scan_inclusive_u32(c, d->colptr[m] + 1, ncols, (uint32_t*)b_sums.p)))
+      break;
+    hipLaunchKernelGGL(triplet_scatter_kernel, dim3(gb), dim3(kRB), 0, c->stream, (const uint32_t*)b_row.p, (const uint32_t*)b_col.p,
+                       (const fq*)b_val.p, nnz, (uint32_t)nrows, (uint32_t)ncols, (const uint32_t*)d->rowptr[m], (const uint32_t*)d->colptr[m],
+                       (uint32_t*)b_rcur.p, (uint32_t*)b_ccur.p, d->csr_col[m], d->csr_val[m], d->csc_row[m], d->csc_val[m]);
+    hipLaunchKernelGGL(long_cols_kernel, dim3((unsigned)std::min<size_t>(4096, (ncols + kRB - 1) / kRB)), dim3(kRB), 0, c->stream,
+                       (const uint32_t*)d->colptr[m], ncols, (uint32_t*)b_long.p, d_flags + 1, kLongCap);
+    uint32_t flags[2] = {0, 0};
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(flags, d_flags, sizeof flags, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) { set_last_error("vpin_r1cs_upload", e); rc = VPIN_EHIP; break; }
+    lap("hist + scan + scatter + long cols");
+    if (flags[0]) { rc = VPIN_ESHAPE; break; }  // lib.rs:171-178 InvalidIndex
+    // the few long columns (the constant 1, the inputs): (column, first entry, end) triples, sorted by column on the host
     std::vector<uint32_t> longs, lfirst, ck0, ck1;
-    for (size_t i = 0; i < ncols; i++)
-      if (colptr[i + 1] - colptr[i] > kLongCol) {
-        longs.push_back((uint32_t)i);
-        lfirst.push_back((uint32_t)ck0.size());
-        for (uint32_t k = colptr[i]; k < colptr[i + 1]; k += kChunk) {
-          ck0.push_back(k);
-          ck1.push_back(std::min<uint32_t>(k + kChunk, colptr[i + 1]));
-        }
+    std::vector<uint32_t> trip;
+    if (flags[1] <= kLongCap) {
+      trip.resize((size_t)flags[1] * 3);
+      if (flags[1]) {
+        e = hipMemcpy(trip.data(), b_long.p, trip.size() * 4, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) { set_last_error("vpin_r1cs_upload", e); rc = VPIN_EHIP; break; }
       }
+    } else {  // more long columns than the device list holds: walk the whole colptr on the host
+      std::vector<uint32_t> colptr(ncols + 1);
+      e = hipMemcpy(colptr.data(), d->colptr[m], (ncols + 1) * 4, hipMemcpyDeviceToHost);
+      if (e != hipSuccess) { set_last_error("vpin_r1cs_upload", e); rc = VPIN_EHIP; break; }
+      for (size_t i = 0; i < ncols; i++)
+        if (colptr[i + 1] - colptr[i] > kLongCol) { trip.push_back((uint32_t)i); trip.push_back(colptr[i]); trip.push_back(colptr[i + 1]); }
+    }
+    std::vector<size_t> order(trip.size() / 3);
+    for (size_t i = 0; i < order.size(); i++) order[i] = i;
+    std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return trip[3 * a] < trip[3 * b]; });
+    for (size_t oi : order) {
+      longs.push_back(trip[3 * oi]);
+      lfirst.push_back((uint32_t)ck0.size());
+      for (uint32_t k = trip[3 * oi + 1]; k < trip[3 * oi + 2]; k += kChunk) {
+        ck0.push_back(k);
+        ck1.push_back(std::min<uint32_t>(k + kChunk, trip[3 * oi + 2]));
+      }
+    }
     lfirst.push_back((uint32_t)ck0.size());
     d->n_long[m] = longs.size();
     d->n_chunks[m] = ck0.size();
-    if ((rc = up(c, &d->rowptr[m], rowptr.data(), nrows + 1)) || (rc = up(c, &d->csr_col[m], ccol.data(), nnz)) ||
-        (rc = up(c, &d->csr_val[m], rval.data(), nnz)) || (rc = up(c, &d->colptr[m], colptr.data(), ncols + 1)) ||
-        (rc = up(c, &d->csc_row[m], crow.data(), nnz)) || (rc = up(c, &d->csc_val[m], cval.data(), nnz)) ||
-        (rc = up(c, &d->long_cols[m], longs.data(), longs.size())) || (rc = up(c, &d->long_first[m], lfirst.data(), lfirst.size())) ||
-        (rc = up(c, &d->chunk_k0[m], ck0.data(), ck0.size())) || (rc = up(c, &d->chunk_k1[m], ck1.data(), ck1.size())))
+    auto upv = [&](uint32_t** dst, const std::vector<uint32_t>& v) {
+      int r2 = alloc(dst, v.size());
+      if (!r2 && !v.empty() && hipMemcpyAsync(*dst, v.data(), v.size() * 4, hipMemcpyHostToDevice, c->stream) != hipSuccess) r2 = VPIN_EHIP;
+      return r2;
+    };
+    if ((rc = upv(&d->long_cols[m], longs)) || (rc = upv(&d->long_first[m], lfirst)) || (rc = upv(&d->chunk_k0[m], ck0)) ||
+        (rc = upv(&d->chunk_k1[m], ck1)))
       break;
-    if (hipStreamSynchronize(c->stream) != hipSuccess) rc = VPIN_EHIP;  // host vectors die at scope end
+    if (hipStreamSynchronize(c->stream) != hipSuccess) rc = VPIN_EHIP;  // host vectors and the DevBufs die at scope end
+    lap("long-column lists");
   }
   if (rc) { vpin_r1cs_free(c, d); return rc; }
   *out = d;

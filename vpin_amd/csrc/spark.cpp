@@ -1461,32 +1461,55 @@ int vpin_spark_encode(vpin_ctx* c, const vpin_r1cs* inst, vpin_spark_decomm** ou
   d->nx = s.nx; d->ny = s.ny; d->N = N; d->M = M;
   auto fail = [&](int rc) { vpin_spark_decomm_free(c, d.release()); return rc; };
 
-  // sparse_to_dense_vecs (:368-380) + AddrTimestamps::new (:232-265) on the host: the timestamps are a
-  // sequential memory trace (audit_ts runs on across A, B, C), O(N) integer work done once per circuit
+  // sparse_to_dense_vecs (:368-380) + AddrTimestamps::new (:232-265).  Round 5: on the device -- the addresses go up as they
+  // are (padded entries read address 0), the time stamps come from a stable sort of each side's 3N accesses (trace.hip); the
+  // host used to walk both traces sequentially (60 % of this call for CNN A).  VPIN_ENCODE_HOST_TRACE=1: the old host walk (A/B).
   vpin::TraceLap lap(c, "spark_encode");
-  std::vector<uint32_t> idx(12 * N + 2 * M, 0);
-  for (int m = 0; m < 3; m++) {
-    for (size_t k = 0; k < inst->nnz[m]; k++) {
-      if (inst->row[m][k] >= inst->num_cons || inst->col[m][k] >= 2 * inst->num_vars) return fail(VPIN_ESHAPE);
-      idx[(size_t)m * N + k] = inst->row[m][k];
-      idx[(size_t)(6 + m) * N + k] = inst->col[m][k];
-    }
-  }
-#pragma omp parallel for schedule(static) num_threads(2)
-  for (int side = 0; side < 2; side++) {
-    uint32_t* audit = idx.data() + 12 * N + (size_t)side * M;
-    for (int m = 0; m < 3; m++) {
-      const uint32_t* addr = idx.data() + (size_t)(side * 6 + m) * N;
-      uint32_t* ts = idx.data() + (size_t)(side * 6 + 3 + m) * N;
-      for (size_t i = 0; i < N; i++) ts[i] = audit[addr[i]]++;
-    }
-  }
-  lap("host idx + timestamps");
   int rc;
-  if ((rc = vpin::dev_alloc(c, idx.size() * 4, (void**)&d->idx))) return fail(rc);
-  if (hipMemcpyAsync(d->idx, idx.data(), idx.size() * 4, hipMemcpyHostToDevice, c->stream) != hipSuccess) return fail(VPIN_EHIP);
-  // comb_ops = merge(row.ops_addr, row.read_ts, col.ops_addr, col.read_ts, val) padded to 16N (:418-426);
-  // comb_mem = row.audit_ts ++ col.audit_ts (:427-428)
+  if ((rc = vpin::dev_alloc(c, (12 * N + 2 * M) * 4, (void**)&d->idx))) return fail(rc);
+  if (getenv("VPIN_ENCODE_HOST_TRACE")) {
+    std::vector<uint32_t> idx(12 * N + 2 * M, 0);
+    for (int m = 0; m < 3; m++) {
+      for (size_t k = 0; k < inst->nnz[m]; k++) {
+        if (inst->row[m][k] >= inst->num_cons || inst->col[m][k] >= 2 * inst->num_vars) return fail(VPIN_ESHAPE);
+        idx[(size_t)m * N + k] = inst->row[m][k];
+        idx[(size_t)(6 + m) * N + k] = inst->col[m][k];
+      }
+    }
+#pragma omp parallel for schedule(static) num_threads(2)
+    for (int side = 0; side < 2; side++) {
+      uint32_t* audit = idx.data() + 12 * N + (size_t)side * M;
+      for (int m = 0; m < 3; m++) {
+        const uint32_t* addr = idx.data() + (size_t)(side * 6 + m) * N;
+        uint32_t* ts = idx.data() + (size_t)(side * 6 + 3 + m) * N;
+        for (size_t i = 0; i < N; i++) ts[i] = audit[addr[i]]++;
+      }
+    }
+    lap("host idx + timestamps");
+    if (hipMemcpy(d->idx, idx.data(), idx.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return fail(VPIN_EHIP);
+  } else {
+    vpin::DevBuf b_bad(c);
+    if (b_bad.alloc(4)) return fail(VPIN_ENOMEM);
+    if (hipMemsetAsync(b_bad.p, 0, 4, c->stream) != hipSuccess) return fail(VPIN_EHIP);
+    for (int side = 0; side < 2; side++) {
+      uint32_t* addr = d->idx + (size_t)side * 6 * N;
+      if (hipMemsetAsync(addr, 0, 3 * N * 4, c->stream) != hipSuccess) return fail(VPIN_EHIP);
+      for (int m = 0; m < 3; m++) {
+        const uint32_t* src = side ? inst->col[m] : inst->row[m];
+        if (inst->nnz[m] && hipMemcpyAsync(addr + (size_t)m * N, src, inst->nnz[m] * 4, hipMemcpyHostToDevice, c->stream) != hipSuccess)
+          return fail(VPIN_EHIP);
+        if ((rc = vpin::spark_check_bounds(c, addr + (size_t)m * N, inst->nnz[m], (uint32_t)(side ? 2 * inst->num_vars : inst->num_cons),
+                                           (uint32_t*)b_bad.p)))
+          return fail(rc);
+      }
+      if ((rc = vpin::spark_trace_timestamps(c, addr, 3 * N, M, addr + 3 * N, d->idx + 12 * N + (size_t)side * M))) return fail(rc);
+    }
+    uint32_t bad = 0;
+    if (hipMemcpyAsync(&bad, b_bad.p, 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess)
+      return fail(VPIN_EHIP);
+    if (bad) return fail(VPIN_ESHAPE);  // lib.rs:171-178 InvalidIndex
+    lap("device idx + timestamps");
+  }
   if ((rc = vpin::dev_alloc(c, 3 * N * 32, (void**)&d->vals))) return fail(rc);
   if (hipMemsetAsync(d->vals, 0, 3 * N * 32, c->stream) != hipSuccess) return fail(VPIN_EHIP);
   for (int m = 0; m < 3; m++)

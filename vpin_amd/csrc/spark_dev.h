@@ -31,6 +31,10 @@ constexpr size_t kSparkHostTop = 32;   // tree levels of at most this many entri
 
 int spark_pinned(vpin_ctx* c);  // allocate ctx->h_spark on first use
 
+// trace.hip: read / audit time stamps of one side of SNARK::encode's memory trace (AddrTimestamps::new) from its n = 3N addresses
+int spark_trace_timestamps(vpin_ctx* c, const uint32_t* addr, size_t n, size_t M, uint32_t* ts, uint32_t* audit);
+int spark_check_bounds(vpin_ctx* c, const uint32_t* a, size_t nnz, uint32_t limit, uint32_t* d_bad);
+
 // dst[i] = Scalar::from(src[i]) (Montgomery form)
 int spark_u32_to_fq(vpin_ctx* c, const uint32_t* src, fq* dst, size_t n);
 // d->comb_ops / d->comb_mem built from idx and vals (no-op when they exist); spark_comb_release frees them again

@@ -40,7 +40,92 @@ def rand_point(rng, pool):
     return (Q - 1, Q - 2)
 
 
+# ---- --mid: instances of 20..700 point-mults (2^17..2^22 constraints) ---------------------------------------------------------
+# The small cases above never leave 2^15 constraints: the hot-column entries of the derefs commitment, the row-per-lane
+# (strip) kernel, the column-chunked row kernels, the mid-size round kernels are fuzzed by nothing.  Here the
+# oracle side (Python gadget model + C oracle, minutes per case) runs in worker processes on the box's host cores while the
+# GPU proves the same inputs; only digests travel.
+
+def mid_ops(seed, it):
+    rng = random.Random(seed * 100003 + it)
+    pool = GM.synthetic_points(seed + it, 16)
+    n = int(round(20 * (35.0 ** rng.random())))          # log-uniform in [20, 700]
+    ops = []
+    for _ in range(n):
+        w = rng.choice([0, 1, 3, 2**128 - 1, rng.randrange(2**16), rng.randrange(2**128), rng.randrange(2**128), rng.randrange(2**128)])
+        x, y = rand_point(rng, pool) if rng.random() < 0.1 else rng.choice(pool)
+        ops.append((w, x, y))
+    sc, sp = bytes(rng.randrange(256) for _ in range(64)), bytes(rng.randrange(256) for _ in range(64))
+    return n, ops, sc, sp
+
+
+def mid_oracle(args):
+    seed, it, threads = args
+    n, ops, sc, sp = mid_ops(seed, it)
+    t0 = time.time()
+    inst = GM.instance_new(GM.build_point_mult([(o[0], o[1] % 2**256, o[2] % 2**256) for o in ops]))
+    t1 = time.time()
+    exp = O.snark_prove(inst, sc, sp, threads=threads)
+    return {"it": it, "n": n, "num_cons": inst["num_cons"], "is_sat": bool(O.is_sat(inst)),
+            "proof": hashlib.sha256(exp["proof"]).hexdigest(), "comm": hashlib.sha256(exp["comm"]).hexdigest(),
+            "comm_para": hashlib.sha256(exp["comm_para"].tobytes()).hexdigest(),
+            "comm_input": hashlib.sha256(exp["comm_input"].tobytes()).hexdigest(),
+            "model_s": round(t1 - t0, 1), "oracle_s": round(time.time() - t1, 1)}
+
+
+def main_mid(cases, seed):
+    import multiprocessing as mp
+    # a one-GPU box gives 16 host cores whatever os.cpu_count() says: 4 workers x 4 oracle threads by default
+    workers = int(os.environ.get("VPIN_FUZZ_WORKERS", "4"))
+    threads = int(os.environ.get("VPIN_FUZZ_THREADS", "4"))
+    t0 = time.time()
+    import threading
+    stop = threading.Event()
+
+    def beat():
+        while not stop.wait(60):
+            print(f"[fuzz --mid] {time.time() - t0:.0f} s, waiting for the oracle workers", flush=True)
+    threading.Thread(target=beat, daemon=True).start()
+    ctxmp = mp.get_context("spawn")   # the parent holds a GPU context: never fork it
+    with ctxmp.Pool(workers) as pool:
+        pending = [pool.apply_async(mid_oracle, ((seed, it, threads),)) for it in range(cases)]
+        bad, taken0 = 0, 0
+        with vpin_amd.Context(0) as ctx:
+            for it in range(cases):
+                n, ops, sc, sp = mid_ops(seed, it)
+                strip = it % 2 == 1
+                if strip:
+                    os.environ["VPIN_MSM_STRIP_MIN"] = "64"   # the row-per-lane kernel from 64 rows on (read per call)
+                try:
+                    g = ctx.gadget_point_mult_dev([o[0] for o in ops], b32(o[1] for o in ops), b32(o[2] for o in ops))
+                    try:
+                        got = g.snark_prove(sc, sp)
+                        sat_dev = g.is_sat()
+                    finally:
+                        g.free()
+                finally:
+                    os.environ.pop("VPIN_MSM_STRIP_MIN", None)
+                taken = ctx.strip_rows_taken()
+                exp = pending[it].get(timeout=3600)
+                same = (hashlib.sha256(got["proof"]).hexdigest() == exp["proof"] and hashlib.sha256(got["comm"]).hexdigest() == exp["comm"]
+                        and hashlib.sha256(got["comm_para"].tobytes()).hexdigest() == exp["comm_para"]
+                        and hashlib.sha256(got["comm_input"].tobytes()).hexdigest() == exp["comm_input"] and sat_dev == exp["is_sat"])
+                if strip and exp["num_cons"] >= (1 << 18) and taken == taken0:
+                    print(f"case {it}: the row-per-lane kernel was asked for and took no row", flush=True)
+                    bad += 1
+                taken0 = taken
+                if not same:
+                    bad += 1
+                print(f"mid case {it}: {n} point-mults, 2^{exp['num_cons'].bit_length() - 1} constraints, sat {exp['is_sat']}, strip rows so far {taken}, "
+                      f"model {exp['model_s']} s oracle {exp['oracle_s']} s: {'ok' if same else 'MISMATCH'}  [{time.time() - t0:.0f} s]", flush=True)
+    stop.set()
+    print(f"fuzz_parity --mid: {cases} random point-mult instances of 20..700 operations (seed {seed}), {bad} mismatches against the oracle")
+    sys.exit(1 if bad else 0)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "--mid":
+        return main_mid(int(sys.argv[2]) if len(sys.argv) > 2 else 16, int(sys.argv[3]) if len(sys.argv) > 3 else 5)
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 50
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 2024
     rng = random.Random(seed)

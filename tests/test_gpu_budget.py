@@ -62,3 +62,54 @@ def test_e_mult_with_150_gb_held_by_another_tenant():
     tight = _run(250)  # ~35 GB free: the budgets shrink to a third of that and the proof still has room
     assert tight["sha"] == want["snark_sha256"]
     assert tight["window_bits"] < 12, tight
+
+
+SCRIPT_TWO_TRACES = r"""
+import ctypes as C, hashlib, json, sys
+sys.path.insert(0, %(root)r)
+import vpin_amd
+from vpin_amd import gadgets as G
+SEED_C, SEED_P = bytes(range(64)), bytes((7 * i + 3) %% 256 for i in range(64))
+gold = json.load(open(%(gold)r))["cases"]
+hip = C.CDLL("libamdhip64.so")
+with vpin_amd.Context(0) as ctx:
+    traces = []
+    for copy in range(2):          # two LeNet traces resident at once: instances, assignments, decommitments
+        built = {}
+        for lab in G.LENET:
+            m = G.synthetic_mult_inputs(lab)
+            if m is not None:
+                built[lab + "-mult"] = ctx.gadget_point_mult_dev(*m)
+            built[lab + "-add"] = ctx.gadget_point_add_dev(*G.synthetic_add_inputs(lab))
+        decs = {k: g.spark_encode()[0] for k, g in built.items()}
+        traces.append((built, decs))
+    ctx.pool_trim()
+    bad = []
+    for built, decs in traces:
+        for k, g in built.items():
+            r = ctx.snark_prove_resident(g.r1cs, decs[k], g.vars_para, g.vars_input, g.vars, g.inputs, SEED_C, SEED_P)
+            if hashlib.sha256(r["proof"]).hexdigest() != gold[k]["snark_sha256"]:
+                bad.append(k)
+    free_b, total_b = C.c_size_t(), C.c_size_t()
+    hip.hipMemGetInfo(C.byref(free_b), C.byref(total_b))
+    held, cached, _ = ctx.pool_stats()
+    for built, decs in traces:
+        for k in built:
+            decs[k].free()
+            built[k].free()
+print(json.dumps(dict(bad=bad, in_use_gib=(total_b.value - free_b.value) / 2**30, resident_gib=(held - cached) / 2**30,
+                      cached_gib=cached / 2**30)))
+"""
+
+
+def test_second_resident_lenet_trace_fits_and_proves():
+    """the resident inputs of a LeNet trace (instances, assignments, decommitments) are 19 GiB since the combined
+    polynomials' address / timestamp slices stay u32 (42 GiB before): a SECOND trace resident beside the first leaves the part
+    a quarter empty, and every one of the 24 SNARKs is the oracle's."""
+    gold = os.path.join(ROOT, "tests", "golden", "config_digests.json")
+    out = subprocess.run([sys.executable, "-c", SCRIPT_TWO_TRACES % dict(root=ROOT, gold=gold)], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    res = json.loads(out.stdout.strip().splitlines()[-1])
+    assert res["bad"] == [], res
+    assert res["resident_gib"] < 45.0, res          # two traces' inputs
+    assert res["in_use_gib"] < 215.0, res           # tables + two traces + one context's temporaries: room left on a 268 GiB part

@@ -76,6 +76,7 @@ def main():
                 if hot:
                     res["_msm_rows_valu_instructions_per_table_add"]["msm_rows_hot_kernel_wave_instructions_per_proof"] = hot / proofs
     top = dict(sorted(((k, v) for k, v in res.items() if not k.startswith("_")), key=lambda kv: -kv[1]["kernel_cycles"])[:16])
+    top.update({k: v for k, v in res.items() if k.startswith("sc_cubic3_kernel")})  # the roofline kernel, however short (bench.py's limiter_frac fallback)
     top.update({k: v for k, v in res.items() if k.startswith("_")})
     doc = {"_how": __doc__.strip().split("\n\n")[0] + "  Command: rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES "
                    "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE -- python3 bench.py --trace L5 --only mult --serial",

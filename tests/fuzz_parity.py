@@ -51,9 +51,10 @@ def mid_ops(seed, it):
     pool = GM.synthetic_points(seed + it, 16)
     n = int(round(20 * (35.0 ** rng.random())))          # log-uniform in [20, 700]
     ops = []
+    odd = rng.random() < 0.5        # half of the instances keep every point on the curve (satisfied), the others get a few odd ones
     for _ in range(n):
         w = rng.choice([0, 1, 3, 2**128 - 1, rng.randrange(2**16), rng.randrange(2**128), rng.randrange(2**128), rng.randrange(2**128)])
-        x, y = rand_point(rng, pool) if rng.random() < 0.1 else rng.choice(pool)
+        x, y = rand_point(rng, pool) if (odd and rng.random() < 0.02) else rng.choice(pool)
         ops.append((w, x, y))
     sc, sp = bytes(rng.randrange(256) for _ in range(64)), bytes(rng.randrange(256) for _ in range(64))
     return n, ops, sc, sp
@@ -71,6 +72,55 @@ def mid_oracle(args):
             "comm_para": hashlib.sha256(exp["comm_para"].tobytes()).hexdigest(),
             "comm_input": hashlib.sha256(exp["comm_input"].tobytes()).hexdigest(),
             "model_s": round(t1 - t0, 1), "oracle_s": round(time.time() - t1, 1)}
+
+
+def main_mid_oracle(cases, seed, out_path):
+    """CPU only: the oracle's digests of the --mid cases -> a JSON fixture (run in the build container; minutes per case)"""
+    import json
+    threads = int(os.environ.get("VPIN_FUZZ_THREADS", str(os.cpu_count() or 8)))
+    doc = {"_source": f"tests/fuzz_parity.py --mid-oracle {cases} {seed}: Python gadget model + C oracle on mid_ops(seed, it)", "seed": seed, "cases": []}
+    if os.path.exists(out_path):
+        doc = json.load(open(out_path))
+    for it in range(len(doc["cases"]), cases):
+        doc["cases"].append(mid_oracle((seed, it, threads)))
+        with open(out_path, "w") as f:
+            json.dump(doc, f, indent=1)
+        print(doc["cases"][-1], flush=True)
+
+
+def main_mid_check(fixture):
+    """GPU: prove the fixture's cases (rebuilt from the same seeds) and compare with the committed oracle digests"""
+    import json
+    doc = json.load(open(fixture))
+    seed, bad, taken0, t0 = doc["seed"], 0, 0, time.time()
+    with vpin_amd.Context(0) as ctx:
+        for exp in doc["cases"]:
+            it = exp["it"]
+            n, ops, sc, sp = mid_ops(seed, it)
+            assert n == exp["n"]
+            strip = it % 2 == 1
+            if strip:
+                os.environ["VPIN_MSM_STRIP_MIN"] = "64"
+            try:
+                g = ctx.gadget_point_mult_dev([o[0] for o in ops], b32(o[1] for o in ops), b32(o[2] for o in ops))
+                try:
+                    got = g.snark_prove(sc, sp)
+                    sat_dev = g.is_sat()
+                finally:
+                    g.free()
+            finally:
+                os.environ.pop("VPIN_MSM_STRIP_MIN", None)
+            taken = ctx.strip_rows_taken()
+            same = (hashlib.sha256(got["proof"]).hexdigest() == exp["proof"] and hashlib.sha256(got["comm"]).hexdigest() == exp["comm"]
+                    and hashlib.sha256(got["comm_para"].tobytes()).hexdigest() == exp["comm_para"]
+                    and hashlib.sha256(got["comm_input"].tobytes()).hexdigest() == exp["comm_input"] and sat_dev == exp["is_sat"])
+            bad += 0 if same else 1
+            print(f"mid case {it}: {n} point-mults, 2^{exp['num_cons'].bit_length() - 1} constraints, sat {exp['is_sat']}, row-per-lane rows "
+                  f"{taken - taken0}{' (forced from 64 rows)' if strip else ''}: {'ok' if same else 'MISMATCH'}  [{time.time() - t0:.0f} s]", flush=True)
+            taken0 = taken
+    print(f"fuzz_parity --mid-check: {len(doc['cases'])} random point-mult instances of 20..700 operations (seed {seed}), {bad} mismatches "
+          "against the oracle's committed digests")
+    sys.exit(1 if bad else 0)
 
 
 def main_mid(cases, seed):
@@ -123,6 +173,10 @@ def main_mid(cases, seed):
 
 
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "--mid-oracle":
+        return main_mid_oracle(int(sys.argv[2]), int(sys.argv[3]), sys.argv[4])
+    if len(sys.argv) > 1 and sys.argv[1] == "--mid-check":
+        return main_mid_check(sys.argv[2])
     if len(sys.argv) > 1 and sys.argv[1] == "--mid":
         return main_mid(int(sys.argv[2]) if len(sys.argv) > 2 else 16, int(sys.argv[3]) if len(sys.argv) > 3 else 5)
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 50

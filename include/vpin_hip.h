@@ -88,6 +88,10 @@ int vpin_ctx_pool_stats(vpin_ctx* ctx, size_t out[3]);
 /* hand the pool's cached (free) blocks back to the driver: after set-up work whose temporaries no proof will reuse (gadget
  * synthesis, SNARK::encode), or when a service changes workload.  Synchronises the context's stream. */
 int vpin_ctx_pool_trim(vpin_ctx* ctx);
+/* Low-memory mode: proofs on this context keep a smaller working set at a small cost in time.  Today: the SPARK mem forest
+ * (4 product circuits over M leaves) is built after the ops forest has been proven, into the memory it frees, its roots coming
+ * first from a product reduction -- 16 GiB less for a 2^25-constraint instance, ~1 % more time.  Same bytes. */
+int vpin_ctx_set_low_memory(vpin_ctx* ctx, int on);
 /* How many proofs the generator window tables built through this context will serve: 0 (default) = many -- the widest
  * windows the table budget allows (fewest additions per scalar; the table costs ~0.2 s to build for the largest
  * instance); n > 0 = a process that proves n times and exits (vpin_prove: a process per label, like `cargo run -- <label>`):

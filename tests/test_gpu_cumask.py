@@ -109,3 +109,15 @@ def test_hash_layer_two_pass_switch_gives_the_same_bytes():
             finally:
                 del os.environ["VPIN_HASH_TWO_PASS"]
             assert a == GOLD[key]["snark_sha256"] == _prove(ctx, key), key
+
+
+def test_low_memory_mode_gives_the_same_bytes():
+    """vpin_ctx_set_low_memory: the mem forest built after the ops forest is proven, its roots from a product reduction over the
+    leaves (spark_mem_roots) -- the same field elements, the same SNARK"""
+    import vpin_amd
+    with vpin_amd.Context(0) as ctx:
+        ctx.set_low_memory(True)
+        for key in ("3_32-add", "3_32-mult", "A-mult", "7_256-add", "E-mult", "L5-mult"):
+            assert _prove(ctx, key) == GOLD[key]["snark_sha256"], key
+        ctx.set_low_memory(False)
+        assert _prove(ctx, "A-mult") == GOLD["A-mult"]["snark_sha256"]

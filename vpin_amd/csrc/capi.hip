@@ -367,6 +367,12 @@ int vpin_ctx_set_shared_device(vpin_ctx* c, int on) {
   return VPIN_OK;
 }
 
+int vpin_ctx_set_low_memory(vpin_ctx* c, int on) {
+  if (!c) return VPIN_EINVAL;
+  c->low_memory = on != 0;
+  return VPIN_OK;
+}
+
 int vpin_ctx_set_expected_proofs(vpin_ctx* c, int n) {
   if (!c || n < 0) return VPIN_EINVAL;
   c->expected_proofs = n;

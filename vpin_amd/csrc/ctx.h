@@ -100,6 +100,7 @@ struct vpin_ctx {
   vpin::fq tail_sums[3 * 18];   // host copies of the current tail round's results (assembled from the mailbox pieces)
   vpin::fq tail_final[6 * 18];
   unsigned long long strip_rows_taken = 0;  // rows handed to msm_strip_kernel so far (vpin_ctx_strip_rows_taken: tests)
+  bool low_memory = false;     // vpin_ctx_set_low_memory: trade ~1 % of a large proof's time for a third less working set
   bool shared_device = false;  // other contexts prove on this device at the same time (vpin_ctx_set_shared_device)
   int expected_proofs = 0;     // proofs the window tables built through this context will serve; 0 = many (vpin_ctx_set_expected_proofs)
   double gens_scalars_per_proof = 0.0;  // set by the caller of vpin_gens_shared: full-size scalars one proof commits under the table
@@ -147,6 +148,7 @@ struct DevBuf {
   explicit DevBuf(vpin_ctx* ctx) : c(ctx) {}
   ~DevBuf() { if (p) dev_free(c, p); }
   int alloc(size_t bytes) { return dev_alloc(c, bytes, &p); }
+  void release() { if (p) { dev_free(c, p); p = nullptr; } }  // back to the pool before the scope ends
 };
 
 int table_alloc_uninit(vpin_ctx* c, size_t len, vpin_table** out);

@@ -1031,7 +1031,12 @@ static int spark_prove(vpin_ctx* c, const vpin_spark_decomm* d, const std::vecto
   const int nl_ops = (dz && !st) ? (int)dz->ops_of[dz->rank].size() : 12, nl_mem = (dz && !st) ? (int)dz->mem_of[dz->rank].size() : 4;
   const size_t nl_dotp = (dz && !st) ? dz->dotp_of[dz->rank].size() : 6;  // the first-fold scratch is numbered by the local half
   const size_t Nf = st ? N / Wz : N, Mf = st ? M / Wz : M;               // leaves per tree on this rank
-  if (b_ops.alloc((size_t)nl_ops * 2 * Nf * 32) || (nl_mem && b_mem.alloc((size_t)nl_mem * 2 * Mf * 32)) ||
+  // Single GPU, a context in low-memory mode (vpin_ctx_set_low_memory, or VPIN_MEM_FOREST_LATE=1; round 5): the mem forest is
+  // built AFTER the ops forest has been proven, into the memory it frees (-16 GiB of working set for the 2^25 instance, the
+  // LeNet step's HBM 197 -> 181 GiB); the four mem roots the transcript wants first come from a product reduction over the
+  // leaves (spark_mem_roots).  It costs 1 % of the 2^25 proof and 1.6 % of the four-lane step, so it is not the default.
+  const bool defer_mem = !dz && (c->low_memory || getenv("VPIN_MEM_FOREST_LATE") != nullptr);
+  if (b_ops.alloc((size_t)nl_ops * 2 * Nf * 32) || (nl_mem && !defer_mem && b_mem.alloc((size_t)nl_mem * 2 * Mf * 32)) ||
       b_scr.alloc(std::max<size_t>(256, 3 * nl_dotp * (Nf / 4) * 32)))
     return VPIN_ENOMEM;
   if ((rc = vpin::comm_mark(c, "network_alloc"))) return rc;
@@ -1041,6 +1046,8 @@ static int spark_prove(vpin_ctx* c, const vpin_spark_decomm* d, const std::vecto
     if ((rc = vpin::spark_build_forests_strided(c, d, comb_loc, mem_rx->d, mem_ry->d, B(&r_hash), B(&r_hash_sqr), B(&r2_boost), B(&gamma),
                                                 &f_ops, &f_mem, rk, Wz)))
       return rc;
+  } else if (defer_mem) {
+    if ((rc = vpin::spark_build_forest_ops(c, d, comb->d, B(&r_hash), B(&r_hash_sqr), B(&r2_boost), B(&gamma), &f_ops))) return rc;
   } else if (!dz) {
     if ((rc = vpin::spark_build_forests(c, d, comb->d, mem_rx->d, mem_ry->d, B(&r_hash), B(&r_hash_sqr), B(&r2_boost), B(&gamma),
                                         &f_ops, &f_mem)))
@@ -1093,7 +1100,11 @@ static int spark_prove(vpin_ctx* c, const vpin_spark_decomm* d, const std::vecto
       for (int i = 0; i < 4; i++) roots[2 * i] = st_roots[2 * (12 + i)];
       t = roots.data();
     } else {
-      if (nl_mem && (rc = vpin::spark_fetch_tops(c, &f_mem, 2))) return rc;
+      if (defer_mem) {
+        if ((rc = vpin::spark_mem_roots(c, d, mem_rx->d, mem_ry->d, B(&r_hash), B(&r_hash_sqr), B(&r2_boost), B(&gamma)))) return rc;
+      } else if (nl_mem && (rc = vpin::spark_fetch_tops(c, &f_mem, 2))) {
+        return rc;
+      }
       t = reinterpret_cast<const Fq*>(c->h_spark);
       if (dz) {
         if ((rc = dist_exchange(c, *dz, true, false, t, 2, roots.data(), "roots"))) return rc;
@@ -1152,6 +1163,15 @@ static int spark_prove(vpin_ctx* c, const vpin_spark_decomm* d, const std::vecto
     if (st) rc = batched_prove_strided(c, f_ops, N, &sdotp, tr, pf_ops, rand_ops, *dz, false);
     else rc = batched_prove(c, f_ops, &dotp, tr, pf_ops, rand_ops, dz, 12);
     if (rc) return rc;
+  }
+  if (defer_mem) {
+    TraceSpan ts("network: mem forest (deferred)");
+    b_ops.release();   // every level of the ops forest has been folded away: its memory takes the mem forest
+    b_scr.release();
+    if (b_mem.alloc((size_t)4 * 2 * M * 32)) return VPIN_ENOMEM;
+    f_mem.base = (vpin::fq*)b_mem.p;
+    if ((rc = vpin::spark_build_forest_mem(c, d, mem_rx->d, mem_ry->d, B(&r_hash), B(&r_hash_sqr), B(&r2_boost), B(&gamma), &f_mem))) return rc;
+    if ((rc = vpin::spark_wait(c))) return rc;
   }
   {
     TraceSpan ts("product: mem forest");

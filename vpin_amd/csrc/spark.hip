@@ -769,6 +769,114 @@ int spark_build_forests(vpin_ctx* c, const vpin_spark_decomm* d, const fq* comb_
   return VPIN_OK;
 }
 
+// ---- the mem circuits' roots without their trees (round 5) --------------------------------------------------------------
+// ProductLayerProof::prove sends the 16 circuits' roots before the first sum-check; the mem forest itself (4 circuits over M
+// leaves: 16 GiB for the 2^25 instance) is only proven AFTER the ops forest (24 GiB).  Building it then, into the memory the
+// ops forest frees, takes a third off the proof's working set; what is needed early is only the product of each circuit's
+// leaves -- the same field element as the tree's root (multiplication mod q is exact and commutative).
+__device__ __forceinline__ fq fq_wave_prod(fq a) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) a = fq_mul(a, fq_shfl_xor(a, off));
+  return a;
+}
+// blockIdx.y = side; parts[(2 * side + kind) * gridDim.x + blockIdx.x] = product of this block's leaves of circuit 2*side + kind
+__global__ __launch_bounds__(kBlock) void hash_mem_roots_kernel(const uint32_t* __restrict__ audit_ts, const fq* __restrict__ mem_rx,
+                                                                const fq* __restrict__ mem_ry, size_t M, HashParams hp,
+                                                                fq* __restrict__ parts) {
+  const int side = blockIdx.y;
+  const fq* mem = side ? mem_ry : mem_rx;
+  const uint32_t* ts = audit_ts + (size_t)side * M;
+  const fq r2c = fq_r2();
+  fq pi = fq_one(), pa = fq_one();
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < M; i += (size_t)gridDim.x * kBlock) {
+    fq h = fq_sub(fq_mul(fq_load(mem + i), hp.r), hp.gamma);
+    if (i) h = fq_add(h, fq_mul(fq_raw_u32((uint32_t)i), r2c));
+    pi = fq_mul(pi, h);
+    const uint32_t t = ts[i];
+    if (t) h = fq_add(h, fq_mul(fq_raw_u32(t), hp.r2_boost));
+    pa = fq_mul(pa, h);
+  }
+  pi = fq_wave_prod(pi);
+  pa = fq_wave_prod(pa);
+  __shared__ fq sh[kBlock / 64][2];
+  if ((threadIdx.x & 63) == 0) { sh[threadIdx.x >> 6][0] = pi; sh[threadIdx.x >> 6][1] = pa; }
+  __syncthreads();
+  if (threadIdx.x < 2) {
+    fq t = sh[0][threadIdx.x];
+    for (int w = 1; w < kBlock / 64; w++) t = fq_mul(t, sh[w][threadIdx.x]);
+    fq_store(parts + (size_t)(2 * side + (int)threadIdx.x) * gridDim.x + blockIdx.x, t);
+  }
+}
+// out[2 * circ] = product of the np partial products of circuit circ (blockIdx.x); the h_spark layout of spark_fetch_tops(f, 2)
+__global__ __launch_bounds__(kBlock) void roots_finish_kernel(const fq* __restrict__ parts, int np, fq* __restrict__ out) {
+  fq p = fq_one();
+  for (int k = (int)threadIdx.x; k < np; k += kBlock) p = fq_mul(p, fq_load(parts + (size_t)blockIdx.x * np + k));
+  p = fq_wave_prod(p);
+  __shared__ fq sh[kBlock / 64];
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = p;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    fq t = sh[0];
+    for (int w = 1; w < kBlock / 64; w++) t = fq_mul(t, sh[w]);
+    fq_store(out + 2 * blockIdx.x, t);
+    fq_store(out + 2 * blockIdx.x + 1, fq_zero());
+  }
+}
+
+static HashParams hash_params(const uint8_t r_hash[32], const uint8_t r_hash_sqr[32], const uint8_t r_hash_sqr_boost[32],
+                              const uint8_t gamma[32]) {
+  HashParams hp;
+  hp.r = load_host_fq(r_hash);
+  hp.r2 = load_host_fq(r_hash_sqr);
+  hp.r2_boost = load_host_fq(r_hash_sqr_boost);
+  hp.gamma = load_host_fq(gamma);
+  return hp;
+}
+
+// roots of the four mem circuits (init / audit per side) -> c->h_spark[2 * circuit], as spark_fetch_tops(&mem_forest, 2) leaves them
+int spark_mem_roots(vpin_ctx* c, const vpin_spark_decomm* d, const fq* mem_rx, const fq* mem_ry, const uint8_t r_hash[32],
+                    const uint8_t r_hash_sqr[32], const uint8_t r_hash_sqr_boost[32], const uint8_t gamma[32]) {
+  if (!c || !d || !mem_rx || !mem_ry || d->M < 2) return VPIN_EINVAL;
+  int rc = spark_pinned(c);
+  if (rc) return rc;
+  (void)hipSetDevice(c->device);
+  const int np = (int)std::min<size_t>(1024, (d->M + kBlock - 1) / kBlock);
+  DevBuf parts(c);
+  if (parts.alloc((size_t)4 * np * sizeof(fq))) return VPIN_ENOMEM;
+  {
+    ProfScope ps(c, VPIN_K_SPARK_BUILD, (double)d->M * 2 * 36.0);
+    hipLaunchKernelGGL(hash_mem_roots_kernel, dim3((unsigned)np, 2), dim3(kBlock), 0, c->stream, (const uint32_t*)(d->idx + 12 * d->N), mem_rx,
+                       mem_ry, d->M, hash_params(r_hash, r_hash_sqr, r_hash_sqr_boost, gamma), (fq*)parts.p);
+  }
+  hipLaunchKernelGGL(roots_finish_kernel, dim3(4), dim3(kBlock), 0, c->stream, (const fq*)parts.p, np, c->h_spark);
+  VPIN_HIP_TRY(hipGetLastError());
+  return spark_wait(c);
+}
+
+// the ops forest alone / the mem forest alone (spark_build_forests below does both)
+int spark_build_forest_ops(vpin_ctx* c, const vpin_spark_decomm* d, const fq* comb_derefs, const uint8_t r_hash[32],
+                           const uint8_t r_hash_sqr[32], const uint8_t r_hash_sqr_boost[32], const uint8_t gamma[32], SparkForest* ops) {
+  if (!c || !d || !ops || !ops->base || !comb_derefs) return VPIN_EINVAL;
+  if (ops->n != d->N || ops->ncirc != 12 || d->N < 2) return VPIN_ESHAPE;
+  (void)hipSetDevice(c->device);
+  ProfScope ps(c, VPIN_K_SPARK_BUILD, (double)d->N * (6 * (8.0 + 32.0) + 12 * 32.0 + 12 * 64.0));
+  hipLaunchKernelGGL(hash_ops_kernel, dim3(grid_for(d->N), 6), dim3(kBlock), 0, c->stream, (const uint32_t*)d->idx, comb_derefs, d->N,
+                     hash_params(r_hash, r_hash_sqr, r_hash_sqr_boost, gamma), ops->base);
+  VPIN_HIP_TRY(hipGetLastError());
+  return build_levels(c, ops);
+}
+int spark_build_forest_mem(vpin_ctx* c, const vpin_spark_decomm* d, const fq* mem_rx, const fq* mem_ry, const uint8_t r_hash[32],
+                           const uint8_t r_hash_sqr[32], const uint8_t r_hash_sqr_boost[32], const uint8_t gamma[32], SparkForest* mem) {
+  if (!c || !d || !mem || !mem->base || !mem_rx || !mem_ry) return VPIN_EINVAL;
+  if (mem->n != d->M || mem->ncirc != 4 || d->M < 2) return VPIN_ESHAPE;
+  (void)hipSetDevice(c->device);
+  ProfScope ps(c, VPIN_K_SPARK_BUILD, (double)d->M * (2 * 36.0 + 4 * 32.0 + 4 * 64.0));
+  hipLaunchKernelGGL(hash_mem_kernel, dim3(grid_for(d->M), 2), dim3(kBlock), 0, c->stream, (const uint32_t*)(d->idx + 12 * d->N), mem_rx,
+                     mem_ry, d->M, hash_params(r_hash, r_hash_sqr, r_hash_sqr_boost, gamma), mem->base);
+  VPIN_HIP_TRY(hipGetLastError());
+  return build_levels(c, mem);
+}
+
 int spark_build_forest_sub(vpin_ctx* c, const vpin_spark_decomm* d, const fq* comb_derefs, const fq* mem_rx, const fq* mem_ry,
                            const uint8_t r_hash[32], const uint8_t r_hash_sqr[32], const uint8_t r_hash_sqr_boost[32],
                            const uint8_t gamma[32], SparkForest* f, const int* ids, bool is_mem) {

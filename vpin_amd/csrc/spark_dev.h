@@ -70,6 +70,15 @@ int spark_build_forests(vpin_ctx* c, const vpin_spark_decomm* d, const fq* comb_
                         const uint8_t r_hash[32], const uint8_t r_hash_sqr[32], const uint8_t r_hash_sqr_boost[32],
                         const uint8_t gamma[32], SparkForest* ops, SparkForest* mem);
 
+// Round 5: the ops forest alone, the mem circuits' roots without their trees (-> c->h_spark[2 * circuit], the layout of
+// spark_fetch_tops(&mem, 2)), and the mem forest alone -- built after the ops forest is proven, into the memory it frees
+int spark_build_forest_ops(vpin_ctx* c, const vpin_spark_decomm* d, const fq* comb_derefs, const uint8_t r_hash[32],
+                           const uint8_t r_hash_sqr[32], const uint8_t r_hash_sqr_boost[32], const uint8_t gamma[32], SparkForest* ops);
+int spark_mem_roots(vpin_ctx* c, const vpin_spark_decomm* d, const fq* mem_rx, const fq* mem_ry, const uint8_t r_hash[32],
+                    const uint8_t r_hash_sqr[32], const uint8_t r_hash_sqr_boost[32], const uint8_t gamma[32]);
+int spark_build_forest_mem(vpin_ctx* c, const vpin_spark_decomm* d, const fq* mem_rx, const fq* mem_ry, const uint8_t r_hash[32],
+                           const uint8_t r_hash_sqr[32], const uint8_t r_hash_sqr_boost[32], const uint8_t gamma[32], SparkForest* mem);
+
 // The same for a subset of the circuits: f holds ncirc trees, ids[j] = global circuit of tree j (ops: side*6 + kind*3 + m,
 // kind 0 read / 1 write; mem: side*2 + kind, kind 0 init / 1 audit).  One proof over several GPUs: a rank's own circuits.
 int spark_build_forest_sub(vpin_ctx* c, const vpin_spark_decomm* d, const fq* comb_derefs, const fq* mem_rx, const fq* mem_ry,

@@ -329,7 +329,16 @@ static int dplog_prove(vpin_ctx* c, const PcGens& pc, Transcript& tr, Transcript
   tr.append_point("Cx", Cx.b);
   out.Cy = compress(commit1(y, blind_y, pc.gens_1));
   tr.append_point("Cy", out.Cy.b);
-  tr.append_scalars("a", Rv.data(), R);
+  if (R >= 8192) {
+    // (the evaluation proofs of a 2^25-constraint SNARK absorb 74 k scalars here: their conversion out of Montgomery form runs
+    // on the context's host team, the hashing stays sequential)
+    std::vector<uint8_t> ab(R * 32);
+#pragma omp parallel for schedule(static) num_threads(host_threads())
+    for (size_t i = 0; i < R; i++) Rv[i].to_bytes(ab.data() + 32 * i);
+    tr.append_scalars_bytes("a", ab.data(), R);
+  } else {
+    tr.append_scalars("a", Rv.data(), R);
+  }
   Fq r_ = tr.challenge_scalar("r");
   // gens_1_scaled.G[0] = r * g[R]; every use below multiplies g[R] by r times something
   Fq blind_Gamma = LZ_blind + r_ * blind_y;

@@ -200,6 +200,13 @@ class Transcript {
     for (size_t i = 0; i < n; i++) append_scalar(label, v[i]);
     append_message(label, "end_append_vector");
   }
+  // the same from canonical bytes the caller has already made (n x 32, e.g. converted by a thread team: the conversion out of
+  // Montgomery form is a third of the cost of absorbing a long vector)
+  void append_scalars_bytes(const char* label, const uint8_t* bytes32, size_t n) {
+    append_message(label, "begin_append_vector");
+    for (size_t i = 0; i < n; i++) append_message(label, bytes32 + 32 * i, 32);
+    append_message(label, "end_append_vector");
+  }
 };
 
 // RandomTape (Spartan/src/random.rs:12-31) with the OsRng draw made an explicit input: seed64

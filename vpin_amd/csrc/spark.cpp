@@ -1192,7 +1192,14 @@ static int spark_prove(vpin_ctx* c, const vpin_spark_decomm* d, const std::vecto
   // the combined polynomials as whole field tables: only the two-pass and the multi-GPU paths read them (this proof's own
   // copies: the decommitment is shared with other contexts)
   vpin_table *comb_ops = nullptr, *comb_mem = nullptr;
-  if (!one_pass) {
+  if (!one_pass && dz) {
+    // a proof split over several GPUs: built once per decommitment on first use and kept (the ranks of a rehearsal share one
+    // decommitment and one copy; on a real node every GPU holds its own)
+    auto* dm = const_cast<vpin_spark_decomm*>(d);
+    dm->comb_unpooled = true;
+    if ((rc = vpin::spark_comb_tables(c, dm))) return rc;
+    comb_ops = dm->comb_ops; comb_mem = dm->comb_mem;
+  } else if (!one_pass) {
     if ((rc = vpin::spark_comb_make(c, d, &comb_ops, &comb_mem))) return rc;
     tg.add(comb_ops); tg.add(comb_mem);
   }

@@ -626,13 +626,25 @@ int spark_u32_to_fq(vpin_ctx* c, const uint32_t* src, fq* dst, size_t n) {
   return VPIN_OK;
 }
 
-int spark_comb_make(vpin_ctx* c, const vpin_spark_decomm* d, vpin_table** ops, vpin_table** mem) {
+// a table of `len` scalars straight from the driver (no pool, no owner: whoever frees the decommitment frees it, whichever
+// contexts are still alive)
+static int table_alloc_unpooled(size_t len, vpin_table** out) {
+  vpin_table* t = new (std::nothrow) vpin_table();
+  if (!t) return VPIN_ENOMEM;
+  if (hipMalloc((void**)&t->d, len * sizeof(fq)) != hipSuccess) { (void)hipGetLastError(); delete t; return VPIN_ENOMEM; }
+  t->len = t->cap = len;
+  t->owner = nullptr;
+  *out = t;
+  return VPIN_OK;
+}
+
+int spark_comb_make(vpin_ctx* c, const vpin_spark_decomm* d, vpin_table** ops, vpin_table** mem, bool pooled) {
   if (!c || !d || !d->idx || !d->vals || !ops || !mem) return VPIN_EINVAL;
   const size_t N = d->N, M = d->M;
   int rc;
   *ops = *mem = nullptr;
-  if ((rc = table_alloc_uninit(c, 16 * N, ops))) return rc;
-  if ((rc = table_alloc_uninit(c, 2 * M, mem))) { vpin_table_free(c, *ops); *ops = nullptr; return rc; }
+  if ((rc = pooled ? table_alloc_uninit(c, 16 * N, ops) : table_alloc_unpooled(16 * N, ops))) return rc;
+  if ((rc = pooled ? table_alloc_uninit(c, 2 * M, mem) : table_alloc_unpooled(2 * M, mem))) { vpin_table_free(c, *ops); *ops = nullptr; return rc; }
   if ((rc = spark_u32_to_fq(c, d->idx, (*ops)->d, 12 * N)) || (rc = spark_u32_to_fq(c, d->idx + 12 * N, (*mem)->d, 2 * M))) return rc;
   VPIN_HIP_TRY(hipMemcpyAsync((*ops)->d + 12 * N, d->vals, 3 * N * sizeof(fq), hipMemcpyDeviceToDevice, c->stream));
   VPIN_HIP_TRY(hipMemsetAsync((*ops)->d + 15 * N, 0, N * sizeof(fq), c->stream));
@@ -641,9 +653,13 @@ int spark_comb_make(vpin_ctx* c, const vpin_spark_decomm* d, vpin_table** ops, v
 
 int spark_comb_tables(vpin_ctx* c, vpin_spark_decomm* d) {
   if (!d) return VPIN_EINVAL;
+  std::lock_guard<std::mutex> g(d->comb_mu);
   if (d->comb_ops && d->comb_mem) return VPIN_OK;
   spark_comb_release(c, d, false);
-  return spark_comb_make(c, d, &d->comb_ops, &d->comb_mem);
+  int rc = spark_comb_make(c, d, &d->comb_ops, &d->comb_mem, d->comb_unpooled);
+  if (!rc && hipStreamSynchronize(c->stream) != hipSuccess) rc = VPIN_EHIP;  // other contexts' streams read them next
+  if (rc) spark_comb_release(c, d, false);
+  return rc;
 }
 
 // to_driver: the blocks leave the context's pool too (SNARK::encode: nothing of a proof reuses 16N scalars; cached, they would

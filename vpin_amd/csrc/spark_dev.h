@@ -1,5 +1,7 @@
 // spark_dev.h -- device-side state and launchers of the SPARK half (spark.hip), driven by spark.cpp
 #pragma once
+#include <mutex>
+
 #include "ctx.h"
 
 // ComputationDecommitment (lib.rs:70-73): MultiSparseMatPolynomialAsDense (sparse_mlpoly.rs:285-292)
@@ -18,6 +20,8 @@ struct vpin_spark_decomm {
   // (spark_comb_tables below).  Round 5: they used to stay resident next to idx -- 17.2 + 2.1 GB for the 2^25 instance.
   vpin_table* comb_ops = nullptr;
   vpin_table* comb_mem = nullptr;
+  std::mutex comb_mu;  // a proof split over several GPUs builds them on first use and leaves them (spark_comb_tables)
+  bool comb_unpooled = false;  // the cached copies come straight from the driver (they outlive whichever context built them)
   // the column that carries a large share of matrix m's entries (the constant 1 in B and C of vPIN's gadgets), found once by
   // SNARK::encode; 0xffffffff: none.  The derefs commitment of every proof takes its entries out of the table walks.
   uint32_t hot_col[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu};
@@ -37,11 +41,12 @@ int spark_check_bounds(vpin_ctx* c, const uint32_t* a, size_t nnz, uint32_t limi
 
 // dst[i] = Scalar::from(src[i]) (Montgomery form)
 int spark_u32_to_fq(vpin_ctx* c, const uint32_t* src, fq* dst, size_t n);
-// d->comb_ops / d->comb_mem built from idx and vals (no-op when they exist); spark_comb_release frees them again
+// d->comb_ops / d->comb_mem built from idx and vals (no-op when they exist; serialised on d->comb_mu and complete on return, so
+// several contexts may call it for one decommitment); spark_comb_release frees them again
 int spark_comb_tables(vpin_ctx* c, vpin_spark_decomm* d);
 // the same as two tables of the caller's (a proof that needs them whole must not touch the shared decommitment: other
 // contexts may be proving from it)
-int spark_comb_make(vpin_ctx* c, const vpin_spark_decomm* d, vpin_table** ops, vpin_table** mem);
+int spark_comb_make(vpin_ctx* c, const vpin_spark_decomm* d, vpin_table** ops, vpin_table** mem, bool pooled = true);
 void spark_comb_release(vpin_ctx* c, vpin_spark_decomm* d, bool to_driver = false);
 
 // Derefs (sparse_mlpoly.rs:267-283,525-531): comb[m*N+i] = mem_rx[row_m[i]], comb[(3+m)*N+i] =

@@ -5,10 +5,13 @@
 //     read_ts[i] = audit[addr[i]]; audit[addr[i]] += 1
 // i.e. read_ts = how many EARLIER accesses went to the same address, audit_ts = how many accesses an address got in all.  The
 // host loop is sequential (round 4: one thread per side, 60 % of vpin_spark_encode's time for CNN A).  Here: a STABLE radix sort
-// of (address, position) pairs (hipCUB's DeviceRadixSort is stable) groups every address's accesses in their original order;
+// of (address, position) pairs (rocPRIM's radix_sort_pairs is stable) groups every address's accesses in their original order;
 // the rank inside the group is the time stamp, the group's size the audit value.  Exact integers either way: the same u32s.
 // (Device-built gadget instances do not come here: gadget_dev.hip writes their trace in closed form.)
-#include <hipcub/hipcub.hpp>
+#include <cstring>
+#include <string.h>
+
+#include <rocprim/rocprim.hpp>
 
 #include "ctx.h"
 #include "spark_dev.h"
@@ -49,7 +52,8 @@ inline unsigned grid_of(size_t n) { return (unsigned)std::min<size_t>(4096, (n +
 
 // addr: n = 3N addresses of one side (every one < M, M a power of two); ts: n read time stamps; audit: M audit time stamps
 int spark_trace_timestamps(vpin_ctx* c, const uint32_t* addr, size_t n, size_t M, uint32_t* ts, uint32_t* audit) {
-  if (!c || !addr || !ts || !audit || n == 0 || n >= ((size_t)1 << 32) || !is_pow2(M)) return VPIN_EINVAL;
+  if (!c || !addr || !ts || !audit || n == 0 || !is_pow2(M)) return VPIN_EINVAL;
+  if (n > (size_t)0x7fffffff) return VPIN_ESHAPE;  // positions are u32 and the library calls take 32-bit sizes
   (void)hipSetDevice(c->device);
   DevBuf b_keys(c), b_pos_in(c), b_pos(c), b_head(c), b_tmp(c);
   if (b_keys.alloc(n * 4) || b_pos_in.alloc(n * 4) || b_pos.alloc(n * 4) || b_head.alloc(n * 4)) return VPIN_ENOMEM;
@@ -58,15 +62,15 @@ int spark_trace_timestamps(vpin_ctx* c, const uint32_t* addr, size_t n, size_t M
   const int end_bit = 32;
   (void)M;
   size_t tmp_sort = 0, tmp_scan = 0;
-  VPIN_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_sort, addr, keys, (const uint32_t*)pos_in, pos, (int)n, 0, end_bit, c->stream));
-  VPIN_HIP_TRY(hipcub::DeviceScan::InclusiveScan(nullptr, tmp_scan, head, head, MaxOp(), (int)n, c->stream));
+  VPIN_HIP_TRY(rocprim::radix_sort_pairs(nullptr, tmp_sort, addr, keys, (const uint32_t*)pos_in, pos, n, 0u, (unsigned)end_bit, c->stream));
+  VPIN_HIP_TRY(rocprim::inclusive_scan(nullptr, tmp_scan, head, head, n, MaxOp(), c->stream));
   size_t tmp_bytes = std::max(tmp_sort, tmp_scan);
   if (b_tmp.alloc(tmp_bytes ? tmp_bytes : 256)) return VPIN_ENOMEM;
   hipLaunchKernelGGL(iota_kernel, dim3(grid_of(n)), dim3(kTB), 0, c->stream, pos_in, n);
-  VPIN_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(b_tmp.p, tmp_bytes, addr, keys, (const uint32_t*)pos_in, pos, (int)n, 0, end_bit, c->stream));
+  VPIN_HIP_TRY(rocprim::radix_sort_pairs(b_tmp.p, tmp_bytes, addr, keys, (const uint32_t*)pos_in, pos, n, 0u, (unsigned)end_bit, c->stream));
   hipLaunchKernelGGL(heads_kernel, dim3(grid_of(n)), dim3(kTB), 0, c->stream, (const uint32_t*)keys, n, head);
   tmp_bytes = std::max(tmp_sort, tmp_scan);
-  VPIN_HIP_TRY(hipcub::DeviceScan::InclusiveScan(b_tmp.p, tmp_bytes, head, head, MaxOp(), (int)n, c->stream));
+  VPIN_HIP_TRY(rocprim::inclusive_scan(b_tmp.p, tmp_bytes, head, head, n, MaxOp(), c->stream));
   VPIN_HIP_TRY(hipMemsetAsync(audit, 0, M * 4, c->stream));
   hipLaunchKernelGGL(ranks_kernel, dim3(grid_of(n)), dim3(kTB), 0, c->stream, (const uint32_t*)keys, (const uint32_t*)pos, (const uint32_t*)head, n,
                      M, ts, audit);

@@ -1134,7 +1134,10 @@ static int gens_build(vpin_ctx* c, const uint8_t* gens_xyzt, size_t nb, size_t b
   // windows: an entry costs ~4x a table addition to construct (projective chain, batched inversion, 96-byte scattered
   // store), so the width minimises entries x 4 + scalars x windows (measured: 142 ms to build the 12-bit table of the 2^25
   // instance, whose one proof then saves 48 ms of additions against the 10-bit one, built in 36 ms).
-  int cmax = 12;
+  // VPIN_GENS_CMAX (experiments): 13-bit windows are 20 instead of 22 additions per scalar for twice the table (129 GB for the
+  // first 16386 generators): measured in round 5, see DESIGN.md section 4
+  static const int env_cmax = [] { const char* e = getenv("VPIN_GENS_CMAX"); int v = e ? atoi(e) : 12; return v < 8 ? 8 : v > 14 ? 14 : v; }();
+  int cmax = env_cmax;
   if (c->expected_proofs > 0 && c->gens_scalars_per_proof > 0.0) {
     const double S = c->gens_scalars_per_proof * (double)c->expected_proofs, n_lo = (double)std::min<size_t>(nb, 16386);
     double best = 0.0;

@@ -156,7 +156,15 @@ int slices_bound(vpin_ctx* c, const uint32_t* Z32, int n32, const fq* Z, size_t 
       T * Rs != N)
     return VPIN_EINVAL;
   (void)hipSetDevice(c->device);
-  const size_t rows_per_chunk = T / 64 ? T / 64 : 1;
+  // Row chunks: only as many as it takes to fill the chip (~4096 workgroups with the column blocks and the slices): every chunk
+  // writes S x Rs partial sums that the reduction reads back -- 64 chunks made that 1 GB for the 2^25 instance's ops polynomial,
+  // more than the 1.6 GB of u32 slices the pass is there to read
+  const size_t col_blocks = (Rs + kPB - 1) / kPB;
+  size_t want_chunks = (4096 + col_blocks * (size_t)S - 1) / (col_blocks * (size_t)S);
+  if (want_chunks > 64) want_chunks = 64;
+  if (want_chunks > T) want_chunks = T;
+  if (want_chunks < 1) want_chunks = 1;
+  const size_t rows_per_chunk = (T + want_chunks - 1) / want_chunks;
   const int chunks = (int)((T + rows_per_chunk - 1) / rows_per_chunk);
   DevBuf bL(c), bR(c), bpart(c), bev(c);
   if (bL.alloc(T * 32) || bR.alloc(Rs * 32) || bpart.alloc((size_t)chunks * S * Rs * 32) || bev.alloc((size_t)S * 32)) return VPIN_ENOMEM;

@@ -109,3 +109,30 @@ def test_gadget_shape_matches_the_built_instances():
         assert (nc, nv) == (d["num_cons"], d["num_vars"]), (kind, n)
         assert nnz == [len(d[m][0]) for m in ("A", "B", "C")], (kind, n)
         inst.free()
+
+
+def test_bench_cpulist_parser_and_overlap_bound():
+    """bench.py's NUMA helper parses sysfs cpulists; dist.replay_trace's overlap flag is a lower bound of the sequential order"""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_for_test", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    import sys
+    argv = sys.argv
+    sys.argv = ["bench.py"]
+    try:
+        spec.loader.exec_module(bench)
+    finally:
+        sys.argv = argv
+    assert bench.parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11]
+    assert bench.parse_cpulist("64-127,192-255")[:2] == [64, 65] and len(bench.parse_cpulist("64-127,192-255")) == 128
+    assert bench.pin_to_gpu_numa_node(0, 1, "off") == {"mode": "off"}
+    from vpin_amd.dist import plan_trace, replay_trace
+    cons = [20_784_000, 2_771_200, 1_039_200, 831_360, 581_952, 70_560, 24_000, 7_680, 4_060, 2_880, 1_860]
+    coop, small, _ = plan_trace(cons, 4, 0.5 * 2**24, 0.5 * 2**22)
+    coop_ms = {k: 100.0 for k in coop}
+    single = [10.0 + c / 4e4 for c in cons]
+    seq = replay_trace(coop, small, 4, coop_ms, single)
+    ov = replay_trace(coop, small, 4, coop_ms, single, overlap=True)
+    assert all(o <= s for o, s in zip(ov, seq)) and max(ov) >= 100.0

@@ -152,7 +152,7 @@ def test_l5_mult_commitment_pinned_and_proof_accepted_by_oracle_verifier(ctx):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("key", ["3_32-mult", "A-add", "7_256-mult", "A-mult"])
+@pytest.mark.parametrize("key", ["3_32-mult", "A-add", "7_256-mult", "A-mult", "E-add", "E-mult"])
 def test_host_built_instances_give_the_same_bytes(ctx, key):
     """the other entry of the boundary: instance and witness built on the HOST (vpin_gadget_point_*), uploaded and proven
     through vpin_snark_prove -- same oracle digests as the device-built path (A-mult: 2^20 entries, so SNARK::encode of the
@@ -166,6 +166,35 @@ def test_host_built_instances_give_the_same_bytes(ctx, key):
     assert hashlib.sha256(got["comm"]).hexdigest() == g["comm_sha256"]
     assert hashlib.sha256(got["proof"]).hexdigest() == g["snark_sha256"]
     assert hashlib.sha256(got["comm_para"].tobytes()).hexdigest() == g["comm_para_sha256"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("key", ["3_32-mult", "A-mult"])
+def test_uploaded_triplets_in_any_order_give_the_same_sat_proof(ctx, key):
+    """vpin_r1cs_upload builds CSR / CSC on the device with atomic cursors (round 5): the order of a row's entries is
+    whatever the atomics give, and the triplets may come in any order -- the sat proof (sums of field elements) is the same
+    bytes; an index out of range is refused like lib.rs:171-178 refuses it"""
+    import vpin_amd
+    from vpin_amd import gadgets as G
+    g = GOLD[key]
+    inst = G.synthetic_mult_instance(g["label"])
+    d = inst.as_dict()
+    inst.free()
+    want = ctx.sat_prove(d, SEED_C, SEED_P)["proof"]
+    assert want == ctx.sat_prove(d, SEED_C, SEED_P)["proof"]      # two uploads of the same triplets: two atomic orders
+    rng = np.random.default_rng(5)
+    sh = dict(d)
+    for m in "ABC":
+        perm = rng.permutation(len(d[m][0]))
+        sh[m] = tuple(np.ascontiguousarray(x[perm]) for x in d[m])
+    assert ctx.sat_prove(sh, SEED_C, SEED_P)["proof"] == want
+    bad = dict(d)
+    rows = d["A"][0].copy()
+    rows[len(rows) // 2] = d["num_cons"]                          # one row index out of range
+    bad["A"] = (rows, d["A"][1], d["A"][2])
+    with pytest.raises(vpin_amd.VpinError):
+        ctx.sat_prove(bad, SEED_C, SEED_P)
+    assert ctx.sat_prove(d, SEED_C, SEED_P)["proof"] == want      # the context is fine afterwards
 
 
 @pytest.mark.gpu

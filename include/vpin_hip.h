@@ -223,6 +223,14 @@ int vpin_hyrax_commit(vpin_ctx* ctx, const vpin_gens* g, const vpin_table* Z, co
  * a contiguous block and the 32-byte results are all-gathered -- no point crosses a link. */
 int vpin_hyrax_commit_rows(vpin_ctx* ctx, const vpin_gens* g, const vpin_table* Z, size_t L, size_t row0, size_t nrows,
                            const uint8_t* blinds, size_t blind_base, uint8_t* out_compressed);
+/* The same commitment (DensePolynomial::commit_inner, Spartan/src/dense_mlpoly.rs:160-175) computed the way
+ * GroupElement::vartime_multiscalar_mul does above 190 terms (Spartan/src/group.rs:103-122, dalek's Pippenger): signed
+ * c_bits-bit digits, bucket accumulation staged in LDS, running-sum reduction -- from the generators alone, no window table
+ * walked.  A measured alternative, NOT what the provers call (it is slower on this part: profiles/r05_pippenger.txt).
+ * blinds may be NULL (commit(gens, None)); c_bits in 9..12, or 0 = the measured best (9).  Same bytes as
+ * vpin_hyrax_commit. */
+int vpin_hyrax_commit_pippenger(vpin_ctx* ctx, const vpin_gens* g, const vpin_table* Z, const uint8_t* blinds, size_t L,
+                                size_t blind_base, int c_bits, uint8_t* out_compressed);
 /* The two commitments of proof_point_{add,mult}.rs:44-52 plus their row-wise sum
  * (:75-80) in one call: out_sum[i] = compress(decompress(a[i]) + decompress(b[i])). */
 int vpin_hyrax_commit_pair(vpin_ctx* ctx, const vpin_gens* g, const vpin_table* Za, const vpin_table* Zb,

@@ -1,0 +1,117 @@
+"""GPU parity: vpin_hyrax_commit_pippenger (bucket accumulation staged in LDS, msm_pip.hip -- the MSM north_star names, kept as a
+measured alternative) against the CPU oracle's Pippenger and against the window-table walk (vpin_hyrax_commit) on the same
+generators and scalars: bit-exact compressed points for every window width."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import pymodel as M
+
+pytestmark = pytest.mark.gpu
+Q = M.Q
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import vpin_amd
+    c = vpin_amd.Context(0)
+    yield c
+    c.close()
+
+
+def _full_width(rng, n):
+    return [int.from_bytes(rng.bytes(40), "little") % Q for _ in range(n)]
+
+
+def _witness_like(rng, n):
+    vals = []
+    for _ in range(n):
+        k = rng.random()
+        vals.append(0 if k < 0.35 else 1 if k < 0.45 else int(rng.integers(0, 2**16)) if k < 0.5
+                    else Q - 1 if k < 0.53 else int(rng.integers(0, 2**62)) ** 4 % Q)
+    return vals
+
+
+def _edge_scalars(c):
+    """digits equal to 2^(c-1) (kept positive), just above it (negated, carry), runs of carries, the top window's largest values"""
+    half, full = 1 << (c - 1), 1 << c
+    vals = [0, 1, half, half + 1, full - 1, full, Q - 1, Q - 2, (Q - 1) // 2, 1 << 252, (1 << 252) - 1,
+            sum(half << (c * w) for w in range(252 // c)),              # every digit exactly 2^(c-1)
+            sum((half + 1) << (c * w) for w in range(252 // c)),        # every digit negated with a carry
+            sum((full - 1) << (c * w) for w in range(252 // c)) % Q,    # carries rippling through every window
+            (1 << 252) + (1 << 124)]
+    return [v % Q for v in vals]
+
+
+@pytest.mark.parametrize("c_bits", [0, 9, 10, 11, 12])
+def test_small_rows_vs_oracle(ctx, c_bits):
+    Rs, Ls = 32, 8
+    xyzt, og = O.gens_stream_xyzt(Rs + 2)
+    g = ctx.gens_create(xyzt)
+    rng = np.random.default_rng(100 + c_bits)
+    vals = _witness_like(rng, Ls * Rs)
+    edges = _edge_scalars(c_bits or 9)
+    vals[:len(edges)] = edges
+    Z = M.ints_to_table(vals)
+    blinds = M.ints_to_table(_full_width(rng, Ls))
+    dZ = ctx.upload(Z)
+    exp = O.hyrax_commit(Z, Ls, blinds, og, Rs + 1)
+    assert np.array_equal(ctx.hyrax_commit_pippenger(g, dZ, blinds, Rs + 1, c_bits=c_bits), exp)
+    # commit(gens, None): no blind
+    zero = np.zeros((Ls, 4), dtype=np.uint64)
+    assert np.array_equal(ctx.hyrax_commit_pippenger(g, dZ, None, 0, Ls=Ls, c_bits=c_bits), O.hyrax_commit(Z, Ls, zero, og, Rs + 1))
+    dZ.free()
+    g.free()
+
+
+@pytest.mark.parametrize("Rs,Ls,c_bits", [(256, 8, 0), (256, 8, 12), (1024, 4, 10), (4096, 16, 0), (4096, 4, 11), (4096, 4, 12)])
+def test_rows_vs_table_walk_and_oracle(ctx, Rs, Ls, c_bits):
+    xyzt, og = O.gens_stream_xyzt(Rs + 2)
+    g = ctx.gens_create(xyzt)
+    rng = np.random.default_rng(Rs + Ls + c_bits)
+    rows = [_full_width(rng, Rs) if i % 2 == 0 else _witness_like(rng, Rs) for i in range(Ls)]
+    rows[-1] = [rows[-1][0]] * Rs          # a constant row (the table walk's prefix-sum shortcut; plain buckets here)
+    if Ls > 2:
+        rows[1] = [0] * Rs                 # an all-zero row: every window empty
+        rows[2] = [int(rng.integers(0, 2)) for _ in range(Rs)]   # bits: only window 0 is populated
+    Z = M.ints_to_table([v for r in rows for v in r])
+    blinds = M.ints_to_table(_full_width(rng, Ls))
+    dZ = ctx.upload(Z)
+    walk = ctx.hyrax_commit(g, dZ, blinds, Rs + 1)
+    got = ctx.hyrax_commit_pippenger(g, dZ, blinds, Rs + 1, c_bits=c_bits)
+    assert np.array_equal(got, walk)
+    k = min(Ls, 3)
+    assert np.array_equal(got[:k], O.hyrax_commit(Z[:k * Rs], k, blinds[:k], og, Rs + 1))
+    dZ.free()
+    g.free()
+
+
+def test_more_pairs_than_the_persistent_grid(ctx):
+    """768 workgroups loop over rows x W (row, window) pairs: 64 rows x 29 windows = 1856 pairs, every workgroup takes several"""
+    Rs, Ls = 512, 64
+    xyzt, og = O.gens_stream_xyzt(Rs + 2)
+    g = ctx.gens_create(xyzt)
+    rng = np.random.default_rng(77)
+    Z = M.ints_to_table(_full_width(rng, Ls * Rs))
+    blinds = M.ints_to_table(_full_width(rng, Ls))
+    dZ = ctx.upload(Z)
+    got = ctx.hyrax_commit_pippenger(g, dZ, blinds, Rs + 1, c_bits=9)
+    assert np.array_equal(got, ctx.hyrax_commit(g, dZ, blinds, Rs + 1))
+    assert np.array_equal(got[:2], O.hyrax_commit(Z[:2 * Rs], 2, blinds[:2], og, Rs + 1))
+    dZ.free()
+    g.free()
+
+
+def test_refused_arguments(ctx):
+    import vpin_amd
+    xyzt, _ = O.gens_stream_xyzt(34)
+    g = ctx.gens_create(xyzt)
+    dZ = ctx.upload(np.zeros((64, 4), dtype=np.uint64))
+    with pytest.raises(vpin_amd.VpinError):
+        ctx.hyrax_commit_pippenger(g, dZ, None, 0, Ls=2, c_bits=8)       # fewer buckets than lanes
+    with pytest.raises(vpin_amd.VpinError):
+        ctx.hyrax_commit_pippenger(g, dZ, None, 0, Ls=1, c_bits=0)       # R = 64 > 34 generators
+    with pytest.raises(vpin_amd.VpinError):
+        ctx.hyrax_commit_pippenger(g, dZ, None, 0, Ls=3, c_bits=0)       # 64 scalars are not 3 rows
+    dZ.free()
+    g.free()

@@ -110,6 +110,7 @@ def lib():
     L.vpin_gens_count.restype = C.c_size_t
     L.vpin_hyrax_commit.argtypes = [vp, vp, vp, vp, C.c_size_t, C.c_size_t, vp]
     L.vpin_hyrax_commit_pair.argtypes = [vp, vp, vp, vp, vp, vp, C.c_size_t, C.c_size_t, vp, vp, vp]
+    L.vpin_hyrax_commit_pippenger.argtypes = [vp, vp, vp, vp, C.c_size_t, C.c_size_t, C.c_int, vp]
     L.vpin_gens_msm.argtypes = [vp, vp, vp, C.c_size_t, C.c_size_t, vp, vp]
     L.vpin_poly_bound.argtypes = [vp, vp, vp, C.c_size_t, vp]
     L.vpin_sat_prove.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_size_t, C.POINTER(C.c_size_t), vp, vp, vp, vp, vp]
@@ -711,6 +712,15 @@ class Context:
         out = np.zeros((Ls, 32), dtype=np.uint8)
         _chk(lib().vpin_hyrax_commit(self.h, gens.h, Z.h, b.ctypes.data_as(C.c_void_p), Ls, blind_base,
                                      out.ctypes.data_as(C.c_void_p)), "vpin_hyrax_commit")
+        return out
+
+    def hyrax_commit_pippenger(self, gens, Z, blinds, blind_base, Ls=None, c_bits=0):
+        """vpin_hyrax_commit_pippenger: the same rows by bucket accumulation (blinds None: commit(gens, None) of Ls rows)"""
+        b = None if blinds is None else np.ascontiguousarray(blinds, dtype=np.uint64).reshape(-1, 4)
+        Ls = b.shape[0] if b is not None else int(Ls)
+        out = np.zeros((Ls, 32), dtype=np.uint8)
+        _chk(lib().vpin_hyrax_commit_pippenger(self.h, gens.h, Z.h, b.ctypes.data_as(C.c_void_p) if b is not None else None, Ls,
+                                               blind_base, c_bits, out.ctypes.data_as(C.c_void_p)), "vpin_hyrax_commit_pippenger")
         return out
 
     def hyrax_commit_pair(self, gens, Za, Zb, blinds_a, blinds_b, blind_base):

@@ -208,6 +208,13 @@ size_t gens_msm_parts_scratch_bytes(size_t rows, size_t ncols);
 int gens_msm_parts_launch(vpin_ctx* c, const vpin_gens* g, const fq* d_scalars, size_t rows, size_t ncols, void* scratch,
                           uint8_t* parts_xyzt, bool host_mapped = false);
 
+// row commitments by Pippenger's bucket method from a compact array of the generators (msm_pip.hip); cbits 0: by row length
+struct ge_niels;
+struct ge_ext;
+int pip_rows(vpin_ctx* c, const ge_niels* d_gn, const fq* dZ, size_t rows, size_t stride, size_t ncols, const fq* d_extra, int n_extra,
+             int cbits, ge_ext* d_points, unsigned long long* d_adds);
+int pip_default_bits(size_t n);
+
 // device side of the bullet reduction (bullet.hip)
 struct BulletState;
 int bullet_begin(vpin_ctx* c, const uint8_t* x_mont, const uint8_t* a_mont, size_t R, BulletState** out);

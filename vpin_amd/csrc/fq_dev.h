@@ -351,6 +351,23 @@ __device__ __forceinline__ fq fq_mul_const(const fq& d, const uint32_t (*tt)[8])
   return o;
 }
 
+// Montgomery form -> canonical integer (Scalar::to_bytes, ristretto255.rs:426-438):
+// montgomery_reduce(a, 0) = a * R^-1 mod q
+__device__ __forceinline__ fq fq_from_mont(const fq& a) {
+  uint32_t t[9];
+#pragma unroll
+  for (int i = 0; i < 8; i++) t[i] = a.v[i];
+  t[8] = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    VPIN_MONT_STEP(t, 0u);
+  }
+  fq r;
+#pragma unroll
+  for (int i = 0; i < 8; i++) r.v[i] = t[i];
+  return fq_cond_sub_q(r);
+}
+
 // ---- wave / block reductions (64-wide wavefront) ----------------------------------
 
 __device__ __forceinline__ fq fq_shfl_xor(const fq& a, int mask) {

@@ -16,6 +16,7 @@
 // vartime MSM.  One 256-thread workgroup per row; per-thread partial sums are combined by
 // an LDS tree.  Integer-ALU bound (~8 field multiplies per table add); no MFMA.
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 #include <condition_variable>
 #include <cstring>
@@ -27,6 +28,7 @@
 #include "ctx.h"
 #include "fp_dev.h"
 #include "fp10_dev.h"
+#include "ge_tree_dev.h"
 #include "mailbox_dev.h"
 
 #ifndef VPIN_NIELS_SLOT
@@ -173,23 +175,6 @@ __global__ __launch_bounds__(64) void gens_table_kernel(const ge_ext* __restrict
 
 // ---- scalar handling --------------------------------------------------------------------
 
-// Montgomery form -> canonical integer (Scalar::to_bytes, ristretto255.rs:426-438):
-// montgomery_reduce(a, 0) = a * R^-1 mod q
-__device__ __forceinline__ fq fq_from_mont(const fq& a) {
-  uint32_t t[9];
-#pragma unroll
-  for (int i = 0; i < 8; i++) t[i] = a.v[i];
-  t[8] = 0;
-#pragma unroll
-  for (int i = 0; i < 8; i++) {
-    VPIN_MONT_STEP(t, 0u);
-  }
-  fq r;
-#pragma unroll
-  for (int i = 0; i < 8; i++) r.v[i] = t[i];
-  return fq_cond_sub_q(r);
-}
-
 __device__ __forceinline__ bool fq_same(const fq& a, const fq& b) {
   uint32_t o = 0;
 #pragma unroll
@@ -335,61 +320,6 @@ constexpr int kMsmBlock = 256;
 // extra dynamic LDS of the row-commitment kernels when other contexts prove on the device (vpin_ctx_set_shared_device): with
 // it one workgroup per CU instead of three (a wave per SIMD), the rest of every CU stays with the other lanes' kernels
 constexpr unsigned kSharedPad = 40000u;
-// ---- block tree with four lanes per addition -----------------------------------------------------------------
-// The few-row MSMs are latency bound: one wave per SIMD issues a modular product in ~0.5 us, and an addition of two
-// extended points is nine of them in a row on one lane.  Here the four products of each half of the addition
-// (add-2008-hwcd-3: A,B,C,D then X3,Y3,Z3,T3) run on the four lanes of a quad -- same code path, operands picked by the
-// lane's role, the halves exchanged with lane shuffles -- so a level costs three products instead of nine.
-__device__ __forceinline__ fp fp_shfl_from(const fp& a, int src) {
-  fp r;
-#pragma unroll
-  for (int i = 0; i < 8; i++) r.v[i] = __shfl(a.v[i], src, 64);
-  return r;
-}
-__device__ __forceinline__ fp fp_pick(bool c, const fp& a, const fp& b) {
-  fp r;
-#pragma unroll
-  for (int i = 0; i < 8; i++) r.v[i] = c ? a.v[i] : b.v[i];
-  return r;
-}
-// sh[0] = sum of sh[0..n) (n a power of two, n <= blockDim.x); every thread of the block calls it.
-// split > 0 (a power of two below n): the entries alternate in runs of `split` between two sums (index & split); the
-// level that would mix them is skipped and the levels below it reduce both runs: sh[0] = sum of the entries with
-// (index & split) == 0, sh[split] = sum of the others.
-__device__ __forceinline__ void ge_tree_quad(ge_ext* sh, int n, int split = 0) {
-  const int role = threadIdx.x & 3, qbase = (threadIdx.x & 63) & ~3;
-  const fp* shf = reinterpret_cast<const fp*>(sh);
-  fp* shw = reinterpret_cast<fp*>(sh);
-  for (int s = n / 2; s >= 1; s >>= 1) {
-    if (s == split) continue;
-    const int items = s < split ? 2 * s : s;
-    for (int w = threadIdx.x >> 2; w < items; w += (int)(blockDim.x >> 2)) {
-      const int i = w < s ? w : split + (w - s);
-      // role 0: (Y1-X1)(Y2-X2)   role 1: (Y1+X1)(Y2+X2)   role 2: 2d T1 T2   role 3: 2 Z1 Z2
-      const int f0 = role < 2 ? 1 : (role == 2 ? 3 : 2);  // Y | T | Z
-      const fp p0 = shf[4 * i + f0], q0 = shf[4 * (i + s) + f0];
-      fp u = p0, v = q0;
-      if (role < 2) {  // uniform per quad pair: both take the same instructions, the select below is per lane
-        const fp p1 = shf[4 * i], q1 = shf[4 * (i + s)];
-        u = fp_pick(role == 0, fp_sub(p0, p1), fp_add(p0, p1));
-        v = fp_pick(role == 0, fp_sub(q0, q1), fp_add(q0, q1));
-      }
-      fp m = fp_mul(u, v);
-      m = fp_mul(m, fp_pick(role == 2, FP_D2(), fp_one()));
-      m = fp_pick(role == 3, fp_add(m, m), m);
-      const fp a = fp_shfl_from(m, qbase), b = fp_shfl_from(m, qbase + 1), c = fp_shfl_from(m, qbase + 2),
-               d = fp_shfl_from(m, qbase + 3);
-      const fp E = fp_sub(b, a), H = fp_add(b, a), F = fp_sub(d, c), G = fp_add(d, c);
-      // X3 = E F, Y3 = G H, Z3 = F G, T3 = E H
-      u = fp_pick(role == 0 || role == 3, E, fp_pick(role == 1, G, F));
-      v = fp_pick(role == 0, F, fp_pick(role == 2, G, H));
-      shw[4 * i + role] = fp_mul(u, v);
-    }
-    __syncthreads();
-  }
-}
-
-
 // rows x (ncols scalars from Z with row stride `stride`) + optional extra scalars on bases
 // [extra_base0, extra_base0 + n_extra).  out[row] = sum_j s[row][j] * g_j  (extended coords)
 constexpr int kSeg = 8192;  // scalars per compaction segment (uint16 indices, 16 KiB of LDS)
@@ -1034,6 +964,15 @@ __global__ __launch_bounds__(64) void ge_add_rows_kernel(const ge_ext* __restric
   fp_store(&out[i].X, r.X); fp_store(&out[i].Y, r.Y); fp_store(&out[i].Z, r.Z); fp_store(&out[i].T, r.T);
 }
 
+// out[j] = generator j (j < n), out[n] = generator blind_base (n_extra = 1): multiple 1 of window 0 in the base's table row
+__global__ __launch_bounds__(256) void pip_gens_kernel(TableView tv, size_t n, size_t blind_base, int n_extra, ge_niels* __restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n + (size_t)n_extra) return;
+  const TableSeg sg = table_seg(tv, i < n ? i : blind_base);
+  const ge_niels e = niels_load(sg.t + sg.j * (size_t)sg.E);
+  fp_store(&out[i].ypx, e.ypx); fp_store(&out[i].ymx, e.ymx); fp_store(&out[i].xy2d, e.xy2d);
+}
+
 // RistrettoPoint::compress for n points, one thread each; also emits canonical X|Y|Z|T
 __global__ __launch_bounds__(64) void ge_compress_kernel(const ge_ext* __restrict__ pts, size_t n, fp* __restrict__ out32,
                                                          fp* __restrict__ out_xyzt) {
@@ -1311,6 +1250,13 @@ int vpin_gens_shared(vpin_ctx* c, const char* label, const uint8_t* gens_xyzt, s
       g_reg_cv.wait(lock);
     }
     if (!gens_xyzt) return VPIN_EINVAL;
+    // A longer prefix of a stream that already has a table: the shorter table stays (views of other contexts point into it)
+    // and the new one is built beside it.  Said once: a service should ask for its largest shape first (vpin_spark_prepare).
+    static std::atomic<bool> said{false};
+    for (auto& e : g_reg)
+      if (e.device == c->device && e.label == label && !said.exchange(true))
+        fprintf(stderr, "vpin_gens_shared: a table of \"%s\" for %zu generators is built beside the one for %zu (both stay allocated): "
+                        "call vpin_spark_prepare / vpin_sat_prepare with the largest shape first\n", label, nb, e.g->nb);
     g_building.push_back(Building{c->device, label, nb});
   }
   // Built with the registry unlocked: other contexts of the process keep finding their tables, and building tables of other
@@ -1440,6 +1386,33 @@ int vpin_hyrax_commit(vpin_ctx* c, const vpin_gens* g, const vpin_table* Z, cons
   if (dbl.alloc(L * 32) || dpts.alloc(L * sizeof(ge_ext)) || dout.alloc(L * 32)) return VPIN_ENOMEM;
   VPIN_HIP_TRY(hipMemcpyAsync(dbl.p, blinds, L * 32, hipMemcpyHostToDevice, c->stream));
   int rc = msm_rows(c, g, Z->d, L, R, R, (const fq*)dbl.p, 1, blind_base, (ge_ext*)dpts.p);
+  if (rc) return rc;
+  hipLaunchKernelGGL(ge_compress_kernel, dim3((unsigned)((L + 63) / 64)), dim3(64), 0, c->stream, (const ge_ext*)dpts.p, L,
+                     (fp*)dout.p, (fp*)nullptr);
+  VPIN_HIP_TRY(hipGetLastError());
+  VPIN_HIP_TRY(hipMemcpyAsync(out_compressed, dout.p, L * 32, hipMemcpyDeviceToHost, c->stream));
+  VPIN_HIP_TRY(hipStreamSynchronize(c->stream));
+  return VPIN_OK;
+}
+
+
+// the same commitment by Pippenger's bucket method from the generators alone (msm_pip.hip): same bytes, no table walked
+int vpin_hyrax_commit_pippenger(vpin_ctx* c, const vpin_gens* g, const vpin_table* Z, const uint8_t* blinds, size_t L,
+                                size_t blind_base, int c_bits, uint8_t* out_compressed) {
+  if (!c || !g || !Z || !Z->d || !out_compressed || L == 0) return VPIN_EINVAL;
+  if (Z->len % L != 0) return VPIN_ESHAPE;
+  const size_t R = Z->len / L;
+  if (R > g->nb || (blinds && blind_base >= g->nb)) return VPIN_ESHAPE;
+  (void)hipSetDevice(c->device);
+  const int n_extra = blinds ? 1 : 0;
+  DevBuf dbl(c), dpts(c), dout(c), dgn(c);
+  if (dbl.alloc(L * 32) || dpts.alloc(L * sizeof(ge_ext)) || dout.alloc(L * 32) || dgn.alloc((R + 1) * sizeof(ge_niels))) return VPIN_ENOMEM;
+  if (blinds) VPIN_HIP_TRY(hipMemcpyAsync(dbl.p, blinds, L * 32, hipMemcpyHostToDevice, c->stream));
+  // the generators themselves: entry (window 0, multiple 1) of every base's table row, packed densely (96 B each)
+  hipLaunchKernelGGL(pip_gens_kernel, dim3((unsigned)((R + 1 + 255) / 256)), dim3(256), 0, c->stream, view(g), R, blind_base, n_extra,
+                     (ge_niels*)dgn.p);
+  int rc = pip_rows(c, (const ge_niels*)dgn.p, Z->d, L, R, R, (const fq*)dbl.p, n_extra, c_bits, (ge_ext*)dpts.p,
+                    c->prof_count_adds ? c->d_add_count : nullptr);
   if (rc) return rc;
   hipLaunchKernelGGL(ge_compress_kernel, dim3((unsigned)((L + 63) / 64)), dim3(64), 0, c->stream, (const ge_ext*)dpts.p, L,
                      (fp*)dout.p, (fp*)nullptr);

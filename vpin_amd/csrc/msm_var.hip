@@ -18,22 +18,6 @@
 
 namespace vpin {
 
-// Montgomery form -> canonical integer (msm.hip has the same helper for the window walks)
-__device__ __forceinline__ fq fqv_from_mont(const fq& a) {
-  uint32_t t[9];
-#pragma unroll
-  for (int i = 0; i < 8; i++) t[i] = a.v[i];
-  t[8] = 0;
-#pragma unroll
-  for (int i = 0; i < 8; i++) {
-    VPIN_MONT_STEP(t, 0u);
-  }
-  fq r;
-#pragma unroll
-  for (int i = 0; i < 8; i++) r.v[i] = t[i];
-  return fq_cond_sub_q(r);
-}
-
 // d = -121665/121666 (RFC 9496 section 4)
 __device__ __forceinline__ fp FP_D() { return fp_const(0x135978a3u, 0x75eb4dcau, 0x4141d8abu, 0x00700a4du, 0x7779e898u, 0x8cc74079u, 0x2b6ffe73u, 0x52036ceeu); }
 
@@ -54,49 +38,6 @@ __device__ __noinline__ bool ge_decompress(const fp& s_in, ge_ext& out) {
   if (!sq || fp_is_negative(t) || fp_is_zero(y)) return false;
   out.X = x; out.Y = y; out.Z = one; out.T = t;
   return true;
-}
-
-// dbl-2008-hwcd in the ten-limb form: 4 squarings + 4 products; input 1x, output 1x
-__device__ __forceinline__ ge10 ge10_double(const ge10& p) {
-  const fe10 A = fe10_mul(p.X, p.X), B = fe10_mul(p.Y, p.Y), ZZ = fe10_mul(p.Z, p.Z);
-  const fe10 C = fe10_add(ZZ, ZZ);                       // 2x
-  const fe10 xy = fe10_add(p.X, p.Y);                    // 2x
-  const fe10 S = fe10_mul(xy, xy);                       // (X+Y)^2, 1x
-  const fe10 H = fe10_add(A, B);                         // 2x      (a = -1: H = -(A+B) up to the sign folded in below)
-  const fe10 E = fe10_sub(H, S);                         // A + B - (X+Y)^2 = -2XY          (4x as fe10_sub's bound; S is 1x)
-  const fe10 G = fe10_sub(A, B);                         // A - B                           (3x)
-  const fe10 F = fe10_add(C, G);                         // C + G                           (5x: too wide as a first factor ...)
-  // ... so bring F down before it multiplies: one product by one costs the same as any, a carry pass is cheaper
-  fe10 Fr = F;
-  {
-    uint32_t c;
-#pragma unroll
-    for (int i = 0; i < 9; i++) {
-      const int bits = (i & 1) ? 25 : 26;
-      c = Fr.v[i] >> bits;
-      Fr.v[i] &= (1u << bits) - 1u;
-      Fr.v[i + 1] += c;
-    }
-    c = Fr.v[9] >> 25;
-    Fr.v[9] &= 0x1ffffffu;
-    Fr.v[0] += 19u * c;                                  // Fr: 1x (+ a few bits on limb 0)
-  }
-  // with e = -E = 2XY, g = -G = B - A, f = -F... the signs: X3 = E F, Y3 = G H', Z3 = F G, T3 = E H' where H' = -(A+B)
-  // for a = -1 (D = -A): E = (X+Y)^2 - A - B, G = D + B = B - A, F = G - C, H' = D - B = -(A + B).
-  // Above: E_ = -E, G_ = -G, F_ = C + G_ = -F, H = -H'.  Products of two negated factors keep their sign:
-  //   X3 = E F = E_ F_,  Y3 = G H' = G_ H,  Z3 = F G = F_ G_,  T3 = E H' = E_ H.
-  ge10 r;
-  r.X = fe10_mul(E, Fr);   // E 4x first, Fr 1x second
-  r.Y = fe10_mul(G, H);    // 3x, 2x
-  r.Z = fe10_mul(G, Fr);   // 3x, 1x
-  r.T = fe10_mul(E, H);    // 4x, 2x
-  return r;
-}
-
-__device__ __forceinline__ ge10 ge10_from_ext(const ge_ext& p) {
-  ge10 r;
-  r.X = fe10_from_fp(p.X); r.Y = fe10_from_fp(p.Y); r.Z = fe10_from_fp(p.Z); r.T = fe10_from_fp(p.T);
-  return r;
 }
 
 constexpr int kVarBlock = 64;  // one wave per workgroup: 16384 points fill the chip
@@ -152,7 +93,7 @@ __global__ __launch_bounds__(kVarBlock) void msm_var_kernel(const fq* __restrict
   if (i < n) {
     ge_ext P;
     fq s = fq_load(scalars + i);
-    if (mont) s = fqv_from_mont(s);
+    if (mont) s = fq_from_mont(s);
     const bool ok = ge_decompress(fp_load(points + i), P);
     if (!ok) atomicOr(bad, 1u);
     if (ok && !fq_is_zero(s)) {

@@ -144,6 +144,35 @@ def test_constant_rows_use_the_prefix_sum_base(ctx):
     g.free()
 
 
+@pytest.mark.parametrize("budget_gb,bits,windows", [(1, 6, 43), (4, 7, 37), (10, 8, 32)])
+def test_narrowest_windows_under_a_tiny_budget(ctx, budget_gb, bits, windows):
+    """16386 generators under a table budget far below the 71 GB of 12-bit windows (a nearly full device: gens_build caps every
+    table at a third of the free memory): 8-, 7- and 6-bit windows -- the narrowest, taken even when over budget -- give the
+    oracle's bytes.  (Round 5: below the 7-bit table's 3.7 GB the layout said c = 6 with the 7-bit table's 37 windows of 64 entries.)"""
+    Rs, Ls = 16384, 2
+    xyzt, og = O.gens_stream_xyzt(Rs + 2)
+    g = ctx.gens_shared(f"test_tiny_budget_{budget_gb}", xyzt, budget_gb)
+    lay = (C.c_size_t * 6)()
+    L = __import__("vpin_amd").lib()
+    L.vpin_gens_layout.argtypes = [C.c_void_p, C.c_void_p]
+    assert L.vpin_gens_layout(g.h, lay) == 0
+    assert (lay[0], lay[1]) == (bits, windows), list(lay)
+    rng = np.random.default_rng(budget_gb)
+    vals = structured_scalars(rng, Ls * Rs)
+    vals[:6] = [Q - 1, (Q - 1) // 2, 1 << 252, (1 << 252) - 1, 1, 0]
+    Z = M.ints_to_table(vals)
+    blinds = M.ints_to_table([int(rng.integers(0, 2**62)) ** 4 % Q for _ in range(Ls)])
+    dZ = ctx.upload(Z)
+    got = ctx.hyrax_commit(g, dZ, blinds, Rs + 1)
+    assert np.array_equal(got, O.hyrax_commit(Z, Ls, blinds, og, Rs + 1))
+    assert np.array_equal(ctx.hyrax_commit_pippenger(g, dZ, blinds, Rs + 1), got)
+    # a few-row MSM over the same table (the kernels that split a scalar's windows over lanes)
+    s = M.ints_to_table(vals[:64])
+    one = ctx.gens_msm(g, s, 1, 64)
+    assert np.array_equal(one, O.hyrax_commit(s, 1, np.zeros((1, 4), dtype=np.uint64), og, Rs + 1))
+    dZ.free()
+
+
 def test_shared_device_hint_changes_nothing_but_occupancy(ctx, gens34):
     """vpin_ctx_set_shared_device only lowers the MSM's workgroups per CU: same commitment bytes"""
     g, og = gens34

@@ -52,6 +52,7 @@ def main():
     ap.add_argument("--rows-large", type=int, default=2048)
     ap.add_argument("--loops", type=int, default=3)
     ap.add_argument("--shapes", default="4096,16384")
+    ap.add_argument("--narrow", default="40,20,10,7,4,1", help="table budgets in GB for the narrow-window walks at R = 16384 ('' = none)")
     a = ap.parse_args()
     os.environ.setdefault("VPIN_GENS_BUDGET_GB", "96")   # the production width: 12-bit windows over 16386 generators are 71 GB
     import ctypes as C
@@ -64,7 +65,8 @@ def main():
         L = a.rows_small if R <= 4096 else a.rows_large
         t0 = time.perf_counter()
         stream = hashlib.shake_256(b"ubench_pippenger").digest(64 * (R + 2))
-        g = ctx.gens_create(ctx.gens_map_stream(stream))
+        xyzt = ctx.gens_map_stream(stream)
+        g = ctx.gens_create(xyzt)
         lay6 = (C.c_size_t * 6)()
         vpin_amd.lib().vpin_gens_layout.argtypes = [C.c_void_p, C.c_void_p]
         vpin_amd.lib().vpin_gens_layout(g.h, lay6)
@@ -75,10 +77,22 @@ def main():
             rng = np.random.default_rng(R + len(kind))
             dZ = ctx.upload(scalars(kind, L * R, rng))
             variants = [("walk", None)] + [("pippenger", c) for c in (9, 10, 11, 12)]
+            # the walk over NARROWER tables (what a part without 71 GB to spare would build): budgets in GB
+            narrow = {}
+            if R >= 16384 and a.narrow:
+                for gb in [int(x) for x in a.narrow.split(",")]:
+                    gn = ctx.gens_shared(f"ubench_pippenger_{R}_{gb}", xyzt, gb)
+                    vpin_amd.lib().vpin_gens_layout(gn.h, lay6)
+                    narrow[f"walk, {gb} GB budget: c = {lay6[0]}, W = {lay6[1]}"] = gn
+                variants += [(nm, gn) for nm, gn in narrow.items()]
             ref = None
             for name, c in variants:
-                run = (lambda: ctx.hyrax_commit(g, dZ, zero_bl, R + 1)) if c is None else \
-                      (lambda c=c: ctx.hyrax_commit_pippenger(g, dZ, zero_bl, R + 1, c_bits=c))
+                if c is None:
+                    run = lambda: ctx.hyrax_commit(g, dZ, zero_bl, R + 1)
+                elif isinstance(c, int):
+                    run = lambda c=c: ctx.hyrax_commit_pippenger(g, dZ, zero_bl, R + 1, c_bits=c)
+                else:
+                    run = lambda gn=c: ctx.hyrax_commit(gn, dZ, zero_bl, R + 1)
                 out = run()   # warm (and the bytes)
                 dig = hashlib.sha256(out.tobytes()).hexdigest()
                 if ref is None:
@@ -96,12 +110,12 @@ def main():
                 ctx.prof_enable(False)
                 ms = (st.get("msm", {}).get("ms", 0.0)) / a.loops
                 adds = (st.get("msm_rows", {}).get("units", 0.0)) / a.loops
-                r = dict(R=R, rows=L, scalars=kind, variant=name if c is None else f"pippenger c={c}", kernel_ms=round(ms, 3),
+                r = dict(R=R, rows=L, scalars=kind, variant=f"pippenger c={c}" if isinstance(c, int) else name, kernel_ms=round(ms, 3),
                          wall_ms=round((t2 - t1) * 1e3 / a.loops, 3), counted_adds=adds, G_adds_s=round(adds / ms / 1e6, 3) if ms else None,
                          G_scalars_s=round(L * R / ms / 1e6, 4) if ms else None, adds_per_scalar=round(adds / (L * R), 3),
                          bytes_equal_walk=(dig == ref), sclk_mhz=pw.get("sclk_mhz_median"), watts=pw.get("watts_median"))
                 results.append(r)
-                print(f"  {kind:10s} {r['variant']:16s} {r['kernel_ms']:10.2f} ms  {r['G_scalars_s']} G scalars/s  {r['adds_per_scalar']:6.2f} counted adds/scalar "
+                print(f"  {kind:10s} {r['variant']:38s} {r['kernel_ms']:10.2f} ms  {r['G_scalars_s']} G scalars/s  {r['adds_per_scalar']:6.2f} counted adds/scalar "
                       f" {r['G_adds_s']} G adds/s  sclk {r['sclk_mhz']} W {r['watts']}  bytes {'ok' if r['bytes_equal_walk'] else 'DIFF'}", flush=True)
             dZ.free()
         g.free()

@@ -1110,12 +1110,18 @@ static int gens_build_once(vpin_ctx* c, const uint8_t* gens_xyzt, size_t nb, siz
   // windows when the budget allows, the rest 8-bit ones: 71 + 6.4 GB for 32 786 bases, the 77 GB a uniform 11-bit
   // table took, and 22 instead of 24 table adds per scalar where the time goes.
   constexpr size_t kSplitBases = 16386;
+  // the widest windows (<= cmax bits) whose table fits the budget; 6 bits (43 windows of 32 entries: 2.2 GB for 16386
+  // generators) at the least, whatever the budget -- that allocation then succeeds or the build fails with VPIN_ENOMEM.
+  // W and E always belong to the width returned (round 5: a budget below the 7-bit table used to leave 7-bit W and E beside
+  // c = 6 -- a table too short for its scalars and WRONG sums; found by tools/ubench_pippenger.py's 1 GB walk, see
+  // test_narrowest_windows_under_a_tiny_budget)
   auto fit = [&](size_t n, size_t bud, int cmax, int* c_, int* W_, int* E_) {
-    for (*c_ = cmax; *c_ > 6; (*c_)--) {
-      *W_ = (254 + *c_ - 1) / *c_;
-      *E_ = 1 << (*c_ - 1);
-      if (n * (size_t)*W_ * (size_t)*E_ * sizeof(niels_slot) <= bud) break;
-    }
+    int cc = cmax;
+    for (; cc > 6; cc--)
+      if (n * (size_t)((254 + cc - 1) / cc) * ((size_t)1 << (cc - 1)) * sizeof(niels_slot) <= bud) break;
+    *c_ = cc;
+    *W_ = (254 + cc - 1) / cc;
+    *E_ = 1 << (cc - 1);
   };
   g->split = nbt;
   fit(nb, budget, cmax, &g->c, &g->W, &g->E);

@@ -62,6 +62,9 @@ def test_e_mult_with_150_gb_held_by_another_tenant():
     tight = _run(250)  # ~35 GB free: the budgets shrink to a third of that and the proof still has room
     assert tight["sha"] == want["snark_sha256"]
     assert tight["window_bits"] < 12, tight
+    tighter = _run(270)  # ~17 GB free when the process starts, under 2 GB when it ends: 8-bit windows, the same bytes
+    assert tighter["sha"] == want["snark_sha256"] and tighter["comm"] == want["comm_sha256"]
+    assert tighter["window_bits"] <= 8, tighter
 
 
 SCRIPT_TWO_TRACES = r"""

@@ -115,3 +115,30 @@ def test_refused_arguments(ctx):
         ctx.hyrax_commit_pippenger(g, dZ, None, 0, Ls=3, c_bits=0)       # 64 scalars are not 3 rows
     dZ.free()
     g.free()
+
+
+@pytest.mark.parametrize("mode", ["1", "11"])
+def test_whole_snarks_with_every_row_commitment_by_buckets(ctx, mode):
+    """VPIN_MSM_PIPPENGER: the provers' row commitments (witness, the SPARK polynomials, the derefs polynomial without its
+    hot-column shortcut) by the bucket method instead of the table walk -- the SNARKs are the oracle's, byte for byte"""
+    import hashlib
+    import json
+    import os
+    from vpin_amd import gadgets as G
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "config_digests.json")) as f:
+        gold = json.load(f)["cases"]
+    seed_c, seed_p = bytes(range(64)), bytes((7 * i + 3) % 256 for i in range(64))
+    os.environ["VPIN_MSM_PIPPENGER"] = mode
+    try:
+        for key in ("3_32-add", "3_32-mult", "A-mult", "7_256-mult") + (("E-mult",) if mode == "1" else ()):
+            g = gold[key]
+            inp = G.synthetic_mult_inputs(g["label"]) if g["kind"] == "mult" else G.synthetic_add_inputs(g["label"])
+            d = ctx.gadget_point_mult_dev(*inp) if g["kind"] == "mult" else ctx.gadget_point_add_dev(*inp)
+            try:
+                res = d.snark_prove(seed_c, seed_p)
+            finally:
+                d.free()
+            assert hashlib.sha256(res["proof"]).hexdigest() == g["snark_sha256"], key
+            assert hashlib.sha256(res["comm"]).hexdigest() == g["comm_sha256"], key
+    finally:
+        del os.environ["VPIN_MSM_PIPPENGER"]

@@ -1331,8 +1331,30 @@ static inline TableView view(const vpin_gens* g) {
   return TableView{g->table, g->table_hi, g->split, g->nbt, g->c, g->W, g->E, g->c_hi, g->W_hi, g->E_hi, g->nb};
 }
 
+// VPIN_MSM_PIPPENGER = c (9..12, or 1 = the default width): every row commitment of the provers by the bucket method of
+// msm_pip.hip instead of the table walk (few-row MSMs, the bullet reduction and single-base terms stay on the table).  For
+// parity runs of whole proofs (tests/test_gpu_msm_pippenger.py) and A/B timing; read per call.
+static int pip_mode() {
+  const char* e = getenv("VPIN_MSM_PIPPENGER");
+  const int v = e ? atoi(e) : 0;
+  return v <= 0 ? 0 : (v >= 9 && v <= 12 ? v : -1);  // -1: the default width
+}
+
+static int msm_rows_pip(vpin_ctx* c, const vpin_gens* g, const fq* dZ, size_t rows, size_t stride, size_t ncols, const fq* d_extra,
+                        int n_extra, size_t extra_base0, int cbits, ge_ext* d_points) {
+  DevBuf dgn(c);
+  if (dgn.alloc((ncols + 1) * sizeof(ge_niels))) return VPIN_ENOMEM;
+  hipLaunchKernelGGL(pip_gens_kernel, dim3((unsigned)((ncols + 1 + 255) / 256)), dim3(256), 0, c->stream, view(g), ncols, extra_base0,
+                     n_extra, (ge_niels*)dgn.p);
+  return pip_rows(c, (const ge_niels*)dgn.p, dZ, rows, stride, ncols, d_extra, n_extra, cbits, d_points,
+                  c->prof_count_adds ? c->d_add_count : nullptr);
+}
+
 static int msm_rows(vpin_ctx* c, const vpin_gens* g, const fq* dZ, size_t rows, size_t stride, size_t ncols,
                     const fq* d_extra, int n_extra, size_t extra_base0, ge_ext* d_points) {
+  if (const int pm = pip_mode())
+    if (n_extra <= 1 && ncols + (size_t)n_extra <= 32768)
+      return msm_rows_pip(c, g, dZ, rows, stride, ncols, d_extra, n_extra, extra_base0, pm < 0 ? 0 : pm, d_points);
   double nz_est = (double)rows * ((double)ncols + n_extra);
   size_t total = ncols + (size_t)n_extra;
   int chunks = 1;
@@ -1411,14 +1433,10 @@ int vpin_hyrax_commit_pippenger(vpin_ctx* c, const vpin_gens* g, const vpin_tabl
   if (R > g->nb || (blinds && blind_base >= g->nb)) return VPIN_ESHAPE;
   (void)hipSetDevice(c->device);
   const int n_extra = blinds ? 1 : 0;
-  DevBuf dbl(c), dpts(c), dout(c), dgn(c);
-  if (dbl.alloc(L * 32) || dpts.alloc(L * sizeof(ge_ext)) || dout.alloc(L * 32) || dgn.alloc((R + 1) * sizeof(ge_niels))) return VPIN_ENOMEM;
+  DevBuf dbl(c), dpts(c), dout(c);
+  if (dbl.alloc(L * 32) || dpts.alloc(L * sizeof(ge_ext)) || dout.alloc(L * 32)) return VPIN_ENOMEM;
   if (blinds) VPIN_HIP_TRY(hipMemcpyAsync(dbl.p, blinds, L * 32, hipMemcpyHostToDevice, c->stream));
-  // the generators themselves: entry (window 0, multiple 1) of every base's table row, packed densely (96 B each)
-  hipLaunchKernelGGL(pip_gens_kernel, dim3((unsigned)((R + 1 + 255) / 256)), dim3(256), 0, c->stream, view(g), R, blind_base, n_extra,
-                     (ge_niels*)dgn.p);
-  int rc = pip_rows(c, (const ge_niels*)dgn.p, Z->d, L, R, R, (const fq*)dbl.p, n_extra, c_bits, (ge_ext*)dpts.p,
-                    c->prof_count_adds ? c->d_add_count : nullptr);
+  int rc = msm_rows_pip(c, g, Z->d, L, R, R, (const fq*)dbl.p, n_extra, blind_base, c_bits, (ge_ext*)dpts.p);
   if (rc) return rc;
   hipLaunchKernelGGL(ge_compress_kernel, dim3((unsigned)((L + 63) / 64)), dim3(64), 0, c->stream, (const ge_ext*)dpts.p, L,
                      (fp*)dout.p, (fp*)nullptr);
@@ -1447,6 +1465,7 @@ int hyrax_commit_derefs_hot(vpin_ctx* c, const vpin_gens* g, const vpin_table* Z
   if (nrows == (size_t)-1) { row0 = 0; nrows = L; row_step = 1; }  // all rows
   if (row_step == 0 || (nrows && row0 + (nrows - 1) * row_step >= L)) return VPIN_ESHAPE;
   if (nrows == 0) return VPIN_OK;
+  if (pip_mode()) return hyrax_commit_rows_strided(c, g, Z, L, row0, nrows, row_step, out_compressed, z_rows);  // plain rows, buckets
   (void)hipSetDevice(c->device);
   DevBuf dpts(c), dout(c), dT(c);
   if (dpts.alloc(nrows * sizeof(ge_ext)) || dout.alloc(nrows * 32)) return VPIN_ENOMEM;

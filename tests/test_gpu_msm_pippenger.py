@@ -97,6 +97,13 @@ def test_more_pairs_than_the_persistent_grid(ctx):
     dZ = ctx.upload(Z)
     got = ctx.hyrax_commit_pippenger(g, dZ, blinds, Rs + 1, c_bits=9)
     assert np.array_equal(got, ctx.hyrax_commit(g, dZ, blinds, Rs + 1))
+    # the rows in chunks (long commitments bound their digit buffer to 2 GiB): 64 rows as 7 + 7 + .. + 1
+    import os
+    os.environ["VPIN_PIP_DIGIT_BYTES"] = str(7 * 29 * (Rs + 1) * 2)
+    try:
+        assert np.array_equal(ctx.hyrax_commit_pippenger(g, dZ, blinds, Rs + 1, c_bits=9), got)
+    finally:
+        del os.environ["VPIN_PIP_DIGIT_BYTES"]
     assert np.array_equal(got[:2], O.hyrax_commit(Z[:2 * Rs], 2, blinds[:2], og, Rs + 1))
     dZ.free()
     g.free()

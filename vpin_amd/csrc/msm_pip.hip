@@ -29,6 +29,7 @@
 // The order in which a bucket's points are added depends on the LDS atomics' order: the SUM is the same group element, its
 // projective representation is not -- the compressed encoding (what a commitment is) is unique.
 #include <algorithm>
+#include <cstdlib>
 
 #include "ctx.h"
 #include "fp_dev.h"
@@ -374,11 +375,18 @@ template <int C>
 int pip_rows_c(vpin_ctx* c, const ge_niels* d_gn, const fq* dZ, size_t rows, size_t stride, size_t ncols, const fq* d_extra, int n_extra,
                ge_ext* d_points, unsigned long long* d_adds) {
   constexpr int W = PipShape<C>::W;
-  const size_t n = ncols + (size_t)n_extra, items = rows * W;
+  const size_t n = ncols + (size_t)n_extra;
   const size_t lds = pip_lds_bytes<C>(n);
-  const unsigned grid = (unsigned)std::min<size_t>(items, (size_t)c->num_cus * 3);
+  // The digits are 2 W bytes per scalar (58 at c = 9): rows are taken in chunks of at most ~2 GiB of digits -- still thousands
+  // of (row, window) pairs per launch -- so that the 2^14 x 2^15 polynomials of the 2^25 instance need 2, not 31 GB
+  // (VPIN_PIP_DIGIT_BYTES: another cap, read per call -- the tests force several chunks with it)
+  const char* e_cap = getenv("VPIN_PIP_DIGIT_BYTES");
+  const size_t cap = e_cap && atol(e_cap) > 0 ? (size_t)atol(e_cap) : (size_t)2 << 30;
+  const size_t chunk_rows = std::min(rows, std::max<size_t>(1, cap / (W * n * 2)));
+  const size_t chunk_items = chunk_rows * W;
+  const unsigned grid = (unsigned)std::min<size_t>(chunk_items, (size_t)c->num_cus * 3);
   DevBuf b_dig(c), b_wsum(c), b_scr(c), b_bad(c);
-  if (b_dig.alloc(items * n * 2) || b_wsum.alloc(items * sizeof(ge_ext)) || b_bad.alloc(4) ||
+  if (b_dig.alloc(chunk_items * n * 2) || b_wsum.alloc(chunk_items * sizeof(ge_ext)) || b_bad.alloc(4) ||
       b_scr.alloc((size_t)grid * pip_scratch_words<C>() * 4))
     return VPIN_ENOMEM;
   VPIN_HIP_TRY(hipMemsetAsync(b_bad.p, 0, 4, c->stream));
@@ -386,12 +394,15 @@ int pip_rows_c(vpin_ctx* c, const ge_niels* d_gn, const fq* dZ, size_t rows, siz
   VPIN_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&pip_window_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096));
   {
     ProfScope ps(c, VPIN_K_MSM, 32.0 * (double)rows * (double)n, VPIN_K_MSM_ROWS);
-    hipLaunchKernelGGL(pip_recode_kernel<C>, dim3((unsigned)((rows * n + kPipBlock - 1) / kPipBlock)), dim3(kPipBlock), 0, c->stream, dZ,
-                       stride, ncols, d_extra, n_extra, rows, (uint16_t*)b_dig.p, (uint32_t*)b_bad.p);
-    hipLaunchKernelGGL(pip_window_kernel<C>, dim3(grid), dim3(kPipBlock), lds, c->stream, (const uint16_t*)b_dig.p, d_gn, (uint32_t)n,
-                       items, (uint32_t*)b_scr.p, (ge_ext*)b_wsum.p, d_adds);
-    hipLaunchKernelGGL(pip_finish_kernel<C>, dim3((unsigned)((rows + 63) / 64)), dim3(64), 0, c->stream, (const ge_ext*)b_wsum.p, rows,
-                       d_points);
+    for (size_t r0 = 0; r0 < rows; r0 += chunk_rows) {
+      const size_t nr = std::min(chunk_rows, rows - r0), items = nr * W;
+      hipLaunchKernelGGL(pip_recode_kernel<C>, dim3((unsigned)((nr * n + kPipBlock - 1) / kPipBlock)), dim3(kPipBlock), 0, c->stream,
+                         dZ + r0 * stride, stride, ncols, d_extra ? d_extra + r0 : d_extra, n_extra, nr, (uint16_t*)b_dig.p, (uint32_t*)b_bad.p);
+      hipLaunchKernelGGL(pip_window_kernel<C>, dim3((unsigned)std::min<size_t>(items, grid)), dim3(kPipBlock), lds, c->stream,
+                         (const uint16_t*)b_dig.p, d_gn, (uint32_t)n, items, (uint32_t*)b_scr.p, (ge_ext*)b_wsum.p, d_adds);
+      hipLaunchKernelGGL(pip_finish_kernel<C>, dim3((unsigned)((nr + 63) / 64)), dim3(64), 0, c->stream, (const ge_ext*)b_wsum.p, nr,
+                         d_points + r0);
+    }
   }
   VPIN_HIP_TRY(hipGetLastError());
   uint32_t bad = 0;

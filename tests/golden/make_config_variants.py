@@ -137,7 +137,58 @@ def l5_sat_variant(seed_key="s1"):
     return ent
 
 
+def l5_full_variant(seed_key="s1"):
+    """L5-mult's WHOLE SNARK under a second seed pair -> key L5-mult#<seed>.  ~95 GB and ~12 minutes of the oracle: run on the GPU
+    box's host cores (nothing touches the GPU), the entry goes to $VPIN_GOLDEN_OUT and is merged into config_variants.json here:
+        gpurun --timeout 1200 -- 'VPIN_GOLDEN_OUT=gpurun_out/l5_s1.json python tests/golden/make_config_variants.py L5-mult#s1'
+    It re-derives the sat half the container produced (L5-mult#sat_<seed>) and refuses to write if that differs."""
+    import resource
+    import threading
+    import oracle_lib as O
+    from vpin_amd import gadgets as G
+    stop = threading.Event()
+
+    def beat():
+        t = time.time()
+        while not stop.wait(60):
+            print(f"[L5-mult#{seed_key}] {time.time() - t:.0f} s, maxrss {resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1e6:.1f} GB", flush=True)
+    threading.Thread(target=beat, daemon=True).start()
+    t0 = time.time()
+    inp = G.synthetic_mult_inputs("L5")
+    inst = MG.model_instance("mult", inp)
+    sc, sp = SEED_PAIRS[seed_key]
+    t1 = time.time()
+    print(f"[L5-mult#{seed_key}] instance built in {t1 - t0:.0f} s", flush=True)
+    res = O.snark_prove(inst, sc, sp, threads=int(os.environ.get("VPIN_ORACLE_THREADS", os.cpu_count() or 1)))
+    t2 = time.time()
+    ok = O.snark_verify(inst, res)
+    stop.set()
+    assert ok == 1
+    with open(OUT) as f:
+        sat = json.load(f)["cases"]["L5-mult#sat_" + seed_key]
+    assert sat["inputs_sha256"] == MG.inputs_digest("mult", inp)
+    assert sat["sat_sha256"] == hashlib.sha256(res["proof"][:sat["sat_len"]]).hexdigest(), "sat half differs from the container's"
+    ent = {"kind": "mult", "ops": len(inp[0]), "num_cons": inst["num_cons"], "num_vars": inst["num_vars"],
+           "seed_commit_hex": sc.hex(), "seed_proof_hex": sp.hex(), "inputs_sha256": MG.inputs_digest("mult", inp),
+           "tampered_at": None, "oracle_is_sat": None, "oracle_verifier_accepts": int(ok),
+           "snark_len": len(res["proof"]), "snark_sha256": hashlib.sha256(res["proof"]).hexdigest(),
+           "comm_sha256": hashlib.sha256(res["comm"]).hexdigest(),
+           "comm_para_sha256": hashlib.sha256(res["comm_para"].tobytes()).hexdigest(),
+           "comm_input_sha256": hashlib.sha256(res["comm_input"].tobytes()).hexdigest(),
+           "oracle_s": round(t2 - t1, 1), "model_s": round(t1 - t0, 1),
+           "where": "GPU box host cores", "maxrss_gb": round(resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1e6, 1)}
+    print("L5-mult#" + seed_key, json.dumps(ent), flush=True)
+    out = os.environ.get("VPIN_GOLDEN_OUT")
+    if out:
+        with open(out, "w") as f:
+            json.dump({"L5-mult#" + seed_key: ent}, f, indent=1, sort_keys=True)
+    return ent
+
+
 def main():
+    if sys.argv[1:] == ["L5-mult#s1"]:   # the GPU box's host cores only: see l5_full_variant
+        l5_full_variant("s1")
+        return
     doc = {"_source": "tests/golden/make_config_variants.py: oracle/ on instances built by tests/gadgets_model.py; see its docstring",
            "cases": {}}
     only = sys.argv[1:]

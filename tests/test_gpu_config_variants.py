@@ -66,13 +66,21 @@ def test_device_built_variants_match_the_oracle(ctx, name):
     assert MV.MG.inputs_digest(kind, inp) == g["inputs_sha256"]
     d = ctx.gadget_point_mult_dev(*inp) if kind == "mult" else ctx.gadget_point_add_dev(*inp)
     try:
-        assert d.is_sat() == bool(g["oracle_is_sat"])
+        if g["oracle_is_sat"] is not None:   # (L5-mult#s1: the 15-minute oracle run recorded the verifier's verdict, not is_sat)
+            assert d.is_sat() == bool(g["oracle_is_sat"])
         got = d.snark_prove(bytes.fromhex(g["seed_commit_hex"]), bytes.fromhex(g["seed_proof_hex"]))
         meta = {"inputs": d.inputs, "num_inputs": d.num_inputs}
     finally:
         d.free()
     check(got, g, name)
     assert ctx.snark_verify(meta, got) == bool(g["oracle_verifier_accepts"])  # the product's verifier: same verdict as the oracle's
+    if name == "L5-mult#s1":
+        # 6000 point-mults, 2^25 constraints: the whole-SNARK digest above comes from the oracle on the GPU box's host cores
+        # (make_config_variants.py l5_full_variant); the sat half was pinned separately by the build container's oracle run --
+        # the first sat_len bytes are its R1CSProof, inst_evals follow (one proof serves both: two do not fit beside the pools)
+        h = GOLD["L5-mult#sat_s1"]
+        assert hashlib.sha256(got["proof"][:h["sat_len"]]).hexdigest() == h["sat_sha256"], "sat half of the SNARK"
+        assert hashlib.sha256(bytes(got["proof"][h["sat_len"]:h["sat_len"] + 96])).hexdigest() == h["inst_evals_sha256"]
 
 
 @pytest.mark.gpu
@@ -102,23 +110,10 @@ def test_fixture_covers_the_large_instances_under_a_second_seed_pair():
     with open(os.path.join(HERE, "golden", "config_digests.json")) as f:
         base = json.load(f)["cases"]["L5-mult"]
     assert g["inputs_sha256"] == base["inputs_sha256"] and g["sat_len"] == base["sat_len"] and g["sat_sha256"] != base["sat_sha256"]
-
-
-@pytest.mark.gpu
-def test_l5_mult_sat_half_under_the_second_seed_pair(ctx):
-    """6000 point-mults, 2^25 constraints, seed pair s1: the first sat_len bytes of the HIP SNARK are the oracle's R1CSProof
-    (both ZK sum-checks, the witness commitments, the evaluation proof), and the product's verifier accepts the whole"""
-    g = GOLD["L5-mult#sat_s1"]
-    kind, inp, _ = MV.variant_inputs("L5-mult#s1")
-    assert MV.MG.inputs_digest(kind, inp) == g["inputs_sha256"]
-    d = ctx.gadget_point_mult_dev(*inp)
-    try:
-        got = d.snark_prove(bytes.fromhex(g["seed_commit_hex"]), bytes.fromhex(g["seed_proof_hex"]))
-        meta = {"inputs": d.inputs, "num_inputs": d.num_inputs}
-    finally:
-        d.free()
-    assert hashlib.sha256(got["proof"][:g["sat_len"]]).hexdigest() == g["sat_sha256"], "sat half of the SNARK"
-    assert hashlib.sha256(got["comm_para"].tobytes()).hexdigest() == g["comm_para_sha256"]
-    assert hashlib.sha256(got["comm_input"].tobytes()).hexdigest() == g["comm_input_sha256"]
-    assert hashlib.sha256(bytes(got["proof"][g["sat_len"]:g["sat_len"] + 96])).hexdigest() == g["inst_evals_sha256"], "inst_evals follow the sat proof"
-    assert ctx.snark_verify(meta, got)
+    # ... and layer 5's WHOLE SNARK under that pair (the oracle on the GPU box's host cores: 93 GB, 11 minutes): same inputs, same
+    # length and computation commitment as under the first pair, other bytes; is_sat was not recorded by that run (null)
+    w = GOLD["L5-mult#s1"]
+    assert w["num_cons"] == 1 << 25 and w["oracle_verifier_accepts"] == 1 and w["oracle_is_sat"] is None
+    assert w["inputs_sha256"] == base["inputs_sha256"] and w["seed_proof_hex"] == g["seed_proof_hex"]
+    assert w["snark_len"] == base["snark_len"] and w["comm_sha256"] == base["comm_sha256"] and w["snark_sha256"] != base["snark_sha256"]
+    assert w["comm_para_sha256"] == g["comm_para_sha256"] and w["comm_input_sha256"] == g["comm_input_sha256"]

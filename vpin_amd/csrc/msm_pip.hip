@@ -16,12 +16,12 @@
 //                          from a compact array that stays in L2) to ONE accumulator in registers -- never reset, so after
 //                          bucket i it holds the running sum B_{K-1} + .. + B_i of the running-sum trick; those K - 1
 //                          intermediate values go to a per-lane scratch slot, their sum is the lane's weighted sum
-//                          W_t = sum_i (i + 1) B_i, the last one its plain sum S_t.  A HEAVY bucket (more than twice a lane's
-//                          average share: the narrow top window's, a witness row's ones) is summed by all lanes together
+//                          W_t = sum_i (i + 1) B_i, the last one its plain sum S_t.  A HEAVY bucket (more than max(32, n / 128)
+//                          entries, twice a lane's share of a long row: the narrow top window's, a witness row's ones) is summed by all lanes together
 //                          first and enters its owner's walk as one point
 //                       3. across lanes: window sum = sum_t (W_t + tK S_t) = sum_t W_t + K sum_{t >= 1} Suf_t with
 //                          Suf_t = S_t + S_{t+1} + ..: a suffix scan of the S_t through LDS (8 steps), log2 K doublings,
-//                          one addition, and the block tree of msm.hip
+//                          one addition, and the block tree of ge_tree_dev.h
 //   pip_finish_kernel   row = sum_w 2^(cw) (window sum w): Horner with c doublings per window, one lane per row
 // Bucket sums live in registers; LDS stages the sort and the cross-lane reduction (40 KB at R = 16384, c = 11: three
 // workgroups per CU).  2^(c-1) extended points of 160 B in LDS per pair would allow one workgroup per CU at c = 11.

@@ -75,7 +75,7 @@ def live_pmc_traffic(timeout_s=240, cus=256):
             d = os.path.join(tmp, tag)
             cmd = [prof, "--pmc"] + ctrs + ["--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable, BENCH,
                    "--trace", "L5", "--only", "mult", "--serial", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-span",
-                   "--no-verify", "--no-roofline-pass", "--no-live-pmc"]
+                   "--no-verify", "--no-roofline-pass", "--no-live-pmc", "--sat-only", "--detail-out", os.path.join(d, "child.json")]
             r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=timeout_s)
             if r.returncode != 0:
                 if tag == "VALU" and "FETCH_SIZE" in out and "WRITE_SIZE" in out:
@@ -162,3 +162,146 @@ class PowerSampler:
         return {"samples": len(pick), "sclk_mhz_median": med(f), "sclk_mhz_min": f[0] if f else None, "sclk_mhz_max": f[-1] if f else None,
                 "watts_median": med(w), "watts_max": w[-1] if w else None,
                 "source": f"hwmon freq1_input / power1_average of this rank's card, every {self.interval_s * 1e3:.0f} ms"}
+
+
+# ---- the ONE line bench.py prints -----------------------------------------------------------------------------------------
+# Round 5's line had grown to 24 KB of nested prose and the driver could not parse it (BENCH_r05.json: parsed = null).  The
+# printed line is now a flat, strict-JSON record of at most LINE_MAX bytes; everything else goes to a side file whose path the
+# line carries in `detail`.  tests/test_bench_line.py builds a line from a stub and checks both properties.
+LINE_MAX = 4096
+
+
+def _num(x, nd=None):
+    """a JSON-safe number (NaN / inf -> None), optionally rounded"""
+    if isinstance(x, bool) or x is None:
+        return x
+    if isinstance(x, (int, float)):
+        if isinstance(x, float) and (x != x or x in (float("inf"), float("-inf"))):
+            return None
+        return round(x, nd) if (nd is not None and isinstance(x, float)) else x
+    return None
+
+
+def _all_true(d):
+    return (all(bool(v) for v in d.values()) if isinstance(d, dict) and d else None)
+
+
+def compact_line(full, detail_path=None):
+    """The flat record the driver reads, made from bench.py's full record.  Scalars only inside `roofline` and `cpu_baseline`;
+    strings bounded; None for what a run did not measure."""
+    rf, cb, cfg = full.get("roofline") or {}, full.get("cpu_baseline") or {}, full.get("config") or {}
+    rs = full.get("reference_span") or {}
+    out = {k: full.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                    "scaling", "vs_baseline", "dtype", "data")}
+    out["metric"] = str(out["metric"])[:160]
+    out["config"] = {"workload": str(cfg.get("workload", ""))[:120],
+                     "constraints_unpadded_per_step": cfg.get("constraints_unpadded_per_step"),
+                     "instances_per_step": len(cfg.get("instances") or {}) or None,
+                     "inputs": str(cfg.get("inputs", ""))[:60],
+                     "parallelism": str(cfg.get("parallelism_short") or cfg.get("parallelism", ""))[:100]}
+    if rf:
+        src = str(rf.get("traffic_source") or "")
+        out["roofline"] = {
+            "kernel": str(rf.get("kernel", ""))[:80], "bound": rf.get("bound"), "achieved": _num(rf.get("achieved"), 2),
+            "peak": rf.get("peak"), "unit": rf.get("unit"), "frac": _num(rf.get("frac"), 4), "traffic": _num(rf.get("traffic"), 0),
+            "traffic_how": ("live_pmc" if src.startswith("measured in this run") else "replayed" if src.startswith("replayed")
+                            else "caller" if src else None),
+            "launches": rf.get("launches"), "avg_launch_us": _num(rf.get("avg_launch_us"), 2),
+            "alg_bytes_per_launch": _num(rf.get("alg_bytes_per_launch"), 0),
+            "traffic_over_algorithmic": _num(rf.get("traffic_over_algorithmic"), 4),
+            "limiter": str(rf.get("limiter", ""))[:24], "limiter_frac": _num(rf.get("limiter_frac"), 4),
+            "limiter_how": ("live_pmc" if str(rf.get("limiter_frac_source", "")).startswith("measured in this run") else
+                            "replayed" if "replayed" in str(rf.get("limiter_frac_source", "")) else "static_model"),
+            "frac_actual": _num(rf.get("frac_actual"), 4),
+            "largest_instance_alone_ms": _num(rf.get("largest_instance_alone_ms"), 2),
+            "msm_G_adds_s": _num(rf.get("msm_G_adds_s"), 3),
+            "msm_frac_of_static_valu_peak": _num(rf.get("msm_frac_of_static_valu_peak"), 4),
+            "msm_frac_of_chain": _num(rf.get("msm_frac_of_chain"), 4),
+            "msm_steady_G_adds_s": _num(rf.get("msm_steady_G_adds_s"), 3), "msm_watts": _num(rf.get("msm_watts"), 0),
+            "msm_sclk_mhz": _num(rf.get("msm_sclk_mhz"), 0),
+            "prod_round_frac": _num(rf.get("prod_round_frac"), 4), "prod_round_valu_frac": _num(rf.get("prod_round_valu_frac"), 4),
+        }
+    if cb:
+        out["cpu_baseline"] = {"value": _num(cb.get("value"), 1), "unit": cb.get("unit"), "cores": cb.get("cores"),
+                               "kind": cb.get("kind"), "sample": str(cb.get("sample_short") or cb.get("sample", ""))[:120],
+                               "seconds": _num(cb.get("seconds"), 2)}
+    if rs:
+        out["value_reference_span"] = _num(full.get("value_reference_span"), 1)
+        out["reference_span_ms"] = _num(rs.get("ms_per_trace"), 1)
+        out["reference_span_lanes_ms"] = _num((rs.get("lanes") or {}).get("ms_per_trace"), 1)
+        out["reference_span_largest_ms"] = _num(max((rs.get("ms") or {"": None}).values(), key=lambda v: v or 0.0), 1)
+        dw = rs.get("dead_work") or {}
+        out["reference_span_with_dead_work_ms"] = _num(dw.get("ms_per_trace_with"), 1)
+        out["dead_work_how"] = dw.get("digest_how")
+        if full.get("span_warning"):
+            out["span_warning"] = str(full["span_warning"])[:160]
+    pw = full.get("power_during_timed_region") or {}
+    out["watts_median"] = _num(pw.get("watts_median"), 0)
+    out["sclk_mhz_median"] = _num(pw.get("sclk_mhz_median"), 0)
+    if pw.get("watts_median") and full.get("ms_per_step"):
+        out["joules_per_step"] = _num(pw["watts_median"] * full["ms_per_step"] * 1e-3, 1)
+    out["hbm_in_use_gib"] = full.get("hbm_in_use_gib_after_timed_region")
+    out["window_tables_gib"] = (full.get("hbm_breakdown") or {}).get("window_tables_gib")
+    out["bytes_ok"] = _all_true(full.get("bytes_equal_oracle_digest"))
+    out["verified_ok"] = _all_true(full.get("verified"))
+    enc = full.get("encode_ms") or {}
+    if enc:
+        out["encode_ms_total"] = _num(sum(enc.values()), 1)
+        out["encode_ms_largest"] = _num(max(enc.values()), 1)
+    out["proof_bytes_per_step"] = sum((full.get("proof_bytes") or {}).values()) or None
+    for k, v in full.items():
+        if k.startswith("strong_") and not isinstance(v, (dict, list)):
+            out[k] = (str(v)[:160] if isinstance(v, str) else _num(v, 3) if isinstance(v, float) else v)
+    out["run_s"] = _num(full.get("run_s"), 1)
+    out["detail"] = detail_path
+    return out
+
+
+def dumps_line(rec):
+    """strict JSON, compact separators; raises when the line is over LINE_MAX bytes or not strictly parseable"""
+    s = json.dumps(rec, allow_nan=False, separators=(",", ":"))
+    if len(s.encode()) > LINE_MAX:
+        raise ValueError(f"bench line is {len(s.encode())} bytes (> {LINE_MAX})")
+    if "\n" in s:
+        raise ValueError("bench line spans lines")
+    json.loads(s, parse_constant=lambda c: (_ for _ in ()).throw(ValueError(c)))
+    return s
+
+
+def write_detail(full, path):
+    """the full record (everything round 5 printed) as a side file; returns the path written, or None"""
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, "w") as f:
+            json.dump(full, f, indent=1, default=str)
+            f.write("\n")
+        return path
+    except OSError:
+        return None
+
+
+def emit(full, detail_path):
+    """write the side file, print the one line; a line that would not fit is cut down to the contract's core instead of failing
+    the run (the numbers were measured: they must come out)"""
+    import math
+    def clean(o):
+        if isinstance(o, float):
+            return o if math.isfinite(o) else None
+        if isinstance(o, dict):
+            return {str(k): clean(v) for k, v in o.items()}
+        if isinstance(o, (list, tuple)):
+            return [clean(v) for v in o]
+        return o
+    full = clean(full)
+    written = write_detail(full, detail_path) if detail_path else None
+    rel = os.path.relpath(written, ROOT) if written else None
+    rec = compact_line(full, rel)
+    try:
+        s = dumps_line(rec)
+    except ValueError as e:
+        core = {k: rec.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                        "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "detail")}
+        core["line_error"] = str(e)[:100]
+        s = json.dumps(core, allow_nan=False, separators=(",", ":"))
+    print(s, flush=True)
+    return s

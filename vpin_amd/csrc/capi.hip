@@ -1,4 +1,5 @@
 // capi.hip -- context, table management and profiling behind include/vpin_hip.h
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -47,6 +48,26 @@ bool ctx_is_live(vpin_ctx* c) {
   return false;
 }
 
+// VPIN_POOL_TRACE=<MiB>: every allocation / release of at least that size on stderr with the bytes in use afterwards and the
+// milliseconds since the first traced event; hipMalloc / hipFree calls with what they took (a multi-GB hipMalloc or the hipFree
+// of a context's cached blocks is the usual suspect when a span jumps by hundreds of ms)
+static size_t pool_trace_min() {
+  static const size_t v = [] { const char* e = getenv("VPIN_POOL_TRACE"); return e ? ((size_t)atol(e) << 20) : (size_t)0; }();
+  return v;
+}
+static double pool_trace_ms() {
+  static const auto t0 = std::chrono::steady_clock::now();
+  return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+}
+static std::atomic<long long> g_in_use{0};
+static void pool_trace(const char* what, size_t cls, bool fresh, double took_ms = 0.0) {
+  if (!pool_trace_min() || cls < pool_trace_min()) return;
+  fprintf(stderr, "[pool %10.2f ms] %-7s %9.1f MiB%s  in use %9.1f MiB", pool_trace_ms(), what, (double)cls / 1048576.0,
+          fresh ? " (hipMalloc)" : "", (double)g_in_use.load() / 1048576.0);
+  if (took_ms > 0.0) fprintf(stderr, "  took %.2f ms", took_ms);
+  fputc('\n', stderr);
+}
+
 // cached (free-listed) blocks of one context back to the driver.  The free lists are taken out under the pool lock; the
 // stream sync (work that last used the blocks is ordered on that stream) and the hipFree calls happen with no lock held, so
 // another lane's in-flight proof does not stall every context of the process behind a global mutex.
@@ -59,20 +80,12 @@ static void pool_release_unlocked(vpin_ctx* c) {
     c->pool_free_lists.clear();
   }
   if (blocks.empty()) return;
+  const double t_a = pool_trace_min() ? pool_trace_ms() : 0.0;
   (void)hipStreamSynchronize(c->stream);
   for (void* p : blocks) (void)hipFree(p);
-}
-
-// VPIN_POOL_TRACE=<MiB>: every allocation / release of at least that size on stderr with the bytes in use afterwards
-static size_t pool_trace_min() {
-  static const size_t v = [] { const char* e = getenv("VPIN_POOL_TRACE"); return e ? ((size_t)atol(e) << 20) : (size_t)0; }();
-  return v;
-}
-static std::atomic<long long> g_in_use{0};
-static void pool_trace(const char* what, size_t cls, bool fresh) {
-  if (!pool_trace_min() || cls < pool_trace_min()) return;
-  fprintf(stderr, "[pool] %-5s %8.1f MiB%s  in use %9.1f MiB\n", what, (double)cls / 1048576.0, fresh ? " (hipMalloc)" : "",
-          (double)g_in_use.load() / 1048576.0);
+  if (pool_trace_min())
+    fprintf(stderr, "[pool %10.2f ms] release %zu cached blocks of ctx %p to the driver: %.2f ms\n", pool_trace_ms(), blocks.size(), (void*)c,
+            pool_trace_ms() - t_a);
 }
 
 int dev_alloc(vpin_ctx* c, size_t bytes, void** out) {
@@ -93,8 +106,10 @@ int dev_alloc(vpin_ctx* c, size_t bytes, void** out) {
     }
   }
   void* p = nullptr;
+  const double t_m = pool_trace_min() ? pool_trace_ms() : 0.0;
   if (hipMalloc(&p, cls) != hipSuccess) {
     (void)hipGetLastError();
+    if (pool_trace_min()) fprintf(stderr, "[pool %10.2f ms] hipMalloc of %.1f MiB FAILED: releasing cached blocks\n", pool_trace_ms(), (double)cls / 1048576.0);
     dev_pool_release(c);  // give this context's cached blocks back and retry
     if (hipMalloc(&p, cls) != hipSuccess) {
       (void)hipGetLastError();
@@ -125,7 +140,7 @@ int dev_alloc(vpin_ctx* c, size_t bytes, void** out) {
   std::lock_guard<std::mutex> g(c->pool_mu);
   c->pool_sizes[p] = cls;
   *out = p;
-  if (pool_trace_min()) { g_in_use += (long long)cls; pool_trace("alloc", cls, true); }
+  if (pool_trace_min()) { g_in_use += (long long)cls; pool_trace("alloc", cls, true, pool_trace_ms() - t_m); }
   return VPIN_OK;
 }
 
@@ -142,11 +157,15 @@ void dev_pool_release(vpin_ctx* c) { pool_release_unlocked(c); }
 
 void dev_release_block(vpin_ctx* c, void* p) {
   if (!p) return;
+  size_t sz = 0;
   {
     std::lock_guard<std::mutex> g(c->pool_mu);
-    c->pool_sizes.erase(p);
+    auto it = c->pool_sizes.find(p);
+    if (it != c->pool_sizes.end()) { sz = it->second; c->pool_sizes.erase(it); }
   }
+  const double t_a = pool_trace_min() ? pool_trace_ms() : 0.0;
   (void)hipFree(p);
+  if (pool_trace_min()) { g_in_use -= (long long)sz; pool_trace("hipFree", sz, false, pool_trace_ms() - t_a); }
 }
 
 static void ctx_switch_stream(vpin_ctx* c, hipStream_t to, int cus, bool masked) {

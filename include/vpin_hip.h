@@ -85,6 +85,11 @@ unsigned long long vpin_ctx_strip_rows_taken(vpin_ctx* ctx);
  * blocks), bytes of those sitting in the free lists (reusable by the next proof), blocks}.  What bench.py's hbm_breakdown and a
  * service's admission control are made of. */
 int vpin_ctx_pool_stats(vpin_ctx* ctx, size_t out[3]);
+/* out = {calls, bytes}: allocations this library has taken from the driver (hipMalloc) since the process started, all contexts
+ * (the contexts' pools, the unpooled tables of a split proof; generator tables not counted).  A proof of a shape its context
+ * has already proven must leave both unchanged: tests/test_gpu_pool.py (round 5's SNARK::encode took 20 GB from the driver
+ * per call -- 0.3 ms most of the time, 0.2-2.8 s every few calls). */
+int vpin_driver_alloc_stats(unsigned long long out[2]);
 /* hand the pool's cached (free) blocks back to the driver: after set-up work whose temporaries no proof will reuse (gadget
  * synthesis, SNARK::encode), or when a service changes workload.  Synchronises the context's stream. */
 int vpin_ctx_pool_trim(vpin_ctx* ctx);

@@ -1,0 +1,53 @@
+"""The device pool serves repeated proofs without going back to the driver (round 6).
+
+Round 5's SNARK::encode passed an inverted flag to spark_comb_make and took its 16N + 2M scalars straight from hipMalloc on every
+call (and hipFree'd them): 20 GB per encode of the 2^25 instance -- 0.3 ms most of the time, 0.2-2.8 s every few proofs, which is
+what doubled the reference span and made encode_ms unstable.  vpin_driver_alloc_stats counts the library's calls into the
+driver's allocator; a proof of a shape the context has already proven must make none."""
+import numpy as np
+import pytest
+
+import vpin_amd
+from vpin_amd import gadgets as G
+
+pytestmark = pytest.mark.gpu
+
+SEED_C, SEED_P = bytes(range(64)), bytes((5 * i + 1) % 256 for i in range(64))
+
+
+@pytest.mark.parametrize("label,n_mult", [("A", 24), ("A", None)])
+def test_repeated_encode_and_prove_take_nothing_from_the_driver(label, n_mult):
+    w, x, y = G.synthetic_mult_inputs(label) if n_mult is None else G.synthetic_mult_inputs(label, n_mult)
+    with vpin_amd.Context(0) as cx:
+        cx.set_expected_proofs(1)   # a one-shot process keeps SNARK::encode's tables pooled for the proof that follows
+        first = None
+        calls = []
+        for k in range(4):
+            before = cx.driver_alloc_stats()
+            g = cx.gadget_point_mult_dev(w, x, y)
+            assert g.is_sat()
+            r = g.snark_prove(SEED_C, SEED_P)
+            g.free()
+            after = cx.driver_alloc_stats()
+            calls.append((after[0] - before[0], after[1] - before[1]))
+            first = first or r
+            assert r["proof"] == first["proof"] and r["comm"] == first["comm"]
+        assert calls[0][0] > 0                       # the first pass fills the pool
+        assert calls[2] == (0, 0) and calls[3] == (0, 0), calls   # a warm pool: not one byte from the driver
+
+
+def test_resident_proofs_take_nothing_from_the_driver():
+    w, x, y = G.synthetic_mult_inputs("A", 40)
+    with vpin_amd.Context(0) as cx:
+        g = cx.gadget_point_mult_dev(w, x, y)
+        cx.sat_prepare(g.num_vars)
+        dec, _ = g.spark_encode()
+        prove = lambda: cx.snark_prove_resident(g.r1cs, dec, g.vars_para, g.vars_input, g.vars, g.inputs, SEED_C, SEED_P)
+        ref = prove()
+        prove()
+        before = cx.driver_alloc_stats()
+        for _ in range(3):
+            assert prove()["proof"] == ref["proof"]
+        assert cx.driver_alloc_stats() == before
+        dec.free()
+        g.free()

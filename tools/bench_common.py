@@ -252,6 +252,8 @@ def compact_line(full, detail_path=None):
     for k, v in full.items():
         if k.startswith("strong_") and not isinstance(v, (dict, list)):
             out[k] = (str(v)[:160] if isinstance(v, str) else _num(v, 3) if isinstance(v, float) else v)
+    if full.get("errors"):
+        out["errors"] = "; ".join(f"{k}: {v}" for k, v in full["errors"].items())[:300]
     out["run_s"] = _num(full.get("run_s"), 1)
     out["detail"] = detail_path
     return out

@@ -579,6 +579,15 @@ class Context:
         _chk(L.vpin_ctx_pool_stats(self.h, C.byref(out)), "vpin_ctx_pool_stats")
         return int(out[0]), int(out[1]), int(out[2])
 
+    @staticmethod
+    def driver_alloc_stats():
+        """(calls, bytes) the library has taken from the driver's allocator since the process started (vpin_driver_alloc_stats)"""
+        L = lib()
+        L.vpin_driver_alloc_stats.argtypes = [C.POINTER(C.c_ulonglong * 2)]
+        out = (C.c_ulonglong * 2)()
+        _chk(L.vpin_driver_alloc_stats(C.byref(out)), "vpin_driver_alloc_stats")
+        return int(out[0]), int(out[1])
+
     def pool_trim(self):
         """cached blocks of this context's device pool back to the driver (vpin_ctx_pool_trim)"""
         L = lib()

@@ -1450,12 +1450,17 @@ static int encode_commit(vpin_ctx* c, const Shape& s, std::unique_ptr<vpin_spark
   lap("generators (views)");
   std::vector<CG> c_ops, c_mem;
   if ((rc = vpin::spark_comb_tables(c, d.get()))) return fail(rc);
-  if ((rc = commit_noblind(c, g_ops, d->comb_ops, c_ops)) || (rc = commit_noblind(c, g_mem, d->comb_mem, c_mem))) return fail(rc);
+  lap("comb tables");
+  if ((rc = commit_noblind(c, g_ops, d->comb_ops, c_ops))) return fail(rc);
+  lap("commit ops");
+  if ((rc = commit_noblind(c, g_mem, d->comb_mem, c_mem))) return fail(rc);
+  lap("commit mem");
   // (commit_noblind has synchronised the stream.)  A service (no expected proof count) hands the blocks back to the driver;
   // a one-shot process keeps them pooled for its proof's temporaries (a hipFree / hipMalloc pair of 17 GB costs more there)
   if (!getenv("VPIN_KEEP_COMB")) vpin::spark_comb_release(c, d.get(), c->expected_proofs == 0);
-  lap("commit ops + mem");
+  lap("comb release");
   if ((rc = vpin::spark_find_hot_cols(c, d.get()))) return fail(rc);
+  lap("hot columns");
   Writer w;
   w.u64(num_cons); w.u64(num_vars); w.u64(num_inputs);
   w.u64(3); w.u64(s.N); w.u64(s.M);

@@ -632,6 +632,7 @@ static int table_alloc_unpooled(size_t len, vpin_table** out) {
   vpin_table* t = new (std::nothrow) vpin_table();
   if (!t) return VPIN_ENOMEM;
   if (hipMalloc((void**)&t->d, len * sizeof(fq)) != hipSuccess) { (void)hipGetLastError(); delete t; return VPIN_ENOMEM; }
+  note_driver_alloc(len * sizeof(fq));
   t->len = t->cap = len;
   t->owner = nullptr;
   *out = t;
@@ -643,11 +644,31 @@ int spark_comb_make(vpin_ctx* c, const vpin_spark_decomm* d, vpin_table** ops, v
   const size_t N = d->N, M = d->M;
   int rc;
   *ops = *mem = nullptr;
+  // VPIN_ENCODE_LAPS=1: host time of every call below on stderr when the whole takes > 100 ms (round 6: SNARK::encode of the 2^25
+  // instance took 68 ms or, every few proofs, 0.5-2 s with the GPU idle -- this is where)
+  static const bool laps_on = getenv("VPIN_ENCODE_LAPS") != nullptr;
+  using clk = std::chrono::steady_clock;
+  clk::time_point tp[8];
+  int np = 0;
+  auto mark = [&] { if (laps_on && np < 8) tp[np++] = clk::now(); };
+  mark();
   if ((rc = pooled ? table_alloc_uninit(c, 16 * N, ops) : table_alloc_unpooled(16 * N, ops))) return rc;
   if ((rc = pooled ? table_alloc_uninit(c, 2 * M, mem) : table_alloc_unpooled(2 * M, mem))) { vpin_table_free(c, *ops); *ops = nullptr; return rc; }
+  mark();
   if ((rc = spark_u32_to_fq(c, d->idx, (*ops)->d, 12 * N)) || (rc = spark_u32_to_fq(c, d->idx + 12 * N, (*mem)->d, 2 * M))) return rc;
+  mark();
   VPIN_HIP_TRY(hipMemcpyAsync((*ops)->d + 12 * N, d->vals, 3 * N * sizeof(fq), hipMemcpyDeviceToDevice, c->stream));
+  mark();
   VPIN_HIP_TRY(hipMemsetAsync((*ops)->d + 15 * N, 0, N * sizeof(fq), c->stream));
+  mark();
+  if (laps_on) {
+    (void)hipStreamSynchronize(c->stream);
+    mark();
+    auto ms = [&](int i) { return std::chrono::duration<double, std::milli>(tp[i + 1] - tp[i]).count(); };
+    if (std::chrono::duration<double, std::milli>(tp[np - 1] - tp[0]).count() > 100.0)
+      fprintf(stderr, "[comb_make] N 2^%d: alloc %.2f | u32_to_fq launches %.2f | hipMemcpyAsync D2D call %.2f | hipMemsetAsync call %.2f | "
+                      "stream sync %.2f ms\n", (int)__builtin_ctzll(N), ms(0), ms(1), ms(2), ms(3), ms(4));
+  }
   return VPIN_OK;
 }
 
@@ -656,7 +677,10 @@ int spark_comb_tables(vpin_ctx* c, vpin_spark_decomm* d) {
   std::lock_guard<std::mutex> g(d->comb_mu);
   if (d->comb_ops && d->comb_mem) return VPIN_OK;
   spark_comb_release(c, d, false);
-  int rc = spark_comb_make(c, d, &d->comb_ops, &d->comb_mem, d->comb_unpooled);
+  // (round 6: this passed comb_unpooled as `pooled` -- every SNARK::encode took its 16N + 2M scalars straight from the driver and
+  // gave them back, a 20 GB hipMalloc / hipFree pair that costs 0.3 ms most of the time and 0.2-2.8 s every few proofs: the
+  // unstable encode_ms and the doubled reference span of round 5)
+  int rc = spark_comb_make(c, d, &d->comb_ops, &d->comb_mem, /*pooled=*/!d->comb_unpooled);
   if (!rc && hipStreamSynchronize(c->stream) != hipSuccess) rc = VPIN_EHIP;  // other contexts' streams read them next
   if (rc) spark_comb_release(c, d, false);
   return rc;
@@ -1457,6 +1481,7 @@ int spark_tail_wait(vpin_ctx* c, int idx, int ninst, int ncirc) {
   const auto t0 = std::chrono::steady_clock::now();
   unsigned done_mask = 0;
   const unsigned all = (1u << ninst) - 1u;
+  double next_nudge = 1.0;
   for (long spins = 0;; spins++) {
     for (int i = 0; i < ninst; i++) {
       if (done_mask >> i & 1u) continue;
@@ -1472,8 +1497,28 @@ int spark_tail_wait(vpin_ctx* c, int idx, int ninst, int ncirc) {
     if (done_mask == all) return VPIN_OK;
     __builtin_ia32_pause();
     if ((spins & 0xfff) == 0xfff) {
-      (void)hipStreamQuery(c->stream);  // nudges runtimes / profilers that submit lazily
-      if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 20.0) {
+      // Round 6: no HIP call in the fast path of this loop.  hipStreamQuery used to be called every 4096 spins (to nudge runtimes /
+      // profilers that submit lazily); a HIP entry point can block behind another host thread's device-wide wait (hipFree, a
+      // NULL-stream copy) which in turn waits for THIS context's resident kernel -- the kernel then polls out its bound for a reply
+      // this thread cannot send.  Now: once per second, and only after a second without an answer.
+      const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+      static const double limit_s = [] { const char* e = getenv("VPIN_TAIL_TIMEOUT_S"); double v = e ? atof(e) : 0.0; return v > 0.0 ? v : 20.0; }();
+      if (waited > next_nudge) {
+        const double tq = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        const hipError_t q = hipStreamQuery(c->stream);
+        const double tq1 = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        fprintf(stderr, "[tail] ctx %p waits %.2f s for round %d of %d (instances done %#x of %#x, seq %u, stream %s, query took %.3f s, "
+                        "masked %d)\n", (void*)c, waited, idx, c->tail_rounds.load(), done_mask, all, want,
+                q == hipSuccess ? "IDLE: the kernel has left" : q == hipErrorNotReady ? "busy" : hipGetErrorName(q), tq1 - tq, (int)c->cu_masked);
+        next_nudge += 1.0;
+      }
+      if (waited > limit_s) {
+        for (int i = 0; i < ninst; i++)
+          if (!(done_mask >> i & 1u)) {
+            const uint32_t* u = up + (size_t)i * kTailUpChunks * 4;
+            fprintf(stderr, "[tail]   instance %d: sequence words of its first sum %u %u %u (want %u); reply slot holds %u\n", i, u[0], u[4], u[8],
+                    want, tail_words(c)[16]);
+          }
         tail_words(c)[0] = 1;  // abort: every workgroup leaves its poll loop
         (void)hipStreamSynchronize(c->stream);
         // retire this launch's sequence numbers: the next proof on this context must not accept the pieces the aborted

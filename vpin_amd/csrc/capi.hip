@@ -85,7 +85,12 @@ static void pool_release_unlocked(vpin_ctx* c) {
   }
   if (blocks.empty()) return;
   const double t_a = pool_trace_min() ? pool_trace_ms() : 0.0;
-  (void)hipStreamSynchronize(c->stream);
+  // both streams of the context: a proof that has switched to its CU-masked second stream (vpin_ctx_set_cumask_after_phase1) may
+  // have the blocks' last use in flight on either, and another thread's reclaim must not read c->stream while it is being
+  // switched -- stream_main / stream_alt only change in calls that own the context
+  if (c->stream_main) (void)hipStreamSynchronize(c->stream_main);
+  if (c->stream_alt) (void)hipStreamSynchronize(c->stream_alt);
+  if (!c->stream_main) (void)hipStreamSynchronize(c->stream);
   for (void* p : blocks) (void)hipFree(p);
   if (pool_trace_min())
     fprintf(stderr, "[pool %10.2f ms] release %zu cached blocks of ctx %p to the driver: %.2f ms\n", pool_trace_ms(), blocks.size(), (void*)c,
@@ -159,6 +164,23 @@ void dev_free(vpin_ctx* c, void* p) {
 }
 
 void dev_pool_release(vpin_ctx* c) { pool_release_unlocked(c); }
+
+// a pooled block back to the pool of the context that allocated it, whichever context (or none) the caller holds: the owner is
+// looked up and pinned under the registry lock, so a concurrent vpin_ctx_destroy of it waits; an owner that is gone has released
+// the block in its destroy.  (freeing through another context's dev_free hipFree'd the block and left the owner's
+// pool_sizes with a stale entry.)
+void dev_free_owned(vpin_ctx* owner, vpin_ctx* fallback, void* p) {
+  if (!p) return;
+  vpin_ctx* pool = owner ? owner : fallback;
+  bool live = false;
+  if (pool) {
+    std::lock_guard<std::mutex> g(g_ctx_mu);
+    for (auto* x : g_live_ctxs) live = live || x == pool;
+    if (live) pool->pins.fetch_add(1, std::memory_order_acq_rel);
+  }
+  if (live) { dev_free(pool, p); pool->pins.fetch_sub(1, std::memory_order_acq_rel); }
+  else if (!owner) (void)hipFree(p);
+}
 
 void dev_release_block(vpin_ctx* c, void* p) {
   if (!p) return;
@@ -555,7 +577,8 @@ int vpin_prof_enable(vpin_ctx* c, int on) {
   if (c->prof_count_adds && !c->d_add_count) {
     (void)hipSetDevice(c->device);
     VPIN_HIP_TRY(hipMalloc((void**)&c->d_add_count, sizeof(unsigned long long)));
-    VPIN_HIP_TRY(hipMemset(c->d_add_count, 0, sizeof(unsigned long long)));
+    VPIN_HIP_TRY(hipMemsetAsync(c->d_add_count, 0, sizeof(unsigned long long), c->stream));
+    VPIN_HIP_TRY(hipStreamSynchronize(c->stream));
   }
   return VPIN_OK;
 }
@@ -583,9 +606,10 @@ static int prof_drain(vpin_ctx* c) {
   c->recs.clear();
   if (c->d_add_count) {  // table additions counted since the last drain (prof level 2)
     unsigned long long n = 0;
-    if (hipMemcpy(&n, c->d_add_count, sizeof n, hipMemcpyDeviceToHost) == hipSuccess && n) {
+    if (hipMemcpyAsync(&n, c->d_add_count, sizeof n, hipMemcpyDeviceToHost, c->stream) == hipSuccess &&
+        hipStreamSynchronize(c->stream) == hipSuccess && n) {
       c->stats[VPIN_K_MSM_ROWS].units += (double)n;
-      (void)hipMemset(c->d_add_count, 0, sizeof n);
+      (void)hipMemsetAsync(c->d_add_count, 0, sizeof n, c->stream);
     }
   }
   return VPIN_OK;

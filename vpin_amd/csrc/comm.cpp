@@ -51,7 +51,14 @@ struct alignas(64) CommSeg {
   std::atomic<uint32_t> serialize;  // ranks that asked for the token mode
   double created_unix_s;            // when rank 0 initialised the segment (a leftover is older than any attach timeout)
   int32_t creator_pid;              // rank 0's process: a segment whose creator is gone belongs to a job that died
+  uint64_t creator_pidns;           // inode of rank 0's /proc/self/ns/pid (0: unknown): a pid means nothing in another namespace
 };
+
+// inode of this process's PID namespace (0 when /proc is not there)
+static uint64_t pid_namespace_id() {
+  struct stat st;
+  return stat("/proc/self/ns/pid", &st) == 0 ? (uint64_t)st.st_ino : 0;
+}
 
 static inline size_t seg_slot_stride(size_t slot_bytes) { return sizeof(CommSlotHdr) + 2 * ((slot_bytes + 63) & ~(size_t)63); }
 static inline size_t seg_size(int world, size_t slot_bytes) { return 4096 + (size_t)world * seg_slot_stride(slot_bytes); }
@@ -113,6 +120,7 @@ static void seg_init(CommSeg* s, int world, size_t slot_bytes) {
   for (int r = 0; r < world; r++) { slot_hdr(s, r)->seq.store(0); slot_hdr(s, r)->busy_s[0] = slot_hdr(s, r)->busy_s[1] = 0.0; }
   s->created_unix_s = std::chrono::duration<double>(std::chrono::system_clock::now().time_since_epoch()).count();
   s->creator_pid = (int32_t)getpid();
+  s->creator_pidns = pid_namespace_id();
   s->magic.store(kCommMagic, std::memory_order_release);
 }
 
@@ -378,7 +386,13 @@ int vpin_comm_create_shm(const char* name, int rank, int world, size_t slot_byte
           // older than any rank would wait, no longer named, or created by a process that no longer exists (the segment of a job
           // that died moments ago, which rank 0 of THIS job has not replaced yet: it passes every other check -- ADVICE r4):
           // a leftover.  (kill(pid, 0): ESRCH = gone; EPERM = exists under another user.)
-          const bool creator_alive = s->creator_pid > 0 && (kill((pid_t)s->creator_pid, 0) == 0 || errno == EPERM);
+          // The pid test only holds when both processes live in the SAME PID namespace (one container per rank
+          // sharing /dev/shm -- --ipc=host, a shared emptyDir -- sees ESRCH for a live creator, and every rank would reject the
+          // live segment until the timeout): the creator's namespace inode travels in the segment; in another namespace, or
+          // when either side cannot tell, the age and the name decide alone, as they did before the pid test existed.
+          const uint64_t my_ns = pid_namespace_id();
+          const bool same_ns = my_ns != 0 && s->creator_pidns != 0 && my_ns == s->creator_pidns;
+          const bool creator_alive = !same_ns || (s->creator_pid > 0 && (kill((pid_t)s->creator_pid, 0) == 0 || errno == EPERM));
           same = age <= timeout + 5.0 && creator_alive && still_named();
         }
         if (ready && same) break;

@@ -601,6 +601,7 @@ static int build_instance(vpin_ctx* c, const TmplSink& ts, int kind, size_t n_op
   if (!d) return fail(VPIN_ENOMEM);
   g->r1cs = d;
   d->pooled = true;
+  d->owner = c;
   d->num_cons = nc_pad; d->num_vars = nv_pad; d->num_inputs = num_inputs;
   const size_t ncols = 2 * nv_pad;
   for (int m = 0; m < 3; m++) {

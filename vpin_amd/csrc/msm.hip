@@ -1556,7 +1556,11 @@ int hyrax_commit_derefs_hot(vpin_ctx* c, const vpin_gens* g, const vpin_table* Z
         }
       if (const char* eshape = getenv("VPIN_MSM_STRIP_SHAPE")) {
         int eg = 0, esn = 0;
-        if (sscanf(eshape, "%d,%d", &eg, &esn) == 2 && eg > 0 && esn > 0 && esn % 8 == 0 && (size_t)esn <= R / 8) { bestG = std::min(G, (size_t)eg); bestS = esn; }
+        if (sscanf(eshape, "%d,%d", &eg, &esn) == 2 && eg > 0 && esn > 0 && esn % 8 == 0 && (size_t)esn <= R / 8) {
+          // the strip's workgroups wait for each other: a forced shape must be resident as a whole like the chosen ones
+          if (std::min(G, (size_t)eg) * (size_t)esn <= slots) { bestG = std::min(G, (size_t)eg); bestS = esn; }
+          else if (getenv("VPIN_MSM_STRIP_TRACE")) fprintf(stderr, "[strip] VPIN_MSM_STRIP_SHAPE=%d,%d refused: %zu workgroups on %zu slots\n", eg, esn, std::min(G, (size_t)eg) * (size_t)esn, slots);
+        }
       }
       const uint32_t n_use = bestG ? (uint32_t)std::min<size_t>(n_strip, bestG * kMsmBlock) : 0;
       if (n_use == 0) {

@@ -379,7 +379,7 @@ void vpin_r1cs_free(vpin_ctx* c, vpin_r1cs_dev* d) {
     void* ps[] = {d->rowptr[m], d->csr_col[m], d->csr_val[m], d->colptr[m], d->csc_row[m], d->csc_val[m], d->long_cols[m],
                   d->long_first[m], d->chunk_k0[m], d->chunk_k1[m]};
     for (void* p : ps)
-      if (p) { if (d->pooled && c) dev_free(c, p); else (void)hipFree(p); }
+      if (p) { if (d->pooled) dev_free_owned(d->owner, c, p); else (void)hipFree(p); }
   }
   delete d;
 }
@@ -401,6 +401,7 @@ int vpin_r1cs_upload(vpin_ctx* c, const vpin_r1cs* inst, vpin_r1cs_dev** out) {
   if (!d) return VPIN_ENOMEM;
   d->num_cons = inst->num_cons; d->num_vars = inst->num_vars; d->num_inputs = inst->num_inputs;
   d->pooled = true;
+  d->owner = c;
   int rc = VPIN_OK;
   TraceLap lap(c, "vpin_r1cs_upload");  // VPIN_CLI_TRACE=1
   auto alloc = [&](auto** p, size_t n) { return dev_alloc(c, (n ? n : 1) * sizeof(**p), (void**)p); };
@@ -454,12 +455,15 @@ int vpin_r1cs_upload(vpin_ctx* c, const vpin_r1cs* inst, vpin_r1cs_dev** out) {
     if (flags[1] <= kLongCap) {
       trip.resize((size_t)flags[1] * 3);
       if (flags[1]) {
-        e = hipMemcpy(trip.data(), b_long.p, trip.size() * 4, hipMemcpyDeviceToHost);
+        // (on the context's stream, never the legacy NULL stream: CU-masked streams are blocking streams and would wait for it)
+        e = hipMemcpyAsync(trip.data(), b_long.p, trip.size() * 4, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
         if (e != hipSuccess) { set_last_error("vpin_r1cs_upload", e); rc = VPIN_EHIP; break; }
       }
     } else {  // more long columns than the device list holds: walk the whole colptr on the host
       std::vector<uint32_t> colptr(ncols + 1);
-      e = hipMemcpy(colptr.data(), d->colptr[m], (ncols + 1) * 4, hipMemcpyDeviceToHost);
+      e = hipMemcpyAsync(colptr.data(), d->colptr[m], (ncols + 1) * 4, hipMemcpyDeviceToHost, c->stream);
+      if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
       if (e != hipSuccess) { set_last_error("vpin_r1cs_upload", e); rc = VPIN_EHIP; break; }
       for (size_t i = 0; i < ncols; i++)
         if (colptr[i + 1] - colptr[i] > kLongCol) { trip.push_back((uint32_t)i); trip.push_back(colptr[i]); trip.push_back(colptr[i + 1]); }

@@ -20,6 +20,7 @@ struct vpin_r1cs_dev {
   size_t n_long[3] = {0, 0, 0}, n_chunks[3] = {0, 0, 0};
   // (no mutable scratch here: the instance is immutable and may be proven from several contexts at once)
   bool pooled = false;  // arrays come from the context pool (dev_alloc) instead of hipMalloc
+  vpin_ctx* owner = nullptr;  // the context whose pool they came from: they go back THERE whatever context frees the handle
 };
 
 namespace vpin {

@@ -1518,7 +1518,9 @@ int vpin_spark_encode(vpin_ctx* c, const vpin_r1cs* inst, vpin_spark_decomm** ou
       }
     }
     lap("host idx + timestamps");
-    if (hipMemcpy(d->idx, idx.data(), idx.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return fail(VPIN_EHIP);
+    if (hipMemcpyAsync(d->idx, idx.data(), idx.size() * 4, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+        hipStreamSynchronize(c->stream) != hipSuccess)
+      return fail(VPIN_EHIP);
   } else {
     vpin::DevBuf b_bad(c);
     if (b_bad.alloc(4)) return fail(VPIN_ENOMEM);

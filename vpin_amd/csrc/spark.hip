@@ -592,7 +592,8 @@ int spark_pinned(vpin_ctx* c) {
   VPIN_HIP_TRY(hipHostMalloc((void**)&c->h_spark, kSparkPinned * sizeof(fq), hipHostMallocDefault));
   memset(c->h_spark, 0, kSparkPinned * sizeof(fq));
   VPIN_HIP_TRY(hipMalloc((void**)&c->d_spark_cnt, 2 * kSparkMaxInst * sizeof(uint32_t)));
-  VPIN_HIP_TRY(hipMemset(c->d_spark_cnt, 0, 2 * kSparkMaxInst * sizeof(uint32_t)));
+  VPIN_HIP_TRY(hipMemsetAsync(c->d_spark_cnt, 0, 2 * kSparkMaxInst * sizeof(uint32_t), c->stream));
+  VPIN_HIP_TRY(hipStreamSynchronize(c->stream));
   c->spark_seq = 0;
   return VPIN_OK;
 }

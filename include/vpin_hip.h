@@ -81,6 +81,9 @@ int vpin_ctx_set_shared_device(vpin_ctx* ctx, int on);
 /* commitment rows this context has handed to the row-per-lane kernel (msm_strip_kernel) since it was created: lets a test
  * or a scheduler see that the path it asked for is the one that ran */
 unsigned long long vpin_ctx_strip_rows_taken(vpin_ctx* ctx);
+/* row chunks the bucket method (vpin_hyrax_commit_pippenger, VPIN_MSM_PIPPENGER) has launched on this context: a commitment
+ * whose digit buffer would pass 2 GiB takes its rows in several (the 2^14 x 2^15 polynomials of a 2^25-constraint instance: 15) */
+unsigned long long vpin_ctx_pip_row_chunks(vpin_ctx* ctx);
 /* the context's device memory pool: out = {bytes obtained from the driver and still held (handles + temporaries + cached
  * blocks), bytes of those sitting in the free lists (reusable by the next proof), blocks}.  What bench.py's hbm_breakdown and a
  * service's admission control are made of. */

@@ -137,6 +137,30 @@ def l5_sat_variant(seed_key="s1"):
     return ent
 
 
+def l5_is_sat(seed_key="s1"):
+    """oracle_is_sat of the L5-mult#<seed> entry (the 15-minute whole-SNARK run on the GPU box recorded the verifier's
+    verdict and left is_sat null).  is_sat does not depend on the seed pair: the model's instance (same inputs digest as the
+    entry) through the oracle's is_sat, ~25 GB and a few minutes of this container:
+        python tests/golden/make_config_variants.py L5-mult#is_sat"""
+    import oracle_lib as O
+    from vpin_amd import gadgets as G
+    t0 = time.time()
+    inp = G.synthetic_mult_inputs("L5")
+    inst = MG.model_instance("mult", inp)
+    with open(OUT) as f:
+        doc = json.load(f)
+    ent = doc["cases"]["L5-mult#" + seed_key]
+    assert ent["inputs_sha256"] == MG.inputs_digest("mult", inp) and ent["num_cons"] == inst["num_cons"]
+    t1 = time.time()
+    ent["oracle_is_sat"] = int(O.is_sat(inst))
+    ent["is_sat_s"] = round(time.time() - t1, 1)
+    print("L5-mult#" + seed_key, "oracle_is_sat", ent["oracle_is_sat"], f"(model {t1 - t0:.0f} s, is_sat {ent['is_sat_s']} s)", flush=True)
+    with open(OUT, "w") as f:
+        json.dump(doc, f, indent=1, sort_keys=True)
+        f.write("\n")
+    return ent
+
+
 def l5_full_variant(seed_key="s1"):
     """L5-mult's WHOLE SNARK under a second seed pair -> key L5-mult#<seed>.  ~95 GB and ~12 minutes of the oracle: run on the GPU
     box's host cores (nothing touches the GPU), the entry goes to $VPIN_GOLDEN_OUT and is merged into config_variants.json here:
@@ -186,6 +210,9 @@ def l5_full_variant(seed_key="s1"):
 
 
 def main():
+    if sys.argv[1:] == ["L5-mult#is_sat"]:
+        l5_is_sat("s1")
+        sys.exit(0)
     if sys.argv[1:] == ["L5-mult#s1"]:   # the GPU box's host cores only: see l5_full_variant
         l5_full_variant("s1")
         return

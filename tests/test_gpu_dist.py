@@ -156,6 +156,40 @@ def test_processes_share_one_gpu_2pow20_instance(world, label):
         assert r[3] > 100
 
 
+@pytest.mark.parametrize("world", [2, 4])
+def test_processes_share_one_gpu_cnn_e_config(world):
+    """BASELINE configs[3] (CNN E: 658 point-mults, 2,279,312 constraints, 2^22 padded) proven by 2 and by 4 PROCESSES together
+    through POSIX shared memory -- config size inside the driver-run suite; bytes = the oracle's digest"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    name = f"/vpin-dist-E-{os.getpid()}-{int(time.time() * 1e3) & 0xffffff}"
+    os.environ.setdefault("VPIN_GENS_BUDGET_GB", "8")
+    os.environ.setdefault("VPIN_SPARK_GENS_BUDGET_GB", "8")
+    ps = [ctx.Process(target=_proc_worker, args=(name, r, world, "E", "mult", None, q)) for r in range(world)]
+    [p.start() for p in ps]
+    res = [q.get(timeout=800) for _ in range(world)]
+    [p.join(120) for p in ps]
+    assert all(not r[1].startswith("error") for r in res), res
+    with open(os.path.join(ROOT, "tests", "golden", "config_digests.json")) as f:
+        want = json.load(f)["cases"]["E-mult"]
+    for r in res:
+        assert r[1] == want["snark_sha256"], (r, want["snark_sha256"])
+        assert r[2] == want["comm_sha256"]
+        assert r[3] > 100
+
+
+def test_threads_l5_mult_by_two_ranks():
+    """BASELINE configs[4]'s large instance (LeNet L5: 6000 point-mults, 20,784,000 constraints, 2^25 padded) proven by two
+    ranks together (threads of this process, one decommitment and one set of window tables between them): every rank returns
+    the single-GPU proof = the oracle's digest"""
+    single, out, st = _prove_threads(2, "L5", "mult", None)
+    _same(single, out)
+    with open(os.path.join(ROOT, "tests", "golden", "config_digests.json")) as f:
+        want = json.load(f)["cases"]["L5-mult"]
+    assert hashlib.sha256(out[-1]["proof"]).hexdigest() == want["snark_sha256"]
+    assert "ops_gather_tables" in st["tags"] and st["collectives"] > 100
+
+
 def test_rccl_world_one_device_allgather():
     """RCCL refuses two ranks on one GPU, so on this box only the world-1 communicator can run: dlopen, ncclGetUniqueId,
     ncclCommInitRank and ncclAllGather on the context's stream are exercised; world > 1 on one GPU takes the staged path"""

@@ -149,3 +149,34 @@ def test_whole_snarks_with_every_row_commitment_by_buckets(ctx, mode):
             assert hashlib.sha256(res["comm"]).hexdigest() == g["comm_sha256"], key
     finally:
         del os.environ["VPIN_MSM_PIPPENGER"]
+
+
+def test_whole_snarks_by_buckets_at_config_size_take_their_rows_in_chunks(ctx):
+    """L3-mult (2^22) and L5-mult (2^25 constraints) with every row commitment by the bucket method.  The 2^25 instance's
+    derefs polynomial is 2^14 rows x 2^14 scalars: at c = 9 a row's digits take 29 x 16385 x 2 B, so the 2 GiB digit buffer
+    holds ~2260 rows and the row loop of pip_rows_c really runs 8 times for that one commitment (the chunking had
+    only been exercised under a forced cap on a 64-row polynomial).  Its 2^14 x 2^15 polynomials (SNARK::encode's) have 32769 terms
+    per row with the blind: one more than a list entry's 15-bit column holds, so those stay on the table walk (msm.hip
+    msm_rows).  Bytes = the oracle's (config digests)."""
+    import hashlib
+    import json
+    import os
+    from vpin_amd import gadgets as G
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "config_digests.json")) as f:
+        gold = json.load(f)["cases"]
+    seed_c, seed_p = bytes(range(64)), bytes((7 * i + 3) % 256 for i in range(64))
+    os.environ["VPIN_MSM_PIPPENGER"] = "1"
+    try:
+        for key, min_chunks in (("L3-mult", 3), ("L5-mult", 12)):
+            g = gold[key]
+            d = ctx.gadget_point_mult_dev(*G.synthetic_mult_inputs(g["label"]))
+            before = ctx.pip_row_chunks()
+            try:
+                res = d.snark_prove(seed_c, seed_p)
+            finally:
+                d.free()
+            assert hashlib.sha256(res["proof"]).hexdigest() == g["snark_sha256"], key
+            assert hashlib.sha256(res["comm"]).hexdigest() == g["comm_sha256"], key
+            assert ctx.pip_row_chunks() - before >= min_chunks, (key, ctx.pip_row_chunks() - before)
+    finally:
+        del os.environ["VPIN_MSM_PIPPENGER"]

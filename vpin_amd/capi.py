@@ -594,6 +594,13 @@ class Context:
         L.vpin_ctx_pool_trim.argtypes = [C.c_void_p]
         _chk(L.vpin_ctx_pool_trim(self.h), "vpin_ctx_pool_trim")
 
+    def pip_row_chunks(self):
+        """row chunks the bucket method has launched on this context (vpin_ctx_pip_row_chunks)"""
+        L = lib()
+        L.vpin_ctx_pip_row_chunks.argtypes = [C.c_void_p]
+        L.vpin_ctx_pip_row_chunks.restype = C.c_ulonglong
+        return int(L.vpin_ctx_pip_row_chunks(self.h))
+
     def strip_rows_taken(self):
         """rows handed to the row-per-lane commitment kernel so far (vpin_ctx_strip_rows_taken)"""
         L = lib()

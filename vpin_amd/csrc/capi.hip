@@ -378,6 +378,7 @@ int vpin_ctx_set_progress_flag(vpin_ctx* c, int* flag) {
 }
 
 unsigned long long vpin_ctx_strip_rows_taken(vpin_ctx* c) { return c ? c->strip_rows_taken : 0ull; }
+unsigned long long vpin_ctx_pip_row_chunks(vpin_ctx* c) { return c ? c->pip_row_chunks : 0ull; }
 
 int vpin_host_register(void* p, size_t bytes) {
   if (!p || !bytes) return VPIN_EINVAL;

@@ -99,6 +99,7 @@ struct vpin_ctx {
   std::atomic<int> tail_rounds{0};  // > 0 while a persistent tail kernel is resident (read by other threads: dev_alloc's reclaim)
   vpin::fq tail_sums[3 * 18];   // host copies of the current tail round's results (assembled from the mailbox pieces)
   vpin::fq tail_final[6 * 18];
+  unsigned long long pip_row_chunks = 0;    // row chunks launched by the bucket method so far (vpin_ctx_pip_row_chunks: tests)
   unsigned long long strip_rows_taken = 0;  // rows handed to msm_strip_kernel so far (vpin_ctx_strip_rows_taken: tests)
   bool low_memory = false;     // vpin_ctx_set_low_memory: trade ~1 % of a large proof's time for a third less working set
   bool shared_device = false;  // other contexts prove on this device at the same time (vpin_ctx_set_shared_device)

@@ -378,7 +378,7 @@ int pip_rows_c(vpin_ctx* c, const ge_niels* d_gn, const fq* dZ, size_t rows, siz
   const size_t n = ncols + (size_t)n_extra;
   const size_t lds = pip_lds_bytes<C>(n);
   // The digits are 2 W bytes per scalar (58 at c = 9): rows are taken in chunks of at most ~2 GiB of digits -- still thousands
-  // of (row, window) pairs per launch -- so that the 2^14 x 2^15 polynomials of the 2^25 instance need 2, not 31 GB
+  // of (row, window) pairs per launch -- so that the 2^14 x 2^14 derefs polynomial of the 2^25 instance needs 2, not 16 GB
   // (VPIN_PIP_DIGIT_BYTES: another cap, read per call -- the tests force several chunks with it)
   const char* e_cap = getenv("VPIN_PIP_DIGIT_BYTES");
   const size_t cap = e_cap && atol(e_cap) > 0 ? (size_t)atol(e_cap) : (size_t)2 << 30;
@@ -396,6 +396,7 @@ int pip_rows_c(vpin_ctx* c, const ge_niels* d_gn, const fq* dZ, size_t rows, siz
     ProfScope ps(c, VPIN_K_MSM, 32.0 * (double)rows * (double)n, VPIN_K_MSM_ROWS);
     for (size_t r0 = 0; r0 < rows; r0 += chunk_rows) {
       const size_t nr = std::min(chunk_rows, rows - r0), items = nr * W;
+      c->pip_row_chunks++;
       hipLaunchKernelGGL(pip_recode_kernel<C>, dim3((unsigned)((nr * n + kPipBlock - 1) / kPipBlock)), dim3(kPipBlock), 0, c->stream,
                          dZ + r0 * stride, stride, ncols, d_extra ? d_extra + r0 : d_extra, n_extra, nr, (uint16_t*)b_dig.p, (uint32_t*)b_bad.p);
       hipLaunchKernelGGL(pip_window_kernel<C>, dim3((unsigned)std::min<size_t>(items, grid)), dim3(kPipBlock), lds, c->stream,

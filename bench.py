@@ -58,7 +58,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 sys.path.insert(0, os.path.join(ROOT, "tools"))  # the other modes and the shared helpers: bench_common / bench_strong / bench_concurrent
 
-from bench_common import SEED_C, SEED_P, PowerSampler, _golden_digests, live_pmc_traffic, emit  # noqa: E402
+from bench_common import SEED_C, SEED_P, PowerSampler, _golden_digests, live_pmc_traffic, emit, host_cpu_throttle  # noqa: E402
 
 T_START = time.perf_counter()
 
@@ -613,6 +613,7 @@ def main():
     sampler = PowerSampler(local_rank)
     barrier()
     sampler.start()
+    thr0 = host_cpu_throttle()
     t0 = time.perf_counter()
     if pipelined:
         run_pipelined(args.steps, False)
@@ -623,6 +624,10 @@ def main():
         cx.sync()
     barrier()
     elapsed = time.perf_counter() - t0
+    thr1 = host_cpu_throttle()
+    host_cpu = dict(thr1, throttled_ms_in_timed_region=round(thr1.get("throttled_ms", 0.0) - thr0.get("throttled_ms", 0.0), 2),
+                    nr_throttled_in_timed_region=thr1.get("nr_throttled", 0) - thr0.get("nr_throttled", 0),
+                    cpu_count=os.cpu_count(), host_threads_per_lane=int(os.environ.get("VPIN_HOST_THREADS", "0"))) if thr1 else {}
     power_rec = sampler.stop()
     stats, stats_lane0 = {}, {}
     for ci, cx in enumerate(ctxs):
@@ -700,6 +705,7 @@ def main():
     line["config"]["lanes"] = lane_names
     line["config"]["low_memory"] = bool(args.low_memory)
     line["host_affinity"] = affinity_rec
+    line["host_cpu"] = host_cpu
 
     # ---- roofline of the fused sum-check round kernel ----
     # with several streams the event time of a kernel on one stream includes waiting for CUs taken by the

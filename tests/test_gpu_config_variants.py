@@ -66,8 +66,8 @@ def test_device_built_variants_match_the_oracle(ctx, name):
     assert MV.MG.inputs_digest(kind, inp) == g["inputs_sha256"]
     d = ctx.gadget_point_mult_dev(*inp) if kind == "mult" else ctx.gadget_point_add_dev(*inp)
     try:
-        if g["oracle_is_sat"] is not None:   # (L5-mult#s1: the 15-minute oracle run recorded the verifier's verdict, not is_sat)
-            assert d.is_sat() == bool(g["oracle_is_sat"])
+        assert g["oracle_is_sat"] is not None, name   # every entry records the oracle's is_sat (round 6: L5-mult#s1 too)
+        assert d.is_sat() == bool(g["oracle_is_sat"])
         got = d.snark_prove(bytes.fromhex(g["seed_commit_hex"]), bytes.fromhex(g["seed_proof_hex"]))
         meta = {"inputs": d.inputs, "num_inputs": d.num_inputs}
     finally:
@@ -111,9 +111,10 @@ def test_fixture_covers_the_large_instances_under_a_second_seed_pair():
         base = json.load(f)["cases"]["L5-mult"]
     assert g["inputs_sha256"] == base["inputs_sha256"] and g["sat_len"] == base["sat_len"] and g["sat_sha256"] != base["sat_sha256"]
     # ... and layer 5's WHOLE SNARK under that pair (the oracle on the GPU box's host cores: 93 GB, 11 minutes): same inputs, same
-    # length and computation commitment as under the first pair, other bytes; is_sat was not recorded by that run (null)
+    # length and computation commitment as under the first pair, other bytes; is_sat comes from the oracle run in the build
+    # container over the same instance (round 6: make_config_variants.py L5-mult#is_sat; it does not depend on the seed pair)
     w = GOLD["L5-mult#s1"]
-    assert w["num_cons"] == 1 << 25 and w["oracle_verifier_accepts"] == 1 and w["oracle_is_sat"] is None
+    assert w["num_cons"] == 1 << 25 and w["oracle_verifier_accepts"] == 1 and w["oracle_is_sat"] == 1
     assert w["inputs_sha256"] == base["inputs_sha256"] and w["seed_proof_hex"] == g["seed_proof_hex"]
     assert w["snark_len"] == base["snark_len"] and w["comm_sha256"] == base["comm_sha256"] and w["snark_sha256"] != base["snark_sha256"]
     assert w["comm_para_sha256"] == g["comm_para_sha256"] and w["comm_input_sha256"] == g["comm_input_sha256"]

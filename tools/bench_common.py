@@ -240,6 +240,10 @@ def compact_line(full, detail_path=None):
     out["sclk_mhz_median"] = _num(pw.get("sclk_mhz_median"), 0)
     if pw.get("watts_median") and full.get("ms_per_step"):
         out["joules_per_step"] = _num(pw["watts_median"] * full["ms_per_step"] * 1e-3, 1)
+    hc = full.get("host_cpu") or {}
+    if hc:
+        out["host_quota_cpus"] = hc.get("quota_cpus")
+        out["host_throttled_ms"] = hc.get("throttled_ms_in_timed_region")
     out["hbm_in_use_gib"] = full.get("hbm_in_use_gib_after_timed_region")
     out["window_tables_gib"] = (full.get("hbm_breakdown") or {}).get("window_tables_gib")
     out["bytes_ok"] = _all_true(full.get("bytes_equal_oracle_digest"))
@@ -307,3 +311,64 @@ def emit(full, detail_path):
         s = json.dumps(core, allow_nan=False, separators=(",", ":"))
     print(s, flush=True)
     return s
+
+
+def host_cpu_throttle():
+    """CFS bandwidth throttling of this process's cgroup so far: {"quota_cpus", "nr_throttled", "throttled_ms"} (cgroup v2
+    cpu.stat / cpu.max or v1 cpu/cpu.stat / cpu.cfs_quota_us), or {} where the files are not there.  A one-GPU box gives a job
+    16 cores of a 128-thread host: lanes x OpenMP teams + spinning waiters beyond that are stopped for the rest of every 100 ms
+    period, which shows as ~10-50 ms stalls of whichever thread happens to run (round 6: asked of the W = 8 rehearsal's stalls)."""
+    out = {}
+    try:
+        for stat, quota in (("/sys/fs/cgroup/cpu.stat", "/sys/fs/cgroup/cpu.max"),
+                            ("/sys/fs/cgroup/cpu/cpu.stat", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us")):
+            if not os.path.exists(stat):
+                continue
+            kv = {}
+            with open(stat) as f:
+                for ln in f:
+                    p = ln.split()
+                    if len(p) == 2:
+                        kv[p[0]] = int(p[1])
+            out["nr_throttled"] = kv.get("nr_throttled", 0)
+            out["throttled_ms"] = kv["throttled_usec"] / 1e3 if "throttled_usec" in kv else kv.get("throttled_time", 0) / 1e6
+            try:
+                with open(quota) as f:
+                    q = f.read().split()
+                if quota.endswith("cpu.max"):
+                    out["quota_cpus"] = None if q[0] == "max" else int(q[0]) / int(q[1])
+                else:
+                    per = 100000
+                    try:
+                        with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f2:
+                            per = int(f2.read())
+                    except (OSError, ValueError):
+                        pass
+                    out["quota_cpus"] = None if int(q[0]) < 0 else int(q[0]) / per
+            except (OSError, ValueError, IndexError):
+                out["quota_cpus"] = None
+            break
+        out["affinity_cpus"] = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None
+    except (OSError, ValueError, KeyError):
+        pass
+    return out
+
+
+def thread_cpu_seconds(top=16):
+    """[(thread name, tid, user + system CPU seconds)] of this process's threads, busiest first (/proc/self/task/*/stat)"""
+    out = []
+    tck = os.sysconf("SC_CLK_TCK")
+    try:
+        for tid in os.listdir("/proc/self/task"):
+            try:
+                with open(f"/proc/self/task/{tid}/stat") as f:
+                    st = f.read()
+                name = st[st.index("(") + 1:st.rindex(")")]
+                rest = st[st.rindex(")") + 2:].split()
+                out.append((name, int(tid), round((int(rest[11]) + int(rest[12])) / tck, 2)))
+            except (OSError, ValueError, IndexError):
+                continue
+    except OSError:
+        return []
+    out.sort(key=lambda x: -x[2])
+    return out[:top]

@@ -233,15 +233,24 @@ def main():
     numa_mode = args.numa or ("local" if world_env > 1 else "off")
     affinity_rec = pin_to_gpu_numa_node(int(os.environ.get("LOCAL_RANK", "0")), world_env, numa_mode)
     if "VPIN_HOST_THREADS" not in os.environ:
-        # The library's OpenMP teams (blind terms of the ZK rounds, generator derivation) are sized per context: 8 threads by
-        # default.  A step runs four lanes (contexts) per rank and a one-GPU box has 16 cores: 4 x 8 threads oversubscribe them
-        # and the lanes' host sections wait for each other -- measured on the default step: 436-443 ms with 8 threads per lane,
-        # 405-408 ms with 2, 3 or 4, 413 ms with 6 (profiles/r04_ab_host_threads.txt).  N ranks share the node's cores.
+        # The library's OpenMP teams (blind terms of the ZK rounds, generator derivation) are sized per context.  What bounds them
+        # is the CPUs the job may use AT ONCE -- its cgroup's CFS quota (16 on a one-GPU box of a 256-thread host), not the
+        # host's core count: a process that runs more threads than that for a while is stopped for the rest of every 100 ms
+        # period.  Round 6 found this behind the ~20 ms stalls of the W = 8 rehearsal (8 rank-threads x teams of 4: 24 of ~90
+        # periods throttled; with teams of 1 or 2 none, and the unfiltered model falls from 231 to 148-164 ms).
+        quota = host_cpu_throttle().get("quota_cpus")
         if "cores" in affinity_rec:   # pinned: this rank's own cores
             cores = affinity_rec["cores"] * world_env
         else:
             cores = (os.cpu_count() or 16) if world_env > 1 else min(16, os.cpu_count() or 16)
-        os.environ["VPIN_HOST_THREADS"] = str(max(2, min(4, cores // (world_env * 4))))
+        if quota:
+            cores = min(cores, int(quota))
+        if args.scaling == "strong" and args.rehearse:   # W rank-threads, one computing at a time, W teams alive
+            os.environ["VPIN_HOST_THREADS"] = str(max(1, min(4, cores // (2 * args.rehearse))))
+        else:
+            # the four-lane step: 16 // 4 = 4 per lane (round 6 re-measured 2 against 4 on one box: 375.6 against 372.2 ms -- the
+            # lanes' host sections are short bursts, the throttled periods they cause cost less than the narrower teams)
+            os.environ["VPIN_HOST_THREADS"] = str(max(2, min(4, cores // (world_env * 4))))
     if args.scaling == "strong":
         from bench_strong import main_strong
         return main_strong(args)

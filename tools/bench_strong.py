@@ -9,6 +9,7 @@ import time
 from bench_common import ROOT, SEED_C, SEED_P, _build_resident, _golden_digests, _prove_res, _strong_work, host_cpu_throttle, thread_cpu_seconds  # noqa: F401
 
 T0 = time.perf_counter()
+THR0 = host_cpu_throttle()
 
 
 def main_strong(args):
@@ -335,6 +336,6 @@ def strong_rehearse(args):
         "finish_ms_per_rank": None if loads is None else [round(x, 3) for x in loads], "instances": per,
         "plan": dict(zip(("owner_ops", "owner_dotp", "owner_mem"), vpin_amd.dist_plan(W))),
         "threads_cpu_s": thread_cpu_seconds(24), "wall_s": round(time.perf_counter() - T0, 2),
-        "host_cpu": dict(host_cpu_throttle(), env={k: os.environ.get(k) for k in ("GPU_MAX_HW_QUEUES", "HSA_ENABLE_INTERRUPT", "VPIN_HOST_THREADS")}),
+        "host_cpu": dict(host_cpu_throttle(), nr_throttled_in_this_run=host_cpu_throttle().get("nr_throttled", 0) - THR0.get("nr_throttled", 0), env={k: os.environ.get(k) for k in ("GPU_MAX_HW_QUEUES", "HSA_ENABLE_INTERRUPT", "VPIN_HOST_THREADS")}),
     }))
     ctx0.close()

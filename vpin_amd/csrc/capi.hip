@@ -42,6 +42,34 @@ void ctx_unregister(vpin_ctx* c) {
   for (size_t i = 0; i < g_live_ctxs.size(); i++)
     if (g_live_ctxs[i] == c) { g_live_ctxs.erase(g_live_ctxs.begin() + (long)i); break; }
 }
+int live_ctx_count() {
+  std::lock_guard<std::mutex> g(g_ctx_mu);
+  return (int)g_live_ctxs.size();
+}
+// CPUs this process may use at once: its cgroup's CFS quota (v2 cpu.max, v1 cpu.cfs_quota_us / cpu.cfs_period_us) when there is
+// one, else the affinity mask.  A one-GPU box hands a job 16 CPUs of a 256-thread host: omp_get_num_procs() says 256, and a
+// process that runs more than 16 threads for a while is stopped for the rest of every 100 ms period (round 6: the ~20 ms stalls of
+// the W = 8 rehearsal -- 8 rank-threads x teams of 4).
+double host_cpu_quota() {
+  static const double q = [] {
+    double v = 0.0;
+    if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+      char a[32] = {0};
+      long per = 0;
+      if (fscanf(f, "%31s %ld", a, &per) == 2 && strcmp(a, "max") != 0 && per > 0) v = atof(a) / (double)per;
+      fclose(f);
+    } else if (FILE* f1 = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {
+      long quota = -1, per = 100000;
+      if (fscanf(f1, "%ld", &quota) != 1) quota = -1;
+      fclose(f1);
+      if (FILE* f2 = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(f2, "%ld", &per) != 1) per = 100000; fclose(f2); }
+      if (quota > 0 && per > 0) v = (double)quota / (double)per;
+    }
+    const double hw = (double)std::thread::hardware_concurrency();
+    return v > 0.0 && (hw <= 0.0 || v < hw) ? v : (hw > 0.0 ? hw : 1.0);
+  }();
+  return q;
+}
 bool ctx_is_live(vpin_ctx* c) {
   std::lock_guard<std::mutex> g(g_ctx_mu);
   for (auto* x : g_live_ctxs) if (x == c) return true;

@@ -138,6 +138,8 @@ struct AltStreamGuard {
 int dev_alloc(vpin_ctx* c, size_t bytes, void** out);
 void note_driver_alloc(size_t bytes);  // every hipMalloc the library makes outside dev_alloc reports here (vpin_driver_alloc_stats)
 void dev_free(vpin_ctx* c, void* p);
+int live_ctx_count();      // contexts of this process that exist right now
+double host_cpu_quota();   // CPUs the process may use at once (cgroup CFS quota, else the hardware's)
 void dev_free_owned(vpin_ctx* owner, vpin_ctx* fallback, void* p);  // to the owner's pool, whichever context frees the handle
 void dev_pool_release(vpin_ctx* c);
 // one block the caller holds (from dev_alloc) straight back to the driver, not to the pool; the caller has synchronised the

@@ -43,17 +43,22 @@ static double secs(Clock::time_point a, Clock::time_point b) { return std::chron
 // Host worker threads for the few batched host loops (generator derivation, per-round blind
 // commitments).  OpenMP workers that spin after a parallel region burn a container's CPU quota and
 // get the whole process throttled, so waiting is made passive and the team is kept small.
+// VPIN_HOST_THREADS = n fixes the team size.  Unset (round 6): at most 8 and at most the process's CPU quota divided by twice
+// the contexts that exist (every context's proving thread plus its team may be busy at once, and the runtime's own threads
+// need room): 16 CPUs / (2 x 8 rank contexts) = 1, / (2 x 4 lanes) = 2, a single context 8.
 static int host_threads() {
-  static int n = [] {
+  static const int fixed = [] {
     setenv("KMP_BLOCKTIME", "0", 0);
     setenv("OMP_WAIT_POLICY", "PASSIVE", 0);
-    int hw = omp_get_num_procs();
     const char* e = getenv("VPIN_HOST_THREADS");
-    int want = e ? atoi(e) : 8;
-    if (want < 1) want = 1;
-    return want < hw ? want : hw;
+    int want = e ? atoi(e) : 0;
+    const int hw = omp_get_num_procs();
+    return want > hw ? hw : want;
   }();
-  return n;
+  if (fixed >= 1) return fixed;
+  const int ctxs = vpin::live_ctx_count();
+  int n = (int)(vpin::host_cpu_quota() / (2.0 * (double)(ctxs > 0 ? ctxs : 1)));
+  return n < 1 ? 1 : n > 8 ? 8 : n;
 }
 
 static size_t log2z(size_t n) { size_t l = 0; while (((size_t)1 << l) < n) l++; return l; }

@@ -138,3 +138,33 @@ def test_every_region_of_the_snark_is_checked(ctx):
         assert not ctx.snark_verify(inst, got, proof=bytes(bad)), pos
         if k % 10 == 0:
             assert O.snark_verify(inst, got, proof=bytes(bad)) == 0, pos
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("wgs", ["2", "8"])
+def test_tail_rounds_on_several_workgroups_per_circuit_give_the_same_bytes(wgs):
+    """VPIN_SPARK_TAIL_WGS (round 6, off by default: measured slower -- profiles/r06_ab_tail_wgs.txt): the rounds between 1024 and
+    8192 pairs per circuit inside the resident tail kernel, on up to 8 workgroups per circuit (classes of the pair index, partial
+    sums added by the last arrival).  Whole SNARKs of conv f=3 and CNN A (2^16 / 2^20 constraints) against the oracle's digests."""
+    import hashlib
+    import json
+    import os
+    import vpin_amd
+    from vpin_amd import gadgets as G
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "config_digests.json")) as f:
+        gold = json.load(f)["cases"]
+    seed_c, seed_p = bytes(range(64)), bytes((7 * i + 3) % 256 for i in range(64))
+    os.environ["VPIN_SPARK_TAIL_WGS"] = wgs
+    try:
+        with vpin_amd.Context(0) as ctx:
+            for key in ("3_32-mult", "A-add", "A-mult"):
+                g = gold[key]
+                inp = G.synthetic_mult_inputs(g["label"]) if g["kind"] == "mult" else G.synthetic_add_inputs(g["label"])
+                d = ctx.gadget_point_mult_dev(*inp) if g["kind"] == "mult" else ctx.gadget_point_add_dev(*inp)
+                try:
+                    res = d.snark_prove(seed_c, seed_p)
+                finally:
+                    d.free()
+                assert hashlib.sha256(res["proof"]).hexdigest() == g["snark_sha256"], key
+    finally:
+        del os.environ["VPIN_SPARK_TAIL_WGS"]

@@ -349,6 +349,8 @@ void vpin_ctx_destroy(vpin_ctx* c) {
   if (c->verify_cache_free) c->verify_cache_free(c);
   if (c->h_spark) (void)hipHostFree(c->h_spark);
   if (c->d_spark_cnt) (void)hipFree(c->d_spark_cnt);
+  if (c->d_tail_cnt) (void)hipFree(c->d_tail_cnt);
+  if (c->d_tail_red) (void)hipFree(c->d_tail_red);
   if (c->d_add_count) (void)hipFree(c->d_add_count);
   ctx_unregister(c);
   ctx_wait_unpinned(c);

@@ -96,6 +96,11 @@ struct vpin_ctx {
   int round_split = 0, round_split_grid = 0, round_split_ncirc = 0;  // the current group sums its partials in round_finish_kernel
   int round_group_ndotp = 0;  // dot-product halves announced for the current launch group (spark_prod_round)
   uint32_t tail_seq = 0;            // persistent tail kernel (spark.hip): sequence base of the current / next launch
+  // tail rounds on several workgroups per circuit (round 6): per-instance arrival counters (self-resetting), the workgroups'
+  // partial sums, this context's share of the device's resident-workgroup budget
+  uint32_t* d_tail_cnt = nullptr;
+  vpin::fq* d_tail_red = nullptr;
+  int tail_reserved = 0;
   std::atomic<int> tail_rounds{0};  // > 0 while a persistent tail kernel is resident (read by other threads: dev_alloc's reclaim)
   vpin::fq tail_sums[3 * 18];   // host copies of the current tail round's results (assembled from the mailbox pieces)
   vpin::fq tail_final[6 * 18];

@@ -446,7 +446,9 @@ static int batched_prove(vpin_ctx* c, vpin::SparkForest& f, DotpCtx* dotp, Trans
       // Rounds with at most spark_tail_pairs() pairs per circuit are proven by ONE resident launch (spark.hip, persistent
       // tail): the kernel publishes a round's sums to pinned memory and polls a pinned mailbox for the challenge this
       // loop derives from the transcript.  Larger rounds take one launch each.
-      const size_t tail_pairs = lead_ok ? vpin::spark_tail_pairs() : 0;
+      // (round 6: a layer without dot-product halves on a single GPU may start it at up to 8192 pairs, on several workgroups per
+      // circuit, when the device has room for them -- spark_tail_launch says so)
+      const size_t tail_pairs = lead_ok ? (pl ? vpin::spark_tail_pairs() : vpin::spark_tail_first_pairs(ndl_here > 0)) : 0;
       if (pl && tail_pairs == 0) {  // the split rounds end in the persistent tail; a zero challenge (never) or VPIN_SPARK_TAIL_PAIRS=0 rules it out
         vpin::set_last_error("one proof over several GPUs needs the persistent tail rounds", hipErrorUnknown);
         return VPIN_ESHAPE;
@@ -460,13 +462,15 @@ static int batched_prove(vpin_ctx* c, vpin::SparkForest& f, DotpCtx* dotp, Trans
         const vpin::fq* E = runs ? pyr->d + pyramid_offset(k, j + 1) : nullptr;
         const uint8_t* rprev = j ? B(&r[j - 1]) : nullptr;
         if (!tail_on && (h >> (j + 1)) <= tail_pairs) {
-          if (runs && (rc = vpin::spark_tail_launch(c, &f, layer_id, k, j, len, pyr->d, rprev, ndl_here ? dotp->d->N : 0,
-                                                    ndl_here ? dotp->d->vals : nullptr,
-                                                    ndl_here ? dotp->comb_derefs : nullptr, ndl_here ? dotp->scratch : nullptr,
-                                                    halves, ndl_here)))
-            return rc;
-          tail_on = true;
-          tail_j0 = j;
+          rc = runs ? vpin::spark_tail_launch(c, &f, layer_id, k, j, len, pyr->d, rprev, ndl_here ? dotp->d->N : 0,
+                                              ndl_here ? dotp->d->vals : nullptr,
+                                              ndl_here ? dotp->comb_derefs : nullptr, ndl_here ? dotp->scratch : nullptr,
+                                              halves, ndl_here) : VPIN_OK;
+          if (rc < 0) return rc;
+          if (rc == 0) {   // (1: no room for the workgroups of an early start -- this round by a launch, asked again at the next)
+            tail_on = true;
+            tail_j0 = j;
+          }
         }
         const Fq* res = nullptr;
         if (tail_on) {

@@ -20,6 +20,7 @@
 // sum_i E[i]*(A_x*B_x)[i] for x = 0,2,3 with E the read-only suffix table of the round, and the
 // host applies the per-round scalar.  Per pair: fold 2 tables (4 products), 3 products A_x*B_x,
 // 3 products by E: 10 Montgomery products, 9 loads, 4 stores.  HBM-streaming integer work.
+#include <atomic>
 #include <chrono>
 #include <cstdlib>
 
@@ -593,6 +594,9 @@ int spark_pinned(vpin_ctx* c) {
   memset(c->h_spark, 0, kSparkPinned * sizeof(fq));
   VPIN_HIP_TRY(hipMalloc((void**)&c->d_spark_cnt, 2 * kSparkMaxInst * sizeof(uint32_t)));
   VPIN_HIP_TRY(hipMemsetAsync(c->d_spark_cnt, 0, 2 * kSparkMaxInst * sizeof(uint32_t), c->stream));
+  VPIN_HIP_TRY(hipMalloc((void**)&c->d_tail_cnt, kSparkMaxInst * sizeof(uint32_t)));
+  VPIN_HIP_TRY(hipMalloc((void**)&c->d_tail_red, (size_t)kSparkMaxInst * 8 * 2 * sizeof(fq)));  // kTailMaxWgs = 8
+  VPIN_HIP_TRY(hipMemsetAsync(c->d_tail_cnt, 0, kSparkMaxInst * sizeof(uint32_t), c->stream));
   VPIN_HIP_TRY(hipStreamSynchronize(c->stream));
   c->spark_seq = 0;
   return VPIN_OK;
@@ -1238,12 +1242,23 @@ struct TailArgs {
   uint32_t seq0;           // round j publishes / waits for seq0 + (j - j0) + 1
   unsigned long long* trace;  // VPIN_TAIL_TRACE: pinned, per round {start, published, reply seen, -} in 100 MHz ticks (instance 0)
   uint32_t poll_sleep;        // VPIN_TAIL_SLEEP=1: s_sleep between two polls of the mailbox (A/B of what the polling wave costs its CU)
+  // Round 6: the rounds between kTailPairs1 and kTailMaxWgs x kTailPairs1 pairs on `wgs` workgroups per circuit (blockIdx.x =
+  // circuit x wgs + g).  Workgroup g owns the pairs whose index / 4 is congruent to g mod wgs -- a fold maps (i, i + pairs,
+  // i + 2 pairs, i + 3 pairs) to (i, i + pairs), all of one class while 4 x wgs divides pairs, so no workgroup ever reads what
+  // another one wrote (128-byte lines are not shared either).  A round's sums: every workgroup stores its partial pair to `red`,
+  // the one that arrives last at the circuit's counter adds them and publishes -- nobody waits for anybody on the device.  When a
+  // round is down to kTailPairs1 pairs, workgroup 0 goes on alone (the host's reply, which needs every partial, is the barrier).
+  int wgs;
+  fq* red;               // [inst][wgs][2]
+  uint32_t* cnt;         // [inst]: arrivals of the current round, 0 between rounds (atomicInc wraps it)
 };
 
 constexpr int kTailBlock = 512;
 constexpr int kTailUpChunks = 32;             // 16-byte pieces per instance: 9 for the sums, 18 for the final entries
 constexpr long kTailSpinLimit = 4000000;      // ~10 s of polling: a lost host ends the kernel instead of hanging the GPU
 constexpr size_t kTailQuadPairs = kTailBlock / 4;  // rounds with at most this many pairs run four lanes per pair
+constexpr size_t kTailPairs1 = 1024;          // rounds with at most this many pairs per circuit: one workgroup per circuit
+constexpr int kTailMaxWgs = 8;                // larger rounds (up to 8192 pairs): up to this many workgroups per circuit
 
 __device__ __forceinline__ fq fq_shfl_from(const fq& a, int src) {
   fq r;
@@ -1274,11 +1289,16 @@ __device__ __forceinline__ fq tail_block_sum3(fq* e, int nw) {
   return t;
 }
 
+// MULTI = false: the kernel as it was (one workgroup per circuit; 161 VGPRs) -- the default.  MULTI = true: launched only when
+// VPIN_SPARK_TAIL_WGS asks for several workgroups per circuit (199 VGPRs; measured slower, profiles/r06_ab_tail_wgs.txt).
+template <bool MULTI>
 __global__ __launch_bounds__(kTailBlock) void spark_tail_kernel(TailArgs a) {
-  const int inst = blockIdx.x;
+  const int W = MULTI ? a.wgs : 1;
+  const int inst = (int)blockIdx.x / W, g = (int)blockIdx.x % W;
   const bool is_dotp = inst >= a.ncirc;
   __shared__ fq sh_r;
   __shared__ int sh_stop;
+  __shared__ int sh_last;
   fq r = a.r_prev;
   size_t len = a.len0;
   fq* A = nullptr;
@@ -1303,9 +1323,43 @@ __global__ __launch_bounds__(kTailBlock) void spark_tail_kernel(TailArgs a) {
     const size_t pairs = bind ? len / 4 : len / 2;
     const uint32_t seq = a.seq0 + (uint32_t)(j - a.j0) + 1u;
     const fq* E = a.pyr + ((((size_t)1) << a.k) - (((size_t)2) << (a.k - (j + 1))));  // pyramid level j + 1
+    const bool multi = W > 1 && pairs > kTailPairs1;   // this round runs on all W workgroups of the circuit
+    if (W > 1 && !multi && g != 0) return;             // from here on workgroup 0 alone (the others' folds are visible: see below)
+    if (a.trace && inst == 0 && g == 0 && threadIdx.x == 0) a.trace[4 * (j - a.j0)] = wall_clock64();
+    if (multi) {
+      // product circuits only (the launcher keeps layers with dot-product halves on one workgroup), leading-coefficient form
+      Acc<4> acc;
+      acc.init();
+      const size_t ngroups = pairs >> 2;  // runs of four pairs = one 128-byte line per table half
+      for (size_t q = (size_t)g + (size_t)W * (threadIdx.x >> 2); q < ngroups; q += (size_t)W * (kTailBlock >> 2)) {
+        const size_t i = 4 * q + (threadIdx.x & 3);
+        fq p1, d1, p2, d2;
+        if (bind) { fold_pd(A, i, pairs, r, p1, d1); fold_pd(Bt, i, pairs, r, p2, d2); }
+        else { load_pd(A, i, pairs, p1, d1); load_pd(Bt, i, pairs, p2, d2); }
+        acc.lead_bc(p1, d1, p2, d2, fq_load(E + i));
+      }
+      if (bind) len /= 2;
+      const size_t mine = pairs / (size_t)W;  // pairs of this workgroup: its first `mine` threads carry them
+      const int nw = mine >= (size_t)kTailBlock ? kTailBlock / 64 : (int)((mine + 63) / 64);
+      const fq t = tail_block_sum3(acc.e, nw);
+      if (threadIdx.x < 2) fq_store(a.red + ((size_t)inst * W + g) * 2 + threadIdx.x, t);
+      __threadfence();  // this workgroup's folds and its partial sums: visible device-wide before it is counted
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        sh_last = atomicInc(a.cnt + inst, (unsigned)(W - 1)) == (unsigned)(W - 1);  // wraps to 0 with the last arrival: self-resetting
+      }
+      __syncthreads();
+      if (sh_last) {  // everybody else of this circuit has stored and fenced: add up and publish
+        __threadfence();
+        if (threadIdx.x < 2) {
+          fq sum = fq_load(a.red + ((size_t)inst * W) * 2 + threadIdx.x);
+          for (int w = 1; w < W; w++) sum = fq_add(sum, fq_load(a.red + ((size_t)inst * W + w) * 2 + threadIdx.x));
+          publish_scalar(up + 12 * threadIdx.x, sum, seq);
+        }
+      }
+    } else {
     Acc<4> acc;
     acc.init();
-    if (a.trace && inst == 0 && threadIdx.x == 0) a.trace[4 * (j - a.j0)] = wall_clock64();
     int nw = kTailBlock / 64, lo_off = 1;
     fq mine = fq_zero();  // quad mode: this lane's folded entry (A[i], A[q+i], B[i], B[q+i] by role)
     if (!is_dotp && pairs <= kTailQuadPairs) {
@@ -1394,7 +1448,8 @@ __global__ __launch_bounds__(kTailBlock) void spark_tail_kernel(TailArgs a) {
         }
       }
     }
-    if (a.trace && inst == 0 && threadIdx.x == 0) a.trace[4 * (j - a.j0) + 1] = wall_clock64();
+    }  // (single-workgroup round)
+    if (a.trace && inst == 0 && g == 0 && threadIdx.x == 0) a.trace[4 * (j - a.j0) + 1] = wall_clock64();
     if (last) break;
     if (threadIdx.x == 0) {
       int stop = 1;
@@ -1403,7 +1458,7 @@ __global__ __launch_bounds__(kTailBlock) void spark_tail_kernel(TailArgs a) {
         // pieces only once the first carries the round's sequence number
         u32x4 c0 = load16_system(a.down), c1, c2;
         if (c0.x != seq) {
-          if (a.poll_sleep) __builtin_amdgcn_s_sleep(16);  // ~1024 cycles off the SIMD's arbiter
+          if (a.poll_sleep || g != 0) __builtin_amdgcn_s_sleep(16);  // ~1024 cycles off the SIMD's arbiter; the extra workgroups of a circuit always
           if ((spin & 15) == 15 && __hip_atomic_load(a.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) break;
           continue;
         }
@@ -1417,11 +1472,14 @@ __global__ __launch_bounds__(kTailBlock) void spark_tail_kernel(TailArgs a) {
         if (__hip_atomic_load(a.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) break;
       }
       sh_stop = stop;
-      if (a.trace && inst == 0) a.trace[4 * (j - a.j0) + 2] = wall_clock64();
+      if (a.trace && inst == 0 && g == 0) a.trace[4 * (j - a.j0) + 2] = wall_clock64();
     }
     __syncthreads();
     if (sh_stop) return;
     r = sh_r;
+    // The reply exists only because every workgroup of every circuit had published (fenced) its round: an acquire here and
+    // the next round may read any class's folded entries -- workgroup 0 does when it goes on alone
+    if (multi) __threadfence();
   }
 }
 
@@ -1435,6 +1493,29 @@ static inline uint32_t* tail_up(vpin_ctx* c) { return reinterpret_cast<uint32_t*
 size_t spark_tail_pairs() {
   static const size_t n = [] { const char* e = getenv("VPIN_SPARK_TAIL_PAIRS"); long v = e ? atol(e) : 1024; return (size_t)(v < 0 ? 0 : v); }();
   return n;  // 0 disables the persistent tail (classic per-round launches only)
+}
+
+// Resident workgroups of persistent tails per device, all contexts of the process: a tail's workgroups wait for the host, and the
+// host for ALL of them, so a launch whose workgroups do not all fit beside the other resident ones would sit out its poll bound.
+// The tail kernel takes a CU per workgroup (161 VGPRs x 8 waves).  One workgroup per circuit (<= 18 per context) always fit; the
+// multi-workgroup rounds reserve their grid against HALF the CUs the context's stream may use (other processes on the device,
+// transient kernels) or run classically for another round (spark_tail_launch returns 1).
+static std::atomic<int> g_tail_resident[16];
+static int tail_max_wgs() {
+  // default 1: measured in round 6, 2 / 4 / 8 workgroups per circuit do not beat a launch per round (a resident workgroup needs
+  // ~30 us for 1024 pairs on its one CU, the chip-wide launch ~25 us for 8192) -- profiles/r06_ab_tail_wgs.txt
+  const char* e = getenv("VPIN_SPARK_TAIL_WGS");  // read per call: tests and A/B runs switch it inside one process
+  const int v = e ? atoi(e) : 1;
+  return v < 1 ? 1 : v > kTailMaxWgs ? kTailMaxWgs : v;
+}
+// pairs per circuit from which the host may ask for the tail (layers without dot-product halves: the multi-workgroup rounds)
+size_t spark_tail_first_pairs(bool with_dotp) {
+  const size_t one = spark_tail_pairs();
+  if (with_dotp || one != kTailPairs1) return one;   // (a non-default VPIN_SPARK_TAIL_PAIRS: experiments keep one workgroup)
+  return one * (size_t)tail_max_wgs();
+}
+static void tail_release(vpin_ctx* c) {
+  if (c->tail_reserved) { g_tail_resident[c->device & 15].fetch_sub(c->tail_reserved, std::memory_order_acq_rel); c->tail_reserved = 0; }
 }
 
 int spark_tail_launch(vpin_ctx* c, const SparkForest* f, int level, int k, int j0, size_t len0, const fq* pyr, const uint8_t* r_prev,
@@ -1463,13 +1544,33 @@ int spark_tail_launch(vpin_ctx* c, const SparkForest* f, int level, int k, int j
   static const bool trace_on = getenv("VPIN_TAIL_TRACE") != nullptr;
   a.trace = trace_on ? reinterpret_cast<unsigned long long*>(c->h_spark + kTailTrace) : nullptr;
   if (trace_on) memset(c->h_spark + kTailTrace, 0, 64 * 32);
-  c->tail_rounds = k - j0;
   const int ninst = f->ncirc + (with_dotp ? ndotp : 0);
+  // workgroups per circuit: the first round's pairs / 1024 (2, 4 or 8) when the host starts the tail early
+  const size_t pairs0 = j0 == 0 ? len0 / 2 : len0 / 4;
+  int wgs = 1;
+  if (pairs0 > kTailPairs1) {
+    if (with_dotp || pairs0 % kTailPairs1 || pairs0 / kTailPairs1 > (size_t)kTailMaxWgs) return VPIN_ESHAPE;
+    wgs = (int)(pairs0 / kTailPairs1);
+  }
+  const int want = ninst * wgs;
+  {
+    std::atomic<int>& res = g_tail_resident[c->device & 15];
+    const int cap = wgs > 1 ? c->num_cus / 2 : (1 << 30);
+    int cur = res.load(std::memory_order_acquire);
+    for (;;) {
+      if (cur + want > cap) return 1;   // declined: the caller proves this round with a launch and may ask again
+      if (res.compare_exchange_weak(cur, cur + want, std::memory_order_acq_rel)) break;
+    }
+    c->tail_reserved = want;
+  }
+  a.wgs = wgs; a.red = c->d_tail_red; a.cnt = c->d_tail_cnt;
+  c->tail_rounds = k - j0;
   {
     ProfScope ps(c, VPIN_K_SPARK_TAIL, 0.0);
-    hipLaunchKernelGGL(spark_tail_kernel, dim3(ninst), dim3(kTailBlock), 0, c->stream, a);
+    if (wgs > 1) hipLaunchKernelGGL(spark_tail_kernel<true>, dim3((unsigned)want), dim3(kTailBlock), 0, c->stream, a);
+    else hipLaunchKernelGGL(spark_tail_kernel<false>, dim3((unsigned)want), dim3(kTailBlock), 0, c->stream, a);
   }
-  VPIN_HIP_TRY(hipGetLastError());
+  if (hipGetLastError() != hipSuccess) { tail_release(c); c->tail_rounds = 0; return VPIN_EHIP; }
   return VPIN_OK;
 }
 
@@ -1526,6 +1627,10 @@ int spark_tail_wait(vpin_ctx* c, int idx, int ninst, int ncirc) {
         // kernel has already published, nor the kernel of the next proof the stale challenge
         c->tail_seq += (uint32_t)c->tail_rounds + 1u;
         c->tail_rounds = 0;
+        tail_release(c);
+        // an aborted multi-workgroup round leaves the arrival counters anywhere: start them over
+        (void)hipMemsetAsync(c->d_tail_cnt, 0, kSparkMaxInst * sizeof(uint32_t), c->stream);
+        (void)hipStreamSynchronize(c->stream);
         set_last_error("spark_tail_wait: the persistent round kernel did not answer", hipErrorUnknown);
         return VPIN_EHIP;
       }
@@ -1547,6 +1652,9 @@ void spark_tail_abort(vpin_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   c->tail_seq += (uint32_t)c->tail_rounds + 1u;
   c->tail_rounds = 0;
+  tail_release(c);
+  (void)hipMemsetAsync(c->d_tail_cnt, 0, kSparkMaxInst * sizeof(uint32_t), c->stream);
+  (void)hipStreamSynchronize(c->stream);
 }
 
 // after the last round's results were taken: retire the sequence numbers of this tail
@@ -1564,6 +1672,7 @@ void spark_tail_end(vpin_ctx* c) {
   }
   c->tail_seq += (uint32_t)c->tail_rounds + 1u;
   c->tail_rounds = 0;
+  tail_release(c);
 }
 
 const fq* spark_tail_sums(vpin_ctx* c) { return c->tail_sums; }

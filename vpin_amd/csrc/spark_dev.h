@@ -141,6 +141,10 @@ int spark_triple_sums_raw(vpin_ctx* c, const fq* comb_derefs, const fq* vals, si
 // round, which also leaves the two live entries of every table at spark_tail_final()[6*inst + 2*table + e]); spark_tail_end
 // retires the launch's sequence numbers.  len0 = live length before round j0; r_prev = r_{j0-1} when j0 > 0.
 size_t spark_tail_pairs();  // rounds with at most this many pairs per circuit go to the tail (0 = never)
+// ... and from this many pairs on the host may ASK for it (layers without dot-product halves: up to 8 workgroups per circuit,
+// 1024 pairs each); spark_tail_launch then returns 1 when the grid does not fit beside the device's other resident tails --
+// the caller proves that round with a launch and asks again at the next one
+size_t spark_tail_first_pairs(bool with_dotp);
 int spark_tail_launch(vpin_ctx* c, const SparkForest* f, int level, int k, int j0, size_t len0, const fq* pyr, const uint8_t* r_prev,
                       size_t N, const fq* vals, const fq* comb_derefs, fq* scratch, const int* halves = nullptr, int ndotp = 6);
 int spark_tail_wait(vpin_ctx* c, int idx, int ninst, int ncirc);

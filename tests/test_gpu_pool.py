@@ -51,3 +51,18 @@ def test_resident_proofs_take_nothing_from_the_driver():
         assert cx.driver_alloc_stats() == before
         dec.free()
         g.free()
+
+
+def test_whole_snarks_from_host_buffers_take_nothing_from_the_driver_once_warm():
+    """vpin_snark_prove from host triplets (upload + CSR/CSC + SNARK::encode + prove per call, a service context: no expected proof
+    count): round 5 handed SNARK::encode's tables back to the driver after every call; they stay pooled now"""
+    inst = G.synthetic_mult_instance("A", 32)
+    d = inst.as_dict()
+    with vpin_amd.Context(0) as cx:
+        ref = cx.snark_prove(d, SEED_C, SEED_P)
+        cx.snark_prove(d, SEED_C, SEED_P)
+        before = cx.driver_alloc_stats()
+        for _ in range(3):
+            assert cx.snark_prove(d, SEED_C, SEED_P)["proof"] == ref["proof"]
+        assert cx.driver_alloc_stats() == before
+    inst.free()

@@ -1459,9 +1459,12 @@ static int encode_commit(vpin_ctx* c, const Shape& s, std::unique_ptr<vpin_spark
   lap("commit ops");
   if ((rc = commit_noblind(c, g_mem, d->comb_mem, c_mem))) return fail(rc);
   lap("commit mem");
-  // (commit_noblind has synchronised the stream.)  A service (no expected proof count) hands the blocks back to the driver;
-  // a one-shot process keeps them pooled for its proof's temporaries (a hipFree / hipMalloc pair of 17 GB costs more there)
-  if (!getenv("VPIN_KEEP_COMB")) vpin::spark_comb_release(c, d.get(), c->expected_proofs == 0);
+  // (commit_noblind has synchronised the stream.)  The blocks go back to the context's POOL, never straight to the driver
+  // (round 6): the proof that follows takes its 16N-scalar temporaries out of them, and a host that encodes per proof
+  // (vpin_snark_prove from host buffers) would otherwise pay a 17 GB hipMalloc / hipFree pair every time -- 0.3 ms usually,
+  // seconds every few calls (bench.py --trace E --host-buffers: 106 -> 975 ms/step when it struck).  A service that encodes
+  // once and keeps proving trims the pool after its set-up (vpin_ctx_pool_trim), as bench.py does.
+  if (!getenv("VPIN_KEEP_COMB")) vpin::spark_comb_release(c, d.get(), false);
   lap("comb release");
   if ((rc = vpin::spark_find_hot_cols(c, d.get()))) return fail(rc);
   lap("hot columns");

@@ -1234,6 +1234,16 @@ def main():
         watchdog = threading.Timer(args.strong_timeout, bail)
         watchdog.daemon = True
         watchdog.start()
+        if rank == 0:
+            # ... and should the first outing of RCCL take the process down instead (a fault inside the library, the launcher's
+            # SIGTERM after another rank died), the weak line is left with a signal handler that writes it out (vpin_crash_line_set)
+            from bench_common import compact_line, dumps_line
+            try:
+                safe = dict(line, strong_error="the strong sub-record ended the process (fatal signal, or the launcher's SIGTERM after "
+                            "another rank died); the weak numbers of this line are unaffected", run_s=time.perf_counter() - T_START)
+                vpin_amd.Context.crash_line_set((dumps_line(compact_line(safe, None)) + "\n").encode())
+            except (ValueError, vpin_amd.VpinError):
+                pass
         ndev = max(1, torch.cuda.device_count())  # (world > 1: torch is imported)
         nsteps = max(1, min(args.steps, 5))
 
@@ -1266,6 +1276,7 @@ def main():
                                                                      "speedup_vs_one_gpu_step_of_this_run")})
         watchdog.cancel()
         if rank == 0:
+            vpin_amd.Context.crash_line_set(b"")
             # the same as scalars (the driver's record keeps scalar fields)
             st_rec = line.get("strong") or {}
             rp = st_rec.get("rccl_pass") or {}

@@ -45,6 +45,11 @@ typedef struct vpin_table vpin_table;
 const char* vpin_strerror(int code);
 /* text of the last HIP failure seen by this thread ("" if none) */
 const char* vpin_last_error(void);
+/* A host that is about to run something that may take the PROCESS down (a first outing of RCCL at world > 1 ...) leaves the line
+ * it has already earned here: on SIGSEGV / SIGBUS / SIGABRT / SIGFPE / SIGTERM the handler writes these bytes to stdout and ends
+ * the process with _exit(0) -- async-signal-safe calls only.  n = 0 disarms (the previous handlers come back).  bench.py arms it
+ * with the weak line before its strong sub-record (n <= 8192). */
+int vpin_crash_line_set(const char* line, size_t n);
 /* ABI version of this library (bumped on any signature change) */
 int vpin_abi_version(void);
 

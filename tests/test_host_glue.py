@@ -136,3 +136,25 @@ def test_bench_cpulist_parser_and_overlap_bound():
     seq = replay_trace(coop, small, 4, coop_ms, single)
     ov = replay_trace(coop, small, 4, coop_ms, single, overlap=True)
     assert all(o <= s for o, s in zip(ov, seq)) and max(ov) >= 100.0
+
+
+def test_crash_line_is_written_when_a_fatal_signal_ends_the_process():
+    """vpin_crash_line_set: bench.py leaves its weak line here before the strong sub-record's first outing of RCCL; a SIGSEGV / SIGTERM
+    then ends the process with that line on stdout and exit code 0"""
+    import subprocess
+    import sys
+    code = ("import os, signal, sys\n"
+            f"sys.path.insert(0, {os.path.dirname(os.path.dirname(os.path.abspath(__file__)))!r})\n"
+            "import vpin_amd\n"
+            "vpin_amd.Context.crash_line_set(b'{\"value\":1}\\n')\n"
+            "sys.stdout.flush()\n"
+            "os.kill(os.getpid(), getattr(signal, sys.argv[1]))\n"
+            "import time; time.sleep(5)\n"
+            "print('not reached')\n")
+    for sig in ("SIGSEGV", "SIGTERM", "SIGABRT"):
+        r = subprocess.run([sys.executable, "-c", code, sig], capture_output=True, text=True, timeout=60)
+        assert r.returncode == 0 and r.stdout == '{"value":1}\n', (sig, r.returncode, r.stdout, r.stderr[-300:])
+    # disarmed: the default disposition is back
+    code2 = code.replace("sys.stdout.flush()", "vpin_amd.Context.crash_line_set(b'')\nsys.stdout.flush()")
+    r = subprocess.run([sys.executable, "-c", code2, "SIGTERM"], capture_output=True, text=True, timeout=60)
+    assert r.returncode != 0 and r.stdout == ""

@@ -580,6 +580,14 @@ class Context:
         return int(out[0]), int(out[1]), int(out[2])
 
     @staticmethod
+    def crash_line_set(line_bytes):
+        """leave `line_bytes` to be written to stdout should a fatal signal or SIGTERM end the process (vpin_crash_line_set);
+        b"" disarms"""
+        L = lib()
+        L.vpin_crash_line_set.argtypes = [C.c_char_p, C.c_size_t]
+        _chk(L.vpin_crash_line_set(line_bytes if line_bytes else None, len(line_bytes)), "vpin_crash_line_set")
+
+    @staticmethod
     def driver_alloc_stats():
         """(calls, bytes) the library has taken from the driver's allocator since the process started (vpin_driver_alloc_stats)"""
         L = lib()

@@ -1,5 +1,7 @@
 // capi.hip -- context, table management and profiling behind include/vpin_hip.h
 #include <chrono>
+#include <csignal>
+#include <unistd.h>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -435,6 +437,44 @@ int vpin_ctx_pool_stats(vpin_ctx* c, size_t out[3]) {
   for (auto& kv : c->pool_sizes) total += kv.second;
   for (auto& kv : c->pool_free_lists) cached += kv.first * kv.second.size();
   out[0] = total; out[1] = cached; out[2] = c->pool_sizes.size();
+  return VPIN_OK;
+}
+
+namespace {
+char g_crash_buf[8192];
+volatile size_t g_crash_len = 0;
+struct sigaction g_crash_old[5];
+const int g_crash_sigs[5] = {SIGSEGV, SIGBUS, SIGABRT, SIGFPE, SIGTERM};
+void crash_handler(int) {
+  const size_t n = g_crash_len;
+  size_t off = 0;
+  while (off < n) {
+    const ssize_t w = write(1, g_crash_buf + off, n - off);
+    if (w <= 0) break;
+    off += (size_t)w;
+  }
+  _exit(0);
+}
+}  // namespace
+
+int vpin_crash_line_set(const char* line, size_t n) {
+  if (n > sizeof g_crash_buf || (n && !line)) return VPIN_EINVAL;
+  const bool was_armed = g_crash_len != 0;
+  if (n == 0) {
+    if (was_armed)
+      for (int i = 0; i < 5; i++) (void)sigaction(g_crash_sigs[i], &g_crash_old[i], nullptr);
+    g_crash_len = 0;
+    return VPIN_OK;
+  }
+  memcpy(g_crash_buf, line, n);
+  g_crash_len = n;
+  if (!was_armed) {
+    struct sigaction sa;
+    memset(&sa, 0, sizeof sa);
+    sa.sa_handler = crash_handler;
+    sigemptyset(&sa.sa_mask);
+    for (int i = 0; i < 5; i++) (void)sigaction(g_crash_sigs[i], &sa, &g_crash_old[i]);
+  }
   return VPIN_OK;
 }
 

@@ -732,7 +732,7 @@ def main():
                 doc = json.load(f)
             pmc_all, pmc_l5 = doc.get("bench_default", {}), doc.get("bench_L5_mult", {})
         traffic_source = "--pmc-traffic (this invocation's caller)" if traffic is not None else None
-        if traffic is None:
+        if traffic is None and trace in ("lenet", "L5"):   # (the committed PMC passes are the 2^25 instance's: no other trace's launches)
             # the largest instance's launches alone (bench_L5_mult section): the default run's average mixes every instance's
             traffic = (pmc_l5 or pmc_all).get("sc_cubic3_kernel<true, true>", {}).get("hbm_bytes_per_launch")
             if traffic is not None:

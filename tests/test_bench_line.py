@@ -79,3 +79,28 @@ def test_over_long_line_is_refused_by_dumps_line():
         B.dumps_line({"x": "y" * (B.LINE_MAX + 1)})
     with pytest.raises(ValueError):
         B.dumps_line({"x": math.nan})
+
+
+def test_host_cpu_helpers_return_well_formed_records():
+    """bench.py's CFS-throttling readout and the per-thread CPU list (round 6: what found the W = 8 rehearsal's stalls): present or
+    empty, never raising, whatever cgroup layout the box has"""
+    t = B.host_cpu_throttle()
+    assert isinstance(t, dict)
+    if t:
+        assert set(t) >= {"nr_throttled", "throttled_ms", "quota_cpus"} and t["throttled_ms"] >= 0.0
+        assert t["quota_cpus"] is None or t["quota_cpus"] > 0
+    th = B.thread_cpu_seconds(4)
+    assert isinstance(th, list) and len(th) <= 4 and all(len(x) == 3 and x[2] >= 0.0 for x in th)
+
+
+def test_compact_line_carries_host_throttling_and_errors():
+    full = {"metric": "m", "value": 1.0, "unit": "constraints/s", "n_gpus": 1, "steps": 1, "warmup": 0, "ms_per_step": 1.0,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u256", "data": "synthetic",
+            "config": {"workload": "w", "constraints_unpadded_per_step": 1, "inputs": "resident in HBM"},
+            "roofline": {"kernel": "k", "bound": "hbm", "achieved": 1.0, "peak": 8000.0, "unit": "GB/s", "frac": 0.1, "traffic": None},
+            "cpu_baseline": {"value": 1.0, "unit": "constraints/s", "cores": 1, "kind": "port", "sample": "s"},
+            "host_cpu": {"quota_cpus": 16.0, "throttled_ms_in_timed_region": 12.5},
+            "errors": {"reference_span": "VpinError('x')", "parity": "proof bytes differ"}}
+    d = _check(B.dumps_line(B.compact_line(full, None)))
+    assert d["host_quota_cpus"] == 16.0 and d["host_throttled_ms"] == 12.5
+    assert "parity" in d["errors"] and "reference_span" in d["errors"]

@@ -155,6 +155,10 @@ def build():
     L.append("|---|---|---|")
     L.append(f"| LeNet trace, 12 whole SNARKs, inputs resident (`python3 bench.py --gpus 1 --steps {steps} --warmup {warm}`, the driver's command) | "
              f"**{ms} ms/step = {M(val)} M constraints/s** | `{D}`: `ms_per_step`, `value` |")
+    b1 = f"{TAG}_bench_default_box1.json"
+    b1_ms, b1_val, b1_frac = g("box1_ms_per_step", b1, "ms_per_step", "ms", 1), g("box1_constraints_per_s", b1, "value", "constraints/s"), g("box1_roofline_frac", b1, "roofline.frac", "", 3)
+    L.append(f"| ... the same command on another box earlier the same day (boxes differ by 2-4 %: 362.8-378.8 ms/step over the round's runs) | "
+             f"{b1_ms} ms/step = {M(b1_val)} M constraints/s, roofline frac {b1_frac} | `{b1}` |")
     L.append(f"| ... the whole `bench.py` run, printed line {os.path.getsize(os.path.join(P, TAG + '_bench_default.line'))} bytes | {run_s} s | `run_s`; `{TAG}_bench_default.line` |")
     L.append(f"| socket power / shader clock over the timed region (medians) | {watts:.0f} W, {sclk:.0f} MHz ({joules:.0f} J per trace) | `power_during_timed_region` |")
     L.append(f"| roofline kernel `sc_cubic3_kernel<true,true>`: algorithmic bytes / HIP-event time | {ach:.0f} GB/s = **{frac} of 8 TB/s** "

@@ -26,18 +26,26 @@ point-mult instances on two; the point-add instances.  All but the first start w
 instance's phase-1 sum-check is done, so its kernels (the roofline sample) are timed undisturbed (--sat-only: two
 lanes, the add lane starts after the largest instance).  `--serial`: one instance at a time.
 
-Beside the headline value the line carries
-  roofline     : the fused phase-1 sum-check round kernel (sc_cubic3_kernel<true>), algorithmic bytes /
-                 HIP-event time over the timed region, against the 8 TB/s HBM3E peak; `traffic` is measured by
-                 this run itself (two `rocprofv3 --pmc` child passes after everything else, N = 1 only);
-                 `secondary`: the kernels that own the step (row commitments: power-bound; product rounds);
-  cpu_baseline : the CPU oracle (a C restatement of the reference prover, oracle/) timed on this box's
-                 host cores: CNN A's whole trace at full size on all threads, a small sample on one;
-  reference_span (+ value_reference_span): the reference's own timed span per instance (witness inputs ->
-                 gadget -> is_sat -> encode -> prove -> bytes), and `dead_work`: the same WITH the work the
-                 reference does inside it and never uses (third commitment, zlib digest of the matrices);
-  strong       : N > 1 only -- the same trace ONCE over all ranks (one LeNet trace, its 2^25 instance
-                 proven by all ranks together; RCCL for device vectors), beside the weak headline.
+The ONE line rank 0 prints is a flat, strict-JSON record of ~2 KB (tools/bench_common.py compact_line / dumps_line: at most
+4096 bytes, scalars only inside `roofline` and `cpu_baseline`); everything else -- per-instance spans, kernel classes, the
+reference span per instance and phase, power series, the strong sub-record in full -- goes to a side file whose path the line
+carries in `detail` (--detail-out, default gpurun_out/bench_detail_n<N>.json).  The line carries
+  roofline     : the fused phase-1 sum-check round kernel (sc_cubic3_kernel<true, true>), algorithmic bytes / HIP-event time
+                 over the timed region, against the 8 TB/s HBM3E peak; `traffic` and `limiter_frac` (share of SIMD-cycles
+                 with a VALU instruction in flight) are measured by this run itself (three `rocprofv3 --pmc` child passes
+                 after everything else, N = 1 only); msm_* / prod_round_*: the kernels that own the step;
+  cpu_baseline : the CPU oracle (a C restatement of the reference prover, oracle/) timed on this box's host threads on a
+                 bounded sample (64 point-mults + 512 point-adds drawn like LeNet layer 1, ~6 s); --cpu-full-label A adds
+                 CNN A's whole trace at full size, --cpu-single-thread the sample on one thread;
+  value_reference_span, reference_span_*: the reference's own timed span per instance (witness inputs -> gadget -> is_sat
+                 -> encode -> prove -> bytes), serially and on the lanes; with the work the reference does inside it and never
+                 uses (third commitment measured; zlib digest measured with --digest, otherwise replayed and labelled so);
+                 span_warning when a span exceeds 1.3 x the newest committed one;
+  host_quota_cpus / host_throttled_ms: the CFS quota of the box and the time its cgroup was throttled inside the timed region;
+  strong_*     : N > 1 only -- the same trace ONCE over all ranks (one LeNet trace, its 2^25 instance proven by all ranks
+                 together; RCCL for device vectors), beside the weak headline; a watchdog and a signal handler
+                 (vpin_crash_line_set) keep the weak line should that first outing of RCCL hang or take the process down;
+  errors       : sections after the timed region that failed (the line still comes out; a parity failure exits 1).
 Other modes: `--scaling strong [--rehearse W]`, `--trace T --concurrent K1,K2,..` (K copies of a small
 trace at once on one GPU).
 """

@@ -31,7 +31,7 @@ def ctx():
 @pytest.fixture(scope="module")
 def big(ctx):
     xyzt, og = O.gens_stream_xyzt(NB, b"gens_r1cs_eval")
-    g = ctx.gens_shared("gens_r1cs_eval", xyzt, 80 if ctx.device_total_bytes() >= (200 << 30) else 24)
+    g = ctx.gens_shared("gens_r1cs_eval", xyzt, 80 if ctx.device_total_bytes() >= (200 << 30) else 24)  # the library's own budgets (spark.cpp)
     import vpin_amd
     lay = (C.c_size_t * 6)()
     L = vpin_amd.lib()

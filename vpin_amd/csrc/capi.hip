@@ -1,6 +1,8 @@
 // capi.hip -- context, table management and profiling behind include/vpin_hip.h
 #include <chrono>
 #include <csignal>
+#include <execinfo.h>
+#include <fcntl.h>
 #include <unistd.h>
 #include <cstdio>
 #include <cstdlib>
@@ -127,6 +129,18 @@ static void pool_release_unlocked(vpin_ctx* c) {
             pool_trace_ms() - t_a);
 }
 
+// hipMalloc only when the device reports room for the block (+ 256 MiB): round 6 saw an out-of-memory hipMalloc take the process
+// down INSIDE the HIP runtime (a 4 GiB request of a split 2^25 proof on a nearly full device: libamdhip64 -> libhsa-runtime64 ->
+// pthread_mutex_lock, SIGSEGV) instead of returning hipErrorOutOfMemory.  Blocks below 64 MiB are not asked about (the query costs
+// more than they do, and they are not what runs a device out of memory).  A failed check is reported exactly like a failed hipMalloc.
+hipError_t driver_malloc(void** p, size_t bytes) {
+  if (bytes >= ((size_t)64 << 20)) {
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b < bytes + ((size_t)256 << 20)) return hipErrorOutOfMemory;
+  }
+  return hipMalloc(p, bytes);
+}
+
 int dev_alloc(vpin_ctx* c, size_t bytes, void** out) {
   size_t cls = 256;
   while (cls < bytes) cls <<= 1;
@@ -146,11 +160,11 @@ int dev_alloc(vpin_ctx* c, size_t bytes, void** out) {
   }
   void* p = nullptr;
   const double t_m = pool_trace_min() ? pool_trace_ms() : 0.0;
-  if (hipMalloc(&p, cls) != hipSuccess) {
+  if (driver_malloc(&p, cls) != hipSuccess) {
     (void)hipGetLastError();
     if (pool_trace_min()) fprintf(stderr, "[pool %10.2f ms] hipMalloc of %.1f MiB FAILED: releasing cached blocks\n", pool_trace_ms(), (double)cls / 1048576.0);
     dev_pool_release(c);  // give this context's cached blocks back and retry
-    if (hipMalloc(&p, cls) != hipSuccess) {
+    if (driver_malloc(&p, cls) != hipSuccess) {
       (void)hipGetLastError();
       // the other contexts on this device (the lanes of a shared GPU) cache multi-GB blocks too
       std::vector<vpin_ctx*> others;
@@ -173,7 +187,7 @@ int dev_alloc(vpin_ctx* c, size_t bytes, void** out) {
           pool_release_unlocked(x);
         x->pins.fetch_sub(1, std::memory_order_acq_rel);
       }
-      if (hipMalloc(&p, cls) != hipSuccess) { (void)hipGetLastError(); return VPIN_ENOMEM; }
+      if (driver_malloc(&p, cls) != hipSuccess) { (void)hipGetLastError(); return VPIN_ENOMEM; }
     }
   }
   note_driver_alloc(cls);
@@ -455,6 +469,36 @@ void crash_handler(int) {
   }
   _exit(0);
 }
+}  // namespace
+
+// VPIN_SEGV_TRACE=1 (development aid): a SIGSEGV / SIGBUS / SIGABRT prints the faulting thread's call stack (module + offset per
+// frame: addr2line -e libvpin_hip.so resolves them) before the default action takes the process down
+namespace {
+int g_segv_fd = 2;  // VPIN_SEGV_TRACE=<path>: the stack goes to that file (a test runner may have captured fd 2); =1: stderr
+void segv_trace_handler(int sig) {
+  void* frames[64];
+  const int n = backtrace(frames, 64);
+  const char msg[] = "[vpin] fatal signal, call stack of the faulting thread:\n";
+  (void)!write(g_segv_fd, msg, sizeof msg - 1);
+  backtrace_symbols_fd(frames, n, g_segv_fd);
+  signal(sig, SIG_DFL);
+  raise(sig);
+}
+struct SegvTraceInit {
+  SegvTraceInit() {
+    const char* e = getenv("VPIN_SEGV_TRACE");
+    if (!e) return;
+    if (e[0] == '/' || e[0] == '.' || strchr(e, '/')) {
+      const int fd = open(e, O_WRONLY | O_CREAT | O_APPEND, 0644);
+      if (fd >= 0) g_segv_fd = fd;
+    }
+    struct sigaction sa;
+    memset(&sa, 0, sizeof sa);
+    sa.sa_handler = segv_trace_handler;
+    sigemptyset(&sa.sa_mask);
+    for (int sg : {SIGSEGV, SIGBUS, SIGABRT}) (void)sigaction(sg, &sa, nullptr);
+  }
+} g_segv_trace_init;
 }  // namespace
 
 int vpin_crash_line_set(const char* line, size_t n) {

@@ -141,6 +141,7 @@ struct AltStreamGuard {
 
 // pooled device allocation (see vpin_ctx::pool_free_lists)
 int dev_alloc(vpin_ctx* c, size_t bytes, void** out);
+hipError_t driver_malloc(void** p, size_t bytes);  // hipMalloc behind a free-memory check (large blocks): no out-of-memory call into the runtime
 void note_driver_alloc(size_t bytes);  // every hipMalloc the library makes outside dev_alloc reports here (vpin_driver_alloc_stats)
 void dev_free(vpin_ctx* c, void* p);
 int live_ctx_count();      // contexts of this process that exist right now

@@ -32,7 +32,15 @@
 #include "mailbox_dev.h"
 
 #ifndef VPIN_NIELS_SLOT
-#define VPIN_NIELS_SLOT 96  // bytes per table entry: 96 (packed) or 128 (one entry per 128-byte line)
+// bytes per table entry: 96 (packed; the default) or 128 (one entry per 128-byte line: a gather is one aligned line, never two
+// half-used ones).  Round 6 re-measured the pair with the spatial split and the strip kernel in place, both libraries built on the box
+// and the 16386 generators of the derefs commitments at 12-bit windows in both (VPIN_SPARK_GENS_BUDGET_GB=100,
+// VPIN_GENS_FREE_FRACTION=0.45): LeNet step 358.4 against 366.3 ms (-2.2 %, 12 W less) for 109 instead of 95 GiB of tables
+// (profiles/r06_ab_slot128.txt).  NOT the default: with 14 GiB less headroom a 2^25 proof split over two rank-threads of ONE GPU
+// (tests, rehearsals) runs out of memory once anything else is resident, and that out-of-memory hipMalloc took the process down
+// inside the HIP runtime instead of returning an error.  Build with -DVPIN_NIELS_SLOT=128 (and the two budgets above) to trade
+// the memory for the time on a part that proves single-GPU traces only.
+#define VPIN_NIELS_SLOT 96
 #endif
 namespace vpin {
 struct alignas(VPIN_NIELS_SLOT == 128 ? 128 : 32) niels_slot : ge_niels {};
@@ -1144,8 +1152,8 @@ static int gens_build_once(vpin_ctx* c, const uint8_t* gens_xyzt, size_t nb, siz
   // returned to the driver (freed VRAM is wiped before it can be handed out again: tools/ubench_malloc2.hip)
   DevBuf raw(c), b_shifts(c), b_prefix(c);
   if (raw.alloc(nbt * 128) != VPIN_OK || b_shifts.alloc(max_shifts * sizeof(ge_ext)) != VPIN_OK ||
-      b_prefix.alloc(max_entries * sizeof(fp)) != VPIN_OK || hipMalloc((void**)&g->table, entries * sizeof(niels_slot)) != hipSuccess ||
-      (n_hi && hipMalloc((void**)&g->table_hi, entries_hi * sizeof(niels_slot)) != hipSuccess)) {
+      b_prefix.alloc(max_entries * sizeof(fp)) != VPIN_OK || driver_malloc((void**)&g->table, entries * sizeof(niels_slot)) != hipSuccess ||
+      (n_hi && driver_malloc((void**)&g->table_hi, entries_hi * sizeof(niels_slot)) != hipSuccess)) {
     if (g->table) (void)hipFree(g->table);
     if (g->table_hi) (void)hipFree(g->table_hi);
     delete g;

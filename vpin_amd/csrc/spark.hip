@@ -636,7 +636,7 @@ int spark_u32_to_fq(vpin_ctx* c, const uint32_t* src, fq* dst, size_t n) {
 static int table_alloc_unpooled(size_t len, vpin_table** out) {
   vpin_table* t = new (std::nothrow) vpin_table();
   if (!t) return VPIN_ENOMEM;
-  if (hipMalloc((void**)&t->d, len * sizeof(fq)) != hipSuccess) { (void)hipGetLastError(); delete t; return VPIN_ENOMEM; }
+  if (driver_malloc((void**)&t->d, len * sizeof(fq)) != hipSuccess) { (void)hipGetLastError(); delete t; return VPIN_ENOMEM; }
   note_driver_alloc(len * sizeof(fq));
   t->len = t->cap = len;
   t->owner = nullptr;

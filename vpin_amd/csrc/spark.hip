@@ -633,10 +633,14 @@ int spark_u32_to_fq(vpin_ctx* c, const uint32_t* src, fq* dst, size_t n) {
 
 // a table of `len` scalars straight from the driver (no pool, no owner: whoever frees the decommitment frees it, whichever
 // contexts are still alive)
-static int table_alloc_unpooled(size_t len, vpin_table** out) {
+static int table_alloc_unpooled(vpin_ctx* c, size_t len, vpin_table** out) {
   vpin_table* t = new (std::nothrow) vpin_table();
   if (!t) return VPIN_ENOMEM;
-  if (driver_malloc((void**)&t->d, len * sizeof(fq)) != hipSuccess) { (void)hipGetLastError(); delete t; return VPIN_ENOMEM; }
+  if (driver_malloc((void**)&t->d, len * sizeof(fq)) != hipSuccess) {
+    (void)hipGetLastError();
+    dev_pool_release(c);  // this context's cached blocks back to the driver, then once more (as dev_alloc does)
+    if (driver_malloc((void**)&t->d, len * sizeof(fq)) != hipSuccess) { (void)hipGetLastError(); delete t; return VPIN_ENOMEM; }
+  }
   note_driver_alloc(len * sizeof(fq));
   t->len = t->cap = len;
   t->owner = nullptr;
@@ -657,8 +661,8 @@ int spark_comb_make(vpin_ctx* c, const vpin_spark_decomm* d, vpin_table** ops, v
   int np = 0;
   auto mark = [&] { if (laps_on && np < 8) tp[np++] = clk::now(); };
   mark();
-  if ((rc = pooled ? table_alloc_uninit(c, 16 * N, ops) : table_alloc_unpooled(16 * N, ops))) return rc;
-  if ((rc = pooled ? table_alloc_uninit(c, 2 * M, mem) : table_alloc_unpooled(2 * M, mem))) { vpin_table_free(c, *ops); *ops = nullptr; return rc; }
+  if ((rc = pooled ? table_alloc_uninit(c, 16 * N, ops) : table_alloc_unpooled(c, 16 * N, ops))) return rc;
+  if ((rc = pooled ? table_alloc_uninit(c, 2 * M, mem) : table_alloc_unpooled(c, 2 * M, mem))) { vpin_table_free(c, *ops); *ops = nullptr; return rc; }
   mark();
   if ((rc = spark_u32_to_fq(c, d->idx, (*ops)->d, 12 * N)) || (rc = spark_u32_to_fq(c, d->idx + 12 * N, (*mem)->d, 2 * M))) return rc;
   mark();

@@ -155,18 +155,26 @@ def build():
     L.append("|---|---|---|")
     L.append(f"| LeNet trace, 12 whole SNARKs, inputs resident (`python3 bench.py --gpus 1 --steps {steps} --warmup {warm}`, the driver's command) | "
              f"**{ms} ms/step = {M(val)} M constraints/s** | `{D}`: `ms_per_step`, `value` |")
-    b1 = f"{TAG}_bench_default_box1.json"
-    b1_ms, b1_val, b1_frac = g("box1_ms_per_step", b1, "ms_per_step", "ms", 1), g("box1_constraints_per_s", b1, "value", "constraints/s"), g("box1_roofline_frac", b1, "roofline.frac", "", 3)
-    L.append(f"| ... the same command on another box earlier the same day (boxes differ by 2-4 %: 362.8-378.8 ms/step over the round's runs) | "
-             f"{b1_ms} ms/step = {M(b1_val)} M constraints/s, roofline frac {b1_frac} | `{b1}` |")
+    others = []
+    for tag in ("box1", "box2"):
+        f = f"{TAG}_bench_default_{tag}.json"
+        others.append((f, g(f"{tag}_ms_per_step", f, "ms_per_step", "ms", 1), g(f"{tag}_constraints_per_s", f, "value", "constraints/s"),
+                       g(f"{tag}_roofline_frac", f, "roofline.frac", "", 3)))
+    L.append("| ... the same command on two other boxes the same day, earlier trees of the round with the same kernels (boxes, and one box "
+             "over 20 minutes, differ by 2-4 %: 362.8-378.8 ms/step over the round's runs) | "
+             + "; ".join(f"{m} ms/step = {M(v)} M constraints/s, roofline frac {fr}" for _, m, v, fr in others)
+             + " | " + ", ".join(f"`{f}`" for f, _, _, _ in others) + " |")
     L.append(f"| ... the whole `bench.py` run, printed line {os.path.getsize(os.path.join(P, TAG + '_bench_default.line'))} bytes | {run_s} s | `run_s`; `{TAG}_bench_default.line` |")
     L.append(f"| socket power / shader clock over the timed region (medians) | {watts:.0f} W, {sclk:.0f} MHz ({joules:.0f} J per trace) | `power_during_timed_region` |")
     L.append(f"| roofline kernel `sc_cubic3_kernel<true,true>`: algorithmic bytes / HIP-event time | {ach:.0f} GB/s = **{frac} of 8 TB/s** "
              f"({launches} launches, {avg_us} us each, {alg / 1e6:.1f} MB algorithmic per launch) | `roofline.*` |")
     L.append(f"| ... HBM bytes per launch, PMC, measured by the run itself | {traffic / 1e6:.1f} MB = {tfrac} x algorithmic ({fact} of peak really moved) | `roofline.traffic` |")
     L.append(f"| ... share of SIMD-cycles with a VALU instruction in flight (PMC) | {lim} | `roofline.limiter_frac` |")
-    L.append(f"| ... the same kernel in `rocprofv3 --kernel-trace --stats` (stream {sid}: the 2^25 instance before the other lanes start) | "
-             f"{kt_avg} us over {kt_calls} launches | `{S}` |")
+    U = f"{TAG}_bench_default_under_rocprof.json"
+    u_us, u_n = g("under_rocprof_avg_launch_us", U, "roofline.avg_launch_us", "us", 2), g("under_rocprof_launches", U, "roofline.launches")
+    L.append(f"| ... the same kernel in `rocprofv3 --kernel-trace --stats` of `bench.py --steps 3` a minute later on that box (stream {sid}: the "
+             f"2^25 instance before the other lanes start, all six proofs of the process) | {kt_avg} us over {kt_calls} launches in the trace; "
+             f"that run's own HIP-event figure: {u_us} us over the {u_n} launches of its timed region | `{S}`, `{U}` |")
     L.append(f"| row-commitment MSM, 2^25 instance alone | {msm_g} G table additions/s = {msm_fr} of the static VALU-issue bound; "
              f"3 s loop: {msm_st} G/s at {msm_clk:.0f} MHz, {msm_w:.0f} W | `roofline.msm_*` |")
     L.append(f"| product rounds >= 2^20 pairs | {prod_fr} of 8 TB/s | `roofline.prod_round_frac` |")

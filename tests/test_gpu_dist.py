@@ -39,6 +39,7 @@ def _prove_threads(world, label, kind, n, serialize=False):
     g = _build(ctxs[0], label, kind, n)
     dec, _comm = g.spark_encode()
     single = ctxs[0].snark_prove_resident(g.r1cs, dec, g.vars_para, g.vars_input, g.vars, g.inputs, SEED_C, SEED_P)
+    ctxs[0].pool_trim()   # the single-GPU proof's cached temporaries (64 GB for the 2^25 instance) are not the ranks' to carry
     comms = Comm.local(world)
     out, errs = [None] * world, []
 

@@ -89,6 +89,11 @@ def parse():
                     "host threads (A = configs[1], ~20 s more); none (default): the bounded sample only, the full-size figure of "
                     "the newest committed profile is carried in the detail file, labelled replayed")
     ap.add_argument("--cpu-single-thread", action="store_true", help="CPU baseline: the sample once more on ONE thread (~2.5x the time)")
+    ap.add_argument("--table-slot", type=int, choices=[96, 128], default=None,
+                    help="bytes per window-table entry (VPIN_TABLE_SLOT).  Default 128 when every rank has a GPU of its own (N = 1, or N > 1 "
+                         "over nccl): one 128-byte line per gather, -2.2 %% on the step for 109 instead of 95 GiB of tables "
+                         "(profiles/r06_ab_slot128.txt; the eval stream's budget goes to 100 GB and the free-memory share of a table to 0.45 "
+                         "so that its 12-bit windows stay); 96 = the library's own default, kept where ranks share a GPU")
     ap.add_argument("--detail-out", default=None, help="path of the side file with the full record (default: "
                     "gpurun_out/bench_detail_n<N>.json under the repo root)")
     ap.add_argument("--serial", action="store_true", help="one instance at a time, one host thread")
@@ -259,6 +264,14 @@ def main():
             # the four-lane step: 16 // 4 = 4 per lane (round 6 re-measured 2 against 4 on one box: 375.6 against 372.2 ms -- the
             # lanes' host sections are short bursts, the throttled periods they cause cost less than the narrower teams)
             os.environ["VPIN_HOST_THREADS"] = str(max(2, min(4, cores // (world_env * 4))))
+    # window-table layout (before the library is loaded: the free-memory share is read once)
+    own_gpu = world_env == 1 or args.backend == "nccl"
+    slot = args.table_slot or (int(os.environ["VPIN_TABLE_SLOT"]) if os.environ.get("VPIN_TABLE_SLOT") else
+                               (128 if (own_gpu and args.scaling == "weak" and not args.concurrent) else 96))
+    os.environ["VPIN_TABLE_SLOT"] = str(slot)
+    if slot == 128:
+        os.environ.setdefault("VPIN_SPARK_GENS_BUDGET_GB", "100")
+        os.environ.setdefault("VPIN_GENS_FREE_FRACTION", "0.45")
     if args.scaling == "strong":
         from bench_strong import main_strong
         return main_strong(args)
@@ -721,6 +734,7 @@ def main():
     detail_path = args.detail_out or os.path.join(ROOT, "gpurun_out", f"bench_detail_n{world}.json")
     line["config"]["lanes"] = lane_names
     line["config"]["low_memory"] = bool(args.low_memory)
+    line["config"]["table_slot_bytes"] = int(os.environ.get("VPIN_TABLE_SLOT", "96"))
     line["host_affinity"] = affinity_rec
     line["host_cpu"] = host_cpu
 

@@ -198,7 +198,8 @@ def compact_line(full, detail_path=None):
                      "constraints_unpadded_per_step": cfg.get("constraints_unpadded_per_step"),
                      "instances_per_step": len(cfg.get("instances") or {}) or None,
                      "inputs": str(cfg.get("inputs", ""))[:60],
-                     "parallelism": str(cfg.get("parallelism_short") or cfg.get("parallelism", ""))[:100]}
+                     "parallelism": str(cfg.get("parallelism_short") or cfg.get("parallelism", ""))[:100],
+                     "table_slot_bytes": cfg.get("table_slot_bytes")}
     if rf:
         src = str(rf.get("traffic_source") or "")
         out["roofline"] = {

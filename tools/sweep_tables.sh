@@ -8,7 +8,7 @@ mkdir -p gpurun_out
 for B in "24 80" "16 48" "10 30" "5 15"; do
   set -- $B
   OUT=gpurun_out/tables_$1_$2.json
-  VPIN_GENS_BUDGET_GB=$1 VPIN_SPARK_GENS_BUDGET_GB=$2 timeout -k 10 300 python3 bench.py --steps $STEPS --warmup 3 --no-cpu-baseline --no-live-pmc \
+  VPIN_GENS_BUDGET_GB=$1 VPIN_SPARK_GENS_BUDGET_GB=$2 timeout -k 10 300 python3 bench.py --table-slot 96 --steps $STEPS --warmup 3 --no-cpu-baseline --no-live-pmc \
       --no-span --no-roofline-pass --detail-out $OUT > gpurun_out/tables_$1_$2.line 2> gpurun_out/tables_$1_$2.err || { echo "budget $1/$2 failed"; tail -3 gpurun_out/tables_$1_$2.err; continue; }
   python3 - $1 $2 gpurun_out/tables_$1_$2.line <<'PY'
 import json, sys

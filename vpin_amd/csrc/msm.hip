@@ -42,17 +42,17 @@
 // the memory for the time on a part that proves single-GPU traces only.
 #define VPIN_NIELS_SLOT 96
 #endif
-namespace vpin {
-struct alignas(VPIN_NIELS_SLOT == 128 ? 128 : 32) niels_slot : ge_niels {};
-static_assert(sizeof(niels_slot) == VPIN_NIELS_SLOT, "table entry size");
-}  // namespace vpin
+static_assert(VPIN_NIELS_SLOT == 96 || VPIN_NIELS_SLOT == 128, "table entry size");
+// Round 6: the slot size is a property of a TABLE (decided when it is built: VPIN_TABLE_SLOT = 96 | 128, default VPIN_NIELS_SLOT), not
+// of the build: an entry is three field elements (y+x, y-x, 2dxy) at the start of a slot of s32 = 3 or 4 32-byte units.
 
 struct vpin_gens {
   // Two segments: bases [0, split) in `table` with wide windows (the generators every large commitment of a proof
   // walks), bases [split, nbt) in `table_hi` with narrow ones (the upper half of the 32k-generator stream, touched by
   // SNARK::encode and one evaluation proof, and the prefix sums).  split == nbt: a single segment.
-  vpin::niels_slot* table = nullptr;     // [W][split][E]
-  vpin::niels_slot* table_hi = nullptr;  // [W_hi][nbt - split][E_hi]
+  vpin::fp* table = nullptr;        // [W][split][E] slots of s32 field elements
+  vpin::fp* table_hi = nullptr;     // [W_hi][nbt - split][E_hi]
+  int s32 = VPIN_NIELS_SLOT / 32;   // 32-byte units per slot: 3 (96 B, packed) or 4 (128 B, a line per entry)
   size_t nb = 0;                    // number of bases in the stream
   size_t nbt = 0;                   // bases in the table: the stream, then the prefix sums S_k = g_0 + ... + g_{2^k - 1}
   size_t split = 0;
@@ -63,22 +63,25 @@ struct vpin_gens {
 namespace vpin {
 
 struct TableView {
-  const niels_slot* t;     // first segment
-  const niels_slot* t_hi;  // second segment
+  const fp* t;     // first segment
+  const fp* t_hi;  // second segment
   size_t split, nbt;       // bases [0, split) | [split, nbt)
   int c, W, E, c_hi, W_hi, E_hi;
   size_t sum0;  // table index of S_0; S_k = g_0 + ... + g_{2^k - 1} sits at sum0 + k
+  int s32;      // field elements per slot (3 or 4)
 };
 
 // the segment of base j: table, index inside it, bases per window, window parameters
 struct TableSeg {
-  const niels_slot* t;
+  const fp* t;
   size_t j, nb;
-  int c, W, E;
+  int c, W, E, s32;
+  // entry d (multiple d + 1) of window w of this base
+  __device__ __forceinline__ const fp* entry(int w, uint32_t d) const { return t + (((size_t)w * nb + j) * (size_t)E + d) * (size_t)s32; }
 };
 __device__ __forceinline__ TableSeg table_seg(const TableView& tv, size_t j) {
-  if (j < tv.split) return TableSeg{tv.t, j, tv.split, tv.c, tv.W, tv.E};
-  return TableSeg{tv.t_hi, j - tv.split, tv.nbt - tv.split, tv.c_hi, tv.W_hi, tv.E_hi};
+  if (j < tv.split) return TableSeg{tv.t, j, tv.split, tv.c, tv.W, tv.E, tv.s32};
+  return TableSeg{tv.t_hi, j - tv.split, tv.nbt - tv.split, tv.c_hi, tv.W_hi, tv.E_hi, tv.s32};
 }
 
 // ---- table construction ---------------------------------------------------------------
@@ -139,9 +142,9 @@ __global__ __launch_bounds__(64) void gens_shift_kernel(const fp* __restrict__ x
   }
 }
 
-__device__ __forceinline__ ge_niels niels_load(const niels_slot* o) {
+__device__ __forceinline__ ge_niels niels_load(const fp* o) {
   ge_niels e;
-  e.ypx = fp_load(&o->ypx); e.ymx = fp_load(&o->ymx); e.xy2d = fp_load(&o->xy2d);
+  e.ypx = fp_load(o); e.ymx = fp_load(o + 1); e.xy2d = fp_load(o + 2);
   return e;
 }
 
@@ -149,7 +152,7 @@ __device__ __forceinline__ ge_niels niels_load(const niels_slot* o) {
 // one inversion per thread (Montgomery's trick): forward pass stores X,Y,Z in the entry slots and
 // the running product of the Z's in `prefix`; the backward pass peels the inverses off.
 __global__ __launch_bounds__(64) void gens_table_kernel(const ge_ext* __restrict__ shifts, size_t nb, int W, int E,
-                                                        niels_slot* __restrict__ table, fp* __restrict__ prefix) {
+                                                        fp* __restrict__ table, int s32, fp* __restrict__ prefix) {
   size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= nb * (size_t)W) return;
   size_t j = idx / W;
@@ -158,12 +161,12 @@ __global__ __launch_bounds__(64) void gens_table_kernel(const ge_ext* __restrict
   ge_ext p;
   p.X = fp_load(&s->X); p.Y = fp_load(&s->Y); p.Z = fp_load(&s->Z); p.T = fp_load(&s->T);
   ge_cached pc = ge_to_cached(p);
-  niels_slot* out = table + ((size_t)w * nb + j) * E;
+  fp* out = table + (((size_t)w * nb + j) * E) * (size_t)s32;  // slot k at out + k * s32: {ypx, ymx, xy2d}
   fp* pre = prefix + ((size_t)w * nb + j) * E;
   ge_ext q = p;
   fp run = fp_one();
   for (int k = 0; k < E; k++) {
-    fp_store(&out[k].ypx, q.X); fp_store(&out[k].ymx, q.Y); fp_store(&out[k].xy2d, q.Z);
+    fp_store(out + (size_t)k * s32, q.X); fp_store(out + (size_t)k * s32 + 1, q.Y); fp_store(out + (size_t)k * s32 + 2, q.Z);
     run = fp_mul(run, q.Z);
     fp_store(pre + k, run);
     if (k + 1 < E) q = ge_add_cached(q, pc);
@@ -171,13 +174,13 @@ __global__ __launch_bounds__(64) void gens_table_kernel(const ge_ext* __restrict
   fp acc = fp_invert(run);
   const fp d2 = FP_D2();
   for (int k = E - 1; k >= 0; k--) {
-    fp X = fp_load(&out[k].ypx), Y = fp_load(&out[k].ymx), Z = fp_load(&out[k].xy2d);
+    fp X = fp_load(out + (size_t)k * s32), Y = fp_load(out + (size_t)k * s32 + 1), Z = fp_load(out + (size_t)k * s32 + 2);
     fp zinv = (k > 0) ? fp_mul(acc, fp_load(pre + k - 1)) : acc;
     acc = fp_mul(acc, Z);
     fp x = fp_mul(X, zinv), y = fp_mul(Y, zinv);
-    fp_store(&out[k].ypx, fp_add(y, x));
-    fp_store(&out[k].ymx, fp_sub(y, x));
-    fp_store(&out[k].xy2d, fp_mul(fp_mul(x, y), d2));
+    fp_store(out + (size_t)k * s32, fp_add(y, x));
+    fp_store(out + (size_t)k * s32 + 1, fp_sub(y, x));
+    fp_store(out + (size_t)k * s32 + 2, fp_mul(fp_mul(x, y), d2));
   }
 }
 
@@ -227,7 +230,7 @@ __device__ __forceinline__ void table_mul_acc(ge_ext& acc, fq s, const TableView
       carry = neg_next ? 1u : 0u;
       neg_next ^= flip;
       if (mag != 0) {
-        e_next = niels_load(sg.t + ((size_t)w * sg.nb + sg.j) * sg.E + (mag - 1));
+        e_next = niels_load(sg.entry(w, mag - 1));
         have_next = true;
       }
     }
@@ -262,7 +265,7 @@ __device__ __forceinline__ void table_mul_acc10(ge10& acc, fq s, const TableView
       carry = neg_next ? 1u : 0u;
       neg_next ^= flip;
       if (mag != 0) {
-        e_next = niels_load(sg.t + ((size_t)w * sg.nb + sg.j) * sg.E + (mag - 1));
+        e_next = niels_load(sg.entry(w, mag - 1));
         have_next = true;
       }
     }
@@ -318,7 +321,7 @@ __device__ __forceinline__ void table_mul_acc_range(ge_ext& acc, const fq& s_in,
     bool neg = v > half;
     uint32_t mag = neg ? full - v : v;
     carry = neg ? 1u : 0u;
-    if (mag != 0) acc = ge_add_niels(acc, niels_load(sg.t + ((size_t)w * sg.nb + sg.j) * sg.E + (mag - 1)), neg != flip);
+    if (mag != 0) acc = ge_add_niels(acc, niels_load(sg.entry(w, mag - 1)), neg != flip);
   }
 }
 
@@ -977,7 +980,7 @@ __global__ __launch_bounds__(256) void pip_gens_kernel(TableView tv, size_t n, s
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n + (size_t)n_extra) return;
   const TableSeg sg = table_seg(tv, i < n ? i : blind_base);
-  const ge_niels e = niels_load(sg.t + sg.j * (size_t)sg.E);
+  const ge_niels e = niels_load(sg.entry(0, 0));
   fp_store(&out[i].ypx, e.ypx); fp_store(&out[i].ymx, e.ymx); fp_store(&out[i].xy2d, e.xy2d);
 }
 
@@ -1102,12 +1105,23 @@ static int gens_build(vpin_ctx* c, const uint8_t* gens_xyzt, size_t nb, size_t b
   }
 }
 
+// bytes of a table slot for the NEXT table built: VPIN_TABLE_SLOT = 96 | 128 (read per build), default VPIN_NIELS_SLOT.  128 puts every
+// entry on a 128-byte line of its own: -2.2 % on the four-lane LeNet step for a third more table memory at the same window width
+// (profiles/r06_ab_slot128.txt) -- bench.py asks for it on a single-GPU run, the library's default stays 96 (headroom of split proofs)
+static size_t table_slot_bytes() {
+  const char* e = getenv("VPIN_TABLE_SLOT");
+  const int v = e ? atoi(e) : VPIN_NIELS_SLOT;
+  return v == 128 ? 128 : v == 96 ? 96 : (size_t)VPIN_NIELS_SLOT;
+}
+
 static int gens_build_once(vpin_ctx* c, const uint8_t* gens_xyzt, size_t nb, size_t budget, int cmax, vpin_gens** out) {
   if (!c || !gens_xyzt || !out || nb == 0) return VPIN_EINVAL;
+  const size_t slot = table_slot_bytes();
   (void)hipSetDevice(c->device);
   vpin_gens* g = new (std::nothrow) vpin_gens();
   if (!g) return VPIN_ENOMEM;
   g->nb = nb;
+  g->s32 = (int)(slot / 32);
   int nsum = 1;
   while (((size_t)2 << (nsum - 1)) <= nb) nsum++;  // S_0 .. S_floor(log2 nb)
   const size_t nbt = nb + (size_t)nsum;
@@ -1126,7 +1140,7 @@ static int gens_build_once(vpin_ctx* c, const uint8_t* gens_xyzt, size_t nb, siz
   auto fit = [&](size_t n, size_t bud, int cmax, int* c_, int* W_, int* E_) {
     int cc = cmax;
     for (; cc > 6; cc--)
-      if (n * (size_t)((254 + cc - 1) / cc) * ((size_t)1 << (cc - 1)) * sizeof(niels_slot) <= bud) break;
+      if (n * (size_t)((254 + cc - 1) / cc) * ((size_t)1 << (cc - 1)) * slot <= bud) break;
     *c_ = cc;
     *W_ = (254 + cc - 1) / cc;
     *E_ = 1 << (cc - 1);
@@ -1136,7 +1150,7 @@ static int gens_build_once(vpin_ctx* c, const uint8_t* gens_xyzt, size_t nb, siz
   if (nb > kSplitBases && getenv("VPIN_GENS_UNIFORM") == nullptr) {
     int c2, W2, E2;
     fit(kSplitBases, budget, cmax, &c2, &W2, &E2);
-    const size_t lo_bytes = kSplitBases * (size_t)W2 * E2 * sizeof(niels_slot);
+    const size_t lo_bytes = kSplitBases * (size_t)W2 * E2 * slot;
     if (c2 > g->c && lo_bytes < budget) {
       g->split = kSplitBases;
       g->c = c2; g->W = W2; g->E = E2;
@@ -1152,8 +1166,8 @@ static int gens_build_once(vpin_ctx* c, const uint8_t* gens_xyzt, size_t nb, siz
   // returned to the driver (freed VRAM is wiped before it can be handed out again: tools/ubench_malloc2.hip)
   DevBuf raw(c), b_shifts(c), b_prefix(c);
   if (raw.alloc(nbt * 128) != VPIN_OK || b_shifts.alloc(max_shifts * sizeof(ge_ext)) != VPIN_OK ||
-      b_prefix.alloc(max_entries * sizeof(fp)) != VPIN_OK || driver_malloc((void**)&g->table, entries * sizeof(niels_slot)) != hipSuccess ||
-      (n_hi && driver_malloc((void**)&g->table_hi, entries_hi * sizeof(niels_slot)) != hipSuccess)) {
+      b_prefix.alloc(max_entries * sizeof(fp)) != VPIN_OK || driver_malloc((void**)&g->table, entries * slot) != hipSuccess ||
+      (n_hi && driver_malloc((void**)&g->table_hi, entries_hi * slot) != hipSuccess)) {
     if (g->table) (void)hipFree(g->table);
     if (g->table_hi) (void)hipFree(g->table_hi);
     delete g;
@@ -1169,12 +1183,12 @@ static int gens_build_once(vpin_ctx* c, const uint8_t* gens_xyzt, size_t nb, siz
     hipLaunchKernelGGL(gens_shift_kernel, dim3((unsigned)((g->split + 63) / 64)), dim3(64), 0, c->stream, (const fp*)raw.p, g->split,
                        g->W, g->c, shifts);
     hipLaunchKernelGGL(gens_table_kernel, dim3((unsigned)((g->split * g->W + 63) / 64)), dim3(64), 0, c->stream, shifts, g->split, g->W,
-                       g->E, g->table, prefix);
+                       g->E, g->table, g->s32, prefix);
     if (n_hi) {  // same temporaries, stream-ordered after the first segment
       hipLaunchKernelGGL(gens_shift_kernel, dim3((unsigned)((n_hi + 63) / 64)), dim3(64), 0, c->stream,
                          (const fp*)raw.p + 4 * g->split, n_hi, g->W_hi, g->c_hi, shifts);
       hipLaunchKernelGGL(gens_table_kernel, dim3((unsigned)((n_hi * g->W_hi + 63) / 64)), dim3(64), 0, c->stream, shifts, n_hi,
-                         g->W_hi, g->E_hi, g->table_hi, prefix);
+                         g->W_hi, g->E_hi, g->table_hi, g->s32, prefix);
     }
     e = hipGetLastError();
   }
@@ -1293,7 +1307,7 @@ size_t vpin_gens_shared_bytes(int device) {
   size_t total = 0;
   for (auto& e : g_reg)
     if (e.device == device)
-      total += sizeof(niels_slot) * ((size_t)e.g->W * e.g->split * (size_t)e.g->E +
+      total += (size_t)32 * (size_t)e.g->s32 * ((size_t)e.g->W * e.g->split * (size_t)e.g->E +
                                      (e.g->split < e.g->nbt ? (size_t)e.g->W_hi * (e.g->nbt - e.g->split) * (size_t)e.g->E_hi : 0));
   return total;
 }
@@ -1326,7 +1340,7 @@ int vpin_gens_layout(const vpin_gens* g, size_t out[6]) {
   out[3] = g->split < g->nbt ? (size_t)g->c_hi : 0; out[4] = g->split < g->nbt ? (size_t)g->W_hi : 0; out[5] = g->nbt;
   return VPIN_OK;
 }
-size_t vpin_gens_entry_bytes(void) { return sizeof(niels_slot); }
+size_t vpin_gens_entry_bytes(void) { return table_slot_bytes(); }  // of the next table built (VPIN_TABLE_SLOT)
 
 // shared implementation: rows of scalars -> points (kept on device), then optional outputs
 // the row kernels' field arithmetic: ten 26/25-bit limbs (fp10_dev.h) unless VPIN_MSM_FP8 asks for the eight-limb form
@@ -1336,7 +1350,7 @@ static inline bool msm_ten_limbs() {
 }
 
 static inline TableView view(const vpin_gens* g) {
-  return TableView{g->table, g->table_hi, g->split, g->nbt, g->c, g->W, g->E, g->c_hi, g->W_hi, g->E_hi, g->nb};
+  return TableView{g->table, g->table_hi, g->split, g->nbt, g->c, g->W, g->E, g->c_hi, g->W_hi, g->E_hi, g->nb, g->s32};
 }
 
 // VPIN_MSM_PIPPENGER = c (9..12, or 1 = the default width): every row commitment of the provers by the bucket method of

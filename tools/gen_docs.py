@@ -160,8 +160,14 @@ def build():
         f = f"{TAG}_bench_default_{tag}.json"
         others.append((f, g(f"{tag}_ms_per_step", f, "ms_per_step", "ms", 1), g(f"{tag}_constraints_per_s", f, "value", "constraints/s"),
                        g(f"{tag}_roofline_frac", f, "roofline.frac", "", 3)))
-    L.append("| ... the same command on two other boxes the same day, earlier trees of the round with the same kernels (boxes, and one box "
-             "over 20 minutes, differ by 2-4 %: 362.8-378.8 ms/step over the round's runs) | "
+    s96 = f"{TAG}_bench_default_slot96.json"
+    s96_ms, s96_val = g("slot96_ms_per_step", s96, "ms_per_step", "ms", 1), g("slot96_constraints_per_s", s96, "value", "constraints/s")
+    s96_hbm, s96_tab = g("slot96_hbm_in_use_gib", s96, "hbm_in_use_gib_after_timed_region", "GiB"), g("slot96_window_tables_gib", s96, "hbm_breakdown.window_tables_gib", "GiB", 1)
+    slotb = g("table_slot_bytes", D, "config.table_slot_bytes", "B")
+    L.append(f"| ... window tables in {slotb}-byte slots (bench.py's choice where every rank owns its GPU); the library's default layout, 96 bytes, "
+             f"on the same box minutes later (`--table-slot 96`) | {s96_ms} ms/step = {M(s96_val)} M constraints/s with {s96_tab} GiB of tables, {s96_hbm} GiB in use | `{s96}` |")
+    L.append("| ... the same command on two other boxes the same day, earlier trees of the round (96-byte slots, same kernels; boxes, and one box "
+             "over 20 minutes, differ by 2-4 %: 362.8-378.8 ms/step over the round's 96-byte runs) | "
              + "; ".join(f"{m} ms/step = {M(v)} M constraints/s, roofline frac {fr}" for _, m, v, fr in others)
              + " | " + ", ".join(f"`{f}`" for f, _, _, _ in others) + " |")
     L.append(f"| ... the whole `bench.py` run, printed line {os.path.getsize(os.path.join(P, TAG + '_bench_default.line'))} bytes | {run_s} s | `run_s`; `{TAG}_bench_default.line` |")

@@ -277,3 +277,40 @@ def test_row_per_lane_derefs_commitment_gives_the_same_bytes(ctx, key, strips):
         del os.environ["VPIN_MSM_STRIP"]
     assert hashlib.sha256(got["proof"]).hexdigest() == g["snark_sha256"]
     assert ctx.strip_rows_taken() == taken1, "VPIN_MSM_STRIP=0 must keep every row on the row kernel"
+
+
+SCRIPT_SLOT128 = r"""
+import hashlib, json, sys
+sys.path.insert(0, %(root)r)
+import vpin_amd
+from vpin_amd import gadgets as G
+seed_c, seed_p = bytes(range(64)), bytes((7 * i + 3) %% 256 for i in range(64))
+out = {}
+with vpin_amd.Context(0) as ctx:
+    for key, lab, kind in (("3_32-mult", "3_32", "mult"), ("A-add", "A", "add"), ("A-mult", "A", "mult")):
+        inp = G.synthetic_mult_inputs(lab) if kind == "mult" else G.synthetic_add_inputs(lab)
+        d = ctx.gadget_point_mult_dev(*inp) if kind == "mult" else ctx.gadget_point_add_dev(*inp)
+        r = d.snark_prove(seed_c, seed_p)
+        d.free()
+        out[key] = [hashlib.sha256(r["proof"]).hexdigest(), hashlib.sha256(r["comm"]).hexdigest()]
+    L = vpin_amd.lib()
+    L.vpin_gens_entry_bytes.restype = __import__("ctypes").c_size_t
+    out["entry_bytes"] = int(L.vpin_gens_entry_bytes())
+print(json.dumps(out))
+"""
+
+
+@pytest.mark.gpu
+def test_whole_snarks_from_tables_in_128_byte_slots():
+    """the layout bench.py proves from when every rank owns its GPU (VPIN_TABLE_SLOT=128, a process of its own: the registry's tables
+    of this process were built in 96-byte slots): conv f=3's and CNN A's SNARKs and computation commitments are the oracle's"""
+    import subprocess
+    import sys
+    env = dict(os.environ, VPIN_TABLE_SLOT="128", VPIN_SPARK_GENS_BUDGET_GB="16", VPIN_GENS_BUDGET_GB="8")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", SCRIPT_SLOT128 % dict(root=root)], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-1500:]
+    got = json.loads(r.stdout.strip().splitlines()[-1])
+    assert got["entry_bytes"] == 128
+    for key in ("3_32-mult", "A-add", "A-mult"):
+        assert got[key] == [GOLD[key]["snark_sha256"], GOLD[key]["comm_sha256"]], key

@@ -239,3 +239,38 @@ def test_table_write_roundtrip(ctx):
     with pytest.raises(vpin_amd.VpinError):
         t.write(60, a)
     t.free()
+
+
+def test_tables_in_128_byte_slots_give_the_same_commitments(ctx):
+    """VPIN_TABLE_SLOT=128 (round 6; what bench.py asks for when every rank owns its GPU): the slot size is a property of a table,
+    read when it is built.  A two-segment-free table of 2050 generators in 128-byte slots beside the default 96-byte ones: row
+    commitments (table walk and buckets -- the bucket method reads multiple 1 of window 0), constant rows (prefix-sum bases) and a
+    few-row MSM against the oracle's Pippenger, and against the same commitments from a 96-byte table."""
+    import os
+    Rs, Ls = 2048, 8
+    xyzt, og = O.gens_stream_xyzt(Rs + 2)
+    L = __import__("vpin_amd").lib()
+    L.vpin_gens_entry_bytes.restype = C.c_size_t
+    g96 = ctx.gens_shared("test_slot_96", xyzt, 2)
+    os.environ["VPIN_TABLE_SLOT"] = "128"
+    try:
+        assert L.vpin_gens_entry_bytes() == 128
+        g128 = ctx.gens_shared("test_slot_128", xyzt, 2)
+    finally:
+        del os.environ["VPIN_TABLE_SLOT"]
+    assert L.vpin_gens_entry_bytes() == 96
+    rng = np.random.default_rng(128)
+    vals = structured_scalars(rng, Ls * Rs)
+    vals[:6] = [Q - 1, (Q - 1) // 2, 1 << 252, (1 << 252) - 1, 1, 0]
+    vals[3 * Rs:4 * Rs] = [vals[3 * Rs]] * Rs            # a constant row: s * (g_0 + ... + g_{R-1})
+    Z = M.ints_to_table(vals)
+    blinds = M.ints_to_table([int(rng.integers(0, 2**62)) ** 4 % Q for _ in range(Ls)])
+    dZ = ctx.upload(Z)
+    exp = O.hyrax_commit(Z, Ls, blinds, og, Rs + 1)
+    for g in (g128, g96):
+        assert np.array_equal(ctx.hyrax_commit(g, dZ, blinds, Rs + 1), exp)
+        assert np.array_equal(ctx.hyrax_commit_pippenger(g, dZ, blinds, Rs + 1), exp)
+        s = M.ints_to_table(vals[:64])
+        one = ctx.gens_msm(g, s, 1, 64)
+        assert np.array_equal(one, O.hyrax_commit(s, 1, np.zeros((1, 4), dtype=np.uint64), og, Rs + 1))
+    dZ.free()
